@@ -1,0 +1,123 @@
+"""ctypes front end of the CPU oracle (oracle/svgf_oracle.cpp) + the frame sequencing of
+src/App.cu:552-556 on top of it.
+
+TEST INFRASTRUCTURE ONLY — see the header of svgf_oracle.cpp.  Imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg, never by svgf_amd/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsvgf_oracle.so")
+_lib = None
+
+STORAGE = {"f32": 0, "f16": 1}
+_CDT = {"f32": np.float32, "f16": np.float16}
+
+DEFAULTS = dict(steps=3, depth_threshold=0.8, normal_threshold=0.9, history_base=24,
+                phi_colour=10.0, phi_normal=128.0, moments_radius=3, mesh_id_test=1)  # src/App.h:109-114
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "svgf_oracle.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libsvgf_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.svgf_oracle_f2h.restype = C.c_uint16
+        _lib.svgf_oracle_f2h.argtypes = [C.c_float]
+        _lib.svgf_oracle_h2f.restype = C.c_float
+        _lib.svgf_oracle_h2f.argtypes = [C.c_uint16]
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return C.c_void_p(0)
+    assert a.flags["C_CONTIGUOUS"], "oracle planes must be C-contiguous"
+    return C.c_void_p(a.ctypes.data)
+
+
+def _geo(W, H, geo):
+    """geo = (y0, rows, yb, ye) or None for the whole frame."""
+    if geo is None:
+        return (0, H, 0, H)
+    return tuple(int(v) for v in geo)
+
+
+def temporal(W, H, storage, prev_colour, cur_in, cur_out, gb_cur, gb_prev, hist_prev, hist_cur, mom_cur, mom_prev,
+             *, depth_threshold, normal_threshold, history_base, mesh_id_test=1, geo=None, nthreads=1):
+    y0, rows, yb, ye = _geo(W, H, geo)
+    rc = lib().svgf_oracle_temporal(
+        W, H, y0, rows, yb, ye, STORAGE[storage], _p(prev_colour), _p(cur_in), _p(cur_out),
+        _p(gb_cur["motion"]), _p(gb_cur["normal"]), _p(gb_cur["uv"]),
+        _p(gb_prev["motion"]), _p(gb_prev["normal"]), _p(gb_prev["uv"]),
+        _p(hist_prev), _p(hist_cur), _p(mom_cur), _p(mom_prev),
+        C.c_float(depth_threshold), C.c_float(normal_threshold), int(history_base), int(mesh_id_test), int(nthreads))
+    assert rc == 0
+
+
+def moments(W, H, storage, colour, out, mom, gb, hist, *, phi_colour, phi_normal, radius=3, geo=None, nthreads=1):
+    y0, rows, yb, ye = _geo(W, H, geo)
+    rc = lib().svgf_oracle_moments(
+        W, H, y0, rows, yb, ye, STORAGE[storage], _p(colour), _p(out), _p(mom), _p(gb["motion"]), _p(gb["normal"]),
+        _p(hist), C.c_float(phi_colour), C.c_float(phi_normal), int(radius), int(nthreads))
+    assert rc == 0
+
+
+def atrous(W, H, storage, src, dst, feedback, gb, *, step, phi_colour, phi_normal, iteration, geo=None, nthreads=1):
+    y0, rows, yb, ye = _geo(W, H, geo)
+    rc = lib().svgf_oracle_atrous(
+        W, H, y0, rows, yb, ye, STORAGE[storage], _p(src), _p(dst), _p(feedback), _p(gb["motion"]), _p(gb["normal"]),
+        int(step), C.c_float(phi_colour), C.c_float(phi_normal), int(iteration), int(nthreads))
+    assert rc == 0
+
+
+class Pipeline:
+    """Whole-frame sequencing: TemporalFilter -> FilterMoments -> WaveletFilter (src/App.cu:552-556,
+    469-514), with the host-side fixes SURVEY.md App. B lists (#1 history ping-pong, #4 current
+    moments, #9 zero-initialised state, #12 no odd-N copy)."""
+
+    def __init__(self, W, H, storage="f32", nthreads=1, **params):
+        self.W, self.H, self.storage, self.nthreads = W, H, storage, nthreads
+        self.p = dict(DEFAULTS)
+        self.p.update(params)
+        dt = _CDT[storage]
+        self.colour = [np.zeros((H, W, 4), dt) for _ in range(2)]   # RenderBuffer[2]   App.h:138
+        self.mom = [np.zeros((H, W, 2), dt) for _ in range(2)]      # MomentsBuffer[2]  App.h:139
+        self.filt = [np.zeros((H, W, 4), dt) for _ in range(2)]     # FilterBuffer[2]   App.h:140
+        self.hist = [np.zeros((H, W), np.uint8) for _ in range(2)]  # HistoryLengthBuffer (ping-ponged)
+        self.P = 0                                                  # PingPongInx       App.cu:374
+        self.taps = {}
+
+    def frame(self, radiance, gb_cur, gb_prev=None):
+        p, P, W, H, st, nt = self.p, self.P, self.W, self.H, self.storage, self.nthreads
+        if gb_prev is None:
+            gb_prev = gb_cur
+        rad = np.ascontiguousarray(radiance.astype(_CDT[st]))
+        temporal(W, H, st, self.colour[1 - P], rad, self.colour[P], gb_cur, gb_prev, self.hist[1 - P], self.hist[P],
+                 self.mom[P], self.mom[1 - P], depth_threshold=p["depth_threshold"],
+                 normal_threshold=p["normal_threshold"], history_base=p["history_base"],
+                 mesh_id_test=p["mesh_id_test"], nthreads=nt)
+        self.taps["temporal"] = self.colour[P].copy()
+        moments(W, H, st, self.colour[P], self.filt[0], self.mom[P], gb_cur, self.hist[P], phi_colour=p["phi_colour"],
+                phi_normal=p["phi_normal"], radius=p["moments_radius"], nthreads=nt)
+        self.taps["moments"] = self.filt[0].copy()
+        pp = 0
+        for i in range(p["steps"]):
+            atrous(W, H, st, self.filt[pp], self.filt[1 - pp], self.colour[P] if i == 0 else None, gb_cur, step=1 << i,
+                   phi_colour=p["phi_colour"], phi_normal=p["phi_normal"], iteration=i, nthreads=nt)
+            pp ^= 1
+        self.P ^= 1
+        return self.filt[pp]

@@ -1,0 +1,175 @@
+"""Independent NumPy restatement of the SVGF hot path, written from SURVEY.md Appendix A
+(not from oracle/svgf_oracle.cpp) so that agreement of the two pins the oracle.
+
+TEST INFRASTRUCTURE ONLY (same rules as svgf_oracle.cpp).  Whole frames only, vectorised
+over pixels, one tap at a time.  fp32 arithmetic, with the fp64 islands of App. A.5.
+
+Reference lines: src/Filter.cuh:55-83 (load/store), :199-207 (depth), :225-258 (reprojection),
+:260-263 (luminance), :359-404 (temporal), :407-427 (weight), :430-525 (moments), :527-624 (a-trous).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+f32 = np.float32
+SKY_Z = f32(1e30)
+
+
+def _ld(a):                      # storage -> float32
+    return a.astype(np.float32)
+
+
+def _clamp01(a):
+    return np.minimum(np.maximum(a, f32(0)), f32(1))
+
+
+def _lum(c):                     # A.2 / Filter.cuh:262
+    return f32(0.2126) * c[..., 0] + f32(0.7152) * c[..., 1] + f32(0.0722) * c[..., 2]
+
+
+def _depth(motion):              # A.0 GetDepth
+    z = motion[..., 2].copy()
+    dz = motion[..., 3].copy()
+    sky = z == 0
+    z[sky] = SKY_Z
+    dz[sky] = 0
+    return z, dz
+
+
+def _normal(normal_bits):
+    return normal_bits[..., :3].view(np.float16).astype(np.float32)
+
+
+def _dot(a, b):
+    return (a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]) + a[..., 2] * b[..., 2]
+
+
+def _weight(zc, zp, phi_d, nc, npix, phi_n, lc, lp, phi_l):      # A.5
+    with np.errstate(all="ignore"):
+        d = _clamp01(_dot(nc, npix))
+        d = np.where(np.isnan(d), f32(0), d)
+        wn = np.power(d, f32(phi_n)).astype(np.float32)
+        wz = np.where(phi_d == 0, f32(0), np.abs(zc - zp) / phi_d).astype(np.float32)
+        wl = (np.abs(lc - lp) / phi_l).astype(np.float32)
+        e = np.exp(0.0 - np.fmax(wl.astype(np.float64), 0.0) - np.fmax(wz.astype(np.float64), 0.0)) * wn.astype(np.float64)
+    return e.astype(np.float32)
+
+
+def temporal(prev_colour, cur, gb_cur, gb_prev, hist_prev, mom_prev, *, depth_threshold, normal_threshold,
+             history_base, mesh_id_test=1):
+    """A.2.  Returns (colour_out, hist_cur, mom_cur) in the storage dtype of `cur`."""
+    sdt = cur.dtype
+    H, W = cur.shape[:2]
+    history_base = min(max(int(history_base), 1), 255)
+    c = _clamp01(_ld(cur))[..., :3]
+    Y, X = np.mgrid[0:H, 0:W]
+    mv = gb_cur["motion"][..., :2]
+    qx = X + np.trunc(mv[..., 0]).astype(np.int64)
+    qy = Y + np.trunc(mv[..., 1]).astype(np.int64)
+    inb = (qx >= 0) & (qx < W) & (qy >= 0) & (qy < H)
+    qxc, qyc = np.clip(qx, 0, W - 1), np.clip(qy, 0, H - 1)
+    zc, _ = _depth(gb_cur["motion"])
+    zp_all, _ = _depth(gb_prev["motion"])
+    zp = zp_all[qyc, qxc]
+    with np.errstate(all="ignore"):
+        ok = inb & ~(np.abs(zp - zc) > f32(depth_threshold))
+    if mesh_id_test:
+        idc = gb_cur["uv"][..., 3].view(np.float16).astype(np.float32).astype(np.int32)
+        idp = gb_prev["uv"][..., 3].view(np.float16).astype(np.float32).astype(np.int32)[qyc, qxc]
+        ok &= idc == idp
+    nc = _normal(gb_cur["normal"])
+    npv = _normal(gb_prev["normal"])[qyc, qxc]
+    ok &= ~(_dot(nc, npv) < f32(normal_threshold))
+
+    cp = np.where(ok[..., None], _clamp01(_ld(prev_colour))[qyc, qxc][..., :3], f32(0))
+    mp = np.where(ok[..., None], _ld(mom_prev)[qyc, qxc], f32(0))
+    hp = hist_prev[qyc, qxc].astype(np.int32)
+    h = np.where(ok, np.minimum(history_base, hp + 1), 1).astype(np.int32)
+    alpha = np.where(ok, (1.0 / h.astype(np.float64)).astype(np.float32), f32(1))
+    L = _lum(c)
+    m = np.stack([L, L * L], -1)
+    a = alpha[..., None]
+    m2 = mp * (f32(1) - a) + m * a
+    var = np.maximum(f32(0), m2[..., 1] - m2[..., 0] * m2[..., 0])
+    c2 = cp * (f32(1) - a) + c * a
+    out = _clamp01(np.concatenate([c2, var[..., None]], -1)).astype(sdt)
+    return out, h.astype(np.uint8), m2.astype(sdt)
+
+
+def moments(colour, mom, gb, hist, *, phi_colour, phi_normal, radius=3):
+    """A.3."""
+    sdt = colour.dtype
+    H, W = colour.shape[:2]
+    craw = _ld(colour)
+    mraw = _ld(mom)
+    h = hist.astype(np.float32)
+    zc, dzc = _depth(gb["motion"])
+    nc = _normal(gb["normal"])
+    lc = _lum(craw)
+    phi_d = (np.maximum(dzc.astype(np.float64), 1e-8) * 3.0).astype(np.float32)
+    Y, X = np.mgrid[0:H, 0:W]
+    sw = np.zeros((H, W), np.float32)
+    sc = np.zeros((H, W, 3), np.float32)
+    sm = np.zeros((H, W, 2), np.float32)
+    for yy in range(-radius, radius + 1):
+        for xx in range(-radius, radius + 1):
+            px, py = X + xx, Y + yy
+            inside = (px < W) & (py < H) & (px >= 0) & (py >= 0)
+            pxc, pyc = np.clip(px, 0, W - 1), np.clip(py, 0, H - 1)
+            cpix = craw[pyc, pxc]
+            ln = np.sqrt(f32(xx * xx + yy * yy))
+            w = _weight(zc, zc[pyc, pxc], phi_d * ln, nc, nc[pyc, pxc], phi_normal, lc, _lum(cpix), f32(phi_colour))
+            w = np.where(inside, w, f32(0))
+            # skipped taps must not touch the sums at all (0*inf would poison them)
+            sw = np.where(inside, sw + w, sw)
+            sc = np.where(inside[..., None], sc + cpix[..., :3] * w[..., None], sc)
+            sm = np.where(inside[..., None], sm + mraw[pyc, pxc] * w[..., None], sm)
+    sw = np.maximum(sw, f32(1e-6))
+    C = sc / sw[..., None]
+    M = sm / sw[..., None]
+    var = M[..., 1] - M[..., 0] * M[..., 0]
+    with np.errstate(all="ignore"):
+        var = (var.astype(np.float64) * (4.0 / h.astype(np.float64))).astype(np.float32)
+    filt = np.concatenate([C, var[..., None]], -1)
+    out = np.where((h < 4)[..., None], filt, craw)
+    return out.astype(sdt)
+
+
+_K = np.array([1.0, 2.0 / 3.0, 1.0 / 6.0]).astype(np.float32)
+
+
+def atrous(src, gb, *, step, phi_colour, phi_normal):
+    """A.4.  Returns (out, feedback_mask): feedback_mask marks the pixels whose value the
+    iteration-0 launch also stores into the feedback plane (all but sky)."""
+    sdt = src.dtype
+    H, W = src.shape[:2]
+    c = _clamp01(_ld(src))
+    lc = _lum(c)
+    var = c[..., 3]
+    zc, dzc = _depth(gb["motion"])
+    nc = _normal(gb["normal"])
+    sky = zc == SKY_Z
+    phi_l = (np.float64(f32(phi_colour)) * np.sqrt(np.maximum(0.0, (f32(1e-10) + var).astype(np.float64)))).astype(np.float32)
+    phi_d = np.maximum(dzc, f32(1e-6)) * f32(step)
+    Y, X = np.mgrid[0:H, 0:W]
+    S = np.ones((H, W), np.float32)
+    acc = c.copy()
+    for yy in range(-2, 3):
+        for xx in range(-2, 3):
+            if xx == 0 and yy == 0:
+                continue
+            px, py = X + xx * step, Y + yy * step
+            inside = (px < W) & (py < H) & (px >= 0) & (py >= 0)
+            pxc, pyc = np.clip(px, 0, W - 1), np.clip(py, 0, H - 1)
+            k = _K[abs(xx)] * _K[abs(yy)]
+            q = c[pyc, pxc]
+            ln = np.sqrt(f32(xx * xx + yy * yy))
+            w = _weight(zc, zc[pyc, pxc], phi_d * ln, nc, nc[pyc, pxc], phi_normal, lc, _lum(q), phi_l)
+            g = w * k
+            S = np.where(inside, S + g, S)
+            acc[..., :3] = np.where(inside[..., None], acc[..., :3] + g[..., None] * q[..., :3], acc[..., :3])
+            acc[..., 3] = np.where(inside, acc[..., 3] + (g * g) * q[..., 3], acc[..., 3])
+    with np.errstate(all="ignore"):
+        out = np.concatenate([acc[..., :3] / S[..., None], (acc[..., 3] / (S * S))[..., None]], -1)
+    out = np.where(sky[..., None], c, out)
+    return out.astype(sdt), ~sky

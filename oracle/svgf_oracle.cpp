@@ -1,0 +1,340 @@
+// svgf_oracle.cpp — scalar CPU restatement of the SVGF hot path of jacquespillet/SVGF.
+//
+// TEST INFRASTRUCTURE ONLY.  Nothing under svgf_amd/ (the product) may include,
+// link, import or execute this file.  Only tests/, __graft_entry__.smoke() and the
+// cpu_baseline leg of bench.py use it, and only as the checker / reported baseline.
+//
+// PARITY UNPINNED: the reference repository has no tests, golden vectors or CPU
+// implementation of the filter and its CUDA sources cannot be
+// built in this image (no nvcc, glm submodule empty).  This restatement is pinned
+// instead by (a) hand-derivable known-answer cases and (b) an independently written
+// NumPy restatement (oracle/svgf_numpy.py); see tests/test_oracle_*.py.
+//
+// Each function cites the reference lines (under /root/reference/) it follows.
+// Arithmetic is fp32 with the reference's fp64 islands kept;
+// compile with -ffp-contract=off so no FMA contraction changes the rounding.
+//
+// Geometry: every plane holds `rows` local rows of a W-wide, H-high global frame,
+// local row 0 being global row y0 (single GPU / whole frame: y0 = 0, rows = H).
+// Stages compute global rows [yb, ye).  "Inside the frame" always means the
+// GLOBAL frame, exactly as the reference kernels test it.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct Geo { int W, H, y0, rows, yb, ye; };
+
+// ---------------------------------------------------------------- storage ----
+// half <-> float: round-to-nearest-even like __float2half / exact like __half2float
+// (reference Filter.cuh:15-52).
+inline float h2f(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp  = (h >> 10) & 0x1fu;
+    uint32_t man  = h & 0x3ffu;
+    uint32_t out;
+    if (exp == 0) {
+        if (man == 0) out = sign;
+        else {  // subnormal: value = man * 2^-24
+            float v = (float)man * 5.9604644775390625e-8f;
+            std::memcpy(&out, &v, 4);
+            out |= sign;
+        }
+    } else if (exp == 31) out = sign | 0x7f800000u | (man << 13);
+    else out = sign | ((exp + 112u) << 23) | (man << 13);
+    float f; std::memcpy(&f, &out, 4); return f;
+}
+
+inline uint16_t f2h(float f) {
+    uint32_t x; std::memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    uint32_t o;
+    if (x >= 0x47800000u) {                 // >= 65536, inf or nan
+        o = (x > 0x7f800000u) ? 0x7e00u : 0x7c00u;
+    } else if (x < 0x38800000u) {           // below the smallest normal half: exact RNE through an fp32 add
+        float a; std::memcpy(&a, &x, 4);
+        const uint32_t magic_u = (uint32_t)((127 - 15) + (23 - 10) + 1) << 23;   // 0.5f
+        float magic; std::memcpy(&magic, &magic_u, 4);
+        a += magic;
+        uint32_t au; std::memcpy(&au, &a, 4);
+        o = au - magic_u;
+    } else {
+        uint32_t odd = (x >> 13) & 1u;
+        x += 0xc8000fffu;                   // rebias exponent (15-127)<<23, plus rounding bias 0xfff
+        x += odd;
+        o = x >> 13;                        // [65520,65536) carries into the exponent -> 0x7c00
+    }
+    return (uint16_t)(o | sign);
+}
+
+struct F32 {                                 // "fp32 storage" extension (BASELINE configs #1-#4)
+    static constexpr int kBytes4 = 16;
+    static void ld4(const void* p, size_t i, float* v) { std::memcpy(v, (const float*)p + 4 * i, 16); }
+    static void st4(void* p, size_t i, const float* v) { std::memcpy((float*)p + 4 * i, v, 16); }
+    static void ld2(const void* p, size_t i, float* v) { std::memcpy(v, (const float*)p + 2 * i, 8); }
+    static void st2(void* p, size_t i, const float* v) { std::memcpy((float*)p + 2 * i, v, 8); }
+};
+struct F16 {                                 // reference-native half4 / half2 (Filter.cuh:15-16)
+    static void ld4(const void* p, size_t i, float* v) { const uint16_t* q = (const uint16_t*)p + 4 * i; for (int k = 0; k < 4; k++) v[k] = h2f(q[k]); }
+    static void st4(void* p, size_t i, const float* v) { uint16_t* q = (uint16_t*)p + 4 * i; for (int k = 0; k < 4; k++) q[k] = f2h(v[k]); }
+    static void ld2(const void* p, size_t i, float* v) { const uint16_t* q = (const uint16_t*)p + 2 * i; v[0] = h2f(q[0]); v[1] = h2f(q[1]); }
+    static void st2(void* p, size_t i, const float* v) { uint16_t* q = (uint16_t*)p + 2 * i; q[0] = f2h(v[0]); q[1] = f2h(v[1]); }
+};
+
+inline float clamp01(float v) { return std::min(std::max(v, 0.0f), 1.0f); }   // glm::clamp = min(max(x,lo),hi)
+
+// imageLoad (Filter.cuh:78-83): value clamped to [0,1] on all four channels.  The coordinate
+// clamp never fires on this path (every caller tests "inside" first), so it is not restated.
+template <class T> inline void image_load(const void* img, size_t idx, float* v) {
+    T::ld4(img, idx, v);
+    for (int k = 0; k < 4; k++) v[k] = clamp01(v[k]);
+}
+// imageStore (Filter.cuh:63-69)
+template <class T> inline void image_store(void* img, size_t idx, const float* v) {
+    float c[4]; for (int k = 0; k < 4; k++) c[k] = clamp01(v[k]);
+    T::st4(img, idx, c);
+}
+
+// G-buffer fetches ------------------------------------------------------------
+// GetDepth (Filter.cuh:199-207): (z,dz) = motion.zw ; z == 0 -> (1e30, 0)
+inline void get_depth(const float* motion, size_t idx, float& z, float& dz) {
+    z = motion[4 * idx + 2]; dz = motion[4 * idx + 3];
+    if (z == 0.0f) { z = 1e30f; dz = 0.0f; }
+}
+// SampleCuTextureHalf4 (Filter.cuh:188-197): 4 x u16 half bits -> floats (xyz used)
+inline void get_normal(const uint16_t* normal, size_t idx, float* n) {
+    n[0] = h2f(normal[4 * idx]); n[1] = h2f(normal[4 * idx + 1]); n[2] = h2f(normal[4 * idx + 2]);
+}
+inline float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }  // glm::dot
+// CalculateLuminance (Filter.cuh:260-263)
+inline float luminance(const float* c) { return 0.2126f * c[0] + 0.7152f * c[1] + 0.0722f * c[2]; }
+inline float mixf(float x, float y, float a) { return x * (1.0f - a) + y * a; }                           // glm::mix
+
+// computeWeight (Filter.cuh:407-427).  The double literals in :424 select CUDA's
+// double max(float,double) and a double exp; the product with weightNormal is in double
+// and rounds to float once.
+inline float compute_weight(float zc, float zp, float phi_depth, const float* nc, const float* np,
+                            float phi_normal, float lc, float lp, float phi_illum) {
+    float d = clamp01(dot3(nc, np));
+    if (!(d == d)) d = 0.0f;                                            // saturate(): NaN -> 0
+    const float wn = std::pow(d, phi_normal);                           // powf
+    const float wz = (phi_depth == 0) ? 0.0f : std::fabs(zc - zp) / phi_depth;
+    const float wl = std::fabs(lc - lp) / phi_illum;
+    const double e = std::exp(0.0 - std::fmax((double)wl, 0.0) - std::fmax((double)wz, 0.0)) * (double)wn;
+    return (float)e;
+}
+
+template <class F> void parallel_rows(int yb, int ye, int nthreads, F&& fn) {
+    if (nthreads <= 1 || ye - yb < 2 * nthreads) { fn(yb, ye); return; }
+    std::vector<std::thread> th;
+    int n = ye - yb;
+    for (int t = 0; t < nthreads; t++) {
+        int a = yb + (int)((long long)n * t / nthreads), b = yb + (int)((long long)n * (t + 1) / nthreads);
+        th.emplace_back([=, &fn] { fn(a, b); });
+    }
+    for (auto& t : th) t.join();
+}
+
+// ---------------------------------------------------------------- temporal ----
+// TemporalFilter (Filter.cuh:359-404) with LoadPreviousData (Filter.cuh:225-258).
+// History is ping-ponged (hist_prev read, hist_cur written): SURVEY.md App. B #1.
+// mesh_id_test=1 implements the intended instance-ID comparison of :245-247, 0 the
+// de-facto no-op (App. B #3).
+template <class T>
+void temporal(const Geo& g, const void* prev_colour, const void* cur_in, void* cur_out,
+              const float* motion_c, const uint16_t* normal_c, const uint16_t* uv_c,
+              const float* motion_p, const uint16_t* normal_p, const uint16_t* uv_p,
+              const uint8_t* hist_prev, uint8_t* hist_cur, void* mom_cur, const void* mom_prev,
+              float depth_thr, float normal_thr, int history_base, int mesh_id_test, int nthreads) {
+    parallel_rows(g.yb, g.ye, nthreads, [&](int ya, int yb2) {
+        for (int y = ya; y < yb2; y++)
+            for (int x = 0; x < g.W; x++) {
+                const size_t idx = (size_t)(y - g.y0) * g.W + x;
+                float c[4]; image_load<T>(cur_in, idx, c);                        // :370
+                float cp[3] = {0, 0, 0}, mp[2] = {0, 0};                          // :371,374
+                int h = 1; float alpha;                                           // :372
+                bool ok = false;
+                const float mvx = motion_c[4 * idx], mvy = motion_c[4 * idx + 1]; // :230-231
+                const int qx = x + (int)mvx, qy = y + (int)mvy;                   // :232 (trunc toward 0)
+                if (qx >= 0 && qx < g.W && qy >= 0 && qy < g.H) {                 // :235
+                    const size_t q = (size_t)(qy - g.y0) * g.W + qx;
+                    float zc, dzc, zp, dzp;
+                    get_depth(motion_c, idx, zc, dzc); get_depth(motion_p, q, zp, dzp);   // :239-240
+                    ok = !(std::fabs(zp - zc) > depth_thr);                       // :242
+                    if (ok && mesh_id_test) {                                     // :245-247
+                        const int idc = (int)h2f(uv_c[4 * idx + 3]), idp = (int)h2f(uv_p[4 * q + 3]);
+                        ok = (idc == idp);
+                    }
+                    if (ok) {                                                     // :250-252
+                        float nc[3], np[3]; get_normal(normal_c, idx, nc); get_normal(normal_p, q, np);
+                        ok = !(dot3(nc, np) < normal_thr);
+                    }
+                    if (ok) {                                                     // :254-256
+                        float pc[4]; image_load<T>(prev_colour, q, pc);
+                        cp[0] = pc[0]; cp[1] = pc[1]; cp[2] = pc[2];
+                        h = (int)hist_prev[q];
+                        T::ld2(mom_prev, q, mp);
+                    }
+                }
+                if (ok) { h = std::min(history_base, h + 1); alpha = (float)(1.0 / (double)h); }   // :380-381
+                else    { alpha = 1.0f; h = 1; }                                                   // :385-386
+                float m[2]; m[0] = luminance(c); m[1] = m[0] * m[0];              // :391-392
+                m[0] = mixf(mp[0], m[0], alpha); m[1] = mixf(mp[1], m[1], alpha); // :393
+                const float var = std::max(0.0f, m[1] - m[0] * m[0]);             // :396
+                float out[4] = {mixf(cp[0], c[0], alpha), mixf(cp[1], c[1], alpha), mixf(cp[2], c[2], alpha), var}; // :398
+                hist_cur[idx] = (uint8_t)h;                                       // :400
+                image_store<T>(cur_out, idx, out);                                // :401
+                T::st2(mom_cur, idx, m);                                          // :402
+            }
+    });
+}
+
+// ---------------------------------------------------------------- moments -----
+// FilterMoments (Filter.cuh:430-525).  `radius` = 3 is the reference (:465).
+template <class T>
+void moments(const Geo& g, const void* colour, void* out, const void* mom, const float* motion,
+             const uint16_t* normal, const uint8_t* hist, float phi_colour, float phi_normal,
+             int radius, int nthreads) {
+    parallel_rows(g.yb, g.ye, nthreads, [&](int ya, int yb2) {
+        for (int y = ya; y < yb2; y++)
+            for (int x = 0; x < g.W; x++) {
+                const size_t idx = (size_t)(y - g.y0) * g.W + x;
+                const float h = (float)hist[idx];                                 // :442
+                float cc[4]; T::ld4(colour, idx, cc);                             // raw, :450
+                if (h < 4.0f) {                                                   // :444
+                    float sw = 0.0f, sc[3] = {0, 0, 0}, sm[2] = {0, 0};
+                    const float lc = luminance(cc);                               // :451
+                    float zc, dzc; get_depth(motion, idx, zc, dzc);               // :453
+                    float nc[3]; get_normal(normal, idx, nc);                     // :459
+                    const float phi_l = phi_colour;                               // :460
+                    const float phi_d = (float)(std::max((double)dzc, 1e-8) * 3.0);   // :461
+                    for (int yy = -radius; yy <= radius; yy++)
+                        for (int xx = -radius; xx <= radius; xx++) {              // :467-469
+                            const int px = x + xx, py = y + yy;
+                            if (!(px < g.W && py < g.H && px >= 0 && py >= 0)) continue;   // :473,477
+                            const size_t p = (size_t)(py - g.y0) * g.W + px;
+                            float cpix[4]; T::ld4(colour, p, cpix);               // :479 raw
+                            float mpix[2]; T::ld2(mom, p, mpix);                  // :480
+                            const float lp = luminance(cpix);                     // :481
+                            float zp, dzp; get_depth(motion, p, zp, dzp);         // :482
+                            float np[3]; get_normal(normal, p, np);               // :483
+                            const float len = std::sqrt((float)(xx * xx + yy * yy));     // glm::length(vec2) :488
+                            const float w = compute_weight(zc, zp, phi_d * len, nc, np, phi_normal, lc, lp, phi_l);
+                            sw += w;                                              // :497
+                            sc[0] += cpix[0] * w; sc[1] += cpix[1] * w; sc[2] += cpix[2] * w;   // :498
+                            sm[0] += mpix[0] * w; sm[1] += mpix[1] * w;           // :499
+                        }
+                    sw = std::max(sw, 1e-6f);                                     // :505
+                    float o[4] = {sc[0] / sw, sc[1] / sw, sc[2] / sw, 0};         // :507
+                    sm[0] /= sw; sm[1] /= sw;                                     // :508
+                    float var = sm[1] - sm[0] * sm[0];                            // :511
+                    var = (float)((double)var * (4.0 / (double)h));               // :514
+                    o[3] = var;
+                    T::st4(out, idx, o);                                          // :516 unclamped
+                } else {
+                    T::st4(out, idx, cc);                                         // :521
+                }
+            }
+    });
+}
+
+// ---------------------------------------------------------------- a-trous -----
+// FilterKernel (Filter.cuh:527-624).
+template <class T>
+void atrous(const Geo& g, const void* in, void* out, void* feedback, const float* motion,
+            const uint16_t* normal, int step, float phi_colour, float phi_normal, int iteration,
+            int nthreads) {
+    const float K[3] = {(float)1.0, (float)(2.0 / 3.0), (float)(1.0 / 6.0)};     // :540
+    parallel_rows(g.yb, g.ye, nthreads, [&](int ya, int yb2) {
+        for (int y = ya; y < yb2; y++)
+            for (int x = 0; x < g.W; x++) {
+                const size_t idx = (size_t)(y - g.y0) * g.W + x;
+                float c[4]; image_load<T>(in, idx, c);                            // :543
+                const float lc = luminance(c);                                    // :544
+                const float var = c[3];                                           // :547
+                float zc, dzc; get_depth(motion, idx, zc, dzc);                   // :552
+                if (zc == 1e30f) { T::st4(out, idx, c); continue; }               // :554-558 (no feedback)
+                float nc[3]; get_normal(normal, idx, nc);                         // :560
+                const float eps = 1e-10f;
+                const float phi_l = (float)((double)phi_colour * std::sqrt(std::max(0.0, (double)(eps + var))));  // :562
+                const float phi_d = std::max(dzc, 1e-6f) * (float)step;           // :563
+                float sw = 1.0f;                                                  // :567
+                float s[4] = {c[0], c[1], c[2], c[3]};                            // :568
+                for (int yy = -2; yy <= 2; yy++)
+                    for (int xx = -2; xx <= 2; xx++) {                            // :571-573
+                        const int px = x + xx * step, py = y + yy * step;         // :576
+                        const bool inside = px < g.W && py < g.H && px >= 0 && py >= 0;   // :579
+                        const float kern = K[std::abs(xx)] * K[std::abs(yy)];     // :582
+                        if (!(inside && (xx != 0 || yy != 0))) continue;          // :584
+                        const size_t p = (size_t)(py - g.y0) * g.W + px;
+                        float q[4]; image_load<T>(in, p, q);                      // :586
+                        const float lp = luminance(q);                            // :587
+                        float zp, dzp; get_depth(motion, p, zp, dzp);             // :588
+                        float np[3]; get_normal(normal, p, np);                   // :589
+                        const float len = std::sqrt((float)(xx * xx + yy * yy));  // :595
+                        const float w = compute_weight(zc, zp, phi_d * len, nc, np, phi_normal, lc, lp, phi_l);
+                        const float iw = w * kern;                                // :604
+                        sw += iw;                                                 // :607
+                        s[0] += iw * q[0]; s[1] += iw * q[1]; s[2] += iw * q[2];  // :608
+                        s[3] += (iw * iw) * q[3];
+                    }
+                float o[4] = {s[0] / sw, s[1] / sw, s[2] / sw, s[3] / (sw * sw)};  // :615
+                T::st4(out, idx, o);                                              // :618 unclamped
+                if (iteration == 0 && feedback) T::st4(feedback, idx, o);         // :619-622
+            }
+    });
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- C entry -----
+extern "C" {
+
+// storage: 0 = fp32 colour/moments, 1 = fp16 colour/moments (reference-native)
+int svgf_oracle_temporal(int W, int H, int y0, int rows, int yb, int ye, int storage,
+                         const void* prev_colour, const void* cur_in, void* cur_out,
+                         const float* motion_c, const uint16_t* normal_c, const uint16_t* uv_c,
+                         const float* motion_p, const uint16_t* normal_p, const uint16_t* uv_p,
+                         const uint8_t* hist_prev, uint8_t* hist_cur, void* mom_cur, const void* mom_prev,
+                         float depth_thr, float normal_thr, int history_base, int mesh_id_test, int nthreads) {
+    Geo g{W, H, y0, rows, yb, ye};
+    history_base = std::min(std::max(history_base, 1), 255);
+    if (storage == 0) temporal<F32>(g, prev_colour, cur_in, cur_out, motion_c, normal_c, uv_c, motion_p, normal_p, uv_p, hist_prev, hist_cur, mom_cur, mom_prev, depth_thr, normal_thr, history_base, mesh_id_test, nthreads);
+    else if (storage == 1) temporal<F16>(g, prev_colour, cur_in, cur_out, motion_c, normal_c, uv_c, motion_p, normal_p, uv_p, hist_prev, hist_cur, mom_cur, mom_prev, depth_thr, normal_thr, history_base, mesh_id_test, nthreads);
+    else return -1;
+    return 0;
+}
+
+int svgf_oracle_moments(int W, int H, int y0, int rows, int yb, int ye, int storage,
+                        const void* colour, void* out, const void* mom, const float* motion,
+                        const uint16_t* normal, const uint8_t* hist, float phi_colour, float phi_normal,
+                        int radius, int nthreads) {
+    Geo g{W, H, y0, rows, yb, ye};
+    if (storage == 0) moments<F32>(g, colour, out, mom, motion, normal, hist, phi_colour, phi_normal, radius, nthreads);
+    else if (storage == 1) moments<F16>(g, colour, out, mom, motion, normal, hist, phi_colour, phi_normal, radius, nthreads);
+    else return -1;
+    return 0;
+}
+
+int svgf_oracle_atrous(int W, int H, int y0, int rows, int yb, int ye, int storage,
+                       const void* in, void* out, void* feedback, const float* motion,
+                       const uint16_t* normal, int step, float phi_colour, float phi_normal,
+                       int iteration, int nthreads) {
+    Geo g{W, H, y0, rows, yb, ye};
+    if (storage == 0) atrous<F32>(g, in, out, feedback, motion, normal, step, phi_colour, phi_normal, iteration, nthreads);
+    else if (storage == 1) atrous<F16>(g, in, out, feedback, motion, normal, step, phi_colour, phi_normal, iteration, nthreads);
+    else return -1;
+    return 0;
+}
+
+// converters exported so the tests can pin them against numpy's float16
+uint16_t svgf_oracle_f2h(float f) { return f2h(f); }
+float svgf_oracle_h2f(uint16_t h) { return h2f(h); }
+
+}  // extern "C"

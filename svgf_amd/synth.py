@@ -1,0 +1,162 @@
+"""Deterministic synthetic G-buffer + 1-spp radiance frames.
+
+The reference's inputs come from an OpenGL rasteriser (resources/shaders/GBuffer.frag:62-88)
+and a CUDA path tracer (src/PathTrace.cuh:618-619); neither exists on the compute box, so
+tests, smoke() and bench.py feed the filter with frames of the same *plane formats*:
+
+  motion  float32[rows, W, 4]  (mv.x, mv.y, depth, ddepth)   mv in pixels, prev - cur
+                               (GBuffer.frag:67-71,81-82); depth == 0 marks sky (App.cu:383)
+  normal  uint16 [rows, W, 4]  IEEE-half bits (nx, ny, nz, matID)        (GBuffer.frag:65,78,85)
+  uv      uint16 [rows, W, 4]  IEEE-half bits (b0, b1, b2, instanceID)   (GBuffer.frag:64,77,86)
+  radiance float32[rows, W, 4] (r, g, b, 1)                              (PathTrace.cuh:618)
+
+Noise is counter based (splitmix64 keyed on seed, frame, y, x, channel): any row range of any
+frame can be produced independently, so strips generated on different ranks tile exactly into
+the single-GPU frame.  SEED is fixed and recorded in bench output.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SEED = 0x5356474600000001  # "SVGF" 0 0 0 1
+
+_U64 = np.uint64
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (x + _U64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = x
+    z = (z ^ (z >> _U64(30))) * _U64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> _U64(27))) * _U64(0x94D049BB133111EB)
+    return z ^ (z >> _U64(31))
+
+
+def uniform01(seed: int, frame: int, ys: np.ndarray, xs: np.ndarray, channel: int) -> np.ndarray:
+    """float32 uniform in [0,1) for every (y, x) of the outer product ys × xs."""
+    with np.errstate(over="ignore"):
+        ky = _splitmix64(ys.astype(np.uint64) * _U64(0xD1B54A32D192ED03) + _U64(seed & 0xFFFFFFFFFFFFFFFF))
+        kx = _splitmix64(xs.astype(np.uint64) * _U64(0x8CB92BA72F3D8DD7) + _U64((frame * 0x100 + channel) & 0xFFFFFFFFFFFFFFFF))
+        h = _splitmix64(ky[:, None] ^ (kx[None, :] * _U64(0x9E3779B97F4A7C15)))
+    return ((h >> _U64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24))).astype(np.float32)
+
+
+# region ids (instanceID); matID = id + 10
+SKY, QUAD_A, QUAD_B, SPHERE, GROUND, QUAD_A2 = 0, 1, 2, 3, 4, 5
+
+_ALBEDO = np.array(
+    [[0.0, 0.0, 0.0], [0.80, 0.25, 0.20], [0.20, 0.55, 0.85], [0.90, 0.85, 0.30], [0.45, 0.50, 0.40], [0.30, 0.75, 0.35]],
+    dtype=np.float64,
+)
+_N_GROUND = np.array([0.0, 0.9486833, -0.31622777])
+_N_QUAD_A = np.array([0.0, 0.0, -1.0])
+_N_QUAD_B = np.array([0.6, 0.0, -0.8])
+
+
+def make_frame(width: int, height: int, frame: int, *, mv=(0.0, 0.0), row_begin: int = 0, row_end: int | None = None,
+               seed: int = SEED, noise: str = "1spp"):
+    """Rows [row_begin, row_end) of synthetic frame `frame`.
+
+    `mv` is the constant per-frame pan (prev - cur, pixels): the surface point seen at pixel p in
+    frame f was at p + mv in frame f-1, i.e. frame f shows the static world at p + f*mv.
+    Returns dict(motion, normal, uv, radiance) of C-contiguous arrays.
+    """
+    if row_end is None:
+        row_end = height
+    rows = row_end - row_begin
+    ys = np.arange(row_begin, row_end, dtype=np.int64)
+    xs = np.arange(width, dtype=np.int64)
+    H = float(height)
+    u = ((xs.astype(np.float64) + frame * float(mv[0])) / H)[None, :].repeat(rows, 0)
+    v = ((ys.astype(np.float64) + frame * float(mv[1])) / H)[:, None].repeat(width, 1)
+
+    region = np.full((rows, width), GROUND, dtype=np.int32)
+    z = 12.0 + 3.0 * u - 6.0 * (v - 0.5)
+    dz = np.full_like(z, 6.0 / H)
+    n = np.broadcast_to(_N_GROUND, (rows, width, 3)).copy()
+
+    # sphere
+    cx, cy, r = 0.45, 0.78, 0.18
+    dx, dy = (u - cx) / r, (v - cy) / r
+    rho2 = dx * dx + dy * dy
+    m = rho2 < 1.0
+    s = np.sqrt(np.clip(1.0 - rho2, 0.0, 1.0))
+    region[m] = SPHERE
+    z[m] = (6.0 - 2.0 * r * s)[m]
+    sd = np.maximum(s, 0.2)
+    dz[m] = (2.0 * np.maximum(np.abs(dx), np.abs(dy)) / sd / H)[m]
+    n[m] = np.stack([dx, dy, -s], -1)[m]
+
+    # tilted quad B
+    m = (u >= 0.9) & (u < 1.4) & (v >= 0.2) & (v < 0.7)
+    region[m] = QUAD_B
+    z[m] = (7.0 + 1.5 * (u - 0.9))[m]
+    dz[m] = 1.5 / H
+    n[m] = _N_QUAD_B
+
+    # fronto-parallel quad A and its coplanar twin A2 (differs by instanceID only)
+    m = (u >= 0.2) & (u < 0.6) & (v >= 0.25) & (v < 0.55)
+    region[m] = QUAD_A
+    z[m] = 4.0
+    dz[m] = 0.0
+    n[m] = _N_QUAD_A
+    m = (u >= 0.6) & (u < 0.7) & (v >= 0.25) & (v < 0.55)
+    region[m] = QUAD_A2
+    z[m] = 4.0
+    dz[m] = 0.0
+    n[m] = _N_QUAD_A
+
+    # sky band (>= 5 % of the frame): depth 0, normal/uv all-zero bits
+    sky = v < (0.08 + 0.02 * np.sin(7.0 * u))
+    region[sky] = SKY
+    z[sky] = 0.0
+    dz[sky] = 0.0
+    n[sky] = 0.0
+
+    motion = np.empty((rows, width, 4), dtype=np.float32)
+    motion[..., 0] = np.float32(mv[0])
+    motion[..., 1] = np.float32(mv[1])
+    motion[..., 2] = z.astype(np.float32)
+    motion[..., 3] = dz.astype(np.float32)
+
+    normal = np.empty((rows, width, 4), dtype=np.uint16)
+    normal[..., :3] = n.astype(np.float32).astype(np.float16).view(np.uint16)
+    normal[..., 3] = np.where(sky, 0, region + 10).astype(np.float16).view(np.uint16)
+
+    uv = np.empty((rows, width, 4), dtype=np.uint16)
+    b0 = uniform01(seed, 0, ys, xs, 8)
+    b1 = uniform01(seed, 0, ys, xs, 9) * (1.0 - b0)
+    uv[..., 0] = b0.astype(np.float16).view(np.uint16)
+    uv[..., 1] = b1.astype(np.float16).view(np.uint16)
+    uv[..., 2] = (1.0 - b0 - b1).astype(np.float16).view(np.uint16)
+    uv[..., 3] = region.astype(np.float16).view(np.uint16)
+    uv[sky] = 0
+
+    # radiance = albedo(region) * shade(normal) * texture, then 1-spp style noise
+    light = np.array([0.35, -0.5, -0.79])
+    shade = 0.55 + 0.45 * np.clip(n @ light, 0.0, 1.0)
+    tex = 0.8 + 0.2 * np.sin(37.0 * u) * np.sin(41.0 * v)
+    base = _ALBEDO[region] * (shade * tex)[..., None] * 0.6 + 0.05
+    base[sky] = np.array([0.25, 0.45, 0.80])
+    radiance = np.empty((rows, width, 4), dtype=np.float32)
+    if noise == "1spp":
+        hit = uniform01(seed, frame + 1, ys, xs, 0) < np.float32(0.25)
+        val = np.where(hit[..., None], base / 0.25, 0.0)
+    elif noise == "mul":
+        k = uniform01(seed, frame + 1, ys, xs, 0).astype(np.float64)
+        val = base * (0.5 + k)[..., None]
+    elif noise == "none":
+        val = base
+    else:
+        raise ValueError(noise)
+    radiance[..., :3] = np.clip(val, 0.0, 1.0).astype(np.float32)
+    radiance[..., 3] = 1.0
+    return {"motion": motion, "normal": normal, "uv": uv, "radiance": radiance, "region": region}
+
+
+def to_storage(a: np.ndarray, storage: str) -> np.ndarray:
+    """float32 colour/moment plane -> storage dtype ('f32' keeps, 'f16' rounds to nearest even)."""
+    if storage == "f32":
+        return np.ascontiguousarray(a, dtype=np.float32)
+    if storage == "f16":
+        return np.ascontiguousarray(a.astype(np.float16))
+    raise ValueError(storage)

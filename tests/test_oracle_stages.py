@@ -1,0 +1,201 @@
+"""Pins the C++ oracle: (1) against the independently written NumPy restatement of SURVEY.md
+Appendix A, stage by stage and over a multi-frame pipeline; (2) against hand-derivable
+known-answer cases.  The reference itself holds no vectors for this path (parity unpinned)."""
+import numpy as np
+import pytest
+
+from oracle import svgf_numpy as snp
+from svgf_amd import synth
+from tests.helpers import CDT, NumpyPipeline, frames, gbuf, half_ulp_diff
+
+P = dict(depth_threshold=0.8, normal_threshold=0.9, history_base=24, phi_colour=10.0, phi_normal=128.0)
+
+
+def _close(got, want, storage, what):
+    if storage == "f32":
+        # differences come only from libm powf/exp vs numpy's: a few fp32 ulps on convex sums
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-7, err_msg=what)
+    else:
+        g, w = np.asarray(got), np.asarray(want)
+        fin = np.isfinite(w.astype(np.float32))
+        assert np.array_equal(np.isfinite(g.astype(np.float32)), fin), what
+        d = half_ulp_diff(g[fin], w[fin])
+        assert d.max() <= 1, f"{what}: {d.max()} half-ulps"
+        assert (d > 0).mean() < 1e-3, f"{what}: {(d > 0).mean():.2e} of values differ by one half-ulp"
+
+
+def _temporal_state(W, H, storage, rng):
+    dt = CDT[storage]
+    prev = rng.uniform(-0.1, 1.2, (H, W, 4)).astype(dt)          # includes values the load clamp must catch
+    mom_prev = rng.uniform(0, 1, (H, W, 2)).astype(dt)
+    hist_prev = rng.integers(0, 40, (H, W)).astype(np.uint8)
+    return prev, mom_prev, hist_prev
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+@pytest.mark.parametrize("mv", [(0.0, 0.0), (1.0, 0.0), (-2.5, 1.5)])
+@pytest.mark.parametrize("mesh", [0, 1])
+def test_temporal_matches_numpy(oracle, storage, mv, mesh):
+    W, H = 97, 61
+    rng = np.random.default_rng(1)
+    f0, f1 = synth.make_frame(W, H, 3, mv=mv), synth.make_frame(W, H, 4, mv=mv)
+    prev, mom_prev, hist_prev = _temporal_state(W, H, storage, rng)
+    cur = (f1["radiance"] * 1.3 - 0.1).astype(CDT[storage])
+    out = np.zeros_like(cur); hist = np.zeros((H, W), np.uint8); mom = np.zeros((H, W, 2), CDT[storage])
+    oracle.temporal(W, H, storage, prev, cur, out, gbuf(f1), gbuf(f0), hist_prev, hist, mom, mom_prev,
+                    depth_threshold=0.8, normal_threshold=0.9, history_base=24, mesh_id_test=mesh)
+    w_out, w_hist, w_mom = snp.temporal(prev, cur, gbuf(f1), gbuf(f0), hist_prev, mom_prev, depth_threshold=0.8,
+                                        normal_threshold=0.9, history_base=24, mesh_id_test=mesh)
+    assert np.array_equal(hist, w_hist)
+    # no transcendental in this stage: bit exact
+    assert np.array_equal(out.view(np.uint8), w_out.view(np.uint8))
+    assert np.array_equal(mom.view(np.uint8), w_mom.view(np.uint8))
+    assert 0.02 < (hist == 1).mean() < 0.98          # both accept and reject branches exercised
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_moments_matches_numpy(oracle, storage):
+    W, H = 83, 47
+    rng = np.random.default_rng(2)
+    f = synth.make_frame(W, H, 0)
+    dt = CDT[storage]
+    col = rng.uniform(0, 1, (H, W, 4)).astype(dt)
+    mom = rng.uniform(0, 1, (H, W, 2)).astype(dt)
+    hist = rng.integers(1, 8, (H, W)).astype(np.uint8)
+    out = np.zeros_like(col)
+    oracle.moments(W, H, storage, col, out, mom, gbuf(f), hist, phi_colour=10.0, phi_normal=128.0)
+    want = snp.moments(col, mom, gbuf(f), hist, phi_colour=10.0, phi_normal=128.0)
+    keep = hist >= 4
+    assert np.array_equal(out[keep].view(np.uint8), col[keep].view(np.uint8))      # pass-through branch is a copy
+    if storage == "f32":
+        np.testing.assert_allclose(out, want, rtol=3e-5, atol=3e-6)   # variance is a difference of sums: looser
+    else:
+        _close(out, want, storage, "moments")
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+@pytest.mark.parametrize("step", [1, 2, 4, 8, 16])
+def test_atrous_matches_numpy(oracle, storage, step):
+    W, H = 101, 67
+    rng = np.random.default_rng(3 + step)
+    f = synth.make_frame(W, H, 0)
+    dt = CDT[storage]
+    src = np.concatenate([f["radiance"][..., :3], rng.uniform(-0.01, 0.05, (H, W, 1)).astype(np.float32)], -1).astype(dt)
+    out = np.zeros_like(src); fb = np.full_like(src, 7)
+    oracle.atrous(W, H, storage, src, out, fb, gbuf(f), step=step, phi_colour=10.0, phi_normal=128.0, iteration=0)
+    want, fbmask = snp.atrous(src, gbuf(f), step=step, phi_colour=10.0, phi_normal=128.0)
+    _close(out, want, storage, f"atrous step {step}")
+    assert np.array_equal(fb[fbmask].view(np.uint8), out[fbmask].view(np.uint8))     # feedback == output where written
+    assert np.all(fb[~fbmask] == 7) and (~fbmask).any()                              # sky: no feedback store (:552-558)
+    out2 = np.zeros_like(src)
+    oracle.atrous(W, H, storage, src, out2, None, gbuf(f), step=step, phi_colour=10.0, phi_normal=128.0, iteration=1)
+    assert np.array_equal(out.view(np.uint8), out2.view(np.uint8))
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+@pytest.mark.parametrize("mv", [(0.0, 0.0), (-2.5, 1.5)])
+def test_pipeline_matches_numpy(oracle, storage, mv):
+    W, H, N = 80, 52, 6
+    fr = frames(W, H, N, mv=mv)
+    a = oracle.Pipeline(W, H, storage, steps=5)
+    b = NumpyPipeline(W, H, storage, steps=5)
+    for k in range(N):
+        ga, gp = gbuf(fr[k]), gbuf(fr[max(k - 1, 0)])
+        oa = a.frame(fr[k]["radiance"], ga, gp)
+        ob = b.frame(fr[k]["radiance"], ga, gp)
+        assert np.array_equal(a.hist[a.P ^ 1], b.taps["hist"]), f"history mask mismatch in frame {k}"
+        if storage == "f32":
+            np.testing.assert_allclose(oa, ob, rtol=1e-4, atol=2e-6, err_msg=f"frame {k}")
+        else:
+            d = np.abs(oa.astype(np.float32) - ob.astype(np.float32))
+            assert d.max() <= 2e-3, f"frame {k}: {d.max()}"
+
+
+# ------------------------------------------------------------------ known answers -------------
+def _flat_gbuf(W, H, z=5.0, dz=0.01):
+    motion = np.zeros((H, W, 4), np.float32); motion[..., 2] = z; motion[..., 3] = dz
+    normal = np.zeros((H, W, 4), np.uint16); normal[..., 2] = np.float16(-1.0).view(np.uint16)
+    uv = np.zeros((H, W, 4), np.uint16)
+    return dict(motion=motion, normal=normal, uv=uv)
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_kat_constant_image_is_fixed_point(oracle, storage):
+    """Uniform colour on a flat surface: every weight is exp(0)*1, so colour comes back unchanged and
+    variance becomes v*(1+sum g^2)/(1+sum g)^2 with g = K[|xx|]K[|yy|] (Filter.cuh:540,604-615)."""
+    W, H = 40, 36
+    gb = _flat_gbuf(W, H)
+    dt = CDT[storage]
+    src = np.empty((H, W, 4), dt); src[...] = np.array([0.25, 0.5, 0.75, 0.125], dt)
+    out = np.zeros_like(src)
+    oracle.atrous(W, H, storage, src, out, None, gb, step=1, phi_colour=10.0, phi_normal=128.0, iteration=1)
+    K = np.array([1.0, 2 / 3, 1 / 6])
+    g = np.outer(K[[2, 1, 0, 1, 2]], K[[2, 1, 0, 1, 2]]); g[2, 2] = 0
+    want_var = 0.125 * (1 + (g ** 2).sum()) / (1 + g.sum()) ** 2
+    inner = out[2:-2, 2:-2].astype(np.float64)
+    tol = 1e-6 if storage == "f32" else 1e-3
+    np.testing.assert_allclose(inner[..., :3], np.broadcast_to([0.25, 0.5, 0.75], inner[..., :3].shape), atol=tol)
+    np.testing.assert_allclose(inner[..., 3], want_var, rtol=1e-5 if storage == "f32" else 2e-3)
+    # corner pixel sees only the 3x3 lower-right quadrant of the kernel
+    gq = np.outer(K, K); gq[0, 0] = 0
+    np.testing.assert_allclose(float(out[0, 0, 3]), 0.125 * (1 + (gq ** 2).sum()) / (1 + gq.sum()) ** 2,
+                               rtol=1e-5 if storage == "f32" else 2e-3)
+
+
+def test_kat_all_sky_is_clamped_copy(oracle):
+    W, H = 24, 20
+    gb = _flat_gbuf(W, H, z=0.0)
+    rng = np.random.default_rng(5)
+    src = rng.uniform(-0.5, 1.5, (H, W, 4)).astype(np.float32)
+    out = np.zeros_like(src); fb = np.full_like(src, 3)
+    oracle.atrous(W, H, "f32", src, out, fb, gb, step=2, phi_colour=10.0, phi_normal=128.0, iteration=0)
+    assert np.array_equal(out, np.clip(src, 0, 1))
+    assert np.all(fb == 3)
+
+
+def test_kat_static_scene_history_counts(oracle):
+    """Zero motion, static G-buffer: history length is 1,2,...,min(k, HistoryLength) on surfaces and
+    stays 1 on sky (zero normals fail the normal test)."""
+    W, H, base = 48, 40, 5
+    fr = frames(W, H, 8)
+    pipe = oracle.Pipeline(W, H, "f32", steps=1, history_base=base)
+    sky = fr[0]["region"] == synth.SKY
+    assert 0.03 < sky.mean() < 0.3
+    for k in range(8):
+        pipe.frame(fr[k]["radiance"], gbuf(fr[k]), gbuf(fr[max(k - 1, 0)]))
+        h = pipe.hist[pipe.P ^ 1]
+        assert np.all(h[~sky] == min(k + 1, base)), k
+        assert np.all(h[sky] == 1)
+
+
+def test_kat_temporal_mean_and_variance(oracle):
+    """After k accepted frames with alpha = 1/h the accumulated colour is the running mean and the
+    stored variance is E[L^2]-E[L]^2 of the k luminances (Filter.cuh:380-398)."""
+    W, H, k = 8, 8, 6
+    gb = _flat_gbuf(W, H)
+    rng = np.random.default_rng(11)
+    rad = rng.uniform(0, 1, (k, H, W, 4)).astype(np.float32)
+    pipe = oracle.Pipeline(W, H, "f32", steps=0)
+    for i in range(k):
+        pipe.frame(rad[i], gb, gb)
+    got = pipe.taps["temporal"].astype(np.float64)
+    np.testing.assert_allclose(got[..., :3], rad[..., :3].astype(np.float64).mean(0), atol=2e-6)
+    L = 0.2126 * rad[..., 0].astype(np.float64) + 0.7152 * rad[..., 1] + 0.0722 * rad[..., 2]
+    np.testing.assert_allclose(got[..., 3], np.maximum(0, (L ** 2).mean(0) - L.mean(0) ** 2), atol=5e-6)
+
+
+def test_strip_geometry_equals_whole_frame(oracle):
+    """Rows computed through the strip geometry (local planes with halo, global frame tests) are
+    bit-identical to the whole-frame result."""
+    W, H, step = 64, 72, 4
+    f = synth.make_frame(W, H, 0)
+    src = f["radiance"].copy(); src[..., 3] = 0.02
+    whole = np.zeros_like(src)
+    oracle.atrous(W, H, "f32", src, whole, None, gbuf(f), step=step, phi_colour=10.0, phi_normal=128.0, iteration=1)
+    yb, ye, halo = 24, 48, 2 * step
+    y0, y1 = yb - halo, ye + halo
+    loc = {k: np.ascontiguousarray(v[y0:y1]) for k, v in gbuf(f).items()}
+    lsrc = np.ascontiguousarray(src[y0:y1]); lout = np.zeros_like(lsrc)
+    oracle.atrous(W, H, "f32", lsrc, lout, None, loc, step=step, phi_colour=10.0, phi_normal=128.0, iteration=1,
+                  geo=(y0, y1 - y0, yb, ye))
+    assert np.array_equal(lout[halo:-halo], whole[yb:ye])
