@@ -1,0 +1,44 @@
+"""Builds libsvgf_mi355x.so (the C-ABI product library) in-tree with hipcc for gfx950."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsvgf_mi355x.so")
+SOURCES = ["svgf_kernels.hip", "svgf_api.hip"]
+HEADERS = ["svgf_kernels.h", os.path.join("..", "..", "include", "svgf.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libsvgf_mi355x.so cannot be built (there is no CPU fallback)")
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    if not force and not stale():
+        return LIB
+    cmd = [hipcc(), *FLAGS, *extra_flags, "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+    print(build_library(force="--force" in sys.argv, verbose=True))

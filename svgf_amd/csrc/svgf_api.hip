@@ -1,0 +1,359 @@
+// svgf_api.hip — the C ABI of include/svgf.h: context, argument validation, the frame driver that
+// replaces application::TemporalFilter/FilterMoments/WaveletFilter (src/App.cu:469-514) and the
+// buffer lifecycle of application::ResizeRenderTextures (src/App.cu:742-778).
+//
+// There is deliberately NO CPU path here: every entry point either launches the gfx950 kernels
+// or returns an error.
+
+#include "../../include/svgf.h"
+#include "svgf_kernels.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+struct svgf_ctx {
+    int W = 0, H = 0;
+    svgf_strip strip{};
+    int rb = 0, re = 0;                 // active compute rows (global)
+    svgf_params p{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // context-owned state (frame driver): RenderBuffer[2], MomentsBuffer[2], FilterBuffer[2] (App.h:138-140)
+    // and the ping-ponged history plane (App.h:141 + SURVEY App. B #1)
+    void* colour[2] = {nullptr, nullptr};
+    void* moments[2] = {nullptr, nullptr};
+    void* filter[2] = {nullptr, nullptr};
+    uint8_t* hist[2] = {nullptr, nullptr};
+    int pingpong = 0;                   // PingPongInx, App.cu:374
+    bool have_state = false;
+    // per-stage timing
+    bool timing = false;
+    struct FrameEvents { std::vector<hipEvent_t> ev; int nstage = 0; };
+    std::vector<FrameEvents> pending;
+    std::vector<hipEvent_t> pool;
+    double ms_sum[2 + SVGF_MAX_STEPS] = {0};
+    int timed_frames = 0;
+};
+
+namespace {
+
+int fail(svgf_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+int hip_fail(svgf_ctx* c, hipError_t e, const char* what) {
+    return fail(c, SVGF_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define SVGF_HIP(c, call)                                         \
+    do {                                                          \
+        hipError_t e_ = (call);                                   \
+        if (e_ != hipSuccess) return hip_fail((c), e_, #call);    \
+    } while (0)
+
+size_t colour_bytes(const svgf_ctx* c) { return (size_t)c->strip.rows * c->W * (c->p.storage == SVGF_F16 ? 8 : 16); }
+size_t moments_bytes(const svgf_ctx* c) { return (size_t)c->strip.rows * c->W * (c->p.storage == SVGF_F16 ? 4 : 8); }
+size_t hist_bytes(const svgf_ctx* c) { return (size_t)c->strip.rows * c->W; }
+
+int check_params(svgf_ctx* c, const svgf_params* p) {
+    if (!p) return fail(c, SVGF_ERR_INVALID, "params is null");
+    if (p->steps < 0 || p->steps > SVGF_MAX_STEPS) return fail(c, SVGF_ERR_INVALID, "steps must be in [0,10] (GUI.cpp:988)");
+    if (p->storage != SVGF_F32 && p->storage != SVGF_F16) return fail(c, SVGF_ERR_INVALID, "storage must be SVGF_F32 or SVGF_F16");
+    if (p->moments_radius < 0 || p->moments_radius > 3) return fail(c, SVGF_ERR_INVALID, "moments_radius must be in [0,3]");
+    if (p->variant < SVGF_VARIANT_AUTO || p->variant > SVGF_VARIANT_LDS) return fail(c, SVGF_ERR_INVALID, "unknown variant");
+    return SVGF_OK;
+}
+
+svgf::Geo geo_of(const svgf_ctx* c) { return svgf::Geo{c->W, c->H, c->strip.y0, c->strip.rows, c->rb, c->re}; }
+
+// rows [rb,re) reading taps up to `reach` rows away must find them in [y0, y0+rows) or outside the frame
+int check_halo(svgf_ctx* c, int reach, const char* stage) {
+    const int lo = std::max(0, c->rb - reach), hi = std::min(c->H, c->re + reach);
+    if (c->re > c->rb && (lo < c->strip.y0 || hi > c->strip.y0 + c->strip.rows))
+        return fail(c, SVGF_ERR_HALO, std::string(stage) + ": rows need a halo of " + std::to_string(reach) + " rows that this strip does not hold");
+    return SVGF_OK;
+}
+
+int check_gbuf(svgf_ctx* c, const svgf_gbuffer* g, bool need_uv, const char* what) {
+    if (!g || !g->motion || !g->normal || (need_uv && !g->uv)) return fail(c, SVGF_ERR_INVALID, std::string(what) + ": null G-buffer plane");
+    return SVGF_OK;
+}
+
+hipEvent_t take_event(svgf_ctx* c) {
+    if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+int alloc_state(svgf_ctx* c) {
+    if (c->have_state) return SVGF_OK;
+    SVGF_HIP(c, hipSetDevice(c->device));
+    for (int i = 0; i < 2; i++) {
+        SVGF_HIP(c, hipMalloc(&c->colour[i], colour_bytes(c)));
+        SVGF_HIP(c, hipMalloc(&c->moments[i], moments_bytes(c)));
+        SVGF_HIP(c, hipMalloc(&c->filter[i], colour_bytes(c)));
+        SVGF_HIP(c, hipMalloc((void**)&c->hist[i], hist_bytes(c)));
+    }
+    c->have_state = true;
+    return svgf_reset_history(c);
+}
+
+}  // namespace
+
+extern "C" {
+
+void svgf_default_params(svgf_params* p) {
+    if (!p) return;
+    p->steps = 3;                 // App.h:109
+    p->depth_threshold = 0.8f;    // App.h:110
+    p->normal_threshold = 0.9f;   // App.h:111
+    p->history_base = 24;         // App.h:112
+    p->phi_colour = 10.0f;        // App.h:113
+    p->phi_normal = 128.0f;       // App.h:114
+    p->moments_radius = 3;        // Filter.cuh:465
+    p->storage = SVGF_F16;        // Filter.cuh:15-16
+    p->mesh_id_test = 1;
+    p->variant = SVGF_VARIANT_AUTO;
+}
+
+const char* svgf_status_string(int s) {
+    switch (s) {
+        case SVGF_OK: return "ok";
+        case SVGF_ERR_INVALID: return "invalid argument";
+        case SVGF_ERR_HIP: return "HIP runtime error";
+        case SVGF_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case SVGF_ERR_HALO: return "strip halo too small";
+        case SVGF_ERR_ALLOC: return "allocation failed";
+        default: return "unknown status";
+    }
+}
+
+const char* svgf_last_error(const svgf_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+int svgf_abi_version(void) { return SVGF_ABI_VERSION; }
+
+int svgf_create_strip(svgf_ctx** out, int width, int height, const svgf_strip* strip, const svgf_params* params,
+                      int device, void* hip_stream) {
+    if (!out) return SVGF_ERR_INVALID;
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || !strip || !params) return SVGF_ERR_INVALID;
+    if (strip->y0 < 0 || strip->rows <= 0 || strip->y0 + strip->rows > height) return SVGF_ERR_INVALID;
+    if (strip->own_begin < strip->y0 || strip->own_end > strip->y0 + strip->rows || strip->own_begin > strip->own_end) return SVGF_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return SVGF_ERR_NO_DEVICE;
+    svgf_ctx* c = new (std::nothrow) svgf_ctx();
+    if (!c) return SVGF_ERR_ALLOC;
+    c->W = width; c->H = height; c->strip = *strip; c->rb = strip->own_begin; c->re = strip->own_end;
+    c->device = device; c->stream = (hipStream_t)hip_stream;
+    int rc = check_params(c, params);
+    if (rc != SVGF_OK) { delete c; return rc; }
+    c->p = *params;
+    c->p.history_base = std::min(std::max(c->p.history_base, 1), 255);
+    *out = c;
+    return SVGF_OK;
+}
+
+int svgf_create(svgf_ctx** out, int width, int height, const svgf_params* params, int device, void* hip_stream) {
+    svgf_strip s{0, height, 0, height};
+    return svgf_create_strip(out, width, height, &s, params, device, hip_stream);
+}
+
+void svgf_destroy(svgf_ctx* c) {
+    if (!c) return;
+    if (c->have_state || !c->pool.empty() || !c->pending.empty()) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+    }
+    for (int i = 0; i < 2; i++) {
+        if (c->colour[i]) (void)hipFree(c->colour[i]);
+        if (c->moments[i]) (void)hipFree(c->moments[i]);
+        if (c->filter[i]) (void)hipFree(c->filter[i]);
+        if (c->hist[i]) (void)hipFree(c->hist[i]);
+    }
+    for (auto& f : c->pending) for (auto e : f.ev) (void)hipEventDestroy(e);
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    delete c;
+}
+
+int svgf_set_params(svgf_ctx* c, const svgf_params* p) {
+    if (!c) return SVGF_ERR_INVALID;
+    int rc = check_params(c, p);
+    if (rc != SVGF_OK) return rc;
+    if (p->storage != c->p.storage) return fail(c, SVGF_ERR_INVALID, "storage cannot change after creation");
+    c->p = *p;
+    c->p.history_base = std::min(std::max(c->p.history_base, 1), 255);
+    return SVGF_OK;
+}
+
+int svgf_set_stream(svgf_ctx* c, void* s) {
+    if (!c) return SVGF_ERR_INVALID;
+    c->stream = (hipStream_t)s;
+    return SVGF_OK;
+}
+
+int svgf_set_rows(svgf_ctx* c, int rb, int re) {
+    if (!c) return SVGF_ERR_INVALID;
+    if (rb == -1 && re == -1) { c->rb = c->strip.own_begin; c->re = c->strip.own_end; return SVGF_OK; }
+    if (rb < c->strip.y0 || re > c->strip.y0 + c->strip.rows || rb > re) return fail(c, SVGF_ERR_INVALID, "row range outside the strip");
+    c->rb = rb; c->re = re;
+    return SVGF_OK;
+}
+
+int svgf_temporal(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, const svgf_gbuffer* cur,
+                  const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur, void* moments_cur,
+                  const void* moments_prev) {
+    if (!c) return SVGF_ERR_INVALID;
+    if (!prev_colour || !radiance || !colour_out || !hist_prev || !hist_cur || !moments_cur || !moments_prev)
+        return fail(c, SVGF_ERR_INVALID, "svgf_temporal: null plane");
+    int rc = check_gbuf(c, cur, true, "svgf_temporal(cur)");
+    if (rc == SVGF_OK) rc = check_gbuf(c, prev, true, "svgf_temporal(prev)");
+    if (rc != SVGF_OK) return rc;
+    if (prev_colour == colour_out || hist_prev == hist_cur || moments_prev == moments_cur)
+        return fail(c, SVGF_ERR_INVALID, "svgf_temporal: previous and current state planes must differ (App. B #1)");
+    svgf::TemporalArgs a{prev_colour, radiance, colour_out,
+                         (const float4*)cur->motion, (const uint2*)cur->normal, (const uint2*)cur->uv,
+                         (const float4*)prev->motion, (const uint2*)prev->normal, (const uint2*)prev->uv,
+                         hist_prev, hist_cur, moments_cur, moments_prev,
+                         c->p.depth_threshold, c->p.normal_threshold, c->p.history_base, c->p.mesh_id_test};
+    SVGF_HIP(c, svgf::launch_temporal(geo_of(c), c->p.storage, a, c->stream));
+    return SVGF_OK;
+}
+
+int svgf_moments(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist) {
+    if (!c) return SVGF_ERR_INVALID;
+    if (!colour || !out || !moments || !hist) return fail(c, SVGF_ERR_INVALID, "svgf_moments: null plane");
+    if (colour == out) return fail(c, SVGF_ERR_INVALID, "svgf_moments: in-place filtering is a race");
+    int rc = check_gbuf(c, g, false, "svgf_moments");
+    if (rc == SVGF_OK) rc = check_halo(c, c->p.moments_radius, "svgf_moments");
+    if (rc != SVGF_OK) return rc;
+    svgf::MomentsArgs a{colour, out, moments, (const float4*)g->motion, (const uint2*)g->normal, hist,
+                        c->p.phi_colour, c->p.phi_normal, c->p.moments_radius};
+    SVGF_HIP(c, svgf::launch_moments(geo_of(c), c->p.storage, a, c->stream));
+    return SVGF_OK;
+}
+
+int svgf_atrous(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration) {
+    if (!c) return SVGF_ERR_INVALID;
+    if (!in || !out) return fail(c, SVGF_ERR_INVALID, "svgf_atrous: null plane");
+    if (in == out || in == feedback) return fail(c, SVGF_ERR_INVALID, "svgf_atrous: in-place filtering is a race");
+    if (step < 1 || step > (1 << SVGF_MAX_STEPS)) return fail(c, SVGF_ERR_INVALID, "svgf_atrous: step out of range");
+    int rc = check_gbuf(c, g, false, "svgf_atrous");
+    if (rc == SVGF_OK) rc = check_halo(c, 2 * step, "svgf_atrous");
+    if (rc != SVGF_OK) return rc;
+    svgf::AtrousArgs a{in, out, iteration == 0 ? feedback : nullptr, (const float4*)g->motion, (const uint2*)g->normal,
+                       step, c->p.phi_colour, c->p.phi_normal};
+    SVGF_HIP(c, svgf::launch_atrous(geo_of(c), c->p.storage, c->p.variant, a, c->stream));
+    return SVGF_OK;
+}
+
+int svgf_reset_history(svgf_ctx* c) {
+    if (!c) return SVGF_ERR_INVALID;
+    if (!c->have_state) return SVGF_OK;
+    for (int i = 0; i < 2; i++) {
+        SVGF_HIP(c, hipMemsetAsync(c->colour[i], 0, colour_bytes(c), c->stream));
+        SVGF_HIP(c, hipMemsetAsync(c->moments[i], 0, moments_bytes(c), c->stream));
+        SVGF_HIP(c, hipMemsetAsync(c->filter[i], 0, colour_bytes(c), c->stream));
+        SVGF_HIP(c, hipMemsetAsync(c->hist[i], 0, hist_bytes(c), c->stream));
+    }
+    c->pingpong = 0;
+    return SVGF_OK;
+}
+
+int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cur, const svgf_gbuffer* prev, const void** result) {
+    if (!c) return SVGF_ERR_INVALID;
+    if (!radiance) return fail(c, SVGF_ERR_INVALID, "svgf_denoise_frame: null radiance");
+    int rc = check_gbuf(c, cur, true, "svgf_denoise_frame(cur)");
+    if (rc != SVGF_OK) return rc;
+    // First frame: state is zero, so reprojecting onto the current G-buffer gives h = 1, alpha = 1 —
+    // the same result as the reference's rejection against its cleared previous framebuffer.
+    if (!prev) prev = cur;
+    rc = alloc_state(c);
+    if (rc != SVGF_OK) return rc;
+    const int P = c->pingpong;
+
+    svgf_ctx::FrameEvents fe;
+    auto stamp = [&]() {
+        if (!c->timing) return;
+        hipEvent_t e = take_event(c);
+        if (e && hipEventRecord(e, c->stream) == hipSuccess) fe.ev.push_back(e);
+    };
+
+    stamp();
+    rc = svgf_temporal(c, c->colour[1 - P], radiance, c->colour[P], cur, prev, c->hist[1 - P], c->hist[P],
+                       c->moments[P], c->moments[1 - P]);                       // App.cu:552
+    if (rc != SVGF_OK) return rc;
+    stamp();
+    rc = svgf_moments(c, c->colour[P], c->filter[0], c->moments[P], cur, c->hist[P]);   // App.cu:554 (current moments: App. B #4)
+    if (rc != SVGF_OK) return rc;
+    stamp();
+    int pp = 0;
+    for (int i = 0; i < c->p.steps; i++) {                                      // App.cu:497-507
+        rc = svgf_atrous(c, c->filter[pp], c->filter[1 - pp], c->colour[P], cur, 1 << i, i);
+        if (rc != SVGF_OK) return rc;
+        stamp();
+        pp ^= 1;
+    }
+    if (c->timing) {
+        fe.nstage = 2 + c->p.steps;
+        if ((int)fe.ev.size() == fe.nstage + 1) c->pending.push_back(std::move(fe));
+        else for (auto e : fe.ev) c->pool.push_back(e);
+    }
+    if (result) *result = c->filter[pp];
+    c->pingpong ^= 1;                                                           // App.cu:374
+    return SVGF_OK;
+}
+
+void* svgf_state_plane(svgf_ctx* c, int plane, int index) {
+    if (!c || !c->have_state || index < 0 || index > 1) return nullptr;
+    switch (plane) {
+        case SVGF_PLANE_COLOUR: return c->colour[index];
+        case SVGF_PLANE_MOMENTS: return c->moments[index];
+        case SVGF_PLANE_FILTER: return c->filter[index];
+        case SVGF_PLANE_HISTORY: return c->hist[index];
+        default: return nullptr;
+    }
+}
+
+int svgf_state_pingpong(const svgf_ctx* c) { return c ? c->pingpong : 0; }
+
+size_t svgf_plane_bytes(const svgf_ctx* c, int plane) {
+    if (!c) return 0;
+    switch (plane) {
+        case SVGF_PLANE_COLOUR: case SVGF_PLANE_FILTER: return colour_bytes(c);
+        case SVGF_PLANE_MOMENTS: return moments_bytes(c);
+        case SVGF_PLANE_HISTORY: return hist_bytes(c);
+        default: return 0;
+    }
+}
+
+int svgf_timing_enable(svgf_ctx* c, int on) {
+    if (!c) return SVGF_ERR_INVALID;
+    c->timing = on != 0;
+    return SVGF_OK;
+}
+
+int svgf_timing_read(svgf_ctx* c, double* ms_sum, int* frames, int slots) {
+    if (!c || !ms_sum || slots <= 0) return SVGF_ERR_INVALID;
+    for (auto& f : c->pending) {
+        SVGF_HIP(c, hipEventSynchronize(f.ev.back()));
+        for (int i = 0; i < f.nstage; i++) {
+            float ms = 0.f;
+            SVGF_HIP(c, hipEventElapsedTime(&ms, f.ev[i], f.ev[i + 1]));
+            c->ms_sum[i] += ms;
+        }
+        for (auto e : f.ev) c->pool.push_back(e);
+        c->timed_frames++;
+    }
+    c->pending.clear();
+    for (int i = 0; i < slots; i++) ms_sum[i] = i < 2 + SVGF_MAX_STEPS ? c->ms_sum[i] : 0.0;
+    if (frames) *frames = c->timed_frames;
+    std::memset(c->ms_sum, 0, sizeof(c->ms_sum));
+    c->timed_frames = 0;
+    return SVGF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,31 @@
+// Internal launcher interface between the C-ABI layer (svgf_api.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace svgf {
+
+// Local planes hold global rows [y0, y0+rows) of a W x H frame; a launch computes rows [yb, ye).
+struct Geo { int W, H, y0, rows, yb, ye; };
+
+struct TemporalArgs {
+    const void* prev_colour; const void* radiance; void* colour_out;
+    const float4* motion_c; const uint2* normal_c; const uint2* uv_c;
+    const float4* motion_p; const uint2* normal_p; const uint2* uv_p;
+    const uint8_t* hist_prev; uint8_t* hist_cur; void* mom_cur; const void* mom_prev;
+    float depth_thr, normal_thr; int history_base; int mesh_id_test;
+};
+struct MomentsArgs {
+    const void* colour; void* out; const void* mom; const float4* motion; const uint2* normal; const uint8_t* hist;
+    float phi_colour, phi_normal; int radius;
+};
+struct AtrousArgs {
+    const void* in; void* out; void* feedback; const float4* motion; const uint2* normal;
+    int step; float phi_colour, phi_normal;
+};
+
+hipError_t launch_temporal(const Geo& g, int storage, const TemporalArgs& a, hipStream_t s);
+hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, hipStream_t s);
+hipError_t launch_atrous(const Geo& g, int storage, int variant, const AtrousArgs& a, hipStream_t s);
+
+}  // namespace svgf

@@ -1,0 +1,281 @@
+"""Python host-side mirror of the reference's filter entry points, bound to the C ABI of
+include/svgf.h (libsvgf_mi355x.so) with ctypes.
+
+`Denoiser.TemporalFilter / FilterMoments / WaveletFilter / Render` keep the names, argument meaning
+and sequencing of `application::TemporalFilter/FilterMoments/WaveletFilter` (src/App.cu:469-514)
+and the `Render` stage order (src/App.cu:552-556).  PyTorch only supplies device memory and
+streams; every computation happens in the HIP library.  There is no CPU fallback: if the library
+or a GPU is missing, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+from . import build as _build
+
+SVGF_F32, SVGF_F16 = 0, 1
+STORAGE = {"f32": SVGF_F32, "f16": SVGF_F16}
+VARIANT = {"auto": 0, "direct": 1, "lds": 2}
+PLANE_COLOUR, PLANE_MOMENTS, PLANE_FILTER, PLANE_HISTORY = 0, 1, 2, 3
+MAX_STEPS = 10
+
+EXPORTS = [
+    "svgf_default_params", "svgf_status_string", "svgf_last_error", "svgf_abi_version", "svgf_create",
+    "svgf_create_strip", "svgf_destroy", "svgf_set_params", "svgf_set_stream", "svgf_set_rows", "svgf_temporal",
+    "svgf_moments", "svgf_atrous", "svgf_denoise_frame", "svgf_reset_history", "svgf_state_plane",
+    "svgf_state_pingpong", "svgf_plane_bytes", "svgf_timing_enable", "svgf_timing_read",
+]
+
+
+class SvgfError(RuntimeError):
+    pass
+
+
+class GBufferC(C.Structure):
+    _fields_ = [("motion", C.c_void_p), ("normal", C.c_void_p), ("uv", C.c_void_p)]
+
+
+class ParamsC(C.Structure):
+    _fields_ = [("steps", C.c_int), ("depth_threshold", C.c_float), ("normal_threshold", C.c_float),
+                ("history_base", C.c_int), ("phi_colour", C.c_float), ("phi_normal", C.c_float),
+                ("moments_radius", C.c_int), ("storage", C.c_int), ("mesh_id_test", C.c_int), ("variant", C.c_int)]
+
+
+class StripC(C.Structure):
+    _fields_ = [("y0", C.c_int), ("rows", C.c_int), ("own_begin", C.c_int), ("own_end", C.c_int)]
+
+
+@dataclass
+class Params:
+    """Tunables of src/App.h:109-114 (+ the build's storage / radius / variant switches)."""
+    steps: int = 3
+    depth_threshold: float = 0.8
+    normal_threshold: float = 0.9
+    history_base: int = 24
+    phi_colour: float = 10.0
+    phi_normal: float = 128.0
+    moments_radius: int = 3
+    storage: str = "f16"
+    mesh_id_test: int = 1
+    variant: str = "auto"
+
+    def to_c(self) -> ParamsC:
+        return ParamsC(self.steps, self.depth_threshold, self.normal_threshold, self.history_base, self.phi_colour,
+                       self.phi_normal, self.moments_radius, STORAGE[self.storage], self.mesh_id_test,
+                       VARIANT[self.variant])
+
+
+_lib = None
+
+
+def library_path() -> str:
+    return _build.LIB
+
+
+def load_library():
+    """dlopen the product library (building it first if hipcc is around and it is stale)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if _build.stale():
+        try:
+            _build.build_library()
+        except Exception as e:  # noqa: BLE001
+            if not os.path.exists(path):
+                raise SvgfError(f"libsvgf_mi355x.so is missing and could not be built: {e}") from e
+    if not os.path.exists(path):
+        raise SvgfError("libsvgf_mi355x.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(path)
+    vp, ip = C.c_void_p, C.c_int
+    lib.svgf_default_params.argtypes = [C.POINTER(ParamsC)]
+    lib.svgf_default_params.restype = None
+    lib.svgf_status_string.argtypes = [ip]
+    lib.svgf_status_string.restype = C.c_char_p
+    lib.svgf_last_error.argtypes = [vp]
+    lib.svgf_last_error.restype = C.c_char_p
+    lib.svgf_abi_version.restype = ip
+    lib.svgf_create.argtypes = [C.POINTER(vp), ip, ip, C.POINTER(ParamsC), ip, vp]
+    lib.svgf_create_strip.argtypes = [C.POINTER(vp), ip, ip, C.POINTER(StripC), C.POINTER(ParamsC), ip, vp]
+    lib.svgf_destroy.argtypes = [vp]
+    lib.svgf_destroy.restype = None
+    lib.svgf_set_params.argtypes = [vp, C.POINTER(ParamsC)]
+    lib.svgf_set_stream.argtypes = [vp, vp]
+    lib.svgf_set_rows.argtypes = [vp, ip, ip]
+    lib.svgf_temporal.argtypes = [vp, vp, vp, vp, C.POINTER(GBufferC), C.POINTER(GBufferC), vp, vp, vp, vp]
+    lib.svgf_moments.argtypes = [vp, vp, vp, vp, C.POINTER(GBufferC), vp]
+    lib.svgf_atrous.argtypes = [vp, vp, vp, vp, C.POINTER(GBufferC), ip, ip]
+    lib.svgf_denoise_frame.argtypes = [vp, vp, C.POINTER(GBufferC), C.POINTER(GBufferC), C.POINTER(vp)]
+    lib.svgf_reset_history.argtypes = [vp]
+    lib.svgf_state_plane.argtypes = [vp, ip, ip]
+    lib.svgf_state_plane.restype = vp
+    lib.svgf_state_pingpong.argtypes = [vp]
+    lib.svgf_plane_bytes.argtypes = [vp, ip]
+    lib.svgf_plane_bytes.restype = C.c_size_t
+    lib.svgf_timing_enable.argtypes = [vp, ip]
+    lib.svgf_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(ip), ip]
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class GBuffer:
+    """Device planes of one G-buffer = `cudaFramebuffer` (src/App.h:41-44) minus Position."""
+
+    def __init__(self, motion, normal, uv):
+        self.motion, self.normal, self.uv = motion, normal, uv
+        self._c = GBufferC(motion.data_ptr(), normal.data_ptr(), uv.data_ptr() if uv is not None else None)
+
+    @property
+    def c(self):
+        return C.byref(self._c)
+
+
+class Denoiser:
+    """One SVGF context on one device (`svgf_ctx`).  Method names follow src/App.cu:469-514."""
+
+    def __init__(self, width, height, params: Params | None = None, *, device=0, stream=None, strip=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise SvgfError("svgf_amd needs an MI355X: no HIP device is visible and there is no CPU fallback")
+        self.lib = load_library()
+        self.params = params or Params()
+        self.W, self.H = width, height
+        self.device = torch.device("cuda", device)
+        self.storage = self.params.storage
+        self._torch = torch
+        h = C.c_void_p()
+        pc = self.params.to_c()
+        s = C.c_void_p(stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream)
+        if strip is None:
+            self.strip = (0, height, 0, height)
+            rc = self.lib.svgf_create(C.byref(h), width, height, C.byref(pc), device, s)
+        else:
+            self.strip = tuple(int(v) for v in strip)
+            sc = StripC(*self.strip)
+            rc = self.lib.svgf_create_strip(C.byref(h), width, height, C.byref(sc), C.byref(pc), device, s)
+        if rc != 0:
+            raise SvgfError(f"svgf_create failed: {self.lib.svgf_status_string(rc).decode()}")
+        self._h = h
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            raise SvgfError(f"{what}: {self.lib.svgf_status_string(rc).decode()}: {self.lib.svgf_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.svgf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    @property
+    def rows(self):
+        return self.strip[1]
+
+    def colour_dtype(self):
+        return self._torch.float32 if self.storage == "f32" else self._torch.float16
+
+    def new_colour(self):
+        return self._torch.zeros((self.rows, self.W, 4), dtype=self.colour_dtype(), device=self.device)
+
+    def new_moments(self):
+        return self._torch.zeros((self.rows, self.W, 2), dtype=self.colour_dtype(), device=self.device)
+
+    def new_history(self):
+        return self._torch.zeros((self.rows, self.W), dtype=self._torch.uint8, device=self.device)
+
+    def set_params(self, params: Params):
+        pc = params.to_c()
+        self._check(self.lib.svgf_set_params(self._h, C.byref(pc)), "svgf_set_params")
+        self.params = params
+
+    def set_stream(self, stream_handle: int):
+        self._check(self.lib.svgf_set_stream(self._h, C.c_void_p(stream_handle)), "svgf_set_stream")
+
+    def set_rows(self, row_begin=-1, row_end=-1):
+        self._check(self.lib.svgf_set_rows(self._h, row_begin, row_end), "svgf_set_rows")
+
+    # -- the three stages (kernel-level API) -------------------------------------------------
+    def TemporalFilter(self, prev_colour, radiance, colour_out, gb_cur: GBuffer, gb_prev: GBuffer, hist_prev, hist_cur,
+                       moments_cur, moments_prev):
+        """application::TemporalFilter, src/App.cu:469-478."""
+        self._check(self.lib.svgf_temporal(self._h, _ptr(prev_colour), _ptr(radiance), _ptr(colour_out), gb_cur.c,
+                                           gb_prev.c, _ptr(hist_prev), _ptr(hist_cur), _ptr(moments_cur),
+                                           _ptr(moments_prev)), "svgf_temporal")
+
+    def FilterMoments(self, colour, out, moments, gb: GBuffer, hist):
+        """application::FilterMoments, src/App.cu:480-489."""
+        self._check(self.lib.svgf_moments(self._h, _ptr(colour), _ptr(out), _ptr(moments), gb.c, _ptr(hist)), "svgf_moments")
+
+    def FilterKernel(self, src, dst, feedback, gb: GBuffer, step: int, iteration: int):
+        """One filter::FilterKernel launch (src/App.cu:504-505)."""
+        self._check(self.lib.svgf_atrous(self._h, _ptr(src), _ptr(dst), _ptr(feedback), gb.c, step, iteration), "svgf_atrous")
+
+    def WaveletFilter(self, filter_buffers, render_buffer, gb: GBuffer, steps=None):
+        """application::WaveletFilter, src/App.cu:491-514: ping-pongs filter_buffers[0/1], iteration 0 feeds
+        render_buffer.  Returns the buffer holding the result (no odd-N copy)."""
+        steps = self.params.steps if steps is None else steps
+        pp = 0
+        for i in range(steps):
+            self.FilterKernel(filter_buffers[pp], filter_buffers[1 - pp], render_buffer, gb, 1 << i, i)
+            pp ^= 1
+        return filter_buffers[pp]
+
+    # -- whole frame on context-owned state --------------------------------------------------
+    def Render(self, radiance, gb_cur: GBuffer, gb_prev: GBuffer | None = None):
+        """The filter share of application::Render (src/App.cu:552-556).  Returns a tensor VIEW of the
+        context-owned result plane (valid until the next call)."""
+        out = C.c_void_p()
+        self._check(self.lib.svgf_denoise_frame(self._h, _ptr(radiance), gb_cur.c, gb_prev.c if gb_prev else None,
+                                                C.byref(out)), "svgf_denoise_frame")
+        return self._wrap(out.value, (self.rows, self.W, 4), self.colour_dtype())
+
+    def reset_history(self):
+        self._check(self.lib.svgf_reset_history(self._h), "svgf_reset_history")
+
+    def pingpong(self) -> int:
+        return self.lib.svgf_state_pingpong(self._h)
+
+    def state_plane(self, plane: int, index: int):
+        p = self.lib.svgf_state_plane(self._h, plane, index)
+        if not p:
+            return None
+        if plane == PLANE_HISTORY:
+            return self._wrap(p, (self.rows, self.W), self._torch.uint8)
+        ch = 2 if plane == PLANE_MOMENTS else 4
+        return self._wrap(p, (self.rows, self.W, ch), self.colour_dtype())
+
+    def _wrap(self, ptr, shape, dtype):
+        """Zero-copy tensor over library-owned device memory (through __cuda_array_interface__)."""
+        torch = self._torch
+        typestr = {torch.float32: "<f4", torch.float16: "<f2", torch.uint8: "|u1"}[dtype]
+
+        class _Holder:
+            pass
+        hld = _Holder()
+        hld.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 3}
+        hld.owner = self
+        return torch.as_tensor(hld, device=self.device)
+
+    # -- timing -------------------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        self._check(self.lib.svgf_timing_enable(self._h, int(on)), "svgf_timing_enable")
+
+    def timing_read(self):
+        """-> (list of per-stage summed ms [temporal, moments, atrous0..], frames)."""
+        n = 2 + MAX_STEPS
+        arr = (C.c_double * n)()
+        fr = C.c_int()
+        self._check(self.lib.svgf_timing_read(self._h, arr, C.byref(fr), n), "svgf_timing_read")
+        return list(arr)[: 2 + self.params.steps], fr.value

@@ -1,0 +1,242 @@
+"""GPU parity: the HIP kernels, called through the C ABI (include/svgf.h), against the CPU oracle on
+the same seeded synthetic inputs.  Tolerances are stated in tests/gpu_helpers.py:TOL."""
+import numpy as np
+import pytest
+
+from svgf_amd import synth
+from tests.helpers import CDT, frames, gbuf
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = ["direct", "lds"]
+
+
+@pytest.fixture(scope="module")
+def G():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from tests import gpu_helpers
+    return gpu_helpers
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+@pytest.mark.parametrize("mv", [(0.0, 0.0), (1.0, 0.0), (-2.5, 1.5)])
+@pytest.mark.parametrize("mesh", [0, 1])
+def test_temporal_bit_exact(G, oracle, storage, mv, mesh):
+    from svgf_amd import filter as F
+    W, H = 331, 203                                  # not multiples of the 64x4 launch tile
+    rng = np.random.default_rng(1)
+    f0, f1 = synth.make_frame(W, H, 3, mv=mv), synth.make_frame(W, H, 4, mv=mv)
+    dt = CDT[storage]
+    prev = rng.uniform(-0.1, 1.2, (H, W, 4)).astype(dt)
+    mom_prev = rng.uniform(0, 1, (H, W, 2)).astype(dt)
+    hist_prev = rng.integers(0, 40, (H, W)).astype(np.uint8)
+    cur = (f1["radiance"] * 1.3 - 0.1).astype(dt)
+    out = np.zeros_like(cur); hist = np.zeros((H, W), np.uint8); mom = np.zeros((H, W, 2), dt)
+    oracle.temporal(W, H, storage, prev, cur, out, gbuf(f1), gbuf(f0), hist_prev, hist, mom, mom_prev,
+                    depth_threshold=0.8, normal_threshold=0.9, history_base=24, mesh_id_test=mesh)
+    d = F.Denoiser(W, H, F.Params(storage=storage, mesh_id_test=mesh))
+    o_col, o_hist, o_mom = d.new_colour(), d.new_history(), d.new_moments()
+    d.TemporalFilter(G.dev(prev), G.dev(cur), o_col, G.gb_dev(f1), G.gb_dev(f0), G.dev(hist_prev), o_hist, o_mom, G.dev(mom_prev))
+    assert np.array_equal(G.host(o_hist), hist), "history / accept-reject mask mismatch"
+    assert np.array_equal(G.host(o_col).view(np.uint8), out.view(np.uint8))
+    assert np.array_equal(G.host(o_mom).view(np.uint8), mom.view(np.uint8))
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+@pytest.mark.parametrize("radius", [3, 1])
+def test_moments(G, oracle, storage, radius):
+    from svgf_amd import filter as F
+    W, H = 203, 131
+    rng = np.random.default_rng(2)
+    f = synth.make_frame(W, H, 0)
+    dt = CDT[storage]
+    col = rng.uniform(0, 1, (H, W, 4)).astype(dt)
+    mom = rng.uniform(0, 1, (H, W, 2)).astype(dt)
+    hist = rng.integers(1, 8, (H, W)).astype(np.uint8)
+    want = np.zeros_like(col)
+    oracle.moments(W, H, storage, col, want, mom, gbuf(f), hist, phi_colour=10.0, phi_normal=128.0, radius=radius)
+    d = F.Denoiser(W, H, F.Params(storage=storage, moments_radius=radius))
+    out = d.new_colour()
+    d.FilterMoments(G.dev(col), out, G.dev(mom), G.gb_dev(f), G.dev(hist))
+    got = G.host(out)
+    keep = hist >= 4
+    assert np.array_equal(got[keep].view(np.uint8), col[keep].view(np.uint8))
+    if storage == "f32":
+        # variance here is a small difference of two weighted sums of O(1) moments: absolute tolerance
+        g, w = got.astype(np.float64), want.astype(np.float64)
+        assert np.abs(g[..., :3] - w[..., :3]).max() <= 2e-5
+        assert np.abs(g[..., 3] - w[..., 3]).max() <= 2e-5 * 4
+    else:
+        G.assert_colour_close(got, want, storage, "moments")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+@pytest.mark.parametrize("step", [1, 2, 4, 8, 16])
+def test_atrous(G, oracle, storage, step, variant):
+    from svgf_amd import filter as F
+    W, H = 333, 207
+    rng = np.random.default_rng(3 + step)
+    f = synth.make_frame(W, H, 0)
+    dt = CDT[storage]
+    src = np.concatenate([f["radiance"][..., :3] * 1.2 - 0.05, rng.uniform(-0.01, 0.05, (H, W, 1)).astype(np.float32)], -1).astype(dt)
+    want = np.zeros_like(src); want_fb = np.full_like(src, 7)
+    oracle.atrous(W, H, storage, src, want, want_fb, gbuf(f), step=step, phi_colour=10.0, phi_normal=128.0, iteration=0)
+    d = F.Denoiser(W, H, F.Params(storage=storage, variant=variant))
+    out = d.new_colour(); fb = G.dev(np.full_like(src, 7))
+    d.FilterKernel(G.dev(src), out, fb, G.gb_dev(f), step, 0)
+    got, got_fb = G.host(out), G.host(fb)
+    G.assert_colour_close(got, want, storage, f"atrous step {step} {variant}")
+    sky = f["region"] == synth.SKY
+    assert np.array_equal(got[sky].view(np.uint8), want[sky].view(np.uint8))            # clamped copy, exact
+    assert np.all(got_fb[sky] == 7)                                                      # no feedback on sky
+    assert np.array_equal(got_fb[~sky].view(np.uint8), got[~sky].view(np.uint8))
+    out2 = d.new_colour(); fb2 = G.dev(np.full_like(src, 7))
+    d.FilterKernel(G.dev(src), out2, fb2, G.gb_dev(f), step, 1)                          # iteration != 0: no feedback
+    assert np.all(G.host(fb2) == 7)
+    assert np.array_equal(G.host(out2).view(np.uint8), got.view(np.uint8))
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+@pytest.mark.parametrize("mv", [(0.0, 0.0), (-2.5, 1.5)])
+def test_pipeline_8_frames(G, oracle, storage, mv, variant):
+    """History feedback through iteration 0 makes frame k depend on every earlier frame."""
+    W, H, N = 256, 144, 8
+    fr = frames(W, H, N, mv=mv)
+    ref = oracle.Pipeline(W, H, storage, steps=5, nthreads=8)
+    hip = G.HipPipeline(W, H, storage, steps=5, variant=variant)
+    gbs = [G.gb_dev(f) for f in fr]
+    for k in range(N):
+        kp = max(k - 1, 0)
+        want = ref.frame(fr[k]["radiance"], gbuf(fr[k]), gbuf(fr[kp]))
+        got = hip.frame(fr[k]["radiance"], gbs[k], gbs[kp])
+        assert np.array_equal(hip.taps["hist"], ref.hist[ref.P ^ 1]), f"frame {k}: history mask mismatch"
+        if storage == "f32":
+            G.assert_colour_close(hip.taps["temporal"], ref.taps["temporal"], storage, f"frame {k} temporal")
+            G.assert_colour_close(got, want, storage, f"frame {k} output")
+        else:
+            d = np.abs(got.astype(np.float32) - want.astype(np.float32))
+            assert d.max() <= 2e-3, f"frame {k}: {d.max()}"                                # App. A.6 end-to-end bound
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_frame_driver_equals_stage_calls(G, storage):
+    """svgf_denoise_frame (context-owned state) == the same stages driven from outside, bitwise."""
+    from svgf_amd import filter as F
+    W, H, N = 200, 120, 5
+    fr = frames(W, H, N, mv=(1.0, 0.0))
+    hip = G.HipPipeline(W, H, storage, steps=3)
+    d = F.Denoiser(W, H, F.Params(storage=storage, steps=3))
+    gbs = [G.gb_dev(f) for f in fr]
+    for k in range(N):
+        kp = max(k - 1, 0)
+        a = hip.frame(fr[k]["radiance"], gbs[k], gbs[kp])
+        b = G.host(d.Render(G.dev(fr[k]["radiance"].astype(G.NPDT[storage])), gbs[k], gbs[kp] if k else None))
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), k
+    assert d.pingpong() == N % 2
+    assert np.array_equal(G.host(d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong())), hip.taps["hist"])
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_strips_bitwise_equal_whole_frame(G, variant):
+    """Row strips with halo (virtual ranks on one device) reproduce the whole-frame à-trous bit for bit."""
+    from svgf_amd import filter as F
+    W, H, step = 320, 240, 8
+    f = synth.make_frame(W, H, 0)
+    src = f["radiance"].copy(); src[..., 3] = 0.02
+    whole = F.Denoiser(W, H, F.Params(storage="f32", variant=variant))
+    out = whole.new_colour()
+    whole.FilterKernel(G.dev(src), out, None, G.gb_dev(f), step, 1)
+    want = G.host(out)
+    for (yb, ye) in [(0, 60), (60, 180), (180, 240)]:
+        halo = 2 * step
+        y0, y1 = max(0, yb - halo), min(H, ye + halo)
+        loc = {k: np.ascontiguousarray(v[y0:y1]) for k, v in f.items() if k != "region"}
+        d = F.Denoiser(W, H, F.Params(storage="f32", variant=variant), strip=(y0, y1 - y0, yb, ye))
+        o = d.new_colour()
+        d.FilterKernel(G.dev(np.ascontiguousarray(src[y0:y1])), o, None, G.gb_dev(loc), step, 1)
+        assert np.array_equal(G.host(o)[yb - y0:ye - y0], want[yb:ye]), (yb, ye)
+
+
+def test_abi_errors(G):
+    from svgf_amd import filter as F
+    W, H = 64, 48
+    f = synth.make_frame(W, H, 0)
+    d = F.Denoiser(W, H, F.Params(storage="f32"), strip=(8, 24, 16, 24))
+    gb = G.gb_dev({k: v[8:32] for k, v in f.items() if k != "region"})
+    a, b = d.new_colour(), d.new_colour()
+    with pytest.raises(F.SvgfError, match="halo"):
+        d.FilterKernel(a, b, None, gb, 8, 1)                     # needs 16 halo rows, strip holds 8
+    with pytest.raises(F.SvgfError, match="in-place"):
+        d.FilterKernel(a, a, None, gb, 1, 1)
+    with pytest.raises(F.SvgfError, match="null"):
+        d.FilterKernel(None, b, None, gb, 1, 1)
+    with pytest.raises(F.SvgfError, match="step"):
+        d.FilterKernel(a, b, None, gb, 0, 1)
+    d.FilterKernel(a, b, None, gb, 4, 1)                         # 8 halo rows: fine
+
+
+# ------------------------------------------------------------------ full-size properties ------
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_4k_properties(G, storage):
+    """At BASELINE's 3840x2160 the oracle is too slow; check size-independent properties instead:
+    (1) all-sky frame -> clamped copy; (2) uniform colour on a flat surface is a fixed point of the colour
+    channels and variance follows v(1+sum g^2)/(1+sum g)^2; (3) two strips tile the whole frame bitwise."""
+    import torch
+    from svgf_amd import filter as F
+    W, H = 3840, 2160
+    dt = torch.float32 if storage == "f32" else torch.float16
+    d = F.Denoiser(W, H, F.Params(storage=storage))
+    motion = torch.zeros((H, W, 4), device="cuda"); normal = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
+    uv = torch.zeros_like(normal)
+    gb_sky = F.GBuffer(motion, normal, uv)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    src = (torch.rand((H, W, 4), device="cuda", generator=g) * 2 - 0.5).to(dt)
+    out = d.new_colour()
+    d.FilterKernel(src, out, None, gb_sky, 4, 1)
+    assert torch.equal(out, src.clamp(0, 1))
+
+    motion2 = motion.clone(); motion2[..., 2] = 5.0; motion2[..., 3] = 0.01
+    normal2 = normal.clone(); normal2[..., 2] = int(np.float16(-1.0).view(np.int16))
+    gb_flat = F.GBuffer(motion2, normal2, uv)
+    src2 = torch.empty((H, W, 4), device="cuda", dtype=dt); src2[...] = torch.tensor([0.25, 0.5, 0.75, 0.125], dtype=dt)
+    for step in (1, 16):
+        d.FilterKernel(src2, out, None, gb_flat, step, 1)
+        m = 2 * step
+        inner = out[m:-m, m:-m].float()
+        K = np.array([1.0, 2 / 3, 1 / 6]); gk = np.outer(K[[2, 1, 0, 1, 2]], K[[2, 1, 0, 1, 2]]); gk[2, 2] = 0
+        want_var = 0.125 * (1 + (gk ** 2).sum()) / (1 + gk.sum()) ** 2
+        tol = 2e-6 if storage == "f32" else 1e-3
+        assert (inner[..., :3] - torch.tensor([0.25, 0.5, 0.75], device="cuda")).abs().max().item() <= tol
+        assert (inner[..., 3] - want_var).abs().max().item() <= (1e-6 if storage == "f32" else 1e-4)
+
+    fr = synth.make_frame(W, H, 0)
+    gbw = G.gb_dev(fr)
+    srcw = G.dev(fr["radiance"].astype(G.NPDT[storage]))
+    d.FilterKernel(srcw, out, None, gbw, 16, 1)
+    for (yb, ye) in [(0, 1080), (1080, 2160)]:
+        y0, y1 = max(0, yb - 32), min(H, ye + 32)
+        ds = F.Denoiser(W, H, F.Params(storage=storage), strip=(y0, y1 - y0, yb, ye))
+        gl = F.GBuffer(gbw.motion[y0:y1].contiguous(), gbw.normal[y0:y1].contiguous(), gbw.uv[y0:y1].contiguous())
+        o = ds.new_colour()
+        ds.FilterKernel(srcw[y0:y1].contiguous(), o, None, gl, 16, 1)
+        assert torch.equal(o[yb - y0:ye - y0], out[yb:ye])
+
+
+def test_1080p_history_counts(G):
+    """Static camera at 1920x1080: history is min(k, HistoryLength) on surfaces, 1 on sky."""
+    import torch
+    from svgf_amd import filter as F
+    W, H, base = 1920, 1080, 5
+    fr = synth.make_frame(W, H, 0)
+    d = F.Denoiser(W, H, F.Params(storage="f16", steps=5, history_base=base))
+    gb = G.gb_dev(fr)
+    rad = G.dev(fr["radiance"].astype(np.float16))
+    sky = torch.from_numpy(fr["region"] == synth.SKY).cuda()
+    for k in range(7):
+        out = d.Render(rad, gb, gb)
+        h = d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong())
+        assert torch.all(h[~sky] == min(k + 1, base)) and torch.all(h[sky] == 1)
+        assert torch.isfinite(out.float()).all()
