@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — Mpixels/s of the full SVGF pass (temporal + moments + 5 à-trous iterations) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one frame through the hot path (svgf_denoise_frame, or the strip runner for N > 1) with all
+inputs resident in HBM.  N = 1: 3840x2160 fp32 (BASELINE.json configs[2], the configuration the metric's
+roofline target is quoted on).  N > 1: one 7680x4320 fp32 frame cut into N row strips with halo exchange
+over RCCL (configs[3]); strong scaling.  One JSON line on stdout (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+# Algorithmic bytes per pixel: every plane a stage touches counted once.
+ALG_BYTES = {
+    "f32": dict(temporal=130, moments=33, atrous_iter=56, atrous_feedback=16, full5=459),
+    "f16": dict(temporal=98, moments=17, atrous_iter=40, atrous_feedback=8, full5=323),
+}
+HBM_PEAK_GBPS = 8000.0        # MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+WORKLOADS = {"1080p": (1920, 1080), "4k": (3840, 2160), "8k": (7680, 4320)}
+PRIME_FRAMES = 8              # history must reach steady state (h >= 4) before anything is timed (§8d)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", choices=list(WORKLOADS), default=None)
+    ap.add_argument("--storage", choices=["f32", "f16"], default="f32")
+    ap.add_argument("--iters", type=int, default=5, help="à-trous iterations (BASELINE: 5)")
+    ap.add_argument("--variant", default="auto")
+    ap.add_argument("--halo-plan", default="auto")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary (1080p) measurement")
+    return ap.parse_args()
+
+
+def alg_bytes_full(storage, iters):
+    b = ALG_BYTES[storage]
+    return b["temporal"] + b["moments"] + iters * b["atrous_iter"] + (b["atrous_feedback"] if iters > 0 else 0)
+
+
+def make_inputs(W, H, storage, device, nframes=4, row_begin=0, row_end=None):
+    """Static camera: one G-buffer, a pool of `nframes` independent 1-spp radiance frames, all in HBM."""
+    import torch
+    from svgf_amd import filter as F
+    from svgf_amd import synth
+    npdt = np.float32 if storage == "f32" else np.float16
+    sc = synth.make_scene(W, H, 0, row_begin=row_begin, row_end=row_end)
+    gb = F.GBuffer(*(torch.from_numpy(sc[k]).to(device) for k in ("motion", "normal", "uv")))
+    rads = [torch.from_numpy(synth.make_radiance(sc["base"], W, k, row_begin=row_begin).astype(npdt)).to(device)
+            for k in range(nframes)]
+    return gb, rads
+
+
+def run_single(W, H, storage, iters, variant, steps, warmup, device, barrier=None):
+    """-> dict(ms_per_step, stage_ms[list], frames).  Timed region: barrier+sync, K frames, sync+barrier."""
+    import torch
+    from svgf_amd import filter as F
+    d = F.Denoiser(W, H, F.Params(storage=storage, steps=iters, variant=variant), device=device.index or 0)
+    gb, rads = make_inputs(W, H, storage, device)
+    for k in range(PRIME_FRAMES):
+        d.Render(rads[k % len(rads)], gb, gb)
+    for k in range(warmup):
+        d.Render(rads[k % len(rads)], gb, gb)
+    d.timing_enable(True)      # HIP events between the stages, on the stream the kernels are launched on
+    torch.cuda.synchronize(device)
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        d.Render(rads[k % len(rads)], gb, gb)
+    torch.cuda.synchronize(device)
+    if barrier:
+        barrier()
+    t1 = time.perf_counter()
+    stage_ms, frames = d.timing_read()
+    d.timing_enable(False)
+    out = d.Render(rads[0], gb, gb)
+    assert bool(torch.isfinite(out.float()).all()), "non-finite output"
+    d.close()
+    return dict(ms_per_step=(t1 - t0) * 1e3 / steps, stage_ms=[m / max(frames, 1) for m in stage_ms], frames=frames)
+
+
+def roofline_block(W, H, storage, iters, stage_ms):
+    """Roofline of the dominant kernel (the LDS-streaming à-trous kernel, `iters` launches per frame)."""
+    b = ALG_BYTES[storage]
+    P = W * H
+    at_ms = stage_ms[2:2 + iters]
+    if not at_ms or sum(at_ms) <= 0:
+        return None, {}
+    bytes_per_launch = (iters * b["atrous_iter"] + b["atrous_feedback"]) * P / iters
+    avg_ms = sum(at_ms) / iters
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get(f"{W}x{H}_{storage}", {}).get("atrous_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
+    roof = {"bound": "hbm", "kernel": "atrous_lds_kernel", "launches_per_step": iters, "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5), "traffic": traffic}
+    names = ["temporal", "moments"] + [f"atrous_step{1 << i}" for i in range(iters)]
+    per_px = [b["temporal"], b["moments"]] + [b["atrous_iter"] + (b["atrous_feedback"] if i == 0 else 0) for i in range(iters)]
+    stages = {n: {"ms": round(ms, 5), "GBps": round(px * P / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
+              for n, ms, px in zip(names, stage_ms, per_px)}
+    return roof, stages
+
+
+def cpu_baseline(storage, iters):
+    """The scalar C++ oracle (kind 'port': the reference has no CPU path) timed on the host cores, on a bounded
+    sample of the same workload: a 960x540 synthetic frame (1/16 of 4K), steady state, all hardware threads."""
+    from oracle import oracle as orc
+    from svgf_amd import synth
+    W, H = 960, 540
+    cores = os.cpu_count() or 1
+    fr = [synth.make_frame(W, H, k) for k in range(2)]
+    gb = {k: fr[0][k] for k in ("motion", "normal", "uv")}
+    pipe = orc.Pipeline(W, H, storage, steps=iters, nthreads=cores)
+    for k in range(4):                       # reach h >= 4
+        pipe.frame(fr[k % 2]["radiance"], gb, gb)
+    n, t0 = 0, time.perf_counter()
+    while n < 2 or (time.perf_counter() - t0 < 8.0 and n < 40):
+        pipe.frame(fr[n % 2]["radiance"], gb, gb)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(W * H * n / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steady-state frames of {W}x{H} {storage} (1/16 of the 4K workload), temporal+moments+{iters} a-trous, "
+                      f"oracle/svgf_oracle.cpp -O2 row-parallel on {cores} threads, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    N = args.gpus
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+        assert world == N, f"--gpus {N} but WORLD_SIZE={world}"
+
+    storage, iters = args.storage, args.iters
+    if N == 1:
+        wl = args.workload or "4k"
+        W, H = WORKLOADS[wl]
+        r = run_single(W, H, storage, iters, args.variant, args.steps, args.warmup, device)
+        ms = r["ms_per_step"]
+        value = W * H / (ms * 1e-3) / 1e6
+        roof, stages = roofline_block(W, H, storage, iters, r["stage_ms"])
+        full_gbps = alg_bytes_full(storage, iters) * W * H / (ms * 1e-3) / 1e9
+        line = {
+            "metric": "Mpixels/s (and ms/frame) for full SVGF temporal+5 a-trous pass at 1080p/4K", "value": round(value, 1),
+            "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if storage == "f32" else "f16",
+            "data": "synthetic",
+            "config": {"workload": f"{W}x{H} {storage} storage, temporal + moments + {iters} a-trous iterations (steps 1..{1 << (iters - 1)}), "
+                                   f"steady state (history >= 4), static camera, 1-spp noise, seed 0x5356474600000001",
+                       "width": W, "height": H, "storage": storage, "atrous_iterations": iters, "variant": args.variant},
+            "roofline": roof,
+            "pass_roofline": {"algorithmic_bytes_per_px": alg_bytes_full(storage, iters), "achieved_GBps": round(full_gbps, 1),
+                              "frac_of_8TBps": round(full_gbps / HBM_PEAK_GBPS, 4), "frac_of_6.29TBps_copy": round(full_gbps / 6290.0, 4)},
+            "stages": stages,
+        }
+        if not args.no_extra and wl != "1080p":
+            W2, H2 = WORKLOADS["1080p"]
+            r2 = run_single(W2, H2, storage, iters, args.variant, max(args.steps, 20), args.warmup, device)
+            line["also"] = {"1920x1080": {"ms_per_step": round(r2["ms_per_step"], 4),
+                                          "Mpixels/s": round(W2 * H2 / (r2["ms_per_step"] * 1e-3) / 1e6, 1)}}
+        if not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(storage, iters)
+        print(json.dumps(line))
+        return
+
+    # N > 1: one 8K frame in N row strips with halo exchange
+    import torch.distributed as dist
+    from svgf_amd import strips
+    wl = args.workload or "8k"
+    W, H = WORKLOADS[wl]
+    res = strips.bench_strips(W, H, storage, iters, args.variant, args.steps, args.warmup, device, plan=args.halo_plan,
+                              make_inputs=make_inputs, prime_frames=PRIME_FRAMES)
+    t = torch.tensor([res["ms_per_step"]], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = float(t.item())
+    if rank == 0:
+        value = W * H / (ms * 1e-3) / 1e6
+        full_gbps = alg_bytes_full(storage, iters) * W * H / (ms * 1e-3) / 1e9
+        line = {
+            "metric": "Mpixels/s (and ms/frame) for full SVGF temporal+5 a-trous pass at 1080p/4K", "value": round(value, 1),
+            "unit": "Mpixels/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if storage == "f32" else "f16",
+            "data": "synthetic",
+            "config": {"workload": f"{W}x{H} {storage} storage in {N} row strips ({res['rows_per_rank']} rows per GPU), halo exchange over "
+                                   f"RCCL send/recv, plan {res['plan']}, temporal + moments + {iters} a-trous iterations, steady state",
+                       "width": W, "height": H, "storage": storage, "atrous_iterations": iters, "halo_plan": res["plan"]},
+            "roofline": None,
+            "pass_roofline": {"algorithmic_bytes_per_px": alg_bytes_full(storage, iters), "achieved_GBps": round(full_gbps, 1),
+                              "frac_of_aggregate_8TBps": round(full_gbps / (HBM_PEAK_GBPS * N), 4)},
+        }
+        print(json.dumps(line))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

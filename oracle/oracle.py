@@ -102,22 +102,31 @@ class Pipeline:
         self.taps = {}
 
     def frame(self, radiance, gb_cur, gb_prev=None):
+        """One frame.  self.taps keeps copies of every stage's inputs and outputs so that a device stage can
+        be compared from bit-identical inputs."""
         p, P, W, H, st, nt = self.p, self.P, self.W, self.H, self.storage, self.nthreads
         if gb_prev is None:
             gb_prev = gb_cur
         rad = np.ascontiguousarray(radiance.astype(_CDT[st]))
+        self.taps = {"prev_colour": self.colour[1 - P].copy(), "prev_hist": self.hist[1 - P].copy(),
+                     "prev_mom": self.mom[1 - P].copy(), "radiance": rad, "atrous_in": [], "atrous_out": []}
         temporal(W, H, st, self.colour[1 - P], rad, self.colour[P], gb_cur, gb_prev, self.hist[1 - P], self.hist[P],
                  self.mom[P], self.mom[1 - P], depth_threshold=p["depth_threshold"],
                  normal_threshold=p["normal_threshold"], history_base=p["history_base"],
                  mesh_id_test=p["mesh_id_test"], nthreads=nt)
         self.taps["temporal"] = self.colour[P].copy()
+        self.taps["hist"] = self.hist[P].copy()
+        self.taps["mom"] = self.mom[P].copy()
         moments(W, H, st, self.colour[P], self.filt[0], self.mom[P], gb_cur, self.hist[P], phi_colour=p["phi_colour"],
                 phi_normal=p["phi_normal"], radius=p["moments_radius"], nthreads=nt)
         self.taps["moments"] = self.filt[0].copy()
         pp = 0
         for i in range(p["steps"]):
+            self.taps["atrous_in"].append(self.filt[pp].copy())
             atrous(W, H, st, self.filt[pp], self.filt[1 - pp], self.colour[P] if i == 0 else None, gb_cur, step=1 << i,
                    phi_colour=p["phi_colour"], phi_normal=p["phi_normal"], iteration=i, nthreads=nt)
+            self.taps["atrous_out"].append(self.filt[1 - pp].copy())
             pp ^= 1
+        self.taps["feedback"] = self.colour[P].copy()
         self.P ^= 1
         return self.filt[pp]

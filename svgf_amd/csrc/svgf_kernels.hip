@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBX* kBY) void moments_kernel(Geo g, MomentsArgs a)
     const float4 cc = Store<ST>::ld4(a.colour, idx);                  // :450 raw load
     if (!(h < 4.0f)) { Store<ST>::st4(a.out, idx, cc); return; }      // :521
 
-    const float lc = lum_fma(cc.x, cc.y, cc.z);
+    const float lc = lum_exact(cc.x, cc.y, cc.z);
     float zc, dzc;
     depth_of(a.motion[idx], zc, dzc);
     const float3 nc = normal_of(a.normal[idx]);
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kBX* kBY) void moments_kernel(Geo g, MomentsArgs a)
             const float3 np = normal_of(a.normal[p]);                 // :483
             const float len = sqrtf((float)(xx * xx + yy * yy));      // :488
             const float iz = (xx == 0 && yy == 0) ? 0.0f : hw_rcp(phi_d * len);   // phiDepth == 0 -> wZ = 0, :420
-            const float w = edge_weight(fabsf(lc - lum_fma(cp.x, cp.y, cp.z)), il, fabsf(zc - zp), iz, dot3_fma(nc, np), a.phi_normal);
+            const float w = edge_weight(fabsf(lc - lum_exact(cp.x, cp.y, cp.z)), il, fabsf(zc - zp), iz, dot3_fma(nc, np), a.phi_normal);
             sw += w;                                                  // :497-499
             sr = fmaf(cp.x, w, sr); sg = fmaf(cp.y, w, sg); sb = fmaf(cp.z, w, sb);
             sm1 = fmaf(mp.x, w, sm1); sm2 = fmaf(mp.y, w, sm2);
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBX* kBY) void atrous_direct_kernel(Geo g, AtrousAr
     depth_of(a.motion[idx], zc, dzc);                                 // :552
     if (zc == kSkyZ) { Store<ST>::st4(a.out, idx, c); return; }       // :554-558
     const float3 nc = normal_of(a.normal[idx]);
-    const float lc = lum_fma(c.x, c.y, c.z);
+    const float lc = lum_exact(c.x, c.y, c.z);
     const float il = hw_rcp(a.phi_colour * sqrtf(fmaxf(0.0f, 1e-10f + c.w)));   // :562
     const float phi_d = fmaxf(dzc, 1e-6f) * (float)a.step;            // :563
     float sw = 1.0f, sr = c.x, sg = c.y, sb = c.z, sv = c.w;          // :567-568
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kBX* kBY) void atrous_direct_kernel(Geo g, AtrousAr
             depth_of(a.motion[p], zp, dzp);
             const float3 np = normal_of(a.normal[p]);
             const float len = sqrtf((float)(xx * xx + yy * yy));      // compile-time after unrolling
-            const float w = edge_weight(fabsf(lc - lum_fma(q.x, q.y, q.z)), il, fabsf(zc - zp), hw_rcp(phi_d * len),
+            const float w = edge_weight(fabsf(lc - lum_exact(q.x, q.y, q.z)), il, fabsf(zc - zp), hw_rcp(phi_d * len),
                                         dot3_fma(nc, np), a.phi_normal);
             const float gk = w * (K[xx < 0 ? -xx : xx] * K[yy < 0 ? -yy : yy]);   // :582,604
             sw += gk;                                                 // :607-608
@@ -243,6 +243,253 @@ __global__ __launch_bounds__(kBX* kBY) void atrous_direct_kernel(Geo g, AtrousAr
     const float4 o = make_float4(sr * inv, sg * inv, sb * inv, sv * (inv * inv));   // :615
     Store<ST>::st4(a.out, idx, o);                                    // :618 unclamped
     if (a.feedback) Store<ST>::st4(a.feedback, idx, o);               // :619-622
+}
+
+
+// ------------------------------------------------------------------ a-trous (LDS streaming) ---
+// Filter.cuh:527-624 re-designed for CDNA4.  For step S a pixel only ever reads pixels of its own
+// row residue (y mod S), so a workgroup owns ONE residue of a band of rows and a 256-pixel-wide
+// column block, and streams down the band: a ring of kRing = kR+4 decimated rows (tile + 2 S-halo
+// columns each side) lives in LDS as fp32 records, every step each thread produces kR vertically
+// adjacent (decimated) outputs of its column from the whole ring, while the next kR rows are already
+// in flight from HBM into registers.  Global loads are always full-width row segments (16 B per
+// lane, coalesced) whatever the step; the y over-fetch is (band+4)/band and the x over-fetch
+// (256+4S)/256 instead of the 25x gather of a per-pixel kernel.
+//
+// LDS record per pixel (36 B): A = {r,g,b,variance} clamped (imageLoad :78-83),
+// B = {luminance, depth (sky -> 1e30), (nx,ny) as packed halfs, nz as float}, D = ddepth.
+// Pixels outside the frame are staged as {0 | 0, +inf, 0, 0}: their weight is exactly 0, which is
+// what skipping the tap (:579,584) does.
+constexpr int kTX = 256;                 // columns per workgroup = threads per workgroup (4 waves)
+constexpr int kR = 2;                    // outputs per thread and step
+constexpr int kRing = kR + 4;
+constexpr int kBand = 32;                // decimated rows per workgroup
+constexpr float kInf = __builtin_inff();
+
+template <int ST> struct RawColour;
+template <> struct RawColour<0> { typedef float4 type; };
+template <> struct RawColour<1> { typedef uint2 type; };
+
+template <int ST> struct RawPx {
+    typename RawColour<ST>::type c;
+    float2 zd;
+    uint2 n;
+};
+
+template <int ST> __device__ __forceinline__ void raw_invalid(RawPx<ST>& r) {
+    if constexpr (ST == 0) r.c = make_float4(0.f, 0.f, 0.f, 0.f); else r.c = make_uint2(0u, 0u);
+    r.zd = make_float2(kInf, 0.f);
+    r.n = make_uint2(0u, 0u);
+}
+
+template <int ST> __device__ __forceinline__ void raw_load(RawPx<ST>& r, const AtrousArgs& a, size_t idx) {
+    r.c = ((const typename RawColour<ST>::type*)a.in)[idx];
+    r.zd = *(const float2*)((const float*)(a.motion + idx) + 2);       // {depth, ddepth} of the motion texel
+    r.n = a.normal[idx];
+}
+
+template <int ST>
+__device__ __forceinline__ void commit_px(const RawPx<ST>& r, float4* recA, float4* recB, float* recD, int at) {
+    float4 c;
+    if constexpr (ST == 0) c = r.c;
+    else { float2 lo = unpack_h2(r.c.x), hi = unpack_h2(r.c.y); c = make_float4(lo.x, lo.y, hi.x, hi.y); }
+    c = clamp01(c);                                                     // imageLoad, :586
+    float z = r.zd.x, dz = r.zd.y;
+    if (z == 0.0f) { z = kSkyZ; dz = 0.0f; }                            // GetDepth, :199-207
+    recA[at] = c;
+    recB[at] = make_float4(lum_exact(c.x, c.y, c.z), z, __uint_as_float(r.n.x), unpack_h2(r.n.y).x);
+    recD[at] = dz;
+}
+
+// log2 of the kernel weight K[|xx|]*K[|yy|] (:540,582), folded into the exponent
+__device__ __forceinline__ constexpr float klog2(int axx, int ayy) {
+    // K = {1, 2/3, 1/6} as floats, product in float like the reference; log2 tabulated offline
+    // (1*2/3, 1*1/6, 2/3*2/3, 2/3*1/6, 1/6*1/6)
+    return (axx + ayy == 1) ? -0.5849624872207642f      // 2/3
+         : (axx == 1 && ayy == 1) ? -1.1699249744415283f // 4/9
+         : (axx + ayy == 2) ? -2.5849626064300537f       // 1/6
+         : (axx + ayy == 3) ? -3.1699249744415283f       // 1/9
+         : -5.169925212860107f;                          // 1/36
+}
+
+template <int ST, int S>
+__global__ __launch_bounds__(kTX, 2) void atrous_lds_kernel(Geo g, AtrousArgs a) {
+    constexpr int WL = kTX + 4 * S;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* recA = (float4*)smem;
+    float4* recB = recA + kRing * WL;
+    float* recD = (float*)(recB + kRing * WL);
+
+    const int t = threadIdx.x;
+    const int x0 = blockIdx.x * kTX;
+    const int rv = blockIdx.y % S;                 // row residue (relative to g.yb) this workgroup owns
+    const int band = blockIdx.y / S;
+    const int nrows = g.ye - g.yb;
+    const int nj = (nrows - rv + S - 1) / S;       // decimated rows of this residue
+    const int j0 = band * kBand;
+    if (j0 >= nj) return;
+    const int j1 = min(nj, j0 + kBand);
+    const int ybase = g.yb + rv;                   // global row of decimated index j: ybase + S*j
+
+    const int gx = x0 + t;                         // own column
+    const bool has_halo = t < 4 * S;
+    const int hx = (t < 2 * S) ? x0 - 2 * S + t : x0 + kTX + t - 2 * S;
+    const int hli = (t < 2 * S) ? t : kTX + t;     // LDS column of the halo pixel
+    const int oli = t + 2 * S;                     // LDS column of the own pixel
+
+    auto fetch = [&](int j, RawPx<ST>& own, RawPx<ST>& halo) {
+        const int y = ybase + S * j;
+        const int yl = y - g.y0;
+        const bool rok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows;
+        const size_t rowoff = (size_t)yl * g.W;
+        if (rok && gx < g.W) raw_load<ST>(own, a, rowoff + gx); else raw_invalid<ST>(own);
+        if (has_halo) {
+            if (rok && hx >= 0 && hx < g.W) raw_load<ST>(halo, a, rowoff + hx); else raw_invalid<ST>(halo);
+        }
+    };
+    auto commit = [&](int slot, const RawPx<ST>& own, const RawPx<ST>& halo) {
+        commit_px<ST>(own, recA, recB, recD, slot * WL + oli);
+        if (has_halo) commit_px<ST>(halo, recA, recB, recD, slot * WL + hli);
+    };
+
+    // prologue: ring rows 0..kRing-1 = decimated rows j0-2 .. j0+kR+1
+#pragma unroll 1
+    for (int r = 0; r < kRing; r += kR) {          // kR rows in flight at a time keeps the prologue's registers small
+        RawPx<ST> o[kR], h[kR];
+#pragma unroll
+        for (int i = 0; i < kR; i++) fetch(j0 - 2 + r + i, o[i], h[i]);
+#pragma unroll
+        for (int i = 0; i < kR; i++) commit(r + i, o[i], h[i]);
+    }
+    __syncthreads();
+
+    const float phi_n = a.phi_normal;
+    int slot0 = 0;
+    for (int j = j0; j < j1; j += kR) {
+        const bool more = (j + kR) < j1;
+        RawPx<ST> po[kR], ph[kR];
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < kR; i++) fetch(j + kR + 2 + i, po[i], ph[i]);
+        }
+
+        int rowbase[kRing];
+#pragma unroll
+        for (int r = 0; r < kRing; r++) { int sl = slot0 + r; sl = sl >= kRing ? sl - kRing : sl; rowbase[r] = sl * WL + oli; }
+
+        // centres
+        float4 cc[kR]; float lc[kR], zc[kR], ncz[kR], il[kR], iz[kR][5], sw[kR], sr[kR], sg[kR], sb[kR], sv[kR];
+        half2_t nc01[kR];
+#pragma unroll
+        for (int i = 0; i < kR; i++) {
+            const float4 A = recA[rowbase[2 + i]], B = recB[rowbase[2 + i]];
+            const float dz = recD[rowbase[2 + i]];
+            cc[i] = A; lc[i] = B.x; zc[i] = B.y; nc01[i] = __builtin_bit_cast(half2_t, __float_as_uint(B.z)); ncz[i] = B.w;
+            const float phi_l = a.phi_colour * sqrtf(fmaxf(0.0f, 1e-10f + A.w));          // :562
+            il[i] = fminf(hw_rcp(phi_l), 1e30f) * kLog2e;
+            const float izb = hw_rcp(fmaxf(dz, 1e-6f) * (float)S) * kLog2e;               // :563
+            iz[i][0] = izb;                              // |(xx,yy)| = 1
+            iz[i][1] = izb * 0.70710678118654752f;       // sqrt 2
+            iz[i][2] = izb * 0.5f;                       // 2
+            iz[i][3] = izb * 0.44721359549995794f;       // sqrt 5
+            iz[i][4] = izb * 0.35355339059327376f;       // 2 sqrt 2
+            sw[i] = 1.0f; sr[i] = A.x; sg[i] = A.y; sb[i] = A.z; sv[i] = A.w;             // :567-568
+        }
+
+        // Software pipeline over the ring rows: the 5 taps (10 x ds_read_b128) of row r+1 are issued before
+        // row r is consumed.  The empty asm statements pin that order: left alone, instruction selection
+        // sinks all arithmetic below all 60 LDS reads of the unrolled step (256 VGPRs + scratch spills).
+        float4 tapA[2][5], tapB[2][5];
+        auto load_row = [&](int r, int buf) {
+#pragma unroll
+            for (int xx = -2; xx <= 2; xx++) { tapA[buf][xx + 2] = recA[rowbase[r] + xx * S]; tapB[buf][xx + 2] = recB[rowbase[r] + xx * S]; }
+        };
+        load_row(0, 0);
+#pragma unroll
+        for (int r = 0; r < kRing; r++) {
+            const int buf = r & 1;
+            if (r + 1 < kRing) load_row(r + 1, buf ^ 1);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int xx = -2; xx <= 2; xx++) {
+                const float4 A = tapA[buf][xx + 2], B = tapB[buf][xx + 2];
+                const half2_t n01 = __builtin_bit_cast(half2_t, __float_as_uint(B.z));
+#pragma unroll
+                for (int i = 0; i < kR; i++) {
+                    const int yy = r - 2 - i;
+                    if (yy < -2 || yy > 2 || (xx == 0 && yy == 0)) continue;              // compile-time
+                    const int axx = xx < 0 ? -xx : xx, ayy = yy < 0 ? -yy : yy;
+                    const int l2 = axx * axx + ayy * ayy;
+                    const int cls = l2 == 1 ? 0 : l2 == 2 ? 1 : l2 == 4 ? 2 : l2 == 5 ? 3 : 4;
+                    float e = klog2(axx, ayy);
+                    const float d = clamp01(fmaf(B.w, ncz[i], __builtin_amdgcn_fdot2(n01, nc01[i], 0.0f, false)));
+                    e = fmaf(hw_log2(d), phi_n, e);                                   // phi_n != 0 here (launcher)
+                    e = fmaf(-fabsf(B.x - lc[i]), il[i], e);
+                    e = fmaf(-fabsf(B.y - zc[i]), iz[i][cls], e);
+                    const float w = hw_exp2(e);
+                    sw[i] += w;                                                           // :607
+                    sr[i] = fmaf(w, A.x, sr[i]); sg[i] = fmaf(w, A.y, sg[i]); sb[i] = fmaf(w, A.z, sb[i]);
+                    sv[i] = fmaf(w * w, A.w, sv[i]);                                      // :608
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < kR; i++)
+                asm volatile("" : "+v"(sw[i]), "+v"(sr[i]), "+v"(sg[i]), "+v"(sb[i]), "+v"(sv[i]) :: "memory");
+        }
+
+#pragma unroll
+        for (int i = 0; i < kR; i++) {
+            const int jj = j + i;
+            if (jj < j1 && gx < g.W) {
+                const size_t idx = (size_t)(ybase + S * jj - g.y0) * g.W + gx;
+                if (zc[i] == kSkyZ) {
+                    Store<ST>::st4(a.out, idx, cc[i]);                                    // :554-558
+                } else {
+                    const float inv = 1.0f / sw[i];
+                    const float4 o = make_float4(sr[i] * inv, sg[i] * inv, sb[i] * inv, sv[i] * (inv * inv));   // :615
+                    Store<ST>::st4(a.out, idx, o);
+                    if (a.feedback) Store<ST>::st4(a.feedback, idx, o);                   // :619-622
+                }
+            }
+        }
+
+        if (more) {
+            __syncthreads();                       // every wave is done reading the two oldest ring rows
+#pragma unroll
+            for (int i = 0; i < kR; i++) { int sl = slot0 + i; sl = sl >= kRing ? sl - kRing : sl; commit(sl, po[i], ph[i]); }
+            slot0 += kR; if (slot0 >= kRing) slot0 -= kRing;
+            __syncthreads();
+        }
+    }
+}
+
+template <int ST, int S>
+hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
+    constexpr int WL = kTX + 4 * S;
+    constexpr size_t lds = (size_t)kRing * WL * 36;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)atrous_lds_kernel<ST, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nrows = g.ye - g.yb;
+    const int njmax = (nrows + S - 1) / S;
+    const dim3 grid((g.W + kTX - 1) / kTX, S * ((njmax + kBand - 1) / kBand));
+    atrous_lds_kernel<ST, S><<<grid, dim3(kTX), lds, s>>>(g, a);
+    return hipGetLastError();
+}
+
+template <int ST>
+hipError_t launch_atrous_lds_step(const Geo& g, const AtrousArgs& a, hipStream_t s) {
+    switch (a.step) {
+        case 1: return launch_atrous_lds<ST, 1>(g, a, s);
+        case 2: return launch_atrous_lds<ST, 2>(g, a, s);
+        case 4: return launch_atrous_lds<ST, 4>(g, a, s);
+        case 8: return launch_atrous_lds<ST, 8>(g, a, s);
+        case 16: return launch_atrous_lds<ST, 16>(g, a, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 inline dim3 grid_for(const Geo& g) { return dim3((g.W + kBX - 1) / kBX, (g.ye - g.yb + kBY - 1) / kBY); }
@@ -267,7 +514,10 @@ hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, hipSt
 
 hipError_t launch_atrous(const Geo& g, int storage, int variant, const AtrousArgs& a, hipStream_t s) {
     if (g.ye <= g.yb) return hipSuccess;
-    (void)variant;
+    const bool lds_ok = a.step == 1 || a.step == 2 || a.step == 4 || a.step == 8 || a.step == 16;
+    // phi_normal == 0 (pow(x,0) = 1 even at x = 0) is left to the direct kernel: the fused exponent would see 0 * -inf
+    if (variant != 1 /* SVGF_VARIANT_DIRECT */ && lds_ok && a.phi_normal != 0.0f)
+        return storage == 0 ? launch_atrous_lds_step<0>(g, a, s) : launch_atrous_lds_step<1>(g, a, s);
     const dim3 block(kBX, kBY), grid = grid_for(g);
     if (storage == 0) atrous_direct_kernel<0><<<grid, block, 0, s>>>(g, a);
     else atrous_direct_kernel<1><<<grid, block, 0, s>>>(g, a);

@@ -52,65 +52,65 @@ _N_QUAD_A = np.array([0.0, 0.0, -1.0])
 _N_QUAD_B = np.array([0.6, 0.0, -0.8])
 
 
-def make_frame(width: int, height: int, frame: int, *, mv=(0.0, 0.0), row_begin: int = 0, row_end: int | None = None,
-               seed: int = SEED, noise: str = "1spp"):
-    """Rows [row_begin, row_end) of synthetic frame `frame`.
-
-    `mv` is the constant per-frame pan (prev - cur, pixels): the surface point seen at pixel p in
-    frame f was at p + mv in frame f-1, i.e. frame f shows the static world at p + f*mv.
-    Returns dict(motion, normal, uv, radiance) of C-contiguous arrays.
-    """
-    if row_end is None:
-        row_end = height
+def _scene_rows(width, height, frame, mv, row_begin, row_end, seed):
+    """Geometry of rows [row_begin,row_end): motion/normal/uv planes, region ids and the noise-free radiance."""
     rows = row_end - row_begin
     ys = np.arange(row_begin, row_end, dtype=np.int64)
     xs = np.arange(width, dtype=np.int64)
     H = float(height)
-    u = ((xs.astype(np.float64) + frame * float(mv[0])) / H)[None, :].repeat(rows, 0)
-    v = ((ys.astype(np.float64) + frame * float(mv[1])) / H)[:, None].repeat(width, 1)
+    u = np.empty((rows, width), np.float64)
+    v = np.empty((rows, width), np.float64)
+    u[...] = ((xs.astype(np.float64) + frame * float(mv[0])) / H)[None, :]
+    v[...] = ((ys.astype(np.float64) + frame * float(mv[1])) / H)[:, None]
 
     region = np.full((rows, width), GROUND, dtype=np.int32)
     z = 12.0 + 3.0 * u - 6.0 * (v - 0.5)
     dz = np.full_like(z, 6.0 / H)
-    n = np.broadcast_to(_N_GROUND, (rows, width, 3)).copy()
+    n = np.empty((rows, width, 3), np.float64)
+    n[...] = _N_GROUND
 
     # sphere
     cx, cy, r = 0.45, 0.78, 0.18
     dx, dy = (u - cx) / r, (v - cy) / r
     rho2 = dx * dx + dy * dy
     m = rho2 < 1.0
-    s = np.sqrt(np.clip(1.0 - rho2, 0.0, 1.0))
-    region[m] = SPHERE
-    z[m] = (6.0 - 2.0 * r * s)[m]
-    sd = np.maximum(s, 0.2)
-    dz[m] = (2.0 * np.maximum(np.abs(dx), np.abs(dy)) / sd / H)[m]
-    n[m] = np.stack([dx, dy, -s], -1)[m]
+    if m.any():
+        s = np.sqrt(np.clip(1.0 - rho2, 0.0, 1.0))
+        region[m] = SPHERE
+        z[m] = (6.0 - 2.0 * r * s)[m]
+        sd = np.maximum(s, 0.2)
+        dz[m] = (2.0 * np.maximum(np.abs(dx), np.abs(dy)) / sd / H)[m]
+        n[m] = np.stack([dx[m], dy[m], -s[m]], -1)
 
     # tilted quad B
     m = (u >= 0.9) & (u < 1.4) & (v >= 0.2) & (v < 0.7)
-    region[m] = QUAD_B
-    z[m] = (7.0 + 1.5 * (u - 0.9))[m]
-    dz[m] = 1.5 / H
-    n[m] = _N_QUAD_B
+    if m.any():
+        region[m] = QUAD_B
+        z[m] = (7.0 + 1.5 * (u - 0.9))[m]
+        dz[m] = 1.5 / H
+        n[m] = _N_QUAD_B
 
     # fronto-parallel quad A and its coplanar twin A2 (differs by instanceID only)
     m = (u >= 0.2) & (u < 0.6) & (v >= 0.25) & (v < 0.55)
-    region[m] = QUAD_A
-    z[m] = 4.0
-    dz[m] = 0.0
-    n[m] = _N_QUAD_A
+    if m.any():
+        region[m] = QUAD_A
+        z[m] = 4.0
+        dz[m] = 0.0
+        n[m] = _N_QUAD_A
     m = (u >= 0.6) & (u < 0.7) & (v >= 0.25) & (v < 0.55)
-    region[m] = QUAD_A2
-    z[m] = 4.0
-    dz[m] = 0.0
-    n[m] = _N_QUAD_A
+    if m.any():
+        region[m] = QUAD_A2
+        z[m] = 4.0
+        dz[m] = 0.0
+        n[m] = _N_QUAD_A
 
     # sky band (>= 5 % of the frame): depth 0, normal/uv all-zero bits (SURVEY.md App. A.3)
     sky = v < (0.08 + 0.02 * np.sin(7.0 * u))
-    region[sky] = SKY
-    z[sky] = 0.0
-    dz[sky] = 0.0
-    n[sky] = 0.0
+    if sky.any():
+        region[sky] = SKY
+        z[sky] = 0.0
+        dz[sky] = 0.0
+        n[sky] = 0.0
 
     motion = np.empty((rows, width, 4), dtype=np.float32)
     motion[..., 0] = np.float32(mv[0])
@@ -131,26 +131,73 @@ def make_frame(width: int, height: int, frame: int, *, mv=(0.0, 0.0), row_begin:
     uv[..., 3] = region.astype(np.float16).view(np.uint16)
     uv[sky] = 0
 
-    # radiance = albedo(region) * shade(normal) * texture, then 1-spp style noise
+    # noise-free radiance = albedo(region) * shade(normal) * texture
     light = np.array([0.35, -0.5, -0.79])
     shade = 0.55 + 0.45 * np.clip(n @ light, 0.0, 1.0)
     tex = 0.8 + 0.2 * np.sin(37.0 * u) * np.sin(41.0 * v)
     base = _ALBEDO[region] * (shade * tex)[..., None] * 0.6 + 0.05
     base[sky] = np.array([0.25, 0.45, 0.80])
-    radiance = np.empty((rows, width, 4), dtype=np.float32)
-    if noise == "1spp":
+    return motion, normal, uv, region, base.astype(np.float32)
+
+
+def _noise_rows(base, width, frame, row_begin, row_end, seed, noise):
+    ys = np.arange(row_begin, row_end, dtype=np.int64)
+    xs = np.arange(width, dtype=np.int64)
+    radiance = np.empty(base.shape[:2] + (4,), dtype=np.float32)
+    if noise == "1spp":        # a path either finds the light (p = 1/4, carrying 4x the radiance) or returns black
         hit = uniform01(seed, frame + 1, ys, xs, 0) < np.float32(0.25)
-        val = np.where(hit[..., None], base / 0.25, 0.0)
+        val = np.where(hit[..., None], base * np.float32(4.0), np.float32(0.0))
     elif noise == "mul":
-        k = uniform01(seed, frame + 1, ys, xs, 0).astype(np.float64)
-        val = base * (0.5 + k)[..., None]
+        k = uniform01(seed, frame + 1, ys, xs, 0)
+        val = base * (np.float32(0.5) + k)[..., None]
     elif noise == "none":
         val = base
     else:
         raise ValueError(noise)
-    radiance[..., :3] = np.clip(val, 0.0, 1.0).astype(np.float32)
+    radiance[..., :3] = np.clip(val, 0.0, 1.0)
     radiance[..., 3] = 1.0
-    return {"motion": motion, "normal": normal, "uv": uv, "radiance": radiance, "region": region}
+    return radiance
+
+
+_CHUNK = 128
+
+
+def make_scene(width: int, height: int, frame: int = 0, *, mv=(0.0, 0.0), row_begin: int = 0, row_end: int | None = None,
+               seed: int = SEED):
+    """G-buffer planes + region ids + noise-free radiance ('base') of rows [row_begin,row_end) of frame `frame`.
+
+    `mv` is the constant per-frame pan (prev - cur, pixels): the surface point seen at pixel p in frame f was at
+    p + mv in frame f-1, i.e. frame f shows the static world at p + f*mv."""
+    if row_end is None:
+        row_end = height
+    rows = row_end - row_begin
+    out = {"motion": np.empty((rows, width, 4), np.float32), "normal": np.empty((rows, width, 4), np.uint16),
+           "uv": np.empty((rows, width, 4), np.uint16), "region": np.empty((rows, width), np.int32),
+           "base": np.empty((rows, width, 3), np.float32)}
+    for a in range(row_begin, row_end, _CHUNK):
+        b = min(a + _CHUNK, row_end)
+        mo, no, uv, rg, ba = _scene_rows(width, height, frame, mv, a, b, seed)
+        sl = slice(a - row_begin, b - row_begin)
+        out["motion"][sl], out["normal"][sl], out["uv"][sl], out["region"][sl], out["base"][sl] = mo, no, uv, rg, ba
+    return out
+
+
+def make_radiance(base: np.ndarray, width: int, frame: int, *, row_begin: int = 0, seed: int = SEED, noise: str = "1spp"):
+    """1-spp style radiance {r,g,b,1} for frame `frame` from the noise-free `base` rows starting at row_begin."""
+    rows = base.shape[0]
+    out = np.empty((rows, width, 4), np.float32)
+    for a in range(0, rows, _CHUNK):
+        b = min(a + _CHUNK, rows)
+        out[a:b] = _noise_rows(base[a:b], width, frame, row_begin + a, row_begin + b, seed, noise)
+    return out
+
+
+def make_frame(width: int, height: int, frame: int, *, mv=(0.0, 0.0), row_begin: int = 0, row_end: int | None = None,
+               seed: int = SEED, noise: str = "1spp"):
+    """Rows [row_begin, row_end) of synthetic frame `frame`: dict(motion, normal, uv, radiance, region, base)."""
+    sc = make_scene(width, height, frame, mv=mv, row_begin=row_begin, row_end=row_end, seed=seed)
+    sc["radiance"] = make_radiance(sc["base"], width, frame, row_begin=row_begin, seed=seed, noise=noise)
+    return sc
 
 
 def to_storage(a: np.ndarray, storage: str) -> np.ndarray:
