@@ -29,14 +29,16 @@ def stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    if not force and not stale():
+def build_library(force: bool = False, verbose: bool = False, extra_flags=(), out: str | None = None) -> str:
+    """Default: the product library.  `out` + extra_flags (e.g. -DSVGF_DIAG) build a diagnostic twin elsewhere."""
+    if out is None and not force and not stale():
         return LIB
-    cmd = [hipcc(), *FLAGS, *extra_flags, "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    out = out or LIB
+    cmd = [hipcc(), *FLAGS, *extra_flags, "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":

@@ -12,6 +12,9 @@
 
 #include "svgf_kernels.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace svgf {
 namespace {
 
@@ -165,7 +168,15 @@ __global__ __launch_bounds__(kBX* kBY) void moments_kernel(Geo g, MomentsArgs a)
     const float lc = lum_exact(cc.x, cc.y, cc.z);
     float zc, dzc;
     depth_of(a.motion[idx], zc, dzc);
-    const float3 nc = normal_of(a.normal[idx]);
+    const uint2 nraw = a.normal[idx];
+    const float3 nc = normal_of(nraw);
+    // A centre whose normal is exactly (0,0,0) — the G-buffer's cleared sky texels — has n.n' = 0 for every tap,
+    // so with phi_normal > 0 every weight is exp(..)*pow(0,phi_n) = 0: the sums stay 0, sumW clamps to 1e-6 and the
+    // result is exactly (0,0,0,0) (:505-516).  Same value, none of the 49 taps.
+    if (((nraw.x & 0x7fff7fffu) | (nraw.y & 0x7fffu)) == 0u && a.phi_normal > 0.0f) {
+        Store<ST>::st4(a.out, idx, make_float4(0.f, 0.f, 0.f, 0.f * (4.0f / h)));
+        return;
+    }
     const float il = hw_rcp(a.phi_colour);                            // :460
     const float phi_d = fmaxf(dzc, 1e-8f) * 3.0f;                     // :461
     float sw = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sm1 = 0.f, sm2 = 0.f;
@@ -250,9 +261,9 @@ __global__ __launch_bounds__(kBX* kBY) void atrous_direct_kernel(Geo g, AtrousAr
 // Filter.cuh:527-624 re-designed for CDNA4.  For step S a pixel only ever reads pixels of its own
 // row residue (y mod S), so a workgroup owns ONE residue of a band of rows and a 256-pixel-wide
 // column block, and streams down the band: a ring of kRing = kR+4 decimated rows (tile + 2 S-halo
-// columns each side) lives in LDS as fp32 records, every step each thread produces kR vertically
-// adjacent (decimated) outputs of its column from the whole ring, while the next kR rows are already
-// in flight from HBM into registers.  Global loads are always full-width row segments (16 B per
+// columns each side) lives in LDS as fp32 records, every step the workgroup produces kRG = 2 vertically
+// adjacent (decimated) rows from the ring, while the next kRG rows are already in flight from HBM into
+// registers.  Global loads are always full-width row segments (16 B per
 // lane, coalesced) whatever the step; the y over-fetch is (band+4)/band and the x over-fetch
 // (256+4S)/256 instead of the 25x gather of a per-pixel kernel.
 //
@@ -260,11 +271,15 @@ __global__ __launch_bounds__(kBX* kBY) void atrous_direct_kernel(Geo g, AtrousAr
 // B = {luminance, depth (sky -> 1e30), (nx,ny) as packed halfs, nz as float}, D = ddepth.
 // Pixels outside the frame are staged as {0 | 0, +inf, 0, 0}: their weight is exactly 0, which is
 // what skipping the tap (:579,584) does.
-constexpr int kTX = 256;                 // columns per workgroup = threads per workgroup (4 waves)
-constexpr int kR = 2;                    // outputs per thread and step
-constexpr int kRing = kR + 4;
-constexpr int kBand = 32;                // decimated rows per workgroup
+constexpr int kTX = 256;                 // columns per workgroup
+constexpr int kRG = 2;                   // decimated rows produced per step (one row group of 4 waves each)
+constexpr int kR = kRG;
+constexpr int kThreads = kTX * kRG;      // 512 threads = 8 waves
+constexpr int kRing = kRG + 4;
 constexpr float kInf = __builtin_inff();
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int ST> struct RawColour;
 template <> struct RawColour<0> { typedef float4 type; };
@@ -289,199 +304,247 @@ template <int ST> __device__ __forceinline__ void raw_load(RawPx<ST>& r, const A
 }
 
 template <int ST>
-__device__ __forceinline__ void commit_px(const RawPx<ST>& r, float4* recA, float4* recB, float* recD, int at) {
+__device__ __forceinline__ void commit_px(const RawPx<ST>& r, f32x4* recA, f32x4* recB, float* recD, int at) {
     float4 c;
     if constexpr (ST == 0) c = r.c;
     else { float2 lo = unpack_h2(r.c.x), hi = unpack_h2(r.c.y); c = make_float4(lo.x, lo.y, hi.x, hi.y); }
     c = clamp01(c);                                                     // imageLoad, :586
     float z = r.zd.x, dz = r.zd.y;
     if (z == 0.0f) { z = kSkyZ; dz = 0.0f; }                            // GetDepth, :199-207
-    recA[at] = c;
-    recB[at] = make_float4(lum_exact(c.x, c.y, c.z), z, __uint_as_float(r.n.x), unpack_h2(r.n.y).x);
+    recA[at] = (f32x4){c.x, c.y, c.z, c.w};
+    recB[at] = (f32x4){lum_exact(c.x, c.y, c.z), z, __uint_as_float(r.n.x), unpack_h2(r.n.y).x};
     recD[at] = dz;
 }
 
 // log2 of the kernel weight K[|xx|]*K[|yy|] (:540,582), folded into the exponent
 __device__ __forceinline__ constexpr float klog2(int axx, int ayy) {
-    // K = {1, 2/3, 1/6} as floats, product in float like the reference; log2 tabulated offline
-    // (1*2/3, 1*1/6, 2/3*2/3, 2/3*1/6, 1/6*1/6)
-    return (axx + ayy == 1) ? -0.5849624872207642f      // 2/3
-         : (axx == 1 && ayy == 1) ? -1.1699249744415283f // 4/9
-         : (axx + ayy == 2) ? -2.5849626064300537f       // 1/6
-         : (axx + ayy == 3) ? -3.1699249744415283f       // 1/9
-         : -5.169925212860107f;                          // 1/36
+    return (axx + ayy == 1) ? -0.5849624872207642f       // 1 * 2/3
+         : (axx == 1 && ayy == 1) ? -1.1699249744415283f // 2/3 * 2/3
+         : (axx + ayy == 2) ? -2.5849626064300537f       // 1 * 1/6
+         : (axx + ayy == 3) ? -3.1699249744415283f       // 2/3 * 1/6
+         : -5.169925212860107f;                          // 1/6 * 1/6
+}
+__device__ __forceinline__ constexpr int len_class(int xx, int yy) {    // |(xx,yy)| in {1, sqrt2, 2, sqrt5, 2sqrt2}
+    const int l2 = xx * xx + yy * yy;
+    return l2 == 1 ? 0 : l2 == 2 ? 1 : l2 == 4 ? 2 : l2 == 5 ? 3 : 4;
+}
+// (nx,ny).(nx',ny') of two packed-half pairs: exact products, one rounding of their sum (v_dot2_f32_f16 with a
+// zero addend; the builtin would pick the accumulating v_dot2c form and spend a v_mov on the zero).  hipcc does not
+// look inside asm statements, so the three wait states a non-dot VALU needs before it may read (or overwrite) a
+// dot result on gfx940+ are part of the statement; with 4 waves per SIMD they cost no VALU issue.
+__device__ __forceinline__ float dot2_h2(uint32_t a, uint32_t b) {
+    float d;
+    asm("v_dot2_f32_f16 %0, %1, %2, 0\n\ts_nop 2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
 }
 
-template <int ST, int S>
-__global__ __launch_bounds__(kTX, 2) void atrous_lds_kernel(Geo g, AtrousArgs a) {
+// MODE is a diagnostic knob (SVGF_DIAG builds only): 0 = the kernel, 1 = streaming only (no tap arithmetic),
+// 2 = arithmetic only (no global prefetch / ring refill after the prologue).
+//
+// Workgroup = 512 threads = 8 waves: thread t owns column (t & 255) and output row group (t >> 8), i.e. waves
+// 0-3 produce decimated row j and waves 4-7 row j+1 of the same 256 columns from the same 6-row ring.  One
+// output per thread keeps the kernel at ~90 VGPRs, so the two workgroups the ring's LDS footprint allows per CU
+// run 4 waves per SIMD — enough to cover LDS latency, the barriers and the exp2/log2 latency of the tap chain.
+template <int ST, int S, int MODE = 0>
+__global__ __launch_bounds__(kThreads, 4) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows) {
     constexpr int WL = kTX + 4 * S;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* recA = (float4*)smem;
-    float4* recB = recA + kRing * WL;
+    f32x4* recA = (f32x4*)smem;
+    f32x4* recB = recA + kRing * WL;
     float* recD = (float*)(recB + kRing * WL);
 
     const int t = threadIdx.x;
+    const int col = t & (kTX - 1);
+    const int rg = t >> 8;                         // row group: which of the kRG rows of a step this thread outputs
     const int x0 = blockIdx.x * kTX;
     const int rv = blockIdx.y % S;                 // row residue (relative to g.yb) this workgroup owns
     const int band = blockIdx.y / S;
     const int nrows = g.ye - g.yb;
     const int nj = (nrows - rv + S - 1) / S;       // decimated rows of this residue
-    const int j0 = band * kBand;
+    const int j0 = band * band_rows;
     if (j0 >= nj) return;
-    const int j1 = min(nj, j0 + kBand);
+    const int j1 = min(nj, j0 + band_rows);
     const int ybase = g.yb + rv;                   // global row of decimated index j: ybase + S*j
 
-    const int gx = x0 + t;                         // own column
-    const bool has_halo = t < 4 * S;
-    const int hx = (t < 2 * S) ? x0 - 2 * S + t : x0 + kTX + t - 2 * S;
-    const int hli = (t < 2 * S) ? t : kTX + t;     // LDS column of the halo pixel
-    const int oli = t + 2 * S;                     // LDS column of the own pixel
+    const int gx = x0 + col;                       // own column
+    const int oli = col + 2 * S;                   // LDS column of the own pixel
+    // halo pixels of the kRG rows a step stages: threads 0 .. kRG*4S-1, 4S per row
+    const bool has_halo = t < kRG * 4 * S;
+    const int hrow = t / (4 * S);                  // which staged row this thread's halo pixel belongs to
+    const int hh = t % (4 * S);
+    const int hx = (hh < 2 * S) ? x0 - 2 * S + hh : x0 + kTX + hh - 2 * S;
+    const int hli = (hh < 2 * S) ? hh : kTX + hh;
 
-    auto fetch = [&](int j, RawPx<ST>& own, RawPx<ST>& halo) {
+    auto fetch_px = [&](int j, int x, RawPx<ST>& px) {
         const int y = ybase + S * j;
         const int yl = y - g.y0;
-        const bool rok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows;
-        const size_t rowoff = (size_t)yl * g.W;
-        if (rok && gx < g.W) raw_load<ST>(own, a, rowoff + gx); else raw_invalid<ST>(own);
-        if (has_halo) {
-            if (rok && hx >= 0 && hx < g.W) raw_load<ST>(halo, a, rowoff + hx); else raw_invalid<ST>(halo);
-        }
+        const bool ok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows && x >= 0 && x < g.W;
+        if (ok) raw_load<ST>(px, a, (size_t)yl * g.W + x); else raw_invalid<ST>(px);
     };
-    auto commit = [&](int slot, const RawPx<ST>& own, const RawPx<ST>& halo) {
-        commit_px<ST>(own, recA, recB, recD, slot * WL + oli);
-        if (has_halo) commit_px<ST>(halo, recA, recB, recD, slot * WL + hli);
+    // stage decimated rows jn .. jn+kRG-1 into ring slots sl .. sl+kRG-1 (mod kRing): own pixel of row jn+rg,
+    // halo pixel of row jn+hrow
+    auto fetch = [&](int jn, RawPx<ST>& own, RawPx<ST>& halo) {
+        fetch_px(jn + rg, gx, own);
+        if (has_halo) fetch_px(jn + hrow, hx, halo);
+    };
+    auto commit = [&](int sl, const RawPx<ST>& own, const RawPx<ST>& halo) {
+        int so = sl + rg; so = so >= kRing ? so - kRing : so;
+        commit_px<ST>(own, recA, recB, recD, so * WL + oli);
+        if (has_halo) { int sh = sl + hrow; sh = sh >= kRing ? sh - kRing : sh; commit_px<ST>(halo, recA, recB, recD, sh * WL + hli); }
     };
 
-    // prologue: ring rows 0..kRing-1 = decimated rows j0-2 .. j0+kR+1
+    // prologue: ring rows 0..kRing-1 = decimated rows j0-2 .. j0+kRG+1
 #pragma unroll 1
-    for (int r = 0; r < kRing; r += kR) {          // kR rows in flight at a time keeps the prologue's registers small
-        RawPx<ST> o[kR], h[kR];
-#pragma unroll
-        for (int i = 0; i < kR; i++) fetch(j0 - 2 + r + i, o[i], h[i]);
-#pragma unroll
-        for (int i = 0; i < kR; i++) commit(r + i, o[i], h[i]);
+    for (int r = 0; r < kRing; r += kRG) {
+        RawPx<ST> o, h;
+        fetch(j0 - 2 + r, o, h);
+        commit(r, o, h);
     }
     __syncthreads();
 
-    const float phi_n = a.phi_normal;
+    const float phi_n = a.phi_normal;              // != 0 (launcher)
     int slot0 = 0;
-    for (int j = j0; j < j1; j += kR) {
-        const bool more = (j + kR) < j1;
-        RawPx<ST> po[kR], ph[kR];
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < kR; i++) fetch(j + kR + 2 + i, po[i], ph[i]);
-        }
+    // Rows are fetched TWO steps ahead of their use: set `pn` holds the rows the next step needs (already landed by
+    // the time they are committed), set `pf` the rows of the step after, in flight during this step's arithmetic.
+    RawPx<ST> pn_o, pn_h;
+    if (MODE != 2 && j0 + kRG < j1) fetch(j0 + kRG + 2, pn_o, pn_h);
+    for (int j = j0; j < j1; j += kRG) {
+        const bool more = MODE != 2 && (j + kRG) < j1;
+        const bool more2 = MODE != 2 && (j + 2 * kRG) < j1;
+        RawPx<ST> pf_o, pf_h;
+        if (more2) fetch(j + 2 * kRG + 2, pf_o, pf_h);
 
-        int rowbase[kRing];
+        // this thread's centre is ring row 2+rg, its taps ring rows rg .. rg+4
+        int rowbase[5];
 #pragma unroll
-        for (int r = 0; r < kRing; r++) { int sl = slot0 + r; sl = sl >= kRing ? sl - kRing : sl; rowbase[r] = sl * WL + oli; }
+        for (int r = 0; r < 5; r++) { int sl = slot0 + rg + r; sl = sl >= kRing ? sl - kRing : sl; rowbase[r] = sl * WL + oli; }
 
-        // centres
-        float4 cc[kR]; float lc[kR], zc[kR], ncz[kR], il[kR], iz[kR][5], sw[kR], sr[kR], sg[kR], sb[kR], sv[kR];
-        half2_t nc01[kR];
-#pragma unroll
-        for (int i = 0; i < kR; i++) {
-            const float4 A = recA[rowbase[2 + i]], B = recB[rowbase[2 + i]];
-            const float dz = recD[rowbase[2 + i]];
-            cc[i] = A; lc[i] = B.x; zc[i] = B.y; nc01[i] = __builtin_bit_cast(half2_t, __float_as_uint(B.z)); ncz[i] = B.w;
-            const float phi_l = a.phi_colour * sqrtf(fmaxf(0.0f, 1e-10f + A.w));          // :562
-            il[i] = fminf(hw_rcp(phi_l), 1e30f) * kLog2e;
-            const float izb = hw_rcp(fmaxf(dz, 1e-6f) * (float)S) * kLog2e;               // :563
-            iz[i][0] = izb;                              // |(xx,yy)| = 1
-            iz[i][1] = izb * 0.70710678118654752f;       // sqrt 2
-            iz[i][2] = izb * 0.5f;                       // 2
-            iz[i][3] = izb * 0.44721359549995794f;       // sqrt 5
-            iz[i][4] = izb * 0.35355339059327376f;       // 2 sqrt 2
-            sw[i] = 1.0f; sr[i] = A.x; sg[i] = A.y; sb[i] = A.z; sv[i] = A.w;             // :567-568
-        }
+        const f32x4 cA = recA[rowbase[2]], cB = recB[rowbase[2]];
+        const float cdz = recD[rowbase[2]];
+        const f32x2 lzc = {cB.x, cB.y};                                                      // centre luminance, depth
+        const float ncz = cB.w;
+        const uint32_t nc01 = __float_as_uint(cB.z);
+        const float phi_l = a.phi_colour * sqrtf(fmaxf(0.0f, 1e-10f + cA.w));                // :562
+        const float il = fminf(hw_rcp(phi_l), 1e30f) * kLog2e;
+        const float izb = hw_rcp(fmaxf(cdz, 1e-6f) * (float)S) * kLog2e;                     // :563
+        const float iz[5] = {izb, izb * 0.70710678118654752f, izb * 0.5f, izb * 0.44721359549995794f, izb * 0.35355339059327376f};
+        // accumulators, packed by channel pairs: (r,g) and (b,variance) advance with one v_pk_fma_f32 each
+        float sw = 1.0f;                                                                      // :567
+        f32x2 srg = {cA.x, cA.y}, sbv = {cA.z, cA.w};                                         // :568
 
-        // Software pipeline over the ring rows: the 5 taps (10 x ds_read_b128) of row r+1 are issued before
-        // row r is consumed.  The empty asm statements pin that order: left alone, instruction selection
-        // sinks all arithmetic below all 60 LDS reads of the unrolled step (256 VGPRs + scratch spills).
-        float4 tapA[2][5], tapB[2][5];
-        auto load_row = [&](int r, int buf) {
+        // One ring row at a time (5 taps = 10 x ds_read_b128 in flight).  The empty asm statements pin that
+        // order: left alone, instruction selection sinks all arithmetic below all 50 LDS reads of the unrolled
+        // loop (256 VGPRs + scratch spills).
+        // a wave whose 64 centres are all sky (a band of cleared texels) has nothing to filter (:554-558)
+        const bool wave_has_surface = __ballot(lzc.y != kSkyZ) != 0ull;
 #pragma unroll
-            for (int xx = -2; xx <= 2; xx++) { tapA[buf][xx + 2] = recA[rowbase[r] + xx * S]; tapB[buf][xx + 2] = recB[rowbase[r] + xx * S]; }
-        };
-        load_row(0, 0);
+        for (int r = 0; r < (MODE == 1 ? 0 : 5); r++) {
+            if (!wave_has_surface) break;
+            const int yy = r - 2;
+            f32x4 tA[5], tB[5];
 #pragma unroll
-        for (int r = 0; r < kRing; r++) {
-            const int buf = r & 1;
-            if (r + 1 < kRing) load_row(r + 1, buf ^ 1);
+            for (int xx = -2; xx <= 2; xx++) { tA[xx + 2] = recA[rowbase[r] + xx * S]; tB[xx + 2] = recB[rowbase[r] + xx * S]; }
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int xx = -2; xx <= 2; xx++) {
-                const float4 A = tapA[buf][xx + 2], B = tapB[buf][xx + 2];
-                const half2_t n01 = __builtin_bit_cast(half2_t, __float_as_uint(B.z));
-#pragma unroll
-                for (int i = 0; i < kR; i++) {
-                    const int yy = r - 2 - i;
-                    if (yy < -2 || yy > 2 || (xx == 0 && yy == 0)) continue;              // compile-time
-                    const int axx = xx < 0 ? -xx : xx, ayy = yy < 0 ? -yy : yy;
-                    const int l2 = axx * axx + ayy * ayy;
-                    const int cls = l2 == 1 ? 0 : l2 == 2 ? 1 : l2 == 4 ? 2 : l2 == 5 ? 3 : 4;
-                    float e = klog2(axx, ayy);
-                    const float d = clamp01(fmaf(B.w, ncz[i], __builtin_amdgcn_fdot2(n01, nc01[i], 0.0f, false)));
-                    e = fmaf(hw_log2(d), phi_n, e);                                   // phi_n != 0 here (launcher)
-                    e = fmaf(-fabsf(B.x - lc[i]), il[i], e);
-                    e = fmaf(-fabsf(B.y - zc[i]), iz[i][cls], e);
-                    const float w = hw_exp2(e);
-                    sw[i] += w;                                                           // :607
-                    sr[i] = fmaf(w, A.x, sr[i]); sg[i] = fmaf(w, A.y, sg[i]); sb[i] = fmaf(w, A.z, sb[i]);
-                    sv[i] = fmaf(w * w, A.w, sv[i]);                                      // :608
-                }
+                if (xx == 0 && yy == 0) continue;                                        // centre: weight 1, already in
+                const f32x4 A = tA[xx + 2], B = tB[xx + 2];
+                const int axx = xx < 0 ? -xx : xx, ayy = yy < 0 ? -yy : yy;
+                const float d = clamp01(fmaf(B.w, ncz, dot2_h2(__float_as_uint(B.z), nc01)));
+                const f32x2 dlz = (f32x2){B.x, B.y} - lzc;                                // (dl, dz): one v_pk_add_f32
+                float e = fmaf(hw_log2(d), phi_n, klog2(axx, ayy));
+                e = fmaf(-fabsf(dlz.x), il, e);
+                e = fmaf(-fabsf(dlz.y), iz[len_class(xx, yy)], e);
+                const float w = hw_exp2(e);
+                const f32x2 ww = {w, w * w};                                              // weights of (b, variance): :604-608
+                sw += w;                                                                  // :607
+                srg = __builtin_elementwise_fma((f32x2){w, w}, (f32x2){A.x, A.y}, srg);
+                sbv = __builtin_elementwise_fma(ww, (f32x2){A.z, A.w}, sbv);
             }
-#pragma unroll
-            for (int i = 0; i < kR; i++)
-                asm volatile("" : "+v"(sw[i]), "+v"(sr[i]), "+v"(sg[i]), "+v"(sb[i]), "+v"(sv[i]) :: "memory");
+            asm volatile("" : "+v"(sw), "+v"(srg), "+v"(sbv) :: "memory");
         }
 
-#pragma unroll
-        for (int i = 0; i < kR; i++) {
-            const int jj = j + i;
-            if (jj < j1 && gx < g.W) {
-                const size_t idx = (size_t)(ybase + S * jj - g.y0) * g.W + gx;
-                if (zc[i] == kSkyZ) {
-                    Store<ST>::st4(a.out, idx, cc[i]);                                    // :554-558
-                } else {
-                    const float inv = 1.0f / sw[i];
-                    const float4 o = make_float4(sr[i] * inv, sg[i] * inv, sb[i] * inv, sv[i] * (inv * inv));   // :615
-                    Store<ST>::st4(a.out, idx, o);
-                    if (a.feedback) Store<ST>::st4(a.feedback, idx, o);                   // :619-622
-                }
+        const int jj = j + rg;
+        if (jj < j1 && gx < g.W) {
+            const size_t idx = (size_t)(ybase + S * jj - g.y0) * g.W + gx;
+            if (lzc.y == kSkyZ) {
+                Store<ST>::st4(a.out, idx, make_float4(cA.x, cA.y, cA.z, cA.w));                   // :554-558
+            } else {
+                const float inv = 1.0f / sw;
+                const float4 o = make_float4(srg.x * inv, srg.y * inv, sbv.x * inv, sbv.y * (inv * inv));   // :615
+                Store<ST>::st4(a.out, idx, o);
+                if (a.feedback) Store<ST>::st4(a.feedback, idx, o);                                // :619-622
             }
         }
 
         if (more) {
-            __syncthreads();                       // every wave is done reading the two oldest ring rows
-#pragma unroll
-            for (int i = 0; i < kR; i++) { int sl = slot0 + i; sl = sl >= kRing ? sl - kRing : sl; commit(sl, po[i], ph[i]); }
-            slot0 += kR; if (slot0 >= kRing) slot0 -= kRing;
+            __syncthreads();                       // every wave is done reading the kRG oldest ring rows
+            commit(slot0, pn_o, pn_h);
+            slot0 += kRG; if (slot0 >= kRing) slot0 -= kRing;
             __syncthreads();
+            pn_o = pf_o; pn_h = pf_h;
         }
     }
 }
 
-template <int ST, int S>
+inline int resident_target() {                    // workgroups that are resident at once: 2 per CU (LDS bound)
+    static int target = 0;
+    if (!target) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        target = 2 * (cus > 0 ? cus : 256);
+    }
+    return target;
+}
+
+template <int ST, int S, int MODE = 0>
 hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     constexpr int WL = kTX + 4 * S;
     constexpr size_t lds = (size_t)kRing * WL * 36;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)atrous_lds_kernel<ST, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)atrous_lds_kernel<ST, S, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    // One round of workgroups: bands are sized so that (x tiles) x (S residues) x (bands) fills the
+    // resident slots of the chip once instead of leaving a partial last round.
     const int nrows = g.ye - g.yb;
     const int njmax = (nrows + S - 1) / S;
-    const dim3 grid((g.W + kTX - 1) / kTX, S * ((njmax + kBand - 1) / kBand));
-    atrous_lds_kernel<ST, S><<<grid, dim3(kTX), lds, s>>>(g, a);
+    const int xtiles = (g.W + kTX - 1) / kTX;
+    int nbands = resident_target() / (xtiles * S);
+    if (nbands < 1) nbands = 1;
+    int band = (njmax + nbands - 1) / nbands;
+    if (band < 8) band = 8;
+    band = (band + kR - 1) / kR * kR;
+    nbands = (njmax + band - 1) / band;
+    const dim3 grid(xtiles, S * nbands);
+#ifdef SVGF_DIAG
+    static bool told = false;
+    if (!told) {
+        told = true;
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)atrous_lds_kernel<ST, S, MODE>, kThreads, lds);
+        fprintf(stderr, "[svgf diag] atrous_lds<ST=%d,S=%d,MODE=%d>: lds %zu B, occupancy %d blocks/CU, grid %u x %u, band %d\n", ST, S, MODE, lds, nb, grid.x, grid.y, band);
+    }
+#endif
+    atrous_lds_kernel<ST, S, MODE><<<grid, dim3(kThreads), lds, s>>>(g, a, band);
     return hipGetLastError();
 }
 
 template <int ST>
 hipError_t launch_atrous_lds_step(const Geo& g, const AtrousArgs& a, hipStream_t s) {
+#ifdef SVGF_DIAG
+    static const int mode = getenv("SVGF_ATROUS_MODE") ? atoi(getenv("SVGF_ATROUS_MODE")) : 0;
+    if (ST == 0 && mode == 1) switch (a.step) {
+        case 1: return launch_atrous_lds<0, 1, 1>(g, a, s); case 2: return launch_atrous_lds<0, 2, 1>(g, a, s);
+        case 4: return launch_atrous_lds<0, 4, 1>(g, a, s); case 8: return launch_atrous_lds<0, 8, 1>(g, a, s);
+        case 16: return launch_atrous_lds<0, 16, 1>(g, a, s); }
+    if (ST == 0 && mode == 2) switch (a.step) {
+        case 1: return launch_atrous_lds<0, 1, 2>(g, a, s); case 2: return launch_atrous_lds<0, 2, 2>(g, a, s);
+        case 4: return launch_atrous_lds<0, 4, 2>(g, a, s); case 8: return launch_atrous_lds<0, 8, 2>(g, a, s);
+        case 16: return launch_atrous_lds<0, 16, 2>(g, a, s); }
+#endif
     switch (a.step) {
         case 1: return launch_atrous_lds<ST, 1>(g, a, s);
         case 2: return launch_atrous_lds<ST, 2>(g, a, s);

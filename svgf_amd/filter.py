@@ -71,7 +71,8 @@ _lib = None
 
 
 def library_path() -> str:
-    return _build.LIB
+    # SVGF_LIBRARY lets the diagnostic tools load a -DSVGF_DIAG twin of the library; tests and bench never set it.
+    return os.environ.get("SVGF_LIBRARY") or _build.LIB
 
 
 def load_library():
@@ -80,7 +81,7 @@ def load_library():
     if _lib is not None:
         return _lib
     path = library_path()
-    if _build.stale():
+    if path == _build.LIB and _build.stale():
         try:
             _build.build_library()
         except Exception as e:  # noqa: BLE001
