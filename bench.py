@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--halo-plan", default="auto")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (1080p) measurement")
+    ap.add_argument("--strips", action="store_true", help="run the strip runner even at N=1 (exercises the N>1 code path)")
     return ap.parse_args()
 
 
@@ -143,6 +144,18 @@ def cpu_baseline(storage, iters):
                       f"oracle/svgf_oracle.cpp -O2 row-parallel on {cores} threads, {dt:.1f} s"}
 
 
+def emit(line):
+    """The JSON line must be the last thing on stdout: RCCL printf()s a version banner into C stdio's buffer, which
+    would otherwise be flushed after Python's own output at exit."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
     import torch
@@ -154,14 +167,17 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     N = args.gpus
-    if world > 1:
+    if world > 1 or args.strips:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
         assert world == N, f"--gpus {N} but WORLD_SIZE={world}"
 
     storage, iters = args.storage, args.iters
-    if N == 1:
+    if N == 1 and not args.strips:
         wl = args.workload or "4k"
         W, H = WORKLOADS[wl]
         r = run_single(W, H, storage, iters, args.variant, args.steps, args.warmup, device)
@@ -189,7 +205,10 @@ def main():
                                           "Mpixels/s": round(W2 * H2 / (r2["ms_per_step"] * 1e-3) / 1e6, 1)}}
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(storage, iters)
-        print(json.dumps(line))
+        if world > 1 or args.strips:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        emit(line)
         return
 
     # N > 1: one 8K frame in N row strips with halo exchange
@@ -202,6 +221,7 @@ def main():
     t = torch.tensor([res["ms_per_step"]], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ms = float(t.item())
+    line = None
     if rank == 0:
         value = W * H / (ms * 1e-3) / 1e6
         full_gbps = alg_bytes_full(storage, iters) * W * H / (ms * 1e-3) / 1e9
@@ -217,9 +237,10 @@ def main():
             "pass_roofline": {"algorithmic_bytes_per_px": alg_bytes_full(storage, iters), "achieved_GBps": round(full_gbps, 1),
                               "frac_of_aggregate_8TBps": round(full_gbps / (HBM_PEAK_GBPS * N), 4)},
         }
-        print(json.dumps(line))
     dist.barrier()
     dist.destroy_process_group()
+    if line is not None:
+        emit(line)
 
 
 if __name__ == "__main__":

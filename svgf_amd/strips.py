@@ -1,0 +1,317 @@
+"""Row-strip execution of the SVGF pass across the GPUs of one node.
+
+The reference is single-GPU (no NCCL/MPI anywhere in src/); this is the build's only parallel strategy: the
+frame is cut into `world` contiguous row strips, one process per GPU, and the strips exchange HALO ROWS with
+their two neighbours through torch.distributed point-to-point ops (backend "nccl" = RCCL over xGMI on MI355X,
+"gloo" in the CPU tests).  There is no collective in the data path: every stage is a bounded-reach gather, so
+strip results are bit-identical to the single-GPU frame.
+
+Halo plan.  À-trous iteration i reaches 2*2^i rows.  A plan groups the iterations; a group's input halo
+(the sum of its iterations' reaches) is exchanged once, before the group, and inside the group iteration i is
+computed on `ext_i` extra rows each side (redundantly with the neighbour, bit-identically) so that the next
+iteration of the group finds its halo locally:
+    "per-iteration"  [[0],[1],[2],[3],[4]]   one exchange before every iteration  (the literal north-star scheme)
+    "grouped"        [[0,1,2],[3,4]]         2 à-trous exchanges per frame, <3 % redundant work   (default)
+    "ghost"          [[0,1,2,3,4]]           no exchange between iterations, 62 ghost rows each side
+The temporal and moments stages are computed redundantly on the first group's halo, so a frame needs ONE more
+exchange, at its start: the previous frame's state (colour feedback, moments, history) on the rows the
+reprojection can reach.  Exchanges are posted before the rows that do not depend on them are computed
+(interior/boundary split), so the transfers overlap the interior kernels.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+PLANS = {
+    "per-iteration": lambda n: [[i] for i in range(n)],
+    "grouped": lambda n: [list(range(0, min(3, n)))] + ([list(range(3, n))] if n > 3 else []),
+    "ghost": lambda n: [list(range(n))] if n else [],
+}
+DEFAULT_PLAN = "grouped"
+
+
+def partition(H: int, world: int):
+    """Owned row range of every rank: contiguous, as even as possible."""
+    return [(H * r // world, H * (r + 1) // world) for r in range(world)]
+
+
+@dataclass
+class Geometry:
+    """Everything a rank needs to know about its strip under a plan."""
+    W: int
+    H: int
+    rank: int
+    world: int
+    steps: int
+    moments_radius: int
+    motion_reach: int
+    groups: list
+    own: tuple = (0, 0)
+    ext_atrous: list = field(default_factory=list)   # extra rows each side iteration i is computed on
+    halo_group: list = field(default_factory=list)   # input halo of group g
+    ext_moments: int = 0
+    ext_temporal: int = 0
+    halo_state: int = 0                               # previous-frame state rows needed beyond the owned rows
+    halo_max: int = 0
+    y0: int = 0
+    y1: int = 0
+
+    @staticmethod
+    def make(W, H, rank, world, steps, plan=DEFAULT_PLAN, moments_radius=3, motion_reach=4):
+        if plan == "auto":
+            plan = DEFAULT_PLAN
+        groups = PLANS[plan](steps) if isinstance(plan, str) else [list(g) for g in plan]
+        assert [i for g in groups for i in g] == list(range(steps)), "plan must list the iterations in order"
+        g = Geometry(W, H, rank, world, steps, moments_radius, motion_reach, groups)
+        g.own = partition(H, world)[rank]
+        g.ext_atrous = [0] * steps
+        for grp in groups:
+            for i in grp:
+                g.ext_atrous[i] = sum(2 << k for k in grp if k > i)
+        g.halo_group = [sum(2 << k for k in grp) for grp in groups]
+        g.ext_moments = g.halo_group[0] if groups else 0
+        g.ext_temporal = g.ext_moments + moments_radius
+        g.halo_state = g.ext_temporal + motion_reach
+        g.halo_max = max([g.halo_state] + g.halo_group)
+        g.y0 = max(0, g.own[0] - g.halo_max)
+        g.y1 = min(H, g.own[1] + g.halo_max)
+        smallest = min(b - a for a, b in partition(H, world))
+        if world > 1 and smallest < g.halo_max:
+            raise ValueError(f"strips of {smallest} rows are shorter than the {g.halo_max}-row halo of plan {plan}: "
+                             f"use fewer ranks or a plan with smaller groups")
+        return g
+
+    def rows(self, ext):
+        """Owned rows grown by `ext` each side, clipped to the frame."""
+        return max(0, self.own[0] - ext), min(self.H, self.own[1] + ext)
+
+    @property
+    def up(self):
+        return self.rank - 1 if self.rank > 0 else None
+
+    @property
+    def down(self):
+        return self.rank + 1 if self.rank < self.world - 1 else None
+
+
+class DistComm:
+    """Halo exchange over torch.distributed point-to-point ops (RCCL send/recv on MI355X, gloo on CPU)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+
+    def start(self, sends, recvs):
+        """sends/recvs: lists of (tensor_slice, peer_rank).  Returns an opaque handle."""
+        d = self.dist
+        ops = [d.P2POp(d.irecv, t, p, group=self.group) for t, p in recvs] + [d.P2POp(d.isend, t, p, group=self.group) for t, p in sends]
+        return d.batch_isend_irecv(ops) if ops else []
+
+    def finish(self, handle):
+        for w in handle:
+            w.wait()
+
+
+class LocalComm:
+    """In-process stand-in for DistComm driving N virtual ranks in lock step (tests: strips on ONE device).
+    start() posts the sends in a mailbox, finish() copies them into the receivers."""
+
+    def __init__(self):
+        self.box = {}
+
+    def for_rank(self, rank):
+        parent = self
+
+        class _C:
+            def start(self, sends, recvs):
+                for t, p in sends:
+                    parent.box.setdefault((rank, p), []).append(t.clone())
+                return recvs
+
+            def finish(self, recvs):
+                for t, p in recvs:
+                    t.copy_(parent.box[(p, rank)].pop(0))
+        return _C()
+
+
+class HipStages:
+    """The three stages on a strip through the C ABI (libsvgf_mi355x.so)."""
+
+    def __init__(self, geo: Geometry, params, device):
+        from . import filter as F
+        self.F, self.geo = F, geo
+        self.d = F.Denoiser(geo.W, geo.H, params, device=device.index or 0, strip=(geo.y0, geo.y1 - geo.y0, geo.own[0], geo.own[1]))
+        self.device = device
+
+    def gbuffer(self, motion, normal, uv):
+        return self.F.GBuffer(motion, normal, uv)
+
+    def temporal(self, rows, prev_colour, radiance, colour_out, gb_cur, gb_prev, hist_prev, hist_cur, mom_cur, mom_prev):
+        self.d.set_rows(*rows)
+        self.d.TemporalFilter(prev_colour, radiance, colour_out, gb_cur, gb_prev, hist_prev, hist_cur, mom_cur, mom_prev)
+
+    def moments(self, rows, colour, out, mom, gb, hist):
+        self.d.set_rows(*rows)
+        self.d.FilterMoments(colour, out, mom, gb, hist)
+
+    def atrous(self, rows, src, dst, feedback, gb, step, iteration):
+        self.d.set_rows(*rows)
+        self.d.FilterKernel(src, dst, feedback, gb, step, iteration)
+
+
+class StripRunner:
+    """One rank's share of the frame sequence application::Render runs (src/App.cu:552-556)."""
+
+    def __init__(self, geo: Geometry, stages, comm, storage="f32", device="cpu"):
+        import torch
+        self.torch, self.geo, self.st, self.comm = torch, geo, stages, comm
+        dt = torch.float32 if storage == "f32" else torch.float16
+        n, W = geo.y1 - geo.y0, geo.W
+        z = lambda ch, d: torch.zeros((n, W, ch) if ch else (n, W), dtype=d, device=device)   # noqa: E731
+        self.colour = [z(4, dt), z(4, dt)]       # RenderBuffer[2]    App.h:138
+        self.mom = [z(2, dt), z(2, dt)]          # MomentsBuffer[2]   App.h:139
+        self.filt = [z(4, dt), z(4, dt)]         # FilterBuffer[2]    App.h:140
+        self.hist = [z(0, torch.uint8), z(0, torch.uint8)]
+        self.P = 0
+
+    # -- halo plumbing -----------------------------------------------------------------------
+    def _halo_ops(self, planes, h):
+        """Send my outermost owned rows, receive the neighbours' into my halo rows; h rows each side."""
+        g = self.geo
+        a, b = g.own[0] - g.y0, g.own[1] - g.y0          # local indices of the owned rows
+        sends, recvs = [], []
+        for t in planes:
+            if g.up is not None:
+                sends.append((t[a:a + h], g.up))
+                recvs.append((t[a - h:a], g.up))
+            if g.down is not None:
+                sends.append((t[b - h:b], g.down))
+                recvs.append((t[b:b + h], g.down))
+        return sends, recvs
+
+    def _split(self, rows, reach):
+        """Rows of `rows` that need no neighbour data when the stage reaches `reach` rows, and the rest."""
+        g = self.geo
+        lo = rows[0] if g.up is None else max(rows[0], g.own[0] + reach)
+        hi = rows[1] if g.down is None else min(rows[1], g.own[1] - reach)
+        if hi <= lo:
+            return None, [rows]
+        edges = [r for r in ((rows[0], lo), (hi, rows[1])) if r[1] > r[0]]
+        return (lo, hi), edges
+
+    # -- one frame ---------------------------------------------------------------------------
+    def frame_steps(self, radiance, gb_cur, gb_prev=None):
+        """Generator: yields between posting an exchange and waiting for it (LocalComm lock step); the value of
+        the finished generator (StopIteration.value) is the plane holding the result."""
+        g, st, P = self.geo, self.st, self.P
+        if gb_prev is None:
+            gb_prev = gb_cur
+        # previous-frame state halo: posted first, needed only by the rows near the strip edges
+        h = self.comm.start(*self._halo_ops([self.colour[1 - P], self.mom[1 - P], self.hist[1 - P]], g.halo_state)) if g.world > 1 else None
+        rows_t = g.rows(g.ext_temporal)
+
+        def temporal(rows):
+            st.temporal(rows, self.colour[1 - P], radiance, self.colour[P], gb_cur, gb_prev, self.hist[1 - P], self.hist[P],
+                        self.mom[P], self.mom[1 - P])
+        if h is not None:
+            inner, edges = self._split(g.own, g.motion_reach)
+            if inner:
+                temporal(inner)
+            yield
+            self.comm.finish(h)
+            done = [inner] if inner else []
+            for r in _subtract(rows_t, done):
+                temporal(r)
+        else:
+            temporal(rows_t)
+        st.moments(g.rows(g.ext_moments), self.colour[P], self.filt[0], self.mom[P], gb_cur, self.hist[P])
+        pp = 0
+        for gi, grp in enumerate(g.groups):
+            h = None
+            if gi > 0 and g.world > 1:
+                h = self.comm.start(*self._halo_ops([self.filt[pp]], g.halo_group[gi]))
+            for k, i in enumerate(grp):
+                rows = g.rows(g.ext_atrous[i])
+                fb = self.colour[P] if i == 0 else None
+                if h is not None and k == 0:
+                    inner, edges = self._split(g.own, 2 << i)
+                    if inner:
+                        st.atrous(inner, self.filt[pp], self.filt[1 - pp], fb, gb_cur, 1 << i, i)
+                    yield
+                    self.comm.finish(h)
+                    for r in _subtract(rows, [inner] if inner else []):
+                        st.atrous(r, self.filt[pp], self.filt[1 - pp], fb, gb_cur, 1 << i, i)
+                else:
+                    st.atrous(rows, self.filt[pp], self.filt[1 - pp], fb, gb_cur, 1 << i, i)
+                pp ^= 1
+        self.P ^= 1
+        return self.filt[pp]
+
+    def frame(self, radiance, gb_cur, gb_prev=None):
+        it = self.frame_steps(radiance, gb_cur, gb_prev)
+        try:
+            while True:
+                next(it)
+        except StopIteration as e:
+            return e.value
+
+    def owned(self, plane):
+        g = self.geo
+        return plane[g.own[0] - g.y0:g.own[1] - g.y0]
+
+
+def _subtract(rows, done):
+    """Row ranges of `rows` not covered by the ranges in `done` (sorted, disjoint, inside rows)."""
+    out, lo = [], rows[0]
+    for a, b in sorted(done):
+        if a > lo:
+            out.append((lo, a))
+        lo = max(lo, b)
+    if lo < rows[1]:
+        out.append((lo, rows[1]))
+    return out
+
+
+def run_virtual(runners, inputs):
+    """Drive N virtual ranks (LocalComm) in lock step through one frame; inputs[r] = (radiance, gb_cur, gb_prev)."""
+    its = [r.frame_steps(*inputs[k]) for k, r in enumerate(runners)]
+    results = [None] * len(its)
+    live = set(range(len(its)))
+    while live:
+        for k in sorted(live):
+            try:
+                next(its[k])
+            except StopIteration as e:
+                results[k] = e.value
+                live.discard(k)
+    return results
+
+
+def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, make_inputs, prime_frames):
+    """bench.py's N > 1 leg: this rank's strip of a W x H frame, `steps` timed frames."""
+    import time
+    import torch
+    import torch.distributed as dist
+    from . import filter as F
+    rank, world = dist.get_rank(), dist.get_world_size()
+    params = F.Params(storage=storage, steps=iters, variant=variant)
+    geo = Geometry.make(W, H, rank, world, iters, plan=plan, moments_radius=params.moments_radius, motion_reach=4)
+    stages = HipStages(geo, params, device)
+    runner = StripRunner(geo, stages, DistComm(), storage=storage, device=device)
+    gb, rads = make_inputs(W, H, storage, device, row_begin=geo.y0, row_end=geo.y1)
+    for k in range(prime_frames + warmup):
+        runner.frame(rads[k % len(rads)], gb, gb)
+    torch.cuda.synchronize(device)
+    dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        runner.frame(rads[k % len(rads)], gb, gb)
+    torch.cuda.synchronize(device)
+    dist.barrier()
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    out = runner.frame(rads[0], gb, gb)
+    assert bool(torch.isfinite(runner.owned(out).float()).all())
+    return dict(ms_per_step=(t1 - t0) * 1e3 / steps, rows_per_rank=geo.own[1] - geo.own[0],
+                plan=plan if plan != "auto" else DEFAULT_PLAN)

@@ -206,6 +206,39 @@ def test_strips_bitwise_equal_whole_frame(G, variant):
         assert np.array_equal(G.host(o)[yb - y0:ye - y0], want[yb:ye]), (yb, ye)
 
 
+@pytest.mark.parametrize("plan", ["per-iteration", "grouped", "ghost"])
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_strip_runner_virtual_ranks(G, plan, storage):
+    """The multi-GPU strip runner with 3 virtual ranks on ONE device (device-to-device copies stand in for the
+    RCCL send/recv): every frame of a panning sequence must equal the single-context result bit for bit."""
+    import torch
+    from svgf_amd import filter as F
+    from svgf_amd import strips
+    W, H, world, N = 320, 420, 3, 4
+    mv = (1.0, -2.5)
+    fr = frames(W, H, N, mv=mv)
+    params = F.Params(storage=storage, steps=5)
+    whole = F.Denoiser(W, H, params)
+    dev = torch.device("cuda:0")
+    lc = strips.LocalComm()
+    geos = [strips.Geometry.make(W, H, r, world, 5, plan=plan, motion_reach=3) for r in range(world)]
+    runners = [strips.StripRunner(g, strips.HipStages(g, params, dev), lc.for_rank(g.rank), storage=storage, device=dev) for g in geos]
+    gbs = [G.gb_dev(f) for f in fr]
+
+    def local_gb(f, g):
+        return F.GBuffer(*(G.dev(np.ascontiguousarray(f[k][g.y0:g.y1])) for k in ("motion", "normal", "uv")))
+    for k in range(N):
+        kp = max(k - 1, 0)
+        want = G.host(whole.Render(G.dev(fr[k]["radiance"].astype(G.NPDT[storage])), gbs[k], gbs[kp] if k else None))
+        inputs = [(G.dev(np.ascontiguousarray(fr[k]["radiance"][g.y0:g.y1].astype(G.NPDT[storage]))), local_gb(fr[k], g), local_gb(fr[kp], g))
+                  for g in geos]
+        outs = strips.run_virtual(runners, inputs)
+        got = np.concatenate([G.host(r.owned(o)) for r, o in zip(runners, outs)], 0)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), f"plan {plan}: frame {k}"
+    hist = np.concatenate([G.host(r.owned(r.hist[r.P ^ 1])) for r in runners], 0)
+    assert np.array_equal(hist, G.host(whole.state_plane(F.PLANE_HISTORY, 1 - whole.pingpong())))
+
+
 def test_abi_errors(G):
     from svgf_amd import filter as F
     W, H = 64, 48

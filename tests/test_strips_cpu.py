@@ -1,0 +1,120 @@
+"""Multi-GPU row-strip path on CPU: geometry/plan arithmetic, lock-step virtual ranks, and a real world_size-2
+torch.distributed run over gloo.  Stage compute comes from the test-only OracleStages backend, so every strip
+result can be demanded bit-identical to the whole-frame oracle pipeline."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from svgf_amd import strips, synth
+from tests.helpers import CDT, gbuf
+from tests.oracle_stages import OracleStages
+
+PARAMS = dict(steps=5, depth_threshold=0.8, normal_threshold=0.9, history_base=24, phi_colour=10.0, phi_normal=128.0,
+              moments_radius=3, mesh_id_test=1)
+
+
+def test_partition_and_geometry():
+    assert strips.partition(4320, 8) == [(540 * r, 540 * (r + 1)) for r in range(8)]
+    assert strips.partition(10, 3) == [(0, 3), (3, 6), (6, 10)]
+    g = strips.Geometry.make(7680, 4320, 3, 8, 5, plan="per-iteration")
+    assert g.groups == [[0], [1], [2], [3], [4]] and g.halo_group == [2, 4, 8, 16, 32] and g.ext_atrous == [0] * 5
+    assert (g.ext_moments, g.ext_temporal, g.halo_state) == (2, 5, 9) and g.halo_max == 32
+    g = strips.Geometry.make(7680, 4320, 3, 8, 5, plan="grouped")
+    assert g.groups == [[0, 1, 2], [3, 4]] and g.halo_group == [14, 48] and g.ext_atrous == [12, 8, 0, 32, 0]
+    assert (g.ext_moments, g.ext_temporal, g.halo_state, g.halo_max) == (14, 17, 21, 48)
+    assert (g.y0, g.y1, g.own) == (1620 - 48, 2160 + 48, (1620, 2160))
+    g = strips.Geometry.make(7680, 4320, 0, 8, 5, plan="ghost")
+    assert g.halo_group == [62] and g.ext_atrous == [60, 56, 48, 32, 0] and g.halo_state == 62 + 3 + 4 and g.y0 == 0
+    with pytest.raises(ValueError, match="shorter than"):
+        strips.Geometry.make(640, 64, 0, 4, 5, plan="ghost")
+    assert strips._subtract((0, 10), [(2, 4), (6, 10)]) == [(0, 2), (4, 6)]
+
+
+def _local_inputs(fr, g):
+    sl = slice(g.y0, g.y1)
+    return {k: torch.from_numpy(np.ascontiguousarray(fr[k][sl])) for k in ("motion", "normal", "uv")}
+
+
+def _reference(oracle, W, H, storage, frs):
+    ref = oracle.Pipeline(W, H, storage, nthreads=4, **PARAMS)
+    outs = []
+    for k, fr in enumerate(frs):
+        outs.append(ref.frame(fr["radiance"], gbuf(fr), gbuf(frs[max(k - 1, 0)])).copy())
+    return outs, ref
+
+
+@pytest.mark.parametrize("plan", ["per-iteration", "grouped", "ghost"])
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_virtual_ranks_bit_identical(oracle, plan, storage):
+    W, H, world, N = 96, 312, 3, 4
+    mv = (1.0, -2.5)
+    frs = [synth.make_frame(W, H, f, mv=mv) for f in range(N)]
+    want, ref = _reference(oracle, W, H, storage, frs)
+    lc = strips.LocalComm()
+    runners, geos = [], []
+    for r in range(world):
+        g = strips.Geometry.make(W, H, r, world, 5, plan=plan, motion_reach=3)
+        geos.append(g)
+        runners.append(strips.StripRunner(g, OracleStages(g, PARAMS, storage), lc.for_rank(r), storage=storage))
+    for k in range(N):
+        inputs = []
+        for g in geos:
+            rad = torch.from_numpy(np.ascontiguousarray(frs[k]["radiance"][g.y0:g.y1].astype(CDT[storage])))
+            inputs.append((rad, _local_inputs(frs[k], g), _local_inputs(frs[max(k - 1, 0)], g)))
+        outs = strips.run_virtual(runners, inputs)
+        got = np.concatenate([r.owned(o).numpy() for r, o in zip(runners, outs)], 0)
+        assert np.array_equal(got.view(np.uint8), want[k].view(np.uint8)), f"plan {plan}: frame {k} differs from the whole frame"
+    hist = np.concatenate([r.owned(r.hist[r.P ^ 1]).numpy() for r in runners], 0)
+    assert np.array_equal(hist, ref.hist[ref.P ^ 1])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_worker(rank, world, port, W, H, N, plan, storage, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = strips.Geometry.make(W, H, rank, world, 5, plan=plan, motion_reach=3)
+        runner = strips.StripRunner(g, OracleStages(g, PARAMS, storage), strips.DistComm(), storage=storage)
+        outs = []
+        for k in range(N):
+            fr = synth.make_frame(W, H, k, mv=(1.0, -2.5), row_begin=g.y0, row_end=g.y1)      # each rank makes only its rows
+            fp = synth.make_frame(W, H, max(k - 1, 0), mv=(1.0, -2.5), row_begin=g.y0, row_end=g.y1)
+            tz = lambda f: {n: torch.from_numpy(f[n]) for n in ("motion", "normal", "uv")}      # noqa: E731
+            out = runner.frame(torch.from_numpy(fr["radiance"].astype(CDT[storage])), tz(fr), tz(fp))
+            outs.append(runner.owned(out).numpy().copy())
+        q.put((rank, outs))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("plan", ["per-iteration", "grouped"])
+def test_gloo_world2_bit_identical(oracle, plan):
+    import torch.multiprocessing as mp
+    W, H, N, world, storage = 64, 200, 3, 2, "f32"
+    frs = [synth.make_frame(W, H, f, mv=(1.0, -2.5)) for f in range(N)]
+    want, _ = _reference(oracle, W, H, storage, frs)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, W, H, N, plan, storage, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k in range(N):
+        got = np.concatenate([res[r][k] for r in range(world)], 0)
+        assert np.array_equal(got.view(np.uint8), want[k].view(np.uint8)), f"frame {k}"
