@@ -258,62 +258,83 @@ __global__ __launch_bounds__(kBX* kBY) void atrous_direct_kernel(Geo g, AtrousAr
 
 
 // ------------------------------------------------------------------ a-trous (LDS streaming) ---
-// Filter.cuh:527-624 re-designed for CDNA4.  For step S a pixel only ever reads pixels of its own
-// row residue (y mod S), so a workgroup owns ONE residue of a band of rows and a 256-pixel-wide
-// column block, and streams down the band: a ring of kRing = kR+4 decimated rows (tile + 2 S-halo
-// columns each side) lives in LDS as fp32 records, every step the workgroup produces kRG = 2 vertically
-// adjacent (decimated) rows from the ring, while the next kRG rows are already in flight from HBM into
-// registers.  Global loads are always full-width row segments (16 B per
-// lane, coalesced) whatever the step; the y over-fetch is (band+4)/band and the x over-fetch
-// (256+4S)/256 instead of the 25x gather of a per-pixel kernel.
+// Filter.cuh:527-624 re-designed for CDNA4.  For step S a pixel only ever reads pixels of its own row residue
+// (y mod S), so a workgroup owns ONE residue of a band of rows and a TX = 256-pixel-wide column block, and
+// streams down the band: a ring of kRing = kRG+4 decimated rows (tile + 2S halo columns each side) lives in LDS
+// as fp32 records; every step the workgroup produces kRG = 2 vertically adjacent decimated rows from the ring
+// (waves 0-3 row j, waves 4-7 row j+1: one output per thread), while the rows of the next two steps are already
+// in flight from HBM into registers.  Global loads are always full-width row segments (16 B per lane, coalesced)
+// whatever the step; the y over-fetch is (band+4)/band and the x over-fetch (256+4S)/256 instead of the 25x
+// gather of a per-pixel kernel.
 //
-// LDS record per pixel (36 B): A = {r,g,b,variance} clamped (imageLoad :78-83),
-// B = {luminance, depth (sky -> 1e30), (nx,ny) as packed halfs, nz as float}, D = ddepth.
-// Pixels outside the frame are staged as {0 | 0, +inf, 0, 0}: their weight is exactly 0, which is
-// what skipping the tap (:579,584) does.
-constexpr int kTX = 256;                 // columns per workgroup
-constexpr int kRG = 2;                   // decimated rows produced per step (one row group of 4 waves each)
-constexpr int kR = kRG;
-constexpr int kThreads = kTX * kRG;      // 512 threads = 8 waves
+// LDS record per pixel (32 B): A = {r,g,b,variance} clamped (imageLoad :78-83), B = {luminance, depth (sky ->
+// 1e30), (nx,ny) as packed halfs, nz as float}.  The centre's ddepth is the only other per-pixel input: the
+// thread that stages a pixel of its own column is the thread that later filters it, so ddepth rides in a
+// three-register queue instead of LDS.
+//
+// Everything that is the same for all lanes of a wave — row offsets, ring slots, validity of a row — is kept in
+// scalar registers: planes are addressed as buffer resources with a per-thread constant byte offset (voffset)
+// plus a per-step scalar row offset (soffset), so staging a row costs no vector ALU at all.  With 4 waves
+// sharing a SIMD every vector instruction outside the tap loop costs as much as inside it.
+// Pixels outside the frame (or the strip) come back as all-zero texels from the buffer range check (a row
+// outside the frame is loaded through a zero-length resource): depth 0 = sky sentinel and a zero normal give
+// weight exactly 0, which is what skipping the tap (:579,584) does.
+constexpr int kRG = 2;                   // decimated rows produced per step (one row group of TX/64 waves each)
 constexpr int kRing = kRG + 4;
-constexpr float kInf = __builtin_inff();
+constexpr int kRecBytes = 32;            // LDS bytes per staged pixel
+constexpr unsigned kOob = 0xFFFFFF00u;   // byte offset no plane reaches (planes are < 4 GiB)
+
+#ifdef SVGF_STAMPS
+// In-kernel phase stamps (a diagnostic twin of the library only, tools/stamps.py; the product build has none of
+// this, and the stamps' own waits slow that twin down: read its shares, not its run time).
+__device__ unsigned long long g_stamps[16];
+#define SVGF_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp_acc[i] += t_ - stamp_t; stamp_t = t_; } while (0)
+#else
+#define SVGF_STAMP(i) do { } while (0)
+#endif
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int ST> struct RawColour;
-template <> struct RawColour<0> { typedef float4 type; };
-template <> struct RawColour<1> { typedef uint2 type; };
+// One staged pixel as it comes off the planes: colour (16 B fp32 / 8 B fp16), {depth, ddepth} (ddepth only for
+// pixels of the thread's own column: DZ), normal.
+template <int ST, bool DZ> struct RawPx;
+template <> struct RawPx<0, true> { u32x4 c; u32x2 zd; u32x2 n; };
+template <> struct RawPx<1, true> { u32x2 c; u32x2 zd; u32x2 n; };
+template <> struct RawPx<0, false> { u32x4 c; unsigned zd; u32x2 n; };
+template <> struct RawPx<1, false> { u32x2 c; unsigned zd; u32x2 n; };
 
-template <int ST> struct RawPx {
-    typename RawColour<ST>::type c;
-    float2 zd;
-    uint2 n;
-};
+struct PlaneRsrc { __amdgpu_buffer_rsrc_t colour, motion, normal; };
 
-template <int ST> __device__ __forceinline__ void raw_invalid(RawPx<ST>& r) {
-    if constexpr (ST == 0) r.c = make_float4(0.f, 0.f, 0.f, 0.f); else r.c = make_uint2(0u, 0u);
-    r.zd = make_float2(kInf, 0.f);
-    r.n = make_uint2(0u, 0u);
+// voff_c / voff_n: the lane's constant byte offsets into the colour(+motion) and normal planes (kOob for a
+// column outside the frame); srow: the row's scalar element offset yl*W.
+template <int ST, bool DZ>
+__device__ __forceinline__ void raw_load(RawPx<ST, DZ>& r, const PlaneRsrc& rs, unsigned voff_c, unsigned voff_m, unsigned voff_n, int srow) {
+    constexpr int cb = ST == 0 ? 16 : 8;
+    if constexpr (ST == 0) r.c = __builtin_amdgcn_raw_buffer_load_b128(rs.colour, voff_c, srow * cb, 0);
+    else r.c = __builtin_amdgcn_raw_buffer_load_b64(rs.colour, voff_c, srow * cb, 0);
+    if constexpr (DZ) r.zd = __builtin_amdgcn_raw_buffer_load_b64(rs.motion, voff_m, srow * 16, 0);      // {depth, ddepth}
+    else r.zd = __builtin_amdgcn_raw_buffer_load_b32(rs.motion, voff_m, srow * 16, 0);                   // depth
+    r.n = __builtin_amdgcn_raw_buffer_load_b64(rs.normal, voff_n, srow * 8, 0);
 }
 
-template <int ST> __device__ __forceinline__ void raw_load(RawPx<ST>& r, const AtrousArgs& a, size_t idx) {
-    r.c = ((const typename RawColour<ST>::type*)a.in)[idx];
-    r.zd = *(const float2*)((const float*)(a.motion + idx) + 2);       // {depth, ddepth} of the motion texel
-    r.n = a.normal[idx];
-}
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int ST>
-__device__ __forceinline__ void commit_px(const RawPx<ST>& r, f32x4* recA, f32x4* recB, float* recD, int at) {
+__device__ __forceinline__ float med01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }   // = min(max(v,0),1) for non-NaN v
+
+template <int ST, bool DZ>
+__device__ __forceinline__ void commit_px(const RawPx<ST, DZ>& r, f32x4* recA, f32x4* recB, int at) {
     float4 c;
-    if constexpr (ST == 0) c = r.c;
+    if constexpr (ST == 0) c = make_float4(__uint_as_float(r.c.x), __uint_as_float(r.c.y), __uint_as_float(r.c.z), __uint_as_float(r.c.w));
     else { float2 lo = unpack_h2(r.c.x), hi = unpack_h2(r.c.y); c = make_float4(lo.x, lo.y, hi.x, hi.y); }
-    c = clamp01(c);                                                     // imageLoad, :586
-    float z = r.zd.x, dz = r.zd.y;
-    if (z == 0.0f) { z = kSkyZ; dz = 0.0f; }                            // GetDepth, :199-207
+    c = make_float4(med01(c.x), med01(c.y), med01(c.z), med01(c.w));    // imageLoad, :586
+    float z;
+    if constexpr (DZ) z = __uint_as_float(r.zd.x); else z = __uint_as_float(r.zd);
+    if (z == 0.0f) z = kSkyZ;                                           // GetDepth, :199-207
     recA[at] = (f32x4){c.x, c.y, c.z, c.w};
     recB[at] = (f32x4){lum_exact(c.x, c.y, c.z), z, __uint_as_float(r.n.x), unpack_h2(r.n.y).x};
-    recD[at] = dz;
 }
 
 // log2 of the kernel weight K[|xx|]*K[|yy|] (:540,582), folded into the exponent
@@ -341,22 +362,26 @@ __device__ __forceinline__ float dot2_h2(uint32_t a, uint32_t b) {
 // MODE is a diagnostic knob (SVGF_DIAG builds only): 0 = the kernel, 1 = streaming only (no tap arithmetic),
 // 2 = arithmetic only (no global prefetch / ring refill after the prologue).
 //
-// Workgroup = 512 threads = 8 waves: thread t owns column (t & 255) and output row group (t >> 8), i.e. waves
-// 0-3 produce decimated row j and waves 4-7 row j+1 of the same 256 columns from the same 6-row ring.  One
-// output per thread keeps the kernel at ~90 VGPRs, so the two workgroups the ring's LDS footprint allows per CU
+// Workgroup = 2*TX threads: thread t owns column (t % TX) and output row group (t / TX), i.e. with TX = 256
+// waves 0-3 produce decimated row j and waves 4-7 row j+1 of the same 256 columns from the same 6-row ring.  One
+// output per thread keeps the kernel near 100 VGPRs, so the two workgroups the ring's LDS footprint allows per CU
 // run 4 waves per SIMD — enough to cover LDS latency, the barriers and the exp2/log2 latency of the tap chain.
-template <int ST, int S, int MODE = 0>
-__global__ __launch_bounds__(kThreads, 4) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows) {
-    constexpr int WL = kTX + 4 * S;
+template <int ST, int S, int TX, int MODE = 0>
+__global__ __launch_bounds__(TX* kRG, 4) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows) {
+    constexpr int WL = TX + 4 * S;                 // staged columns per ring row
+    constexpr int CB = ST == 0 ? 16 : 8;           // bytes per colour texel
+    constexpr int NH = 4 * S / (TX / 64);          // halo pixels each wave stages per row (lanes 0..NH-1)
+    static_assert(NH >= 1 && NH <= 64, "halo does not fit the row group's waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* recA = (f32x4*)smem;
     f32x4* recB = recA + kRing * WL;
-    float* recD = (float*)(recB + kRing * WL);
 
     const int t = threadIdx.x;
-    const int col = t & (kTX - 1);
-    const int rg = t >> 8;                         // row group: which of the kRG rows of a step this thread outputs
-    const int x0 = blockIdx.x * kTX;
+    const int lane = t & 63;
+    const int col = t % TX;
+    const int rg = __builtin_amdgcn_readfirstlane(t / TX);          // row group: wave-uniform -> scalar
+    const int wig = __builtin_amdgcn_readfirstlane((t % TX) >> 6);  // wave index inside its row group
+    const int x0 = blockIdx.x * TX;
     const int rv = blockIdx.y % S;                 // row residue (relative to g.yb) this workgroup owns
     const int band = blockIdx.y / S;
     const int nrows = g.ye - g.yb;
@@ -366,61 +391,85 @@ __global__ __launch_bounds__(kThreads, 4) void atrous_lds_kernel(Geo g, AtrousAr
     const int j1 = min(nj, j0 + band_rows);
     const int ybase = g.yb + rv;                   // global row of decimated index j: ybase + S*j
 
+    // per-lane constants
     const int gx = x0 + col;                       // own column
-    const int oli = col + 2 * S;                   // LDS column of the own pixel
-    // halo pixels of the kRG rows a step stages: threads 0 .. kRG*4S-1, 4S per row
-    const bool has_halo = t < kRG * 4 * S;
-    const int hrow = t / (4 * S);                  // which staged row this thread's halo pixel belongs to
-    const int hh = t % (4 * S);
-    const int hx = (hh < 2 * S) ? x0 - 2 * S + hh : x0 + kTX + hh - 2 * S;
-    const int hli = (hh < 2 * S) ? hh : kTX + hh;
+    const int oli = col + 2 * S;                   // its LDS column
+    const bool has_halo = lane < NH;               // this lane also stages one halo pixel of its row group's row
+    const int hh = wig * NH + lane;                // 0 .. 4S-1
+    const int hx = (hh < 2 * S) ? x0 - 2 * S + hh : x0 + TX + hh - 2 * S;
+    const int hli = (hh < 2 * S) ? hh : TX + hh;
+    const bool own_ok = gx < g.W, halo_ok = has_halo && hx >= 0 && hx < g.W;
+    const unsigned vo_c = own_ok ? (unsigned)gx * CB : kOob, vo_m = own_ok ? (unsigned)gx * 16u + 8u : kOob, vo_n = own_ok ? (unsigned)gx * 8u : kOob;
+    const unsigned vh_c = halo_ok ? (unsigned)hx * CB : kOob, vh_m = halo_ok ? (unsigned)hx * 16u + 8u : kOob, vh_n = halo_ok ? (unsigned)hx * 8u : kOob;
 
-    auto fetch_px = [&](int j, int x, RawPx<ST>& px) {
-        const int y = ybase + S * j;
-        const int yl = y - g.y0;
-        const bool ok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows && x >= 0 && x < g.W;
-        if (ok) raw_load<ST>(px, a, (size_t)yl * g.W + x); else raw_invalid<ST>(px);
+    PlaneRsrc rs, rs_none;
+    __amdgpu_buffer_rsrc_t rs_out, rs_fb;
+    {
+        const unsigned npx = (unsigned)g.rows * (unsigned)g.W;
+        rs.colour = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, (int)(npx * CB), 0x00020000);
+        rs.motion = __builtin_amdgcn_make_buffer_rsrc((void*)a.motion, 0, (int)(npx * 16u), 0x00020000);
+        rs.normal = __builtin_amdgcn_make_buffer_rsrc((void*)a.normal, 0, (int)(npx * 8u), 0x00020000);
+        rs_none.colour = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, 0, 0x00020000);   // zero records: every load returns 0
+        rs_none.motion = __builtin_amdgcn_make_buffer_rsrc((void*)a.motion, 0, 0, 0x00020000);
+        rs_none.normal = __builtin_amdgcn_make_buffer_rsrc((void*)a.normal, 0, 0, 0x00020000);
+        rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(npx * CB), 0x00020000);
+        rs_fb = __builtin_amdgcn_make_buffer_rsrc(a.feedback ? a.feedback : a.out, 0, a.feedback ? (int)(npx * CB) : 0, 0x00020000);
+    }
+
+    // stage decimated rows jn .. jn+kRG-1: this wave's row is jn+rg (own pixel, and a halo pixel on lanes < NH)
+    typedef RawPx<ST, true> OwnPx;
+    typedef RawPx<ST, false> HaloPx;
+    auto fetch = [&](int jn, OwnPx& own, HaloPx& halo) __attribute__((always_inline)) {
+        const int y = ybase + S * (jn + rg), yl = y - g.y0;                                 // scalar
+        const bool rok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows;
+        const int srow = rok ? yl * g.W : 0;
+        if (rok) { raw_load<ST, true>(own, rs, vo_c, vo_m, vo_n, srow); raw_load<ST, false>(halo, rs, vh_c, vh_m, vh_n, srow); }
+        else { raw_load<ST, true>(own, rs_none, vo_c, vo_m, vo_n, 0); raw_load<ST, false>(halo, rs_none, vh_c, vh_m, vh_n, 0); }
     };
-    // stage decimated rows jn .. jn+kRG-1 into ring slots sl .. sl+kRG-1 (mod kRing): own pixel of row jn+rg,
-    // halo pixel of row jn+hrow
-    auto fetch = [&](int jn, RawPx<ST>& own, RawPx<ST>& halo) {
-        fetch_px(jn + rg, gx, own);
-        if (has_halo) fetch_px(jn + hrow, hx, halo);
-    };
-    auto commit = [&](int sl, const RawPx<ST>& own, const RawPx<ST>& halo) {
-        int so = sl + rg; so = so >= kRing ? so - kRing : so;
-        commit_px<ST>(own, recA, recB, recD, so * WL + oli);
-        if (has_halo) { int sh = sl + hrow; sh = sh >= kRing ? sh - kRing : sh; commit_px<ST>(halo, recA, recB, recD, sh * WL + hli); }
+    auto commit = [&](int sl, const OwnPx& own, const HaloPx& halo) __attribute__((always_inline)) {
+        int so = sl + rg; so = so >= kRing ? so - kRing : so;                                // scalar
+        commit_px<ST, true>(own, recA, recB, so * WL + oli);
+        if (has_halo) commit_px<ST, false>(halo, recA, recB, so * WL + hli);
     };
 
-    // prologue: ring rows 0..kRing-1 = decimated rows j0-2 .. j0+kRG+1
+    // ddepth of this thread's next two centres (rows j0+rg, j0+2+rg).  A staged row becomes a centre two steps
+    // after it is committed; its ddepth is taken over at commit time (never at fetch time: that would wait for
+    // the prefetch it was issued with).
+    float dq0 = 0.f, dq1 = 0.f;
 #pragma unroll 1
     for (int r = 0; r < kRing; r += kRG) {
-        RawPx<ST> o, h;
+        OwnPx o;
+        HaloPx h;
         fetch(j0 - 2 + r, o, h);
         commit(r, o, h);
+        if (r == 2) dq0 = __uint_as_float(o.zd.y);
+        if (r == 4) dq1 = __uint_as_float(o.zd.y);
     }
     __syncthreads();
 
     const float phi_n = a.phi_normal;              // != 0 (launcher)
     int slot0 = 0;
-    // Rows are fetched TWO steps ahead of their use: set `pn` holds the rows the next step needs (already landed by
-    // the time they are committed), set `pf` the rows of the step after, in flight during this step's arithmetic.
-    RawPx<ST> pn_o, pn_h;
-    if (MODE != 2 && j0 + kRG < j1) fetch(j0 + kRG + 2, pn_o, pn_h);
-    for (int j = j0; j < j1; j += kRG) {
+#ifdef SVGF_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t) :: "memory");
+#endif
+
+    // One step: produce decimated rows j (waves of row group 0) and j+1 (row group 1) from the ring.  `cs` holds
+    // the rows the NEXT step needs (fetched during the previous step, landed by now; committed at the end of this
+    // one), `fs` receives the rows of the step after that — in flight during this step's arithmetic.
+    auto step = [&](int j, OwnPx& cs_o, HaloPx& cs_h, OwnPx& fs_o, HaloPx& fs_h) __attribute__((always_inline)) {
         const bool more = MODE != 2 && (j + kRG) < j1;
         const bool more2 = MODE != 2 && (j + 2 * kRG) < j1;
-        RawPx<ST> pf_o, pf_h;
-        if (more2) fetch(j + 2 * kRG + 2, pf_o, pf_h);
+        if (more2) fetch(j + 2 * kRG + 2, fs_o, fs_h);
+        SVGF_STAMP(0);                             // fetch issue
 
-        // this thread's centre is ring row 2+rg, its taps ring rows rg .. rg+4
+        // this thread's centre is ring row 2+rg, its taps ring rows rg .. rg+4; columns oli-2S .. oli+2S
         int rowbase[5];
 #pragma unroll
-        for (int r = 0; r < 5; r++) { int sl = slot0 + rg + r; sl = sl >= kRing ? sl - kRing : sl; rowbase[r] = sl * WL + oli; }
+        for (int r = 0; r < 5; r++) { int sl = slot0 + rg + r; sl = sl >= kRing ? sl - kRing : sl; rowbase[r] = sl * WL + col; }   // scalar + lane constant
 
-        const f32x4 cA = recA[rowbase[2]], cB = recB[rowbase[2]];
-        const float cdz = recD[rowbase[2]];
+        const f32x4 cA = recA[rowbase[2] + 2 * S], cB = recB[rowbase[2] + 2 * S];
+        const float cdz = cB.y == kSkyZ ? 0.0f : dq0;                                        // GetDepth: sky -> ddepth 0
         const f32x2 lzc = {cB.x, cB.y};                                                      // centre luminance, depth
         const float ncz = cB.w;
         const uint32_t nc01 = __float_as_uint(cB.z);
@@ -432,18 +481,18 @@ __global__ __launch_bounds__(kThreads, 4) void atrous_lds_kernel(Geo g, AtrousAr
         float sw = 1.0f;                                                                      // :567
         f32x2 srg = {cA.x, cA.y}, sbv = {cA.z, cA.w};                                         // :568
 
+        // a wave whose 64 centres are all sky (a band of cleared texels) has nothing to filter (:554-558)
+        const bool wave_has_surface = __ballot(lzc.y != kSkyZ) != 0ull;
         // One ring row at a time (5 taps = 10 x ds_read_b128 in flight).  The empty asm statements pin that
         // order: left alone, instruction selection sinks all arithmetic below all 50 LDS reads of the unrolled
         // loop (256 VGPRs + scratch spills).
-        // a wave whose 64 centres are all sky (a band of cleared texels) has nothing to filter (:554-558)
-        const bool wave_has_surface = __ballot(lzc.y != kSkyZ) != 0ull;
 #pragma unroll
         for (int r = 0; r < (MODE == 1 ? 0 : 5); r++) {
             if (!wave_has_surface) break;
             const int yy = r - 2;
             f32x4 tA[5], tB[5];
 #pragma unroll
-            for (int xx = -2; xx <= 2; xx++) { tA[xx + 2] = recA[rowbase[r] + xx * S]; tB[xx + 2] = recB[rowbase[r] + xx * S]; }
+            for (int k = 0; k < 5; k++) { tA[k] = recA[rowbase[r] + k * S]; tB[k] = recB[rowbase[r] + k * S]; }
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int xx = -2; xx <= 2; xx++) {
@@ -451,7 +500,7 @@ __global__ __launch_bounds__(kThreads, 4) void atrous_lds_kernel(Geo g, AtrousAr
                 const f32x4 A = tA[xx + 2], B = tB[xx + 2];
                 const int axx = xx < 0 ? -xx : xx, ayy = yy < 0 ? -yy : yy;
                 const float d = clamp01(fmaf(B.w, ncz, dot2_h2(__float_as_uint(B.z), nc01)));
-                const f32x2 dlz = (f32x2){B.x, B.y} - lzc;                                // (dl, dz): one v_pk_add_f32
+                const f32x2 dlz = (f32x2){B.x, B.y} - lzc;
                 float e = fmaf(hw_log2(d), phi_n, klog2(axx, ayy));
                 e = fmaf(-fabsf(dlz.x), il, e);
                 e = fmaf(-fabsf(dlz.y), iz[len_class(xx, yy)], e);
@@ -463,60 +512,96 @@ __global__ __launch_bounds__(kThreads, 4) void atrous_lds_kernel(Geo g, AtrousAr
             }
             asm volatile("" : "+v"(sw), "+v"(srg), "+v"(sbv) :: "memory");
         }
+        SVGF_STAMP(1);                             // centre setup + tap loop
 
-        const int jj = j + rg;
-        if (jj < j1 && gx < g.W) {
-            const size_t idx = (size_t)(ybase + S * jj - g.y0) * g.W + gx;
-            if (lzc.y == kSkyZ) {
-                Store<ST>::st4(a.out, idx, make_float4(cA.x, cA.y, cA.z, cA.w));                   // :554-558
+        // Output value now, its stores AFTER the ring refill: hipcc's vmcnt bookkeeping cannot tell that the rows
+        // committed below were fetched long before this step's stores, so stores issued first would be waited for.
+        float4 o;
+        if (lzc.y == kSkyZ) {
+            o = make_float4(cA.x, cA.y, cA.z, cA.w);                                               // :554-558
+        } else {
+            const float inv = hw_rcp(sw);                                                          // sw >= 1
+            o = make_float4(srg.x * inv, srg.y * inv, sbv.x * inv, sbv.y * (inv * inv));           // :615
+        }
+        SVGF_STAMP(2);                             // epilogue
+        if (more) {
+            // Raw barriers: __syncthreads() would also wait for vmcnt(0), i.e. for the prefetch issued at the
+            // start of this step — exactly the latency the two-step prefetch exists to hide.  Only this wave's
+            // LDS reads/writes have to be done.
+            lds_barrier();                         // every wave is done reading the kRG oldest ring rows
+            SVGF_STAMP(3);                         // barrier 1
+            commit(slot0, cs_o, cs_h);
+            dq0 = dq1; dq1 = __uint_as_float(cs_o.zd.y);                                     // row j+4+rg: the centre two steps on
+            slot0 += kRG; if (slot0 >= kRing) slot0 -= kRing;
+            SVGF_STAMP(4);                         // wait for the staged rows + convert + LDS writes
+            lds_barrier();
+            SVGF_STAMP(5);                         // barrier 2
+        }
+        if (j + rg < j1) {                                                                         // scalar
+            const int srow = (ybase + S * (j + rg) - g.y0) * g.W;
+            // columns outside the frame carry the out-of-range offset: the store is dropped by the range check
+            if constexpr (ST == 0) {
+                const u32x4 raw = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(raw, rs_out, vo_c, srow * CB, 0);                       // :618
+                __builtin_amdgcn_raw_buffer_store_b128(raw, rs_fb, lzc.y == kSkyZ ? kOob : vo_c, srow * CB, 0);   // :619-622 (not for sky)
             } else {
-                const float inv = 1.0f / sw;
-                const float4 o = make_float4(srg.x * inv, srg.y * inv, sbv.x * inv, sbv.y * (inv * inv));   // :615
-                Store<ST>::st4(a.out, idx, o);
-                if (a.feedback) Store<ST>::st4(a.feedback, idx, o);                                // :619-622
+                const u32x2 raw = {pack_h2(o.x, o.y), pack_h2(o.z, o.w)};
+                __builtin_amdgcn_raw_buffer_store_b64(raw, rs_out, vo_c, srow * CB, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(raw, rs_fb, lzc.y == kSkyZ ? kOob : vo_c, srow * CB, 0);
             }
         }
+    };
 
-        if (more) {
-            __syncthreads();                       // every wave is done reading the kRG oldest ring rows
-            commit(slot0, pn_o, pn_h);
-            slot0 += kRG; if (slot0 >= kRing) slot0 -= kRing;
-            __syncthreads();
-            pn_o = pf_o; pn_h = pf_h;
-        }
+    // two register sets take turns as "commit next" / "fetch for the step after" (no copies between steps)
+    OwnPx pa_o, pb_o;
+    HaloPx pa_h, pb_h;
+    if (MODE != 2 && j0 + kRG < j1) fetch(j0 + kRG + 2, pa_o, pa_h);
+    for (int j = j0; j < j1; j += 2 * kRG) {
+        step(j, pa_o, pa_h, pb_o, pb_h);
+        if (j + kRG < j1) step(j + kRG, pb_o, pb_h, pa_o, pa_h);
     }
+#ifdef SVGF_STAMPS
+    if ((t & 63) == 0) {
+        for (int i = 0; i < 6; i++) atomicAdd(&g_stamps[i], stamp_acc[i]);
+        atomicAdd(&g_stamps[8], 1ull);
+    }
+#endif
 }
 
-inline int resident_target() {                    // workgroups that are resident at once: 2 per CU (LDS bound)
-    static int target = 0;
-    if (!target) {
-        int dev = 0, cus = 256;
+inline int num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        target = 2 * (cus > 0 ? cus : 256);
+        if (cus <= 0) cus = 256;
     }
-    return target;
+    return cus;
 }
 
-template <int ST, int S, int MODE = 0>
+template <int ST, int S, int TX, int MODE = 0>
 hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
-    constexpr int WL = kTX + 4 * S;
-    constexpr size_t lds = (size_t)kRing * WL * 36;
+    constexpr int WL = TX + 4 * S;
+    constexpr size_t lds = (size_t)kRing * WL * kRecBytes;
+    constexpr int threads = TX * kRG;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)atrous_lds_kernel<ST, S, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)atrous_lds_kernel<ST, S, TX, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    // One round of workgroups: bands are sized so that (x tiles) x (S residues) x (bands) fills the
-    // resident slots of the chip once instead of leaving a partial last round.
+    // One round of workgroups: bands are sized so that (x tiles) x (S residues) x (bands) fills the resident
+    // slots of the chip once (LDS: 160 KiB per CU; registers: 4 waves per SIMD) instead of leaving a partial round.
+    constexpr int per_cu_lds = (int)((160 * 1024) / lds), per_cu_waves = 16 / (threads / 64);
+    constexpr int per_cu = per_cu_lds < per_cu_waves ? per_cu_lds : per_cu_waves;
     const int nrows = g.ye - g.yb;
     const int njmax = (nrows + S - 1) / S;
-    const int xtiles = (g.W + kTX - 1) / kTX;
-    int nbands = resident_target() / (xtiles * S);
+    const int xtiles = (g.W + TX - 1) / TX;
+    int nbands = per_cu * num_cus() / (xtiles * S);
     if (nbands < 1) nbands = 1;
     int band = (njmax + nbands - 1) / nbands;
     if (band < 8) band = 8;
-    band = (band + kR - 1) / kR * kR;
+    band = (band + kRG - 1) / kRG * kRG;
     nbands = (njmax + band - 1) / band;
     const dim3 grid(xtiles, S * nbands);
 #ifdef SVGF_DIAG
@@ -524,35 +609,48 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     if (!told) {
         told = true;
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)atrous_lds_kernel<ST, S, MODE>, kThreads, lds);
-        fprintf(stderr, "[svgf diag] atrous_lds<ST=%d,S=%d,MODE=%d>: lds %zu B, occupancy %d blocks/CU, grid %u x %u, band %d\n", ST, S, MODE, lds, nb, grid.x, grid.y, band);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)atrous_lds_kernel<ST, S, TX, MODE>, threads, lds);
+        fprintf(stderr, "[svgf diag] atrous_lds<ST=%d,S=%d,TX=%d,MODE=%d>: lds %zu B, occupancy %d blocks/CU (planned %d), grid %u x %u, band %d\n", ST, S, TX, MODE, lds, nb, per_cu, grid.x, grid.y, band);
     }
 #endif
-    atrous_lds_kernel<ST, S, MODE><<<grid, dim3(kThreads), lds, s>>>(g, a, band);
+    atrous_lds_kernel<ST, S, TX, MODE><<<grid, dim3(threads), lds, s>>>(g, a, band);
     return hipGetLastError();
+}
+
+#ifdef SVGF_DIAG
+inline int diag_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#endif
+
+template <int ST, int MODE>
+hipError_t launch_atrous_lds_step_tx(const Geo& g, const AtrousArgs& a, hipStream_t s, int tx) {
+    if (tx == 128) switch (a.step) {
+        case 1: return launch_atrous_lds<ST, 1, 128, MODE>(g, a, s);
+        case 2: return launch_atrous_lds<ST, 2, 128, MODE>(g, a, s);
+        case 4: return launch_atrous_lds<ST, 4, 128, MODE>(g, a, s);
+        case 8: return launch_atrous_lds<ST, 8, 128, MODE>(g, a, s);
+        case 16: return launch_atrous_lds<ST, 16, 128, MODE>(g, a, s);
+        default: return hipErrorInvalidValue;
+    }
+    switch (a.step) {
+        case 1: return launch_atrous_lds<ST, 1, 256, MODE>(g, a, s);
+        case 2: return launch_atrous_lds<ST, 2, 256, MODE>(g, a, s);
+        case 4: return launch_atrous_lds<ST, 4, 256, MODE>(g, a, s);
+        case 8: return launch_atrous_lds<ST, 8, 256, MODE>(g, a, s);
+        case 16: return launch_atrous_lds<ST, 16, 256, MODE>(g, a, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 template <int ST>
 hipError_t launch_atrous_lds_step(const Geo& g, const AtrousArgs& a, hipStream_t s) {
+    int tx = 256;
 #ifdef SVGF_DIAG
-    static const int mode = getenv("SVGF_ATROUS_MODE") ? atoi(getenv("SVGF_ATROUS_MODE")) : 0;
-    if (ST == 0 && mode == 1) switch (a.step) {
-        case 1: return launch_atrous_lds<0, 1, 1>(g, a, s); case 2: return launch_atrous_lds<0, 2, 1>(g, a, s);
-        case 4: return launch_atrous_lds<0, 4, 1>(g, a, s); case 8: return launch_atrous_lds<0, 8, 1>(g, a, s);
-        case 16: return launch_atrous_lds<0, 16, 1>(g, a, s); }
-    if (ST == 0 && mode == 2) switch (a.step) {
-        case 1: return launch_atrous_lds<0, 1, 2>(g, a, s); case 2: return launch_atrous_lds<0, 2, 2>(g, a, s);
-        case 4: return launch_atrous_lds<0, 4, 2>(g, a, s); case 8: return launch_atrous_lds<0, 8, 2>(g, a, s);
-        case 16: return launch_atrous_lds<0, 16, 2>(g, a, s); }
+    tx = diag_env("SVGF_ATROUS_TX", tx);
+    const int mode = diag_env("SVGF_ATROUS_MODE", 0);
+    if (ST == 0 && mode == 1) return launch_atrous_lds_step_tx<0, 1>(g, a, s, tx);
+    if (ST == 0 && mode == 2) return launch_atrous_lds_step_tx<0, 2>(g, a, s, tx);
 #endif
-    switch (a.step) {
-        case 1: return launch_atrous_lds<ST, 1>(g, a, s);
-        case 2: return launch_atrous_lds<ST, 2>(g, a, s);
-        case 4: return launch_atrous_lds<ST, 4>(g, a, s);
-        case 8: return launch_atrous_lds<ST, 8>(g, a, s);
-        case 16: return launch_atrous_lds<ST, 16>(g, a, s);
-        default: return hipErrorInvalidValue;
-    }
+    return launch_atrous_lds_step_tx<ST, 0>(g, a, s, tx);
 }
 
 inline dim3 grid_for(const Geo& g) { return dim3((g.W + kBX - 1) / kBX, (g.ye - g.yb + kBY - 1) / kBY); }
@@ -574,6 +672,16 @@ hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, hipSt
     else moments_kernel<1><<<grid, block, 0, s>>>(g, a);
     return hipGetLastError();
 }
+
+#ifdef SVGF_STAMPS
+extern "C" int svgf_diag_stamps(unsigned long long* out, int reset) {
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < 16; i++) out[i] = h[i];
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
+    return 0;
+}
+#endif
 
 hipError_t launch_atrous(const Geo& g, int storage, int variant, const AtrousArgs& a, hipStream_t s) {
     if (g.ye <= g.yb) return hipSuccess;

@@ -1,0 +1,37 @@
+"""Diagnostic: per-phase cycle shares of the LDS a-trous kernel from in-kernel s_memtime stamps (SVGF_DIAG build)."""
+import ctypes as C, os, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+from svgf_amd import build as b
+lib_path = os.path.join(R, "build", "libsvgf_stamps.so")
+os.makedirs(os.path.dirname(lib_path), exist_ok=True)
+b.build_library(extra_flags=["-DSVGF_DIAG", "-DSVGF_STAMPS"], out=lib_path)
+os.environ["SVGF_LIBRARY"] = lib_path
+import torch
+from svgf_amd import filter as F
+sys.argv = ["bench.py"]
+import bench
+lib = F.load_library()
+W, H = 3840, 2160
+dev = torch.device("cuda:0")
+gb, rads = bench.make_inputs(W, H, "f32", dev, nframes=2)
+d = F.Denoiser(W, H, F.Params(storage="f32", steps=5))
+for k in range(10):
+    d.Render(rads[k % 2], gb, gb)
+torch.cuda.synchronize()
+out = (C.c_ulonglong * 16)()
+lib.svgf_diag_stamps(out, 1)
+src, dst = d.new_colour(), d.new_colour()
+src.copy_(d.Render(rads[0], gb, gb))
+names = ["fetch issue", "setup + tap loop", "epilogue + stores", "barrier 1", "wait rows + commit", "barrier 2"]
+for step in (1, 4, 16):
+    lib.svgf_diag_stamps(out, 1)
+    for _ in range(5):
+        d.FilterKernel(src, dst, None, gb, step, 1)
+    torch.cuda.synchronize()
+    lib.svgf_diag_stamps(out, 1)
+    tot = sum(out[i] for i in range(6))
+    waves = out[8]
+    print(f"step {step}: waves {waves}, ticks per wave {tot / max(waves,1):.0f} (s_memtime ticks)")
+    for i, n in enumerate(names):
+        print(f"   {n:22s} {100.0 * out[i] / tot:5.1f} %   {out[i] / max(waves,1):9.0f} ticks/wave")
