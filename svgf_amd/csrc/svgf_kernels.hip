@@ -279,9 +279,10 @@ __global__ __launch_bounds__(kBX* kBY) void atrous_direct_kernel(Geo g, AtrousAr
 // Pixels outside the frame (or the strip) come back as all-zero texels from the buffer range check (a row
 // outside the frame is loaded through a zero-length resource): depth 0 = sky sentinel and a zero normal give
 // weight exactly 0, which is what skipping the tap (:579,584) does.
-constexpr int kRG = 2;                   // decimated rows produced per step (one row group of TX/64 waves each)
-constexpr int kRing = kRG + 4;
+constexpr int kRS = 2;                   // decimated rows produced per step
+constexpr int kRing = kRS + 4;
 constexpr int kRecBytes = 32;            // LDS bytes per staged pixel
+constexpr int kDefaultKR = 1;            // outputs per thread of the kernel the library launches (see atrous_lds_kernel)
 constexpr unsigned kOob = 0xFFFFFF00u;   // byte offset no plane reaches (planes are < 4 GiB)
 
 #ifdef SVGF_STAMPS
@@ -362,15 +363,19 @@ __device__ __forceinline__ float dot2_h2(uint32_t a, uint32_t b) {
 // MODE is a diagnostic knob (SVGF_DIAG builds only): 0 = the kernel, 1 = streaming only (no tap arithmetic),
 // 2 = arithmetic only (no global prefetch / ring refill after the prologue).
 //
-// Workgroup = 2*TX threads: thread t owns column (t % TX) and output row group (t / TX), i.e. with TX = 256
-// waves 0-3 produce decimated row j and waves 4-7 row j+1 of the same 256 columns from the same 6-row ring.  One
-// output per thread keeps the kernel near 100 VGPRs, so the two workgroups the ring's LDS footprint allows per CU
-// run 4 waves per SIMD — enough to cover LDS latency, the barriers and the exp2/log2 latency of the tap chain.
-template <int ST, int S, int TX, int MODE = 0>
-__global__ __launch_bounds__(TX* kRG, 4) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows) {
+// Every step produces kRS = 2 decimated rows of the workgroup's TX columns.  KR = outputs per thread:
+//   KR = 1: 2*TX threads, thread t owns column t % TX and row group t / TX (waves 0-3 row j, waves 4-7 row j+1);
+//           ~105 VGPRs, 4 waves per SIMD with the two workgroups per CU the ring's LDS footprint allows.
+//   KR = 2: TX threads, each thread produces rows j and j+1 of its column and shares the 20 taps the two outputs
+//           have in common (30 LDS record pairs per 2 outputs instead of 50): on CDNA4 an LDS read's data return
+//           occupies the SIMD's register-file write path for ~16 cycles per ds_read_b128 and delays vector ALU
+//           issue by as much (tools/ubench/tap_lds.hip), so LDS bytes per output are paid for like instructions.
+template <int ST, int S, int TX, int KR, int MODE = 0>
+__global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows) {
     constexpr int WL = TX + 4 * S;                 // staged columns per ring row
     constexpr int CB = ST == 0 ? 16 : 8;           // bytes per colour texel
     constexpr int NH = 4 * S / (TX / 64);          // halo pixels each wave stages per row (lanes 0..NH-1)
+    constexpr int NR = KR + 4;                     // ring rows a thread reads
     static_assert(NH >= 1 && NH <= 64, "halo does not fit the row group's waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* recA = (f32x4*)smem;
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(TX* kRG, 4) void atrous_lds_kernel(Geo g, AtrousArg
     // per-lane constants
     const int gx = x0 + col;                       // own column
     const int oli = col + 2 * S;                   // its LDS column
-    const bool has_halo = lane < NH;               // this lane also stages one halo pixel of its row group's row
+    const bool has_halo = lane < NH;               // this lane also stages one halo pixel per row of its row group
     const int hh = wig * NH + lane;                // 0 .. 4S-1
     const int hx = (hh < 2 * S) ? x0 - 2 * S + hh : x0 + TX + hh - 2 * S;
     const int hli = (hh < 2 * S) ? hh : TX + hh;
@@ -416,34 +421,43 @@ __global__ __launch_bounds__(TX* kRG, 4) void atrous_lds_kernel(Geo g, AtrousArg
         rs_fb = __builtin_amdgcn_make_buffer_rsrc(a.feedback ? a.feedback : a.out, 0, a.feedback ? (int)(npx * CB) : 0, 0x00020000);
     }
 
-    // stage decimated rows jn .. jn+kRG-1: this wave's row is jn+rg (own pixel, and a halo pixel on lanes < NH)
+    // A thread's share of one staged step: KR rows (jn + rg*KR + k): own pixel, and a halo pixel on lanes < NH
     typedef RawPx<ST, true> OwnPx;
     typedef RawPx<ST, false> HaloPx;
-    auto fetch = [&](int jn, OwnPx& own, HaloPx& halo) __attribute__((always_inline)) {
-        const int y = ybase + S * (jn + rg), yl = y - g.y0;                                 // scalar
-        const bool rok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows;
-        const int srow = rok ? yl * g.W : 0;
-        if (rok) { raw_load<ST, true>(own, rs, vo_c, vo_m, vo_n, srow); raw_load<ST, false>(halo, rs, vh_c, vh_m, vh_n, srow); }
-        else { raw_load<ST, true>(own, rs_none, vo_c, vo_m, vo_n, 0); raw_load<ST, false>(halo, rs_none, vh_c, vh_m, vh_n, 0); }
+    struct Staged { OwnPx o[KR]; HaloPx h[KR]; };
+    auto fetch = [&](int jn, Staged& st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < KR; k++) {
+            const int y = ybase + S * (jn + rg * KR + k), yl = y - g.y0;                    // scalar
+            const bool rok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows;
+            const int srow = rok ? yl * g.W : 0;
+            if (rok) { raw_load<ST, true>(st.o[k], rs, vo_c, vo_m, vo_n, srow); raw_load<ST, false>(st.h[k], rs, vh_c, vh_m, vh_n, srow); }
+            else { raw_load<ST, true>(st.o[k], rs_none, vo_c, vo_m, vo_n, 0); raw_load<ST, false>(st.h[k], rs_none, vh_c, vh_m, vh_n, 0); }
+        }
     };
-    auto commit = [&](int sl, const OwnPx& own, const HaloPx& halo) __attribute__((always_inline)) {
-        int so = sl + rg; so = so >= kRing ? so - kRing : so;                                // scalar
-        commit_px<ST, true>(own, recA, recB, so * WL + oli);
-        if (has_halo) commit_px<ST, false>(halo, recA, recB, so * WL + hli);
+    auto commit = [&](int sl, const Staged& st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < KR; k++) {
+            int so = sl + rg * KR + k; so = so >= kRing ? so - kRing : so;                   // scalar
+            commit_px<ST, true>(st.o[k], recA, recB, so * WL + oli);
+            if (has_halo) commit_px<ST, false>(st.h[k], recA, recB, so * WL + hli);
+        }
     };
 
-    // ddepth of this thread's next two centres (rows j0+rg, j0+2+rg).  A staged row becomes a centre two steps
-    // after it is committed; its ddepth is taken over at commit time (never at fetch time: that would wait for
-    // the prefetch it was issued with).
-    float dq0 = 0.f, dq1 = 0.f;
+    // ddepth of this thread's next two centres per output row (rows j0+rg*KR+k and two rows further).  A staged row
+    // becomes a centre two steps after it is committed; its ddepth is taken over at commit time (never at fetch
+    // time: that would wait for the prefetch it was issued with).
+    float dq0[KR], dq1[KR];
 #pragma unroll 1
-    for (int r = 0; r < kRing; r += kRG) {
-        OwnPx o;
-        HaloPx h;
-        fetch(j0 - 2 + r, o, h);
-        commit(r, o, h);
-        if (r == 2) dq0 = __uint_as_float(o.zd.y);
-        if (r == 4) dq1 = __uint_as_float(o.zd.y);
+    for (int r = 0; r < kRing; r += kRS) {
+        Staged st;
+        fetch(j0 - 2 + r, st);
+        commit(r, st);
+#pragma unroll
+        for (int k = 0; k < KR; k++) {
+            if (r == 2) dq0[k] = __uint_as_float(st.o[k].zd.y);
+            if (r == 4) dq1[k] = __uint_as_float(st.o[k].zd.y);
+        }
     }
     __syncthreads();
 
@@ -454,111 +468,139 @@ __global__ __launch_bounds__(TX* kRG, 4) void atrous_lds_kernel(Geo g, AtrousArg
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t) :: "memory");
 #endif
 
-    // One step: produce decimated rows j (waves of row group 0) and j+1 (row group 1) from the ring.  `cs` holds
-    // the rows the NEXT step needs (fetched during the previous step, landed by now; committed at the end of this
-    // one), `fs` receives the rows of the step after that — in flight during this step's arithmetic.
-    auto step = [&](int j, OwnPx& cs_o, HaloPx& cs_h, OwnPx& fs_o, HaloPx& fs_h) __attribute__((always_inline)) {
-        const bool more = MODE != 2 && (j + kRG) < j1;
-        const bool more2 = MODE != 2 && (j + 2 * kRG) < j1;
-        if (more2) fetch(j + 2 * kRG + 2, fs_o, fs_h);
+    // One step: produce decimated rows j and j+1 from the ring.  `cs` holds the rows the NEXT step needs (fetched
+    // during the previous step, landed by now; committed at the end of this one), `fs` receives the rows of the
+    // step after that — in flight during this step's arithmetic.
+    auto step = [&](int j, Staged& cs, Staged& fs) __attribute__((always_inline)) {
+        const bool more = MODE != 2 && (j + kRS) < j1;
+        const bool more2 = MODE != 2 && (j + 2 * kRS) < j1;
+        if (more2) fetch(j + 2 * kRS + 2, fs);
         SVGF_STAMP(0);                             // fetch issue
 
-        // this thread's centre is ring row 2+rg, its taps ring rows rg .. rg+4; columns oli-2S .. oli+2S
-        int rowbase[5];
+        // this thread's centres are ring rows 2+rg*KR+k, its taps ring rows rg*KR .. rg*KR+KR+3; columns oli-2S .. oli+2S
+        int rowbase[NR];
 #pragma unroll
-        for (int r = 0; r < 5; r++) { int sl = slot0 + rg + r; sl = sl >= kRing ? sl - kRing : sl; rowbase[r] = sl * WL + col; }   // scalar + lane constant
+        for (int r = 0; r < NR; r++) { int sl = slot0 + rg * KR + r; sl = sl >= kRing ? sl - kRing : sl; rowbase[r] = sl * WL + col; }   // scalar + lane constant
 
-        const f32x4 cA = recA[rowbase[2] + 2 * S], cB = recB[rowbase[2] + 2 * S];
-        const float cdz = cB.y == kSkyZ ? 0.0f : dq0;                                        // GetDepth: sky -> ddepth 0
-        const f32x2 lzc = {cB.x, cB.y};                                                      // centre luminance, depth
-        const float ncz = cB.w;
-        const uint32_t nc01 = __float_as_uint(cB.z);
-        const float phi_l = a.phi_colour * sqrtf(fmaxf(0.0f, 1e-10f + cA.w));                // :562
-        const float il = fminf(hw_rcp(phi_l), 1e30f) * kLog2e;
-        const float izb = hw_rcp(fmaxf(cdz, 1e-6f) * (float)S) * kLog2e;                     // :563
-        const float iz[5] = {izb, izb * 0.70710678118654752f, izb * 0.5f, izb * 0.44721359549995794f, izb * 0.35355339059327376f};
-        // accumulators, packed by channel pairs: (r,g) and (b,variance) advance with one v_pk_fma_f32 each
-        float sw = 1.0f;                                                                      // :567
-        f32x2 srg = {cA.x, cA.y}, sbv = {cA.z, cA.w};                                         // :568
+        f32x4 cA[KR];
+        f32x2 lzc[KR], srg[KR], sbv[KR];
+        float ncz[KR], il[KR], iz[KR][5], sw[KR];
+        uint32_t nc01[KR];
+        bool any_surface = false;
+#pragma unroll
+        for (int k = 0; k < KR; k++) {
+            const f32x4 A = recA[rowbase[2 + k] + 2 * S], B = recB[rowbase[2 + k] + 2 * S];
+            cA[k] = A;
+            const float cdz = B.y == kSkyZ ? 0.0f : dq0[k];                                  // GetDepth: sky -> ddepth 0
+            lzc[k] = (f32x2){B.x, B.y};                                                      // centre luminance, depth
+            ncz[k] = B.w;
+            nc01[k] = __float_as_uint(B.z);
+            const float phi_l = a.phi_colour * sqrtf(fmaxf(0.0f, 1e-10f + A.w));             // :562
+            il[k] = fminf(hw_rcp(phi_l), 1e30f) * kLog2e;
+            const float izb = hw_rcp(fmaxf(cdz, 1e-6f) * (float)S) * kLog2e;                 // :563
+            iz[k][0] = izb; iz[k][1] = izb * 0.70710678118654752f; iz[k][2] = izb * 0.5f;
+            iz[k][3] = izb * 0.44721359549995794f; iz[k][4] = izb * 0.35355339059327376f;
+            // accumulators, packed by channel pairs: (r,g) and (b,variance) advance with one v_pk_fma_f32 each
+            sw[k] = 1.0f;                                                                     // :567
+            srg[k] = (f32x2){A.x, A.y}; sbv[k] = (f32x2){A.z, A.w};                           // :568
+            any_surface = any_surface || B.y != kSkyZ;
+        }
 
-        // a wave whose 64 centres are all sky (a band of cleared texels) has nothing to filter (:554-558)
-        const bool wave_has_surface = __ballot(lzc.y != kSkyZ) != 0ull;
-        // One ring row at a time (5 taps = 10 x ds_read_b128 in flight).  The empty asm statements pin that
-        // order: left alone, instruction selection sinks all arithmetic below all 50 LDS reads of the unrolled
-        // loop (256 VGPRs + scratch spills).
+        // a wave whose centres are all sky (a band of cleared texels) has nothing to filter (:554-558)
+        const bool wave_has_surface = __ballot(any_surface) != 0ull;
+        // One ring row at a time (5 taps = 10 x ds_read_b128 in flight; KR = 2 reads the next row before it
+        // consumes the current one).  The empty asm statements pin that order: left alone, instruction selection
+        // sinks all arithmetic below all LDS reads of the unrolled loop (256 VGPRs + scratch spills).
+        f32x4 tA[KR][5], tB[KR][5];
+        auto load_row = [&](int r, int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < (MODE == 1 ? 0 : 5); r++) {
-            if (!wave_has_surface) break;
-            const int yy = r - 2;
-            f32x4 tA[5], tB[5];
+            for (int c = 0; c < 5; c++) { tA[buf][c] = recA[rowbase[r] + c * S]; tB[buf][c] = recB[rowbase[r] + c * S]; }
+        };
+        if (MODE != 1 && wave_has_surface) {
+            if (KR == 2) load_row(0, 0);
 #pragma unroll
-            for (int k = 0; k < 5; k++) { tA[k] = recA[rowbase[r] + k * S]; tB[k] = recB[rowbase[r] + k * S]; }
-            asm volatile("" ::: "memory");
+            for (int r = 0; r < NR; r++) {
+                const int buf = KR == 2 ? (r & 1) : 0;
+                if (KR == 2) { if (r + 1 < NR) load_row(r + 1, buf ^ 1); } else load_row(r, 0);
+                asm volatile("" ::: "memory");
 #pragma unroll
-            for (int xx = -2; xx <= 2; xx++) {
-                if (xx == 0 && yy == 0) continue;                                        // centre: weight 1, already in
-                const f32x4 A = tA[xx + 2], B = tB[xx + 2];
-                const int axx = xx < 0 ? -xx : xx, ayy = yy < 0 ? -yy : yy;
-                const float d = clamp01(fmaf(B.w, ncz, dot2_h2(__float_as_uint(B.z), nc01)));
-                const f32x2 dlz = (f32x2){B.x, B.y} - lzc;
-                float e = fmaf(hw_log2(d), phi_n, klog2(axx, ayy));
-                e = fmaf(-fabsf(dlz.x), il, e);
-                e = fmaf(-fabsf(dlz.y), iz[len_class(xx, yy)], e);
-                const float w = hw_exp2(e);
-                const f32x2 ww = {w, w * w};                                              // weights of (b, variance): :604-608
-                sw += w;                                                                  // :607
-                srg = __builtin_elementwise_fma((f32x2){w, w}, (f32x2){A.x, A.y}, srg);
-                sbv = __builtin_elementwise_fma(ww, (f32x2){A.z, A.w}, sbv);
+                for (int xx = -2; xx <= 2; xx++) {
+                    const f32x4 A = tA[buf][xx + 2], B = tB[buf][xx + 2];
+#pragma unroll
+                    for (int k = 0; k < KR; k++) {
+                        const int yy = r - 2 - k;
+                        if (yy < -2 || yy > 2 || (xx == 0 && yy == 0)) continue;             // compile time; centre: weight 1, already in
+                        const int axx = xx < 0 ? -xx : xx, ayy = yy < 0 ? -yy : yy;
+                        const float d = clamp01(fmaf(B.w, ncz[k], dot2_h2(__float_as_uint(B.z), nc01[k])));
+                        const f32x2 dlz = (f32x2){B.x, B.y} - lzc[k];
+                        float e = fmaf(hw_log2(d), phi_n, klog2(axx, ayy));
+                        e = fmaf(-fabsf(dlz.x), il[k], e);
+                        e = fmaf(-fabsf(dlz.y), iz[k][len_class(xx, yy)], e);
+                        const float w = hw_exp2(e);
+                        const f32x2 ww = {w, w * w};                                          // weights of (b, variance): :604-608
+                        sw[k] += w;                                                           // :607
+                        srg[k] = __builtin_elementwise_fma((f32x2){w, w}, (f32x2){A.x, A.y}, srg[k]);
+                        sbv[k] = __builtin_elementwise_fma(ww, (f32x2){A.z, A.w}, sbv[k]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < KR; k++) asm volatile("" : "+v"(sw[k]), "+v"(srg[k]), "+v"(sbv[k]) :: "memory");
             }
-            asm volatile("" : "+v"(sw), "+v"(srg), "+v"(sbv) :: "memory");
         }
         SVGF_STAMP(1);                             // centre setup + tap loop
 
-        // Output value now, its stores AFTER the ring refill: hipcc's vmcnt bookkeeping cannot tell that the rows
+        // Output values now, their stores AFTER the ring refill: hipcc's vmcnt bookkeeping cannot tell that the rows
         // committed below were fetched long before this step's stores, so stores issued first would be waited for.
-        float4 o;
-        if (lzc.y == kSkyZ) {
-            o = make_float4(cA.x, cA.y, cA.z, cA.w);                                               // :554-558
-        } else {
-            const float inv = hw_rcp(sw);                                                          // sw >= 1
-            o = make_float4(srg.x * inv, srg.y * inv, sbv.x * inv, sbv.y * (inv * inv));           // :615
+        float4 o[KR];
+#pragma unroll
+        for (int k = 0; k < KR; k++) {
+            if (lzc[k].y == kSkyZ) {
+                o[k] = make_float4(cA[k].x, cA[k].y, cA[k].z, cA[k].w);                            // :554-558
+            } else {
+                const float inv = hw_rcp(sw[k]);                                                   // sw >= 1
+                o[k] = make_float4(srg[k].x * inv, srg[k].y * inv, sbv[k].x * inv, sbv[k].y * (inv * inv));   // :615
+            }
         }
         SVGF_STAMP(2);                             // epilogue
         if (more) {
             // Raw barriers: __syncthreads() would also wait for vmcnt(0), i.e. for the prefetch issued at the
             // start of this step — exactly the latency the two-step prefetch exists to hide.  Only this wave's
             // LDS reads/writes have to be done.
-            lds_barrier();                         // every wave is done reading the kRG oldest ring rows
+            lds_barrier();                         // every wave is done reading the kRS oldest ring rows
             SVGF_STAMP(3);                         // barrier 1
-            commit(slot0, cs_o, cs_h);
-            dq0 = dq1; dq1 = __uint_as_float(cs_o.zd.y);                                     // row j+4+rg: the centre two steps on
-            slot0 += kRG; if (slot0 >= kRing) slot0 -= kRing;
+            commit(slot0, cs);
+#pragma unroll
+            for (int k = 0; k < KR; k++) { dq0[k] = dq1[k]; dq1[k] = __uint_as_float(cs.o[k].zd.y); }   // rows j+4+..: the centres two steps on
+            slot0 += kRS; if (slot0 >= kRing) slot0 -= kRing;
             SVGF_STAMP(4);                         // wait for the staged rows + convert + LDS writes
             lds_barrier();
             SVGF_STAMP(5);                         // barrier 2
         }
-        if (j + rg < j1) {                                                                         // scalar
-            const int srow = (ybase + S * (j + rg) - g.y0) * g.W;
-            // columns outside the frame carry the out-of-range offset: the store is dropped by the range check
-            if constexpr (ST == 0) {
-                const u32x4 raw = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
-                __builtin_amdgcn_raw_buffer_store_b128(raw, rs_out, vo_c, srow * CB, 0);                       // :618
-                __builtin_amdgcn_raw_buffer_store_b128(raw, rs_fb, lzc.y == kSkyZ ? kOob : vo_c, srow * CB, 0);   // :619-622 (not for sky)
-            } else {
-                const u32x2 raw = {pack_h2(o.x, o.y), pack_h2(o.z, o.w)};
-                __builtin_amdgcn_raw_buffer_store_b64(raw, rs_out, vo_c, srow * CB, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(raw, rs_fb, lzc.y == kSkyZ ? kOob : vo_c, srow * CB, 0);
+#pragma unroll
+        for (int k = 0; k < KR; k++) {
+            if (j + rg * KR + k < j1) {                                                            // scalar
+                const int srow = (ybase + S * (j + rg * KR + k) - g.y0) * g.W;
+                const bool sky = lzc[k].y == kSkyZ;
+                // columns outside the frame carry the out-of-range offset: the store is dropped by the range check
+                if constexpr (ST == 0) {
+                    const u32x4 raw = {__float_as_uint(o[k].x), __float_as_uint(o[k].y), __float_as_uint(o[k].z), __float_as_uint(o[k].w)};
+                    __builtin_amdgcn_raw_buffer_store_b128(raw, rs_out, vo_c, srow * CB, 0);                   // :618
+                    __builtin_amdgcn_raw_buffer_store_b128(raw, rs_fb, sky ? kOob : vo_c, srow * CB, 0);      // :619-622 (not for sky)
+                } else {
+                    const u32x2 raw = {pack_h2(o[k].x, o[k].y), pack_h2(o[k].z, o[k].w)};
+                    __builtin_amdgcn_raw_buffer_store_b64(raw, rs_out, vo_c, srow * CB, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(raw, rs_fb, sky ? kOob : vo_c, srow * CB, 0);
+                }
             }
         }
     };
 
     // two register sets take turns as "commit next" / "fetch for the step after" (no copies between steps)
-    OwnPx pa_o, pb_o;
-    HaloPx pa_h, pb_h;
-    if (MODE != 2 && j0 + kRG < j1) fetch(j0 + kRG + 2, pa_o, pa_h);
-    for (int j = j0; j < j1; j += 2 * kRG) {
-        step(j, pa_o, pa_h, pb_o, pb_h);
-        if (j + kRG < j1) step(j + kRG, pb_o, pb_h, pa_o, pa_h);
+    Staged pa, pb;
+    if (MODE != 2 && j0 + kRS < j1) fetch(j0 + kRS + 2, pa);
+    for (int j = j0; j < j1; j += 2 * kRS) {
+        step(j, pa, pb);
+        if (j + kRS < j1) step(j + kRS, pb, pa);
     }
 #ifdef SVGF_STAMPS
     if ((t & 63) == 0) {
@@ -579,20 +621,20 @@ inline int num_cus() {
     return cus;
 }
 
-template <int ST, int S, int TX, int MODE = 0>
+template <int ST, int S, int TX, int KR, int MODE = 0>
 hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     constexpr int WL = TX + 4 * S;
     constexpr size_t lds = (size_t)kRing * WL * kRecBytes;
-    constexpr int threads = TX * kRG;
+    constexpr int threads = TX * (kRS / KR);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)atrous_lds_kernel<ST, S, TX, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)atrous_lds_kernel<ST, S, TX, KR, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     // One round of workgroups: bands are sized so that (x tiles) x (S residues) x (bands) fills the resident
-    // slots of the chip once (LDS: 160 KiB per CU; registers: 4 waves per SIMD) instead of leaving a partial round.
-    constexpr int per_cu_lds = (int)((160 * 1024) / lds), per_cu_waves = 16 / (threads / 64);
+    // slots of the chip once (LDS: 160 KiB per CU; registers: 4 / 2 waves per SIMD) instead of leaving a partial round.
+    constexpr int per_cu_lds = (int)((160 * 1024) / lds), per_cu_waves = (KR == 1 ? 16 : 8) / (threads / 64);
     constexpr int per_cu = per_cu_lds < per_cu_waves ? per_cu_lds : per_cu_waves;
     const int nrows = g.ye - g.yb;
     const int njmax = (nrows + S - 1) / S;
@@ -601,7 +643,7 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     if (nbands < 1) nbands = 1;
     int band = (njmax + nbands - 1) / nbands;
     if (band < 8) band = 8;
-    band = (band + kRG - 1) / kRG * kRG;
+    band = (band + kRS - 1) / kRS * kRS;
     nbands = (njmax + band - 1) / band;
     const dim3 grid(xtiles, S * nbands);
 #ifdef SVGF_DIAG
@@ -609,11 +651,11 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     if (!told) {
         told = true;
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)atrous_lds_kernel<ST, S, TX, MODE>, threads, lds);
-        fprintf(stderr, "[svgf diag] atrous_lds<ST=%d,S=%d,TX=%d,MODE=%d>: lds %zu B, occupancy %d blocks/CU (planned %d), grid %u x %u, band %d\n", ST, S, TX, MODE, lds, nb, per_cu, grid.x, grid.y, band);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)atrous_lds_kernel<ST, S, TX, KR, MODE>, threads, lds);
+        fprintf(stderr, "[svgf diag] atrous_lds<ST=%d,S=%d,TX=%d,KR=%d,MODE=%d>: lds %zu B, occupancy %d blocks/CU (planned %d), grid %u x %u, band %d\n", ST, S, TX, KR, MODE, lds, nb, per_cu, grid.x, grid.y, band);
     }
 #endif
-    atrous_lds_kernel<ST, S, TX, MODE><<<grid, dim3(threads), lds, s>>>(g, a, band);
+    atrous_lds_kernel<ST, S, TX, KR, MODE><<<grid, dim3(threads), lds, s>>>(g, a, band);
     return hipGetLastError();
 }
 
@@ -621,36 +663,29 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
 inline int diag_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 #endif
 
-template <int ST, int MODE>
-hipError_t launch_atrous_lds_step_tx(const Geo& g, const AtrousArgs& a, hipStream_t s, int tx) {
-    if (tx == 128) switch (a.step) {
-        case 1: return launch_atrous_lds<ST, 1, 128, MODE>(g, a, s);
-        case 2: return launch_atrous_lds<ST, 2, 128, MODE>(g, a, s);
-        case 4: return launch_atrous_lds<ST, 4, 128, MODE>(g, a, s);
-        case 8: return launch_atrous_lds<ST, 8, 128, MODE>(g, a, s);
-        case 16: return launch_atrous_lds<ST, 16, 128, MODE>(g, a, s);
-        default: return hipErrorInvalidValue;
-    }
+template <int ST, int KR, int MODE>
+hipError_t launch_atrous_lds_step_kr(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     switch (a.step) {
-        case 1: return launch_atrous_lds<ST, 1, 256, MODE>(g, a, s);
-        case 2: return launch_atrous_lds<ST, 2, 256, MODE>(g, a, s);
-        case 4: return launch_atrous_lds<ST, 4, 256, MODE>(g, a, s);
-        case 8: return launch_atrous_lds<ST, 8, 256, MODE>(g, a, s);
-        case 16: return launch_atrous_lds<ST, 16, 256, MODE>(g, a, s);
+        case 1: return launch_atrous_lds<ST, 1, 256, KR, MODE>(g, a, s);
+        case 2: return launch_atrous_lds<ST, 2, 256, KR, MODE>(g, a, s);
+        case 4: return launch_atrous_lds<ST, 4, 256, KR, MODE>(g, a, s);
+        case 8: return launch_atrous_lds<ST, 8, 256, KR, MODE>(g, a, s);
+        case 16: return launch_atrous_lds<ST, 16, 256, KR, MODE>(g, a, s);
         default: return hipErrorInvalidValue;
     }
 }
 
 template <int ST>
 hipError_t launch_atrous_lds_step(const Geo& g, const AtrousArgs& a, hipStream_t s) {
-    int tx = 256;
+    int kr = kDefaultKR;
 #ifdef SVGF_DIAG
-    tx = diag_env("SVGF_ATROUS_TX", tx);
+    kr = diag_env("SVGF_ATROUS_KR", kr);
     const int mode = diag_env("SVGF_ATROUS_MODE", 0);
-    if (ST == 0 && mode == 1) return launch_atrous_lds_step_tx<0, 1>(g, a, s, tx);
-    if (ST == 0 && mode == 2) return launch_atrous_lds_step_tx<0, 2>(g, a, s, tx);
+    if (ST == 0 && mode == 1) return kr == 2 ? launch_atrous_lds_step_kr<0, 2, 1>(g, a, s) : launch_atrous_lds_step_kr<0, 1, 1>(g, a, s);
+    if (ST == 0 && mode == 2) return kr == 2 ? launch_atrous_lds_step_kr<0, 2, 2>(g, a, s) : launch_atrous_lds_step_kr<0, 1, 2>(g, a, s);
+    if (kr != kDefaultKR) return kr == 2 ? launch_atrous_lds_step_kr<ST, 2, 0>(g, a, s) : launch_atrous_lds_step_kr<ST, 1, 0>(g, a, s);
 #endif
-    return launch_atrous_lds_step_tx<ST, 0>(g, a, s, tx);
+    return launch_atrous_lds_step_kr<ST, kDefaultKR, 0>(g, a, s);
 }
 
 inline dim3 grid_for(const Geo& g) { return dim3((g.W + kBX - 1) / kBX, (g.ye - g.yb + kBY - 1) / kBY); }
