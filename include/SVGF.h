@@ -140,6 +140,8 @@ public:
         }
         return Buffers.FilterPlane(PingPong);
     }
+    // application::TAA (App.cu:516-522): Filtered -> Out with the previous Out as history
+    void TAA(const void* Filtered, const void* History, void* Out) { check(svgf_taa(Ctx, Filtered, History, Out), "svgf_taa"); }
     // application::EndFrame's share (App.cu:374): this frame's colour/moments/history become the previous frame's
     void EndFrame() {
         std::swap(Buffers.ColourBuffer, Buffers.HistoryBufferColour);

@@ -119,6 +119,11 @@ int svgf_moments(svgf_ctx* ctx, const void* colour, void* out, const void* momen
 int svgf_atrous(svgf_ctx* ctx, const void* in, void* out, void* feedback, const svgf_gbuffer* gbuf,
                 int step, int iteration);
 
+/* The stage after the path — replaces application::TAA (App.cu:516-522) launching filter::TAAFilterKernel
+ * (Filter.cuh:288-357): neighbourhood-clamped temporal anti-aliasing in PAL-YUV + linear->sRGB.  `history` is the
+ * previous call's `out` (a separate plane: the reference reads it from the buffer it is writing, a race). */
+int svgf_taa(svgf_ctx* ctx, const void* filtered, const void* history, void* out);
+
 /* Whole frame — replaces the sequence application::Render runs (App.cu:552-556) on context-owned
  * state (RenderBuffer[2], MomentsBuffer[2], FilterBuffer[2], history; App.h:138-141).
  * `prev` may be NULL on the first frame.  *result receives the device pointer of the final

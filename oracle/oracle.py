@@ -84,6 +84,13 @@ def atrous(W, H, storage, src, dst, feedback, gb, *, step, phi_colour, phi_norma
     assert rc == 0
 
 
+def taa(W, H, storage, filtered, history, out, *, geo=None, nthreads=1):
+    """TAAFilterKernel (src/Filter.cuh:288-357) with a separate previous-output plane."""
+    y0, rows, yb, ye = _geo(W, H, geo)
+    rc = lib().svgf_oracle_taa(W, H, y0, rows, yb, ye, STORAGE[storage], _p(filtered), _p(history), _p(out), int(nthreads))
+    assert rc == 0
+
+
 class Pipeline:
     """Whole-frame sequencing: TemporalFilter -> FilterMoments -> WaveletFilter (src/App.cu:552-556,
     469-514), with the host-side fixes SURVEY.md App. B lists (#1 history ping-pong, #4 current

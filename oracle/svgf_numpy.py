@@ -173,3 +173,62 @@ def atrous(src, gb, *, step, phi_colour, phi_normal):
         out = np.concatenate([acc[..., :3] / S[..., None], (acc[..., 3] / (S * S))[..., None]], -1)
     out = np.where(sky[..., None], c, out)
     return out.astype(sdt), ~sky
+
+
+# ------------------------------------------------------------------ TAA + sRGB (next stage) -------
+def _tex(k, n):
+    """textureSample's coordinate: floor(uv * (n-1)) clamped, uv = k * (1/n) (+- 1/n for neighbours), all fp32."""
+    return np.clip(np.floor(k * f32(n - 1)).astype(np.int64), 0, n - 1)
+
+
+def _enc(rgb):
+    c = np.power(rgb, f32(2.0)).astype(np.float32)
+    r, g, b = c[..., 0], c[..., 1], c[..., 2]
+    return np.stack([(r * f32(0.299) + g * f32(0.587)) + b * f32(0.114),
+                     (r * f32(-0.14713) + g * f32(-0.28886)) + b * f32(0.436),
+                     (r * f32(0.615) + g * f32(-0.51499)) + b * f32(-0.10001)], -1)
+
+
+def _srgb(c):
+    with np.errstate(all="ignore"):
+        hi = f32(1 + np.float32(0.055)) * np.power(c, f32(1) / f32(2.4)).astype(np.float32) - f32(0.055)
+    return np.where(c <= f32(0.0031308), f32(12.92) * c, hi).astype(np.float32)
+
+
+def taa(filtered, history):
+    """Filter.cuh:288-357, history read from a separate plane.  Returns the new output plane."""
+    sdt = filtered.dtype
+    H, W = filtered.shape[:2]
+    inp = _clamp01(_ld(filtered))
+    hist = _clamp01(_ld(history))
+    iw, ih = f32(1.0) / f32(W), f32(1.0) / f32(H)
+    u = (np.arange(W, dtype=np.float32) * iw)[None, :].repeat(H, 0)
+    v = (np.arange(H, dtype=np.float32) * ih)[:, None].repeat(W, 1)
+
+    def samp(img, uu, vv):
+        return img[_tex(vv, H), _tex(uu, W)]
+    last = samp(hist, u, v)
+    mix = np.minimum(last[..., 3], f32(0.5))[..., None]
+    in0 = samp(inp, u, v)[..., :3]
+    aa = np.sqrt((last[..., :3] * last[..., :3]) * (f32(1) - mix) + (in0 * in0) * mix).astype(np.float32)
+    offs = [(0, 0), (1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, 1), (1, -1), (-1, -1)]
+    ys = [_enc(samp(inp, u + f32(a) * iw if a else u, v + f32(b) * ih if b else v)[..., :3]) for a, b in offs]
+    ya = _enc(aa)
+    mn = np.minimum(np.minimum(np.minimum(ys[0], ys[1]), np.minimum(ys[2], ys[3])), ys[4])
+    mx = np.maximum(np.maximum(np.maximum(ys[0], ys[1]), np.maximum(ys[2], ys[3])), ys[4])
+    mn2 = np.minimum(np.minimum(np.minimum(ys[5], ys[6]), np.minimum(ys[7], ys[8])), mn)
+    mx2 = np.maximum(np.maximum(np.maximum(ys[5], ys[6]), np.maximum(ys[7], ys[8])), mx)
+    mn = mn * f32(0.5) + mn2 * f32(0.5)
+    mx = mx * f32(0.5) + mx2 * f32(0.5)
+    ya = np.minimum(np.maximum(ya, mn), mx)
+    with np.errstate(all="ignore"):
+        r = (ya[..., 0] * f32(1) + ya[..., 1] * f32(0)) + ya[..., 2] * f32(1.13983)
+        g = (ya[..., 0] * f32(1) + ya[..., 1] * f32(-0.39465)) + ya[..., 2] * f32(-0.58060)
+        b = (ya[..., 0] * f32(1) + ya[..., 1] * f32(2.03211)) + ya[..., 2] * f32(0)
+        rgb = np.power(np.stack([r, g, b], -1), f32(0.5)).astype(np.float32)
+    bad = np.isnan(rgb).any(-1)
+    rgb = np.where(bad[..., None], f32(0), rgb)
+    out = np.concatenate([_srgb(rgb), np.where(bad, f32(0), f32(1))[..., None]], -1)
+    out[bad] = 0          # fragColor = vec4(0) then ToSRGB(0) = 0, alpha forced back to 1 by :353
+    out[..., 3] = 1
+    return _clamp01(out).astype(sdt)

@@ -291,6 +291,77 @@ void atrous(const Geo& g, const void* in, void* out, void* feedback, const float
     });
 }
 
+
+// ---------------------------------------------------------------- TAA + sRGB --
+// TAAFilterKernel (Filter.cuh:288-357) with its helpers textureSample (:116-131: the bilinear path is dead code,
+// it returns the nearest texel c00), encodePalYuv/decodePalYuv (:267-285) and ToSRGB (:145-157).
+// The reference reads the history from the very buffer it writes (Output, App.cu:520) at a DIFFERENT pixel
+// (the uv*(W-1) mapping below lands on pixel k-1), a cross-thread race; here the previous output is a separate
+// plane (snapshot semantics), like the history-length fix of the temporal stage.
+inline int tex_coord(float uv, int n) {                                  // :118-130
+    const float x = uv * (float)(n - 1);
+    const int x0 = (int)std::floor(x);
+    return std::min(std::max(x0, 0), n - 1);
+}
+inline void enc_yuv(const float* rgb, float* yuv) {                       // :267-275
+    const float r = std::pow(rgb[0], 2.0f), g = std::pow(rgb[1], 2.0f), b = std::pow(rgb[2], 2.0f);
+    yuv[0] = (r * (float)0.299 + g * (float)0.587) + b * (float)0.114;
+    yuv[1] = (r * (float)-0.14713 + g * (float)-0.28886) + b * (float)0.436;
+    yuv[2] = (r * (float)0.615 + g * (float)-0.51499) + b * (float)-0.10001;
+}
+inline void dec_yuv(const float* yuv, float* rgb) {                       // :277-285
+    const float r = (yuv[0] * 1.0f + yuv[1] * 0.0f) + yuv[2] * (float)1.13983;
+    const float g = (yuv[0] * 1.0f + yuv[1] * (float)-0.39465) + yuv[2] * (float)-0.58060;
+    const float b = (yuv[0] * 1.0f + yuv[1] * (float)2.03211) + yuv[2] * 0.0f;
+    rgb[0] = std::pow(r, 0.5f); rgb[1] = std::pow(g, 0.5f); rgb[2] = std::pow(b, 0.5f);
+}
+inline float to_srgb(float c) {                                           // :145-148
+    return (c <= 0.0031308f) ? 12.92f * c : (1 + 0.055f) * std::pow(c, 1 / 2.4f) - 0.055f;
+}
+
+template <class T>
+void taa(const Geo& g, const void* input, const void* history, void* out, int nthreads) {
+    const float inv_w = 1.0f / (float)g.W, inv_h = 1.0f / (float)g.H;     // InvTexResolution :294, off :304
+    auto sample = [&](const void* img, float u, float v, float* c) {      // textureSample + imageLoad (value clamp)
+        const int sx = tex_coord(u, g.W), sy = tex_coord(v, g.H);
+        image_load<T>(img, (size_t)(sy - g.y0) * g.W + sx, c);
+    };
+    parallel_rows(g.yb, g.ye, nthreads, [&](int ya, int yb2) {
+        for (int y = ya; y < yb2; y++)
+            for (int x = 0; x < g.W; x++) {
+                const float u = (float)x * inv_w, v = (float)y * inv_h;   // :296
+                float last[4]; sample(history, u, v, last);               // :299
+                float aa[3] = {last[0], last[1], last[2]};
+                const float mix_rate = (float)std::min((double)last[3], 0.5);   // :302
+                float in[9][4];
+                sample(input, u, v, in[0]);                               // :305
+                for (int k = 0; k < 3; k++) aa[k] = std::sqrt(mixf(aa[k] * aa[k], in[0][k] * in[0][k], mix_rate));   // :307-308
+                sample(input, u + inv_w, v, in[1]);          sample(input, u - inv_w, v, in[2]);            // :310-311
+                sample(input, u, v + inv_h, in[3]);          sample(input, u, v - inv_h, in[4]);            // :312-313
+                sample(input, u + inv_w, v + inv_h, in[5]);  sample(input, u - inv_w, v + inv_h, in[6]);    // :314-315
+                sample(input, u + inv_w, v - inv_h, in[7]);  sample(input, u - inv_w, v - inv_h, in[8]);    // :316-317
+                float ya_[3]; enc_yuv(aa, ya_);                           // :319
+                float yin[9][3];
+                for (int k = 0; k < 9; k++) enc_yuv(in[k], yin[k]);       // :320-328
+                float mn[3], mx[3];
+                for (int k = 0; k < 3; k++) {
+                    mn[k] = std::min(std::min(std::min(yin[0][k], yin[1][k]), std::min(yin[2][k], yin[3][k])), yin[4][k]);   // :330
+                    mx[k] = std::max(std::max(std::max(yin[0][k], yin[1][k]), std::max(yin[2][k], yin[3][k])), yin[4][k]);   // :331
+                    const float mn2 = std::min(std::min(std::min(yin[5][k], yin[6][k]), std::min(yin[7][k], yin[8][k])), mn[k]);
+                    const float mx2 = std::max(std::max(std::max(yin[5][k], yin[6][k]), std::max(yin[7][k], yin[8][k])), mx[k]);
+                    mn[k] = mixf(mn[k], mn2, 0.5f);                       // :332-333
+                    mx[k] = mixf(mx[k], mx2, 0.5f);                       // :334-335
+                    ya_[k] = std::min(std::max(ya_[k], mn[k]), mx[k]);    // :338 (the mixRate update :340-346 has no effect on the output)
+                }
+                float rgb[3]; dec_yuv(ya_, rgb);                          // :348
+                float o[4] = {rgb[0], rgb[1], rgb[2], 1.0f};              // :350
+                if (std::isnan(o[0]) || std::isnan(o[1]) || std::isnan(o[2])) o[0] = o[1] = o[2] = o[3] = 0.0f;   // :351
+                float res[4] = {to_srgb(o[0]), to_srgb(o[1]), to_srgb(o[2]), 1.0f};   // :353
+                image_store<T>(out, (size_t)(y - g.y0) * g.W + x, res);   // :355
+            }
+    });
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- C entry -----
@@ -329,6 +400,15 @@ int svgf_oracle_atrous(int W, int H, int y0, int rows, int yb, int ye, int stora
     Geo g{W, H, y0, rows, yb, ye};
     if (storage == 0) atrous<F32>(g, in, out, feedback, motion, normal, step, phi_colour, phi_normal, iteration, nthreads);
     else if (storage == 1) atrous<F16>(g, in, out, feedback, motion, normal, step, phi_colour, phi_normal, iteration, nthreads);
+    else return -1;
+    return 0;
+}
+
+int svgf_oracle_taa(int W, int H, int y0, int rows, int yb, int ye, int storage, const void* input, const void* history,
+                    void* out, int nthreads) {
+    Geo g{W, H, y0, rows, yb, ye};
+    if (storage == 0) taa<F32>(g, input, history, out, nthreads);
+    else if (storage == 1) taa<F16>(g, input, history, out, nthreads);
     else return -1;
     return 0;
 }

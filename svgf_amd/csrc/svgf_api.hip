@@ -250,6 +250,16 @@ int svgf_atrous(svgf_ctx* c, const void* in, void* out, void* feedback, const sv
     return SVGF_OK;
 }
 
+int svgf_taa(svgf_ctx* c, const void* filtered, const void* history, void* out) {
+    if (!c) return SVGF_ERR_INVALID;
+    if (!filtered || !history || !out) return fail(c, SVGF_ERR_INVALID, "svgf_taa: null plane");
+    if (out == filtered || out == history) return fail(c, SVGF_ERR_INVALID, "svgf_taa: in-place filtering is a race");
+    int rc = check_halo(c, 2, "svgf_taa");
+    if (rc != SVGF_OK) return rc;
+    SVGF_HIP(c, svgf::launch_taa(geo_of(c), c->p.storage, filtered, history, out, c->stream));
+    return SVGF_OK;
+}
+
 int svgf_reset_history(svgf_ctx* c) {
     if (!c) return SVGF_ERR_INVALID;
     if (!c->have_state) return SVGF_OK;

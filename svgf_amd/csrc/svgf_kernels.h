@@ -27,5 +27,6 @@ struct AtrousArgs {
 hipError_t launch_temporal(const Geo& g, int storage, const TemporalArgs& a, hipStream_t s);
 hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, hipStream_t s);
 hipError_t launch_atrous(const Geo& g, int storage, int variant, const AtrousArgs& a, hipStream_t s);
+hipError_t launch_taa(const Geo& g, int storage, const void* filtered, const void* history, void* out, hipStream_t s);
 
 }  // namespace svgf

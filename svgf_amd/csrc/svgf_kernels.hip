@@ -677,15 +677,85 @@ hipError_t launch_atrous_lds_step_kr(const Geo& g, const AtrousArgs& a, hipStrea
 
 template <int ST>
 hipError_t launch_atrous_lds_step(const Geo& g, const AtrousArgs& a, hipStream_t s) {
-    int kr = kDefaultKR;
 #ifdef SVGF_DIAG
-    kr = diag_env("SVGF_ATROUS_KR", kr);
+    const int kr = diag_env("SVGF_ATROUS_KR", kDefaultKR);
     const int mode = diag_env("SVGF_ATROUS_MODE", 0);
     if (ST == 0 && mode == 1) return kr == 2 ? launch_atrous_lds_step_kr<0, 2, 1>(g, a, s) : launch_atrous_lds_step_kr<0, 1, 1>(g, a, s);
     if (ST == 0 && mode == 2) return kr == 2 ? launch_atrous_lds_step_kr<0, 2, 2>(g, a, s) : launch_atrous_lds_step_kr<0, 1, 2>(g, a, s);
     if (kr != kDefaultKR) return kr == 2 ? launch_atrous_lds_step_kr<ST, 2, 0>(g, a, s) : launch_atrous_lds_step_kr<ST, 1, 0>(g, a, s);
 #endif
     return launch_atrous_lds_step_kr<ST, kDefaultKR, 0>(g, a, s);
+}
+
+// ------------------------------------------------------------------ TAA + sRGB -----------------
+// filter::TAAFilterKernel (Filter.cuh:288-357): the stage application::Render runs right after the wavelet
+// filter (App.cu:558).  Neighbourhood clamp in gamma-2 PAL-YUV of the previous output against the 3x3
+// neighbourhood of the filtered frame, then linear -> sRGB.  Quirks kept: textureSample returns
+// the nearest texel (:101-102,130-131) at floor(uv*(W-1)), i.e. one pixel up-left of the fragment; the stored alpha
+// is always 1 and the updated mixRate is never used.  The previous output is read from a separate plane: the
+// reference reads it from the buffer it is writing (App.cu:520), at a different pixel — a race.
+__device__ __forceinline__ int tex_coord(float uv, int n) {
+    const int x0 = (int)floorf(uv * (float)(n - 1));
+    return min(max(x0, 0), n - 1);
+}
+__device__ __forceinline__ float3 enc_yuv(float3 c) {                   // :267-275; pow(x,2) = x*x correctly rounded
+    const float r = c.x * c.x, g = c.y * c.y, b = c.z * c.z;
+    return make_float3((r * 0.299f + g * 0.587f) + b * 0.114f, (r * -0.14713f + g * -0.28886f) + b * 0.436f,
+                       (r * 0.615f + g * -0.51499f) + b * -0.10001f);
+}
+__device__ __forceinline__ float to_srgb(float c) {                     // :145-148
+    return (c <= 0.0031308f) ? 12.92f * c : 1.055f * hw_exp2(hw_log2(c) * (1.0f / 2.4f)) - 0.055f;
+}
+
+template <int ST>
+__global__ __launch_bounds__(kBX* kBY) void taa_kernel(Geo g, const void* filtered, const void* history, void* out) {
+    const int x = blockIdx.x * kBX + threadIdx.x;
+    const int y = g.yb + blockIdx.y * kBY + threadIdx.y;
+    if (x >= g.W || y >= g.ye) return;
+    const float iw = 1.0f / (float)g.W, ih = 1.0f / (float)g.H;
+    const float u = (float)x * iw, v = (float)y * ih;                    // :296
+    const int sx[3] = {tex_coord(u - iw, g.W), tex_coord(u, g.W), tex_coord(u + iw, g.W)};
+    const int sy[3] = {tex_coord(v - ih, g.H), tex_coord(v, g.H), tex_coord(v + ih, g.H)};
+    auto at = [&](const void* img, int ix, int iy) { return clamp01(Store<ST>::ld4(img, (size_t)(sy[iy] - g.y0) * g.W + sx[ix])); };
+    const float4 last = at(history, 1, 1);                                // :299
+    const float mix = fminf(last.w, 0.5f);                                // :302
+    const float4 c0 = at(filtered, 1, 1);                                 // :305
+    float3 aa = make_float3(sqrtf(mix_exact(last.x * last.x, c0.x * c0.x, mix)), sqrtf(mix_exact(last.y * last.y, c0.y * c0.y, mix)),
+                            sqrtf(mix_exact(last.z * last.z, c0.z * c0.z, mix)));   // :307-308
+    float3 ya = enc_yuv(aa);                                              // :319
+    // :310-317,320-335: plus-shaped and diagonal neighbourhoods
+    float3 mn, mx, mnd, mxd;
+    {
+        const float3 y0_ = enc_yuv(make_float3(c0.x, c0.y, c0.z));
+        mn = y0_; mx = y0_;
+        const int px[4] = {2, 0, 1, 1}, py[4] = {1, 1, 2, 0};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float4 c = at(filtered, px[k], py[k]);
+            const float3 yk = enc_yuv(make_float3(c.x, c.y, c.z));
+            mn = make_float3(fminf(mn.x, yk.x), fminf(mn.y, yk.y), fminf(mn.z, yk.z));
+            mx = make_float3(fmaxf(mx.x, yk.x), fmaxf(mx.y, yk.y), fmaxf(mx.z, yk.z));
+        }
+        mnd = mn; mxd = mx;
+        const int dx[4] = {2, 0, 2, 0}, dy[4] = {2, 2, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float4 c = at(filtered, dx[k], dy[k]);
+            const float3 yk = enc_yuv(make_float3(c.x, c.y, c.z));
+            mnd = make_float3(fminf(mnd.x, yk.x), fminf(mnd.y, yk.y), fminf(mnd.z, yk.z));
+            mxd = make_float3(fmaxf(mxd.x, yk.x), fmaxf(mxd.y, yk.y), fmaxf(mxd.z, yk.z));
+        }
+    }
+    mn = make_float3(mix_exact(mn.x, mnd.x, 0.5f), mix_exact(mn.y, mnd.y, 0.5f), mix_exact(mn.z, mnd.z, 0.5f));
+    mx = make_float3(mix_exact(mx.x, mxd.x, 0.5f), mix_exact(mx.y, mxd.y, 0.5f), mix_exact(mx.z, mxd.z, 0.5f));
+    ya = make_float3(fminf(fmaxf(ya.x, mn.x), mx.x), fminf(fmaxf(ya.y, mn.y), mx.y), fminf(fmaxf(ya.z, mn.z), mx.z));   // :338
+    // :277-285; pow(x, 0.5) = sqrt(x), NaN for negative x
+    float r = sqrtf((ya.x * 1.0f + ya.y * 0.0f) + ya.z * 1.13983f);
+    float gg = sqrtf((ya.x * 1.0f + ya.y * -0.39465f) + ya.z * -0.58060f);
+    float b = sqrtf((ya.x * 1.0f + ya.y * 2.03211f) + ya.z * 0.0f);
+    if (r != r || gg != gg || b != b) { r = 0.f; gg = 0.f; b = 0.f; }     // :351
+    const float4 o = make_float4(to_srgb(r), to_srgb(gg), to_srgb(b), 1.0f);   // :353
+    Store<ST>::st4(out, (size_t)(y - g.y0) * g.W + x, clamp01(o));        // :355 imageStore
 }
 
 inline dim3 grid_for(const Geo& g) { return dim3((g.W + kBX - 1) / kBX, (g.ye - g.yb + kBY - 1) / kBY); }
@@ -727,6 +797,14 @@ hipError_t launch_atrous(const Geo& g, int storage, int variant, const AtrousArg
     const dim3 block(kBX, kBY), grid = grid_for(g);
     if (storage == 0) atrous_direct_kernel<0><<<grid, block, 0, s>>>(g, a);
     else atrous_direct_kernel<1><<<grid, block, 0, s>>>(g, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_taa(const Geo& g, int storage, const void* filtered, const void* history, void* out, hipStream_t s) {
+    if (g.ye <= g.yb) return hipSuccess;
+    const dim3 block(kBX, kBY), grid = grid_for(g);
+    if (storage == 0) taa_kernel<0><<<grid, block, 0, s>>>(g, filtered, history, out);
+    else taa_kernel<1><<<grid, block, 0, s>>>(g, filtered, history, out);
     return hipGetLastError();
 }
 

@@ -24,7 +24,7 @@ MAX_STEPS = 10
 EXPORTS = [
     "svgf_default_params", "svgf_status_string", "svgf_last_error", "svgf_abi_version", "svgf_create",
     "svgf_create_strip", "svgf_destroy", "svgf_set_params", "svgf_set_stream", "svgf_set_rows", "svgf_temporal",
-    "svgf_moments", "svgf_atrous", "svgf_denoise_frame", "svgf_reset_history", "svgf_state_plane",
+    "svgf_moments", "svgf_atrous", "svgf_taa", "svgf_denoise_frame", "svgf_reset_history", "svgf_state_plane",
     "svgf_state_pingpong", "svgf_plane_bytes", "svgf_timing_enable", "svgf_timing_read",
 ]
 
@@ -108,6 +108,7 @@ def load_library():
     lib.svgf_temporal.argtypes = [vp, vp, vp, vp, C.POINTER(GBufferC), C.POINTER(GBufferC), vp, vp, vp, vp]
     lib.svgf_moments.argtypes = [vp, vp, vp, vp, C.POINTER(GBufferC), vp]
     lib.svgf_atrous.argtypes = [vp, vp, vp, vp, C.POINTER(GBufferC), ip, ip]
+    lib.svgf_taa.argtypes = [vp, vp, vp, vp]
     lib.svgf_denoise_frame.argtypes = [vp, vp, C.POINTER(GBufferC), C.POINTER(GBufferC), C.POINTER(vp)]
     lib.svgf_reset_history.argtypes = [vp]
     lib.svgf_state_plane.argtypes = [vp, ip, ip]
@@ -232,6 +233,10 @@ class Denoiser:
             self.FilterKernel(filter_buffers[pp], filter_buffers[1 - pp], render_buffer, gb, 1 << i, i)
             pp ^= 1
         return filter_buffers[pp]
+
+    def TAA(self, filtered, history, out):
+        """application::TAA, src/App.cu:516-522 (history = the previous call's out)."""
+        self._check(self.lib.svgf_taa(self._h, _ptr(filtered), _ptr(history), _ptr(out)), "svgf_taa")
 
     # -- whole frame on context-owned state --------------------------------------------------
     def Render(self, radiance, gb_cur: GBuffer, gb_prev: GBuffer | None = None):

@@ -319,3 +319,31 @@ def test_1080p_history_counts(G):
         h = d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong())
         assert torch.all(h[~sky] == min(k + 1, base)) and torch.all(h[sky] == 1)
         assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_taa(G, oracle, storage):
+    """The stage after the path: TAA + sRGB, two chained frames, against the oracle."""
+    from svgf_amd import filter as F
+    W, H = 333, 207
+    rng = np.random.default_rng(31)
+    dt = CDT[storage]
+    f = synth.make_frame(W, H, 0)
+    frames_ = [np.concatenate([f["base"] * s, np.ones((H, W, 1), np.float32)], -1).astype(dt) for s in (1.0, 1.3)]
+    hist = rng.uniform(0, 1, (H, W, 4)).astype(dt)
+    d = F.Denoiser(W, H, F.Params(storage=storage))
+    h_dev = G.dev(hist)
+    for fr in frames_:
+        want = np.zeros_like(fr)
+        oracle.taa(W, H, storage, fr, hist, want)
+        out = d.new_colour()
+        d.TAA(G.dev(fr), h_dev, out)
+        got = G.host(out)
+        if storage == "f32":
+            assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= 2e-6      # hardware exp2/log2 in sRGB
+        else:
+            from tests.helpers import half_ulp_diff
+            assert half_ulp_diff(got, want).max() <= 1
+        hist, h_dev = want, G.dev(want)
+    with pytest.raises(F.SvgfError, match="in-place"):
+        d.TAA(h_dev, h_dev, h_dev)

@@ -199,3 +199,46 @@ def test_strip_geometry_equals_whole_frame(oracle):
     oracle.atrous(W, H, "f32", lsrc, lout, None, loc, step=step, phi_colour=10.0, phi_normal=128.0, iteration=1,
                   geo=(y0, y1 - y0, yb, ye))
     assert np.array_equal(lout[halo:-halo], whole[yb:ye])
+
+
+# ------------------------------------------------------------------ TAA + sRGB (the stage after the path) -------
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_taa_matches_numpy(oracle, storage):
+    W, H = 71, 53
+    rng = np.random.default_rng(21)
+    dt = CDT[storage]
+    filt = rng.uniform(-0.1, 1.1, (H, W, 4)).astype(dt)
+    hist = rng.uniform(0, 1, (H, W, 4)).astype(dt)
+    out = np.zeros_like(filt)
+    oracle.taa(W, H, storage, filt, hist, out)
+    want = snp.taa(filt, hist)
+    if storage == "f32":
+        np.testing.assert_allclose(out, want, rtol=0, atol=1e-6)
+    else:
+        assert half_ulp_diff(out, want).max() <= 1
+    assert np.all(out[..., 3] == 1)
+
+
+def test_taa_kat_constant_image(oracle):
+    """Constant history == constant input c: the clamp is a no-op and the output is sRGB(c) (Filter.cuh:145-148)."""
+    W, H = 20, 16
+    c = np.array([0.05, 0.2, 0.7, 1.0], np.float32)
+    img = np.broadcast_to(c, (H, W, 4)).copy()
+    out = np.zeros_like(img)
+    oracle.taa(W, H, "f32", img, img, out)
+    want = np.where(c[:3] <= 0.0031308, 12.92 * c[:3], 1.055 * c[:3] ** (1 / 2.4) - 0.055)
+    # the reference's YUV matrices (5-digit coefficients, :270-282) are not exact inverses: ~1e-5 on squared values
+    np.testing.assert_allclose(out[..., :3], np.broadcast_to(want, (H, W, 3)), atol=3e-4)
+    assert np.all(out[..., 3] == 1)
+
+
+def test_taa_strip_geometry(oracle):
+    W, H = 48, 60
+    rng = np.random.default_rng(22)
+    filt = rng.uniform(0, 1, (H, W, 4)).astype(np.float32); hist = rng.uniform(0, 1, (H, W, 4)).astype(np.float32)
+    whole = np.zeros_like(filt)
+    oracle.taa(W, H, "f32", filt, hist, whole)
+    yb, ye, y0 = 20, 40, 18
+    lo = np.zeros((ye - y0, W, 4), np.float32)
+    oracle.taa(W, H, "f32", np.ascontiguousarray(filt[y0:ye]), np.ascontiguousarray(hist[y0:ye]), lo, geo=(y0, ye - y0, yb, ye))
+    assert np.array_equal(lo[yb - y0:], whole[yb:ye])
