@@ -203,9 +203,26 @@ int svgf_set_rows(svgf_ctx* c, int rb, int re) {
     return SVGF_OK;
 }
 
+static int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, const svgf_gbuffer* cur,
+                         const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur, void* moments_cur,
+                         const void* moments_prev, void* passthrough_out);
+static int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist, int cold_only);
+
 int svgf_temporal(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, const svgf_gbuffer* cur,
                   const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur, void* moments_cur,
                   const void* moments_prev) {
+    return temporal_impl(c, prev_colour, radiance, colour_out, cur, prev, hist_prev, hist_cur, moments_cur, moments_prev, nullptr);
+}
+
+int svgf_moments(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist) {
+    return moments_impl(c, colour, out, moments, g, hist, 0);
+}
+
+}  // extern "C"
+
+static int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, const svgf_gbuffer* cur,
+                         const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur, void* moments_cur,
+                         const void* moments_prev, void* passthrough_out) {
     if (!c) return SVGF_ERR_INVALID;
     if (!prev_colour || !radiance || !colour_out || !hist_prev || !hist_cur || !moments_cur || !moments_prev)
         return fail(c, SVGF_ERR_INVALID, "svgf_temporal: null plane");
@@ -218,12 +235,12 @@ int svgf_temporal(svgf_ctx* c, const void* prev_colour, const void* radiance, vo
                          (const float4*)cur->motion, (const uint2*)cur->normal, (const uint2*)cur->uv,
                          (const float4*)prev->motion, (const uint2*)prev->normal, (const uint2*)prev->uv,
                          hist_prev, hist_cur, moments_cur, moments_prev,
-                         c->p.depth_threshold, c->p.normal_threshold, c->p.history_base, c->p.mesh_id_test};
+                         c->p.depth_threshold, c->p.normal_threshold, c->p.history_base, c->p.mesh_id_test, passthrough_out};
     SVGF_HIP(c, svgf::launch_temporal(geo_of(c), c->p.storage, a, c->stream));
     return SVGF_OK;
 }
 
-int svgf_moments(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist) {
+static int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist, int cold_only) {
     if (!c) return SVGF_ERR_INVALID;
     if (!colour || !out || !moments || !hist) return fail(c, SVGF_ERR_INVALID, "svgf_moments: null plane");
     if (colour == out) return fail(c, SVGF_ERR_INVALID, "svgf_moments: in-place filtering is a race");
@@ -231,10 +248,12 @@ int svgf_moments(svgf_ctx* c, const void* colour, void* out, const void* moments
     if (rc == SVGF_OK) rc = check_halo(c, c->p.moments_radius, "svgf_moments");
     if (rc != SVGF_OK) return rc;
     svgf::MomentsArgs a{colour, out, moments, (const float4*)g->motion, (const uint2*)g->normal, hist,
-                        c->p.phi_colour, c->p.phi_normal, c->p.moments_radius};
+                        c->p.phi_colour, c->p.phi_normal, c->p.moments_radius, cold_only};
     SVGF_HIP(c, svgf::launch_moments(geo_of(c), c->p.storage, a, c->stream));
     return SVGF_OK;
 }
+
+extern "C" {
 
 int svgf_atrous(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration) {
     if (!c) return SVGF_ERR_INVALID;
@@ -293,11 +312,13 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     };
 
     stamp();
-    rc = svgf_temporal(c, c->colour[1 - P], radiance, c->colour[P], cur, prev, c->hist[1 - P], c->hist[P],
-                       c->moments[P], c->moments[1 - P]);                       // App.cu:552
+    // The temporal launch also writes the filter buffer where history >= 4 (there FilterMoments is a copy), the
+    // moments launch then only works on young pixels: same planes, 32 B/px less traffic in steady state.
+    rc = temporal_impl(c, c->colour[1 - P], radiance, c->colour[P], cur, prev, c->hist[1 - P], c->hist[P],
+                       c->moments[P], c->moments[1 - P], c->filter[0]);         // App.cu:552
     if (rc != SVGF_OK) return rc;
     stamp();
-    rc = svgf_moments(c, c->colour[P], c->filter[0], c->moments[P], cur, c->hist[P]);   // App.cu:554 (current moments: App. B #4)
+    rc = moments_impl(c, c->colour[P], c->filter[0], c->moments[P], cur, c->hist[P], 1);   // App.cu:554 (current moments: App. B #4)
     if (rc != SVGF_OK) return rc;
     stamp();
     int pp = 0;

@@ -14,10 +14,12 @@ struct TemporalArgs {
     const float4* motion_p; const uint2* normal_p; const uint2* uv_p;
     const uint8_t* hist_prev; uint8_t* hist_cur; void* mom_cur; const void* mom_prev;
     float depth_thr, normal_thr; int history_base; int mesh_id_test;
+    void* passthrough_out;   // frame driver only: where history >= 4 the moments stage is a copy (Filter.cuh:521) — write it here directly
 };
 struct MomentsArgs {
     const void* colour; void* out; const void* mom; const float4* motion; const uint2* normal; const uint8_t* hist;
     float phi_colour, phi_normal; int radius;
+    int cold_only;           // 1: pixels with history >= 4 were already written by the temporal stage (passthrough_out)
 };
 struct AtrousArgs {
     const void* in; void* out; void* feedback; const float4* motion; const uint2* normal;

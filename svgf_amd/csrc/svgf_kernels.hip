@@ -150,6 +150,10 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
     a.hist_cur[idx] = (uint8_t)h;                                     // :400
     Store<ST>::st4(a.colour_out, idx, clamp01(o));                    // :401 imageStore
     Store<ST>::st2(a.mom_cur, idx, m);                                // :402
+    // Frame-driver fusion: for history >= 4 FilterMoments only copies this pixel into the filter buffer
+    // (:521; store(load(x)) == x in both storage types), so it is written from here and the moments launch
+    // touches nothing but the history byte of such pixels (-32 B/px of traffic in steady state).
+    if (a.passthrough_out && h >= 4) Store<ST>::st4(a.passthrough_out, idx, clamp01(o));
 }
 
 // ------------------------------------------------------------------ moments -------------------
@@ -162,6 +166,7 @@ __global__ __launch_bounds__(kBX* kBY) void moments_kernel(Geo g, MomentsArgs a)
     if (x >= g.W || y >= g.ye) return;
     const size_t idx = (size_t)(y - g.y0) * g.W + x;
     const float h = (float)a.hist[idx];                               // :442
+    if (a.cold_only && !(h < 4.0f)) return;                           // already written by temporal_kernel (passthrough_out)
     const float4 cc = Store<ST>::ld4(a.colour, idx);                  // :450 raw load
     if (!(h < 4.0f)) { Store<ST>::st4(a.out, idx, cc); return; }      // :521
 
