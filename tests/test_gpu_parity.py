@@ -347,3 +347,37 @@ def test_taa(G, oracle, storage):
         hist, h_dev = want, G.dev(want)
     with pytest.raises(F.SvgfError, match="in-place"):
         d.TAA(h_dev, h_dev, h_dev)
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_atrous_large_steps_and_degenerate_phis(G, oracle, storage):
+    """GUI ranges (src/GUI.cpp:988-993): up to 10 iterations (steps 32..512 take the direct kernel), PhiNormal = 0
+    (pow(x,0) = 1 also at x = 0) and PhiColour = 0 (|dl|/0: inf, or NaN -> 0 through fmax, Filter.cuh:422-424)."""
+    from svgf_amd import filter as F
+    W, H = 300, 180
+    rng = np.random.default_rng(77)
+    f = synth.make_frame(W, H, 0)
+    dt = CDT[storage]
+    src = np.concatenate([f["radiance"][..., :3], rng.uniform(0.0, 0.05, (H, W, 1)).astype(np.float32)], -1).astype(dt)
+    gb = G.gb_dev(f)
+    for step, phi_c, phi_n in [(32, 10.0, 128.0), (64, 10.0, 128.0), (512, 10.0, 128.0), (2, 10.0, 0.0), (16, 10.0, 0.0), (1, 0.0, 128.0), (4, 0.0, 0.0)]:
+        want = np.zeros_like(src)
+        oracle.atrous(W, H, storage, src, want, None, gbuf(f), step=step, phi_colour=phi_c, phi_normal=phi_n, iteration=1, nthreads=8)
+        d = F.Denoiser(W, H, F.Params(storage=storage, phi_colour=phi_c, phi_normal=phi_n))
+        out = d.new_colour()
+        d.FilterKernel(G.dev(src), out, None, gb, step, 1)
+        G.assert_colour_close(G.host(out), want, storage, f"step {step} phi_colour {phi_c} phi_normal {phi_n}")
+
+
+def test_frame_sizes_and_ten_iterations(G, oracle):
+    """Odd sizes around the 256-column / 64-lane tiles, narrower than one tile, and the GUI's maximum of 10 iterations."""
+    for (W, H, steps) in [(64, 40, 3), (255, 33, 5), (257, 65, 5), (513, 130, 10)]:
+        fr = frames(W, H, 3, mv=(1.0, 0.0))
+        ref = oracle.Pipeline(W, H, "f32", steps=steps, nthreads=8)
+        hip = G.HipPipeline(W, H, "f32", steps=steps)
+        gbs = [G.gb_dev(f) for f in fr]
+        for k in range(3):
+            want = ref.frame(fr[k]["radiance"], gbuf(fr[k]), gbuf(fr[max(k - 1, 0)]))
+            got = hip.frame(fr[k]["radiance"], gbs[k], gbs[max(k - 1, 0)])
+            assert np.array_equal(hip.taps["hist"], ref.taps["hist"]), (W, H, k)
+            G.assert_colour_close(got, want, "f32", f"{W}x{H} steps {steps} frame {k}")
