@@ -616,6 +616,10 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
 #endif
 }
 
+#ifdef SVGF_DIAG
+inline int diag_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#endif
+
 inline int num_cus() {
     static int cus = 0;
     if (!cus) {
@@ -645,7 +649,11 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     const int nrows = g.ye - g.yb;
     const int njmax = (nrows + S - 1) / S;
     const int xtiles = (g.W + TX - 1) / TX;
-    int nbands = per_cu * num_cus() / (xtiles * S);
+    int slots = per_cu * num_cus();
+#ifdef SVGF_DIAG
+    slots = diag_env("SVGF_ATROUS_SLOTS", slots);
+#endif
+    int nbands = slots / (xtiles * S);
     if (nbands < 1) nbands = 1;
     int band = (njmax + nbands - 1) / nbands;
     if (band < 8) band = 8;
@@ -664,10 +672,6 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     atrous_lds_kernel<ST, S, TX, KR, MODE><<<grid, dim3(threads), lds, s>>>(g, a, band);
     return hipGetLastError();
 }
-
-#ifdef SVGF_DIAG
-inline int diag_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
-#endif
 
 template <int ST, int KR, int MODE>
 hipError_t launch_atrous_lds_step_kr(const Geo& g, const AtrousArgs& a, hipStream_t s) {
