@@ -287,6 +287,7 @@ __global__ __launch_bounds__(kBX* kBY) void atrous_direct_kernel(Geo g, AtrousAr
 constexpr int kRS = 2;                   // decimated rows produced per step
 constexpr int kRing = kRS + 4;
 constexpr int kRecBytes = 32;            // LDS bytes per staged pixel
+constexpr int kNarrowMaxStep = 4;           // steps up to this one use 128-column workgroups
 constexpr int kDefaultKR = 1;            // outputs per thread of the kernel the library launches (see atrous_lds_kernel)
 constexpr unsigned kOob = 0xFFFFFF00u;   // byte offset no plane reaches (planes are < 4 GiB)
 
@@ -675,6 +676,22 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
 
 template <int ST, int KR, int MODE>
 hipError_t launch_atrous_lds_step_kr(const Geo& g, const AtrousArgs& a, hipStream_t s) {
+    // Steps 1-4: 128-column workgroups (4 waves, 4 per CU).  Their 4S-column halo is small next to 128 columns, and
+    // twice the column blocks means bands twice as long for the same number of resident workgroups, so the 6-row
+    // ring prologue is amortised over more rows (measured 1-3 % per launch at 1080p and 4K; steps 8 and 16 are
+    // better off with 256 columns).
+    bool narrow = a.step <= kNarrowMaxStep;
+#ifdef SVGF_DIAG
+    narrow = diag_env("SVGF_ATROUS_TX", narrow ? 128 : 256) == 128;
+#endif
+    if (KR == 1 && MODE == 0 && narrow) switch (a.step) {
+        case 1: return launch_atrous_lds<ST, 1, 128, 1, 0>(g, a, s);
+        case 2: return launch_atrous_lds<ST, 2, 128, 1, 0>(g, a, s);
+        case 4: return launch_atrous_lds<ST, 4, 128, 1, 0>(g, a, s);
+        case 8: return launch_atrous_lds<ST, 8, 128, 1, 0>(g, a, s);
+        case 16: return launch_atrous_lds<ST, 16, 128, 1, 0>(g, a, s);
+        default: return hipErrorInvalidValue;
+    }
     switch (a.step) {
         case 1: return launch_atrous_lds<ST, 1, 256, KR, MODE>(g, a, s);
         case 2: return launch_atrous_lds<ST, 2, 256, KR, MODE>(g, a, s);
