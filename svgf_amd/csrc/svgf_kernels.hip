@@ -454,6 +454,8 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
     // becomes a centre two steps after it is committed; its ddepth is taken over at commit time (never at fetch
     // time: that would wait for the prefetch it was issued with).
     float dq0[KR], dq1[KR];
+    // prologue: two ring rows at a time (requesting all six at once measured the same: the launch is one resident
+    // round, so the first memory latency is paid once per kernel either way)
 #pragma unroll 1
     for (int r = 0; r < kRing; r += kRS) {
         Staged st;
