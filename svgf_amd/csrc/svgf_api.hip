@@ -30,6 +30,7 @@ struct svgf_ctx {
     void* filter[2] = {nullptr, nullptr};
     uint8_t* hist[2] = {nullptr, nullptr};
     int pingpong = 0;                   // PingPongInx, App.cu:374
+    int frames_since_reset = 0;
     bool have_state = false;
     // per-stage timing
     bool timing = false;
@@ -206,7 +207,7 @@ int svgf_set_rows(svgf_ctx* c, int rb, int re) {
 static int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, const svgf_gbuffer* cur,
                          const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur, void* moments_cur,
                          const void* moments_prev, void* passthrough_out);
-static int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist, int cold_only);
+static int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist, int cold_only, int dense);
 
 int svgf_temporal(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, const svgf_gbuffer* cur,
                   const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur, void* moments_cur,
@@ -215,7 +216,8 @@ int svgf_temporal(svgf_ctx* c, const void* prev_colour, const void* radiance, vo
 }
 
 int svgf_moments(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist) {
-    return moments_impl(c, colour, out, moments, g, hist, 0);
+    // stage call: history is unknown to the host, so the per-pixel kernel — unless the caller asks for the LDS variant
+    return moments_impl(c, colour, out, moments, g, hist, 0, c && c->p.variant == SVGF_VARIANT_LDS);
 }
 
 }  // extern "C"
@@ -240,7 +242,7 @@ static int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radia
     return SVGF_OK;
 }
 
-static int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist, int cold_only) {
+static int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist, int cold_only, int dense) {
     if (!c) return SVGF_ERR_INVALID;
     if (!colour || !out || !moments || !hist) return fail(c, SVGF_ERR_INVALID, "svgf_moments: null plane");
     if (colour == out) return fail(c, SVGF_ERR_INVALID, "svgf_moments: in-place filtering is a race");
@@ -248,7 +250,7 @@ static int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* 
     if (rc == SVGF_OK) rc = check_halo(c, c->p.moments_radius, "svgf_moments");
     if (rc != SVGF_OK) return rc;
     svgf::MomentsArgs a{colour, out, moments, (const float4*)g->motion, (const uint2*)g->normal, hist,
-                        c->p.phi_colour, c->p.phi_normal, c->p.moments_radius, cold_only};
+                        c->p.phi_colour, c->p.phi_normal, c->p.moments_radius, cold_only, dense};
     SVGF_HIP(c, svgf::launch_moments(geo_of(c), c->p.storage, a, c->stream));
     return SVGF_OK;
 }
@@ -289,6 +291,7 @@ int svgf_reset_history(svgf_ctx* c) {
         SVGF_HIP(c, hipMemsetAsync(c->hist[i], 0, hist_bytes(c), c->stream));
     }
     c->pingpong = 0;
+    c->frames_since_reset = 0;
     return SVGF_OK;
 }
 
@@ -318,7 +321,8 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
                        c->moments[P], c->moments[1 - P], c->filter[0]);         // App.cu:552
     if (rc != SVGF_OK) return rc;
     stamp();
-    rc = moments_impl(c, c->colour[P], c->filter[0], c->moments[P], cur, c->hist[P], 1);   // App.cu:554 (current moments: App. B #4)
+    // the first three frames after a reset have history <= 3 everywhere: the LDS-streaming moments kernel
+    rc = moments_impl(c, c->colour[P], c->filter[0], c->moments[P], cur, c->hist[P], 1, c->frames_since_reset < 3 && c->p.variant != SVGF_VARIANT_DIRECT);   // App.cu:554 (current moments: App. B #4)
     if (rc != SVGF_OK) return rc;
     stamp();
     int pp = 0;
@@ -335,6 +339,7 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     }
     if (result) *result = c->filter[pp];
     c->pingpong ^= 1;                                                           // App.cu:374
+    if (c->frames_since_reset < (1 << 30)) c->frames_since_reset++;
     return SVGF_OK;
 }
 

@@ -20,6 +20,7 @@ struct MomentsArgs {
     const void* colour; void* out; const void* mom; const float4* motion; const uint2* normal; const uint8_t* hist;
     float phi_colour, phi_normal; int radius;
     int cold_only;           // 1: pixels with history >= 4 were already written by the temporal stage (passthrough_out)
+    int dense;               // 1: (nearly) every pixel has history < 4 (first frames of a sequence): use the LDS-streaming kernel
 };
 struct AtrousArgs {
     const void* in; void* out; void* feedback; const float4* motion; const uint2* normal;

@@ -70,9 +70,9 @@ __device__ __forceinline__ float3 normal_of(uint2 n) {
 // glm::dot order; exact (no contraction) — used by threshold tests
 __device__ __forceinline__ float dot3_exact(float3 a, float3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ float dot3_fma(float3 a, float3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
-// CalculateLuminance, Filter.cuh:260-263
+// CalculateLuminance, Filter.cuh:260-263, in the reference's operation order: where the temporal variance is 0 the
+// a-trous weights amplify a one-ulp luminance difference ~1e4 times (Tolerance), so no FMA here
 __device__ __forceinline__ float lum_exact(float r, float g, float b) { return 0.2126f * r + 0.7152f * g + 0.0722f * b; }
-__device__ __forceinline__ float lum_fma(float r, float g, float b) { return fmaf(0.0722f, b, fmaf(0.7152f, g, 0.2126f * r)); }
 __device__ __forceinline__ float mix_exact(float x, float y, float a) { return x * (1.0f - a) + y * a; }   // glm::mix
 
 __device__ __forceinline__ float hw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -82,8 +82,7 @@ __device__ __forceinline__ float hw_rcp(float x) { return __builtin_amdgcn_rcpf(
 // Edge-stopping weight, computeWeight Filter.cuh:407-427:
 //   w = exp(-max(|dl|/phi_l,0) - max(|dz|/phi_z,0)) * pow(saturate(n.n'), phi_n)
 // evaluated as exp2( phi_n*log2(sat(n.n')) - (max(|dl|*il,0) + |dz|*iz)*log2(e) ) with il = 1/phi_l,
-// iz = 1/phi_z precomputed per pixel.  n_scale = phi_n, or 0 with n_mask = 0 when phi_n == 0
-// (pow(x,0) = 1 even at x = 0).
+// iz = 1/phi_z precomputed per pixel; phi_n == 0 drops the normal term (pow(x,0) = 1 even at x = 0).
 __device__ __forceinline__ float edge_weight(float dl_abs, float il, float dz_abs, float iz, float ndot, float phi_n) {
     const float d = clamp01(ndot);                                    // NaN -> 0 like saturate()
     const float ln = (phi_n == 0.0f) ? 0.0f : phi_n * hw_log2(d);
@@ -716,6 +715,207 @@ hipError_t launch_atrous_lds_step(const Geo& g, const AtrousArgs& a, hipStream_t
     return launch_atrous_lds_step_kr<ST, kDefaultKR, 0>(g, a, s);
 }
 
+// ------------------------------------------------------------------ moments (LDS streaming, cold frames) ----
+// Filter.cuh:430-525 for frames in which (nearly) every pixel is young (history < 4: the first three frames of a
+// sequence): the 7x7 window is served from an 8-row LDS ring exactly like the à-trous kernel's 5x5 window
+// (streaming down a band, 256 columns x 2 rows per step, one output per thread, rows fetched one step ahead), instead
+// of 49 x 4 gathers per pixel through L1.  Records are RAW (this stage does not clamp, :450,479):
+// A = {r,g,b,m1}, B = {luminance, depth, (nx,ny) halfs, nz}, C = m2.  Pixels with history >= 4 are a copy (:521).
+constexpr int kMR = 3;                       // window radius (the reference's, :465)
+constexpr int kMRing = kRS + 2 * kMR;        // 8 ring rows
+constexpr int kMTX = 256;
+
+__device__ __forceinline__ constexpr int len_class7(int xx, int yy) {   // |(xx,yy)|^2 in {1,2,4,5,8,9,10,13,18}
+    const int l2 = xx * xx + yy * yy;
+    return l2 == 1 ? 0 : l2 == 2 ? 1 : l2 == 4 ? 2 : l2 == 5 ? 3 : l2 == 8 ? 4 : l2 == 9 ? 5 : l2 == 10 ? 6 : l2 == 13 ? 7 : 8;
+}
+
+template <int ST>
+__global__ __launch_bounds__(kMTX* kRS, 4) void moments_lds_kernel(Geo g, MomentsArgs a, int band_rows) {
+    constexpr int TX = kMTX, WL = TX + 2 * kMR, CB = ST == 0 ? 16 : 8, MB = ST == 0 ? 8 : 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* recA = (f32x4*)smem;
+    f32x4* recB = recA + kMRing * WL;
+    float* recC = (float*)(recB + kMRing * WL);
+
+    const int t = threadIdx.x, lane = t & 63, col = t % TX;
+    const int rg = __builtin_amdgcn_readfirstlane(t / TX);
+    const int wig = __builtin_amdgcn_readfirstlane((t % TX) >> 6);
+    const int x0 = blockIdx.x * TX;
+    const int nrows = g.ye - g.yb;
+    const int j0 = blockIdx.y * band_rows;
+    if (j0 >= nrows) return;
+    const int j1 = min(nrows, j0 + band_rows);
+
+    const int gx = x0 + col, oli = col + kMR;
+    const bool has_halo = wig == 0 && lane < 2 * kMR;       // six halo pixels per row: lanes 0-5 of the row group's first wave
+    const int hx = (lane < kMR) ? x0 - kMR + lane : x0 + TX + lane - kMR;
+    const int hli = (lane < kMR) ? lane : TX + lane;
+    const bool own_ok = gx < g.W, halo_ok = has_halo && hx >= 0 && hx < g.W;
+    const unsigned vo = own_ok ? (unsigned)gx : 0u, vh = halo_ok ? (unsigned)hx : 0u;
+    const unsigned vo_c = own_ok ? vo * CB : kOob, vo_mo = own_ok ? vo * MB : kOob, vo_m = own_ok ? vo * 16u + 8u : kOob, vo_n = own_ok ? vo * 8u : kOob, vo_h = own_ok ? vo : kOob;
+    const unsigned vh_c = halo_ok ? vh * CB : kOob, vh_mo = halo_ok ? vh * MB : kOob, vh_m = halo_ok ? vh * 16u + 8u : kOob, vh_n = halo_ok ? vh * 8u : kOob;
+
+    const unsigned npx = (unsigned)g.rows * (unsigned)g.W;
+    auto mk = [](const void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); };
+    const __amdgpu_buffer_rsrc_t rs_c = mk(a.colour, npx * CB), rs_mo = mk(a.mom, npx * MB), rs_m = mk(a.motion, npx * 16u),
+                                 rs_n = mk(a.normal, npx * 8u), rs_h = mk(a.hist, npx), rs_out = mk(a.out, npx * CB);
+    const __amdgpu_buffer_rsrc_t rz_c = mk(a.colour, 0), rz_mo = mk(a.mom, 0), rz_m = mk(a.motion, 0), rz_n = mk(a.normal, 0);
+
+    struct Px { u32x4 c; u32x2 mo; unsigned z; u32x2 n; };
+    auto load_px = [&](Px& p, bool rok, int srow, unsigned o_c, unsigned o_mo, unsigned o_m, unsigned o_n) __attribute__((always_inline)) {
+        if (rok) {
+            if constexpr (ST == 0) { p.c = __builtin_amdgcn_raw_buffer_load_b128(rs_c, o_c, srow * CB, 0); p.mo = __builtin_amdgcn_raw_buffer_load_b64(rs_mo, o_mo, srow * MB, 0); }
+            else { const u32x2 c2 = __builtin_amdgcn_raw_buffer_load_b64(rs_c, o_c, srow * CB, 0); p.c = (u32x4){c2.x, c2.y, 0u, 0u}; p.mo = (u32x2){__builtin_amdgcn_raw_buffer_load_b32(rs_mo, o_mo, srow * MB, 0), 0u}; }
+            p.z = __builtin_amdgcn_raw_buffer_load_b32(rs_m, o_m, srow * 16, 0);
+            p.n = __builtin_amdgcn_raw_buffer_load_b64(rs_n, o_n, srow * 8, 0);
+        } else {
+            if constexpr (ST == 0) { p.c = __builtin_amdgcn_raw_buffer_load_b128(rz_c, o_c, 0, 0); p.mo = __builtin_amdgcn_raw_buffer_load_b64(rz_mo, o_mo, 0, 0); }
+            else { const u32x2 c2 = __builtin_amdgcn_raw_buffer_load_b64(rz_c, o_c, 0, 0); p.c = (u32x4){c2.x, c2.y, 0u, 0u}; p.mo = (u32x2){__builtin_amdgcn_raw_buffer_load_b32(rz_mo, o_mo, 0, 0), 0u}; }
+            p.z = __builtin_amdgcn_raw_buffer_load_b32(rz_m, o_m, 0, 0);
+            p.n = __builtin_amdgcn_raw_buffer_load_b64(rz_n, o_n, 0, 0);
+        }
+    };
+    auto row_of = [&](int j, bool& rok) __attribute__((always_inline)) {      // scalar: decimated == actual rows here
+        const int y = g.yb + j, yl = y - g.y0;
+        rok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows;
+        return rok ? yl * g.W : 0;
+    };
+    struct Staged { Px o, h; };
+    auto fetch = [&](int jn, Staged& st) __attribute__((always_inline)) {     // rows jn, jn+1: this wave's is jn+rg
+        bool rok; const int srow = row_of(jn + rg, rok);
+        load_px(st.o, rok, srow, vo_c, vo_mo, vo_m, vo_n);
+        load_px(st.h, rok, srow, vh_c, vh_mo, vh_m, vh_n);
+    };
+    auto commit_one = [&](const Px& p, int at) __attribute__((always_inline)) {
+        float4 c; float2 m;
+        if constexpr (ST == 0) { c = make_float4(__uint_as_float(p.c.x), __uint_as_float(p.c.y), __uint_as_float(p.c.z), __uint_as_float(p.c.w)); m = make_float2(__uint_as_float(p.mo.x), __uint_as_float(p.mo.y)); }
+        else { const float2 lo = unpack_h2(p.c.x), hi = unpack_h2(p.c.y); c = make_float4(lo.x, lo.y, hi.x, hi.y); m = unpack_h2(p.mo.x); }
+        float z = __uint_as_float(p.z);
+        if (z == 0.0f) z = kSkyZ;                                                   // GetDepth, :199-207
+        recA[at] = (f32x4){c.x, c.y, c.z, m.x};                                     // raw loads, :479-480
+        recB[at] = (f32x4){lum_exact(c.x, c.y, c.z), z, __uint_as_float(p.n.x), unpack_h2(p.n.y).x};
+        recC[at] = m.y;
+    };
+    auto commit = [&](int sl, const Staged& st) __attribute__((always_inline)) {
+        int so = sl + rg; so = so >= kMRing ? so - kMRing : so;
+        commit_one(st.o, so * WL + oli);
+        if (has_halo) commit_one(st.h, so * WL + hli);
+    };
+    // the centre's own history byte and ddepth come straight from the planes, one step ahead (L2 hits)
+    struct Centre { unsigned h; unsigned dz; };
+    auto fetch_centre = [&](int j, Centre& c) __attribute__((always_inline)) {
+        bool rok; const int srow = row_of(j + rg, rok);
+        if (rok) { c.h = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_h, vo_h, srow, 0); c.dz = __builtin_amdgcn_raw_buffer_load_b32(rs_m, own_ok ? vo * 16u + 12u : kOob, srow * 16, 0); }
+        else { c.h = 255u; c.dz = 0u; }
+    };
+
+#pragma unroll 1
+    for (int r = 0; r < kMRing; r += kRS) {               // ring rows 0..7 = rows j0-3 .. j0+4
+        Staged st;
+        fetch(j0 - kMR + r, st);
+        commit(r, st);
+    }
+    Centre cen, cen_next;
+    fetch_centre(j0, cen);
+    __syncthreads();
+
+    const float phi_n = a.phi_normal;                      // != 0 (launcher)
+    const float il = hw_rcp(a.phi_colour) * kLog2e;        // :460
+    int slot0 = 0;
+    for (int j = j0; j < j1; j += kRS) {
+        const bool more = (j + kRS) < j1;
+        Staged fs;
+        if (more) { fetch(j + kRS + kMR, fs); fetch_centre(j + kRS, cen_next); }       // rows j+5, j+6 enter the ring next step
+
+        int rowbase[2 * kMR + 1];
+#pragma unroll
+        for (int r = 0; r <= 2 * kMR; r++) { int sl = slot0 + rg + r; sl = sl >= kMRing ? sl - kMRing : sl; rowbase[r] = sl * WL + col; }
+        const f32x4 cB = recB[rowbase[kMR] + kMR];
+        const float lc = cB.x, zc = cB.y, ncz = cB.w;
+        const uint32_t nc01 = __float_as_uint(cB.z);
+        const float h = (float)cen.h;                                               // :442
+        const float dzc = zc == kSkyZ ? 0.0f : __uint_as_float(cen.dz);
+        const float izb = hw_rcp(fmaxf(dzc, 1e-8f) * 3.0f) * kLog2e;                // :461
+        const float iz[9] = {izb, izb * 0.70710678118654752f, izb * 0.5f, izb * 0.44721359549995794f, izb * 0.35355339059327376f,
+                             izb * 0.33333333333333333f, izb * 0.31622776601683794f, izb * 0.27735009811261456f, izb * 0.23570226039551584f};
+        float sw = 0.0f, sm2 = 0.0f;
+        f32x2 srg = {0.f, 0.f}, sbm = {0.f, 0.f};
+        const bool zero_normal = ((nc01 & 0x7fff7fffu) == 0u) && (ncz == 0.0f);     // cleared sky texel: every weight is 0 (see moments_kernel)
+        const bool need = (h < 4.0f) && !zero_normal && (j + rg < j1);
+        if (__ballot(need) != 0ull) {
+#pragma unroll
+            for (int r = 0; r <= 2 * kMR; r++) {
+                const int yy = r - kMR;
+                f32x4 tA[2 * kMR + 1], tB[2 * kMR + 1];
+                float tC[2 * kMR + 1];
+#pragma unroll
+                for (int k = 0; k <= 2 * kMR; k++) { tA[k] = recA[rowbase[r] + k]; tB[k] = recB[rowbase[r] + k]; tC[k] = recC[rowbase[r] + k]; }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int xx = -kMR; xx <= kMR; xx++) {
+                    const f32x4 A = tA[xx + kMR], B = tB[xx + kMR];
+                    const float d = clamp01(fmaf(B.w, ncz, dot2_h2(__float_as_uint(B.z), nc01)));
+                    float e = hw_log2(d) * phi_n;
+                    e = fmaf(-fabsf(B.x - lc), il, e);
+                    if (xx != 0 || yy != 0) e = fmaf(-fabsf(B.y - zc), iz[len_class7(xx, yy)], e);   // phiDepth == 0 -> wZ = 0 at the centre, :420
+                    const float w = hw_exp2(e);
+                    sw += w;                                                         // :497-499
+                    srg = __builtin_elementwise_fma((f32x2){w, w}, (f32x2){A.x, A.y}, srg);
+                    sbm = __builtin_elementwise_fma((f32x2){w, w}, (f32x2){A.z, A.w}, sbm);
+                    sm2 = fmaf(w, tC[xx + kMR], sm2);
+                }
+                asm volatile("" : "+v"(sw), "+v"(srg), "+v"(sbm), "+v"(sm2) :: "memory");
+            }
+        }
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f * (4.0f / h));
+        if (!zero_normal) {
+            sw = fmaxf(sw, 1e-6f);                                                  // :505
+            const float inv = 1.0f / sw;
+            const float m1 = sbm.y * inv, m2 = sm2 * inv;
+            o = make_float4(srg.x * inv, srg.y * inv, sbm.x * inv, (m2 - m1 * m1) * (4.0f / h));   // :507-516
+        }
+        if (more) {
+            lds_barrier();
+            commit(slot0, fs);
+            slot0 += kRS; if (slot0 >= kMRing) slot0 -= kMRing;
+            lds_barrier();
+        }
+        if (j + rg < j1) {
+            const int srow = (g.yb + j + rg - g.y0) * g.W;
+            if (h < 4.0f) {
+                if constexpr (ST == 0) __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)}, rs_out, vo_c, srow * CB, 0);
+                else __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_h2(o.x, o.y), pack_h2(o.z, o.w)}, rs_out, vo_c, srow * CB, 0);
+            } else if (!a.cold_only) {                                              // :521 copy
+                if constexpr (ST == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_amdgcn_raw_buffer_load_b128(rs_c, vo_c, srow * CB, 0), rs_out, vo_c, srow * CB, 0);
+                else __builtin_amdgcn_raw_buffer_store_b64(__builtin_amdgcn_raw_buffer_load_b64(rs_c, vo_c, srow * CB, 0), rs_out, vo_c, srow * CB, 0);
+            }
+        }
+        cen = cen_next;
+    }
+}
+
+template <int ST>
+hipError_t launch_moments_lds(const Geo& g, const MomentsArgs& a, hipStream_t s) {
+    constexpr int WL = kMTX + 2 * kMR;
+    constexpr size_t lds = (size_t)kMRing * WL * 36;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)moments_lds_kernel<ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nrows = g.ye - g.yb, xtiles = (g.W + kMTX - 1) / kMTX;
+    int nbands = 2 * num_cus() / xtiles;                  // one resident round: 2 workgroups per CU (LDS)
+    if (nbands < 1) nbands = 1;
+    int band = (nrows + nbands - 1) / nbands;
+    if (band < 8) band = 8;
+    band = (band + kRS - 1) / kRS * kRS;
+    nbands = (nrows + band - 1) / band;
+    moments_lds_kernel<ST><<<dim3(xtiles, nbands), dim3(kMTX * kRS), lds, s>>>(g, a, band);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ TAA + sRGB -----------------
 // filter::TAAFilterKernel (Filter.cuh:288-357): the stage application::Render runs right after the wavelet
 // filter (App.cu:558).  Neighbourhood clamp in gamma-2 PAL-YUV of the previous output against the 3x3
@@ -801,6 +1001,10 @@ hipError_t launch_temporal(const Geo& g, int storage, const TemporalArgs& a, hip
 
 hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, hipStream_t s) {
     if (g.ye <= g.yb) return hipSuccess;
+    // dense: the caller knows (nearly) every pixel is young — the LDS-streaming kernel; it needs the reference's
+    // radius and a non-degenerate PhiNormal (the fused exponent would see 0 * -inf)
+    if (a.dense && a.radius == kMR && a.phi_normal != 0.0f)
+        return storage == 0 ? launch_moments_lds<0>(g, a, s) : launch_moments_lds<1>(g, a, s);
     const dim3 block(kBX, kBY), grid = grid_for(g);
     if (storage == 0) moments_kernel<0><<<grid, block, 0, s>>>(g, a);
     else moments_kernel<1><<<grid, block, 0, s>>>(g, a);

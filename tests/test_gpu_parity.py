@@ -43,9 +43,10 @@ def test_temporal_bit_exact(G, oracle, storage, mv, mesh):
     assert np.array_equal(G.host(o_mom).view(np.uint8), mom.view(np.uint8))
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("storage", ["f32", "f16"])
 @pytest.mark.parametrize("radius", [3, 1])
-def test_moments(G, oracle, storage, radius):
+def test_moments(G, oracle, storage, radius, variant):
     from svgf_amd import filter as F
     W, H = 203, 131
     rng = np.random.default_rng(2)
@@ -56,7 +57,7 @@ def test_moments(G, oracle, storage, radius):
     hist = rng.integers(1, 8, (H, W)).astype(np.uint8)
     want = np.zeros_like(col)
     oracle.moments(W, H, storage, col, want, mom, gbuf(f), hist, phi_colour=10.0, phi_normal=128.0, radius=radius)
-    d = F.Denoiser(W, H, F.Params(storage=storage, moments_radius=radius))
+    d = F.Denoiser(W, H, F.Params(storage=storage, moments_radius=radius, variant=variant))   # lds: the streaming kernel (radius 3)
     out = d.new_colour()
     d.FilterMoments(G.dev(col), out, G.dev(mom), G.gb_dev(f), G.dev(hist))
     got = G.host(out)
@@ -169,12 +170,14 @@ def test_pipeline_free_running(G, oracle, storage, mv, variant):
 
 @pytest.mark.parametrize("storage", ["f32", "f16"])
 def test_frame_driver_equals_stage_calls(G, storage):
-    """svgf_denoise_frame (context-owned state) == the same stages driven from outside, bitwise."""
+    """svgf_denoise_frame (context-owned state, moments pass-through folded into the temporal launch) == the same
+    stages driven from outside, bitwise — with variant "direct", where both paths run the same kernels (the default
+    driver switches to the LDS moments kernel while the whole frame is young, which rounds differently)."""
     from svgf_amd import filter as F
-    W, H, N = 200, 120, 5
+    W, H, N = 200, 120, 6
     fr = frames(W, H, N, mv=(1.0, 0.0))
-    hip = G.HipPipeline(W, H, storage, steps=3)
-    d = F.Denoiser(W, H, F.Params(storage=storage, steps=3))
+    hip = G.HipPipeline(W, H, storage, steps=3, variant="direct")
+    d = F.Denoiser(W, H, F.Params(storage=storage, steps=3, variant="direct"))
     gbs = [G.gb_dev(f) for f in fr]
     for k in range(N):
         kp = max(k - 1, 0)
@@ -183,6 +186,32 @@ def test_frame_driver_equals_stage_calls(G, storage):
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), k
     assert d.pingpong() == N % 2
     assert np.array_equal(G.host(d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong())), hip.taps["hist"])
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_frame_driver_default_path(G, oracle, storage):
+    """The default driver (LDS moments kernel while history < 4 everywhere, fused pass-through afterwards, LDS
+    à-trous) against the oracle, free running over the cold -> steady transition."""
+    from svgf_amd import filter as F
+    W, H, N = 256, 144, 8
+    fr = frames(W, H, N, mv=(-2.5, 1.5))
+    ref = oracle.Pipeline(W, H, storage, steps=5, nthreads=8)
+    d = F.Denoiser(W, H, F.Params(storage=storage, steps=5))
+    gbs = [G.gb_dev(f) for f in fr]
+    tight = 2e-5 if storage == "f32" else 1e-3
+    loose = 2e-3 if storage == "f32" else 3e-2
+    for k in range(N):
+        kp = max(k - 1, 0)
+        want = ref.frame(fr[k]["radiance"], gbuf(fr[k]), gbuf(fr[kp])).astype(np.float64)
+        got = G.host(d.Render(G.dev(fr[k]["radiance"].astype(G.NPDT[storage])), gbs[k], gbs[kp] if k else None)).astype(np.float64)
+        assert np.array_equal(G.host(d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong())), ref.taps["hist"]), f"frame {k}: history"
+        err = np.abs(got - want)[..., :3]
+        assert err.max() <= loose, f"frame {k}: max colour error {err.max():.3e}"
+        assert (err > tight + 1e-5 * np.abs(want[..., :3])).mean() <= 5e-3, f"frame {k}"
+    d.reset_history()
+    want0 = oracle.Pipeline(W, H, storage, steps=5, nthreads=8).frame(fr[0]["radiance"], gbuf(fr[0]), gbuf(fr[0]))
+    got0 = G.host(d.Render(G.dev(fr[0]["radiance"].astype(G.NPDT[storage])), gbs[0], None))
+    assert np.abs(got0.astype(np.float64) - want0.astype(np.float64)).max() <= loose      # reset_history restarts the cold path
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -218,7 +247,7 @@ def test_strip_runner_virtual_ranks(G, plan, storage):
     mv = (1.0, -2.5)
     fr = frames(W, H, N, mv=mv)
     params = F.Params(storage=storage, steps=5)
-    whole = F.Denoiser(W, H, params)
+    whole = G.HipPipeline(W, H, storage, steps=5)          # the same stage calls the strips make, on the whole frame
     dev = torch.device("cuda:0")
     lc = strips.LocalComm()
     geos = [strips.Geometry.make(W, H, r, world, 5, plan=plan, motion_reach=3) for r in range(world)]
@@ -229,14 +258,14 @@ def test_strip_runner_virtual_ranks(G, plan, storage):
         return F.GBuffer(*(G.dev(np.ascontiguousarray(f[k][g.y0:g.y1])) for k in ("motion", "normal", "uv")))
     for k in range(N):
         kp = max(k - 1, 0)
-        want = G.host(whole.Render(G.dev(fr[k]["radiance"].astype(G.NPDT[storage])), gbs[k], gbs[kp] if k else None))
+        want = whole.frame(fr[k]["radiance"], gbs[k], gbs[kp])
         inputs = [(G.dev(np.ascontiguousarray(fr[k]["radiance"][g.y0:g.y1].astype(G.NPDT[storage]))), local_gb(fr[k], g), local_gb(fr[kp], g))
                   for g in geos]
         outs = strips.run_virtual(runners, inputs)
         got = np.concatenate([G.host(r.owned(o)) for r, o in zip(runners, outs)], 0)
         assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), f"plan {plan}: frame {k}"
     hist = np.concatenate([G.host(r.owned(r.hist[r.P ^ 1])) for r in runners], 0)
-    assert np.array_equal(hist, G.host(whole.state_plane(F.PLANE_HISTORY, 1 - whole.pingpong())))
+    assert np.array_equal(hist, whole.taps["hist"])
 
 
 def test_abi_errors(G):
