@@ -124,6 +124,24 @@ int svgf_atrous(svgf_ctx* ctx, const void* in, void* out, void* feedback, const 
  * previous call's `out` (a separate plane: the reference reads it from the buffer it is writing, a race). */
 int svgf_taa(svgf_ctx* ctx, const void* filtered, const void* history, void* out);
 
+/* The stage in front of the path — the G-buffer texels resources/shaders/GBuffer.frag:62-88 writes, computed from
+ * linear attribute planes (for producers that are not the reference's OpenGL rasteriser):
+ *   position float[4] {world x,y,z, primitive id}   = OutPosition   (GBuffer.frag:63,80)
+ *   normal   float[4] {world normal (any length), material id}      (GBuffer.frag:62,79)
+ *   bary     float[4] {b0,b1,b2, instance id}                       (GBuffer.frag:61,78)
+ * and the camera of application::Rasterize (App.cu:396-398).  Geometry is taken to be static between the two frames
+ * (PreviousMVP * vertex == prev_view_proj * world position).  motion = (prev - cur) NDC * 0.5 * (W,H), depth =
+ * |camera - position|, ddepth = max(|dFdx|,|dFdy|) by 2x2-quad differences of depth (0 towards a texel without
+ * geometry; OpenGL extrapolates the triangle there, which no image-space adapter can).  A texel whose normal is
+ * (0,0,0) has no geometry and is written as the cleared texel (all zero = sky for the filter). */
+typedef struct svgf_camera {
+    float view_proj[16];       /* column-major, Projection * inverse(Frame)          */
+    float prev_view_proj[16];  /* column-major, Projection * inverse(PreviousFrame)  */
+    float position[3];         /* Frame * (0,0,0,1)                                  */
+} svgf_camera;
+int svgf_pack_gbuffer(svgf_ctx* ctx, const void* position, const void* normal, const void* bary, const svgf_camera* camera,
+                      void* motion_out, void* normal_out, void* uv_out);
+
 /* Whole frame — replaces the sequence application::Render runs (App.cu:552-556) on context-owned
  * state (RenderBuffer[2], MomentsBuffer[2], FilterBuffer[2], history; App.h:138-141).
  * `prev` may be NULL on the first frame.  *result receives the device pointer of the final

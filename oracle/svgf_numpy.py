@@ -232,3 +232,40 @@ def taa(filtered, history):
     out[bad] = 0          # fragColor = vec4(0) then ToSRGB(0) = 0, alpha forced back to 1 by :353
     out[..., 3] = 1
     return _clamp01(out).astype(sdt)
+
+
+# ------------------------------------------------------------------ G-buffer adapter --------------
+def pack_gbuffer(position, normal, bary, view_proj, prev_view_proj, cam):
+    """resources/shaders/GBuffer.frag:62-88 (+ GBuffer.vert:21-34) from linear attribute planes, static geometry.
+    Matrices: 16 floats, column-major.  Unfused fp32 in the order of svgf_amd/csrc (bit-exact contract)."""
+    H, W = position.shape[:2]
+    p = position.astype(np.float32)
+    n = normal.astype(np.float32)
+    covered = ~((n[..., 0] == 0) & (n[..., 1] == 0) & (n[..., 2] == 0))
+
+    def mul(m, q):
+        m = np.asarray(m, np.float32)
+        return [((m[r] * q[..., 0] + m[4 + r] * q[..., 1]) + m[8 + r] * q[..., 2]) + m[12 + r] for r in range(4)]
+    cam = np.asarray(cam, np.float32)
+    dx, dy, dz = cam[0] - p[..., 0], cam[1] - p[..., 1], cam[2] - p[..., 2]
+    depth = np.sqrt((dx * dx + dy * dy) + dz * dz).astype(np.float32)
+    with np.errstate(all="ignore"):
+        cur, prev = mul(view_proj, p), mul(prev_view_proj, p)
+        mvx = (prev[0] / prev[3] - cur[0] / cur[3]) * (f32(0.5) * f32(W))
+        mvy = (prev[1] / prev[3] - cur[1] / cur[3]) * (f32(0.5) * f32(H))
+    Y, X = np.mgrid[0:H, 0:W]
+    xp, yp = X ^ 1, Y ^ 1
+    okx, oky = xp < W, yp < H
+    xpc, ypc = np.minimum(xp, W - 1), np.minimum(yp, H - 1)
+    ddx = np.where(okx & covered[Y, xpc], np.abs(depth[Y, xpc] - depth), f32(0))
+    ddy = np.where(oky & covered[ypc, X], np.abs(depth[ypc, X] - depth), f32(0))
+    motion = np.stack([mvx, mvy, depth, np.maximum(ddx, ddy)], -1).astype(np.float32)
+    motion[~covered] = 0
+    with np.errstate(all="ignore"):
+        ln = np.sqrt((n[..., 0] * n[..., 0] + n[..., 1] * n[..., 1]) + n[..., 2] * n[..., 2]).astype(np.float32)
+        nn = np.stack([n[..., 0] / ln, n[..., 1] / ln, n[..., 2] / ln, n[..., 3]], -1).astype(np.float32)
+    nout = nn.astype(np.float16).view(np.uint16)
+    nout[~covered] = 0
+    uvout = bary.astype(np.float32).astype(np.float16).view(np.uint16).copy()
+    uvout[~covered] = 0
+    return motion, nout, uvout

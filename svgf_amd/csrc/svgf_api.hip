@@ -281,6 +281,20 @@ int svgf_taa(svgf_ctx* c, const void* filtered, const void* history, void* out) 
     return SVGF_OK;
 }
 
+int svgf_pack_gbuffer(svgf_ctx* c, const void* position, const void* normal, const void* bary, const svgf_camera* cam,
+                      void* motion_out, void* normal_out, void* uv_out) {
+    if (!c) return SVGF_ERR_INVALID;
+    if (!position || !normal || !bary || !cam || !motion_out || !normal_out || !uv_out) return fail(c, SVGF_ERR_INVALID, "svgf_pack_gbuffer: null argument");
+    int rc = check_halo(c, 1, "svgf_pack_gbuffer");                       // the 2x2 quad partner row
+    if (rc != SVGF_OK) return rc;
+    svgf::PackArgs a;
+    a.position = (const float4*)position; a.normal = (const float4*)normal; a.bary = (const float4*)bary;
+    std::memcpy(a.vp, cam->view_proj, sizeof(a.vp)); std::memcpy(a.pvp, cam->prev_view_proj, sizeof(a.pvp)); std::memcpy(a.cam, cam->position, sizeof(a.cam));
+    a.motion = (float4*)motion_out; a.normal_out = (uint2*)normal_out; a.uv_out = (uint2*)uv_out;
+    SVGF_HIP(c, svgf::launch_pack_gbuffer(geo_of(c), a, c->stream));
+    return SVGF_OK;
+}
+
 int svgf_reset_history(svgf_ctx* c) {
     if (!c) return SVGF_ERR_INVALID;
     if (!c->have_state) return SVGF_OK;

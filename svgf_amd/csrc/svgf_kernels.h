@@ -30,6 +30,12 @@ struct AtrousArgs {
 hipError_t launch_temporal(const Geo& g, int storage, const TemporalArgs& a, hipStream_t s);
 hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, hipStream_t s);
 hipError_t launch_atrous(const Geo& g, int storage, int variant, const AtrousArgs& a, hipStream_t s);
+struct PackArgs {
+    const float4* position; const float4* normal; const float4* bary;
+    float vp[16], pvp[16], cam[3];
+    float4* motion; uint2* normal_out; uint2* uv_out;
+};
+hipError_t launch_pack_gbuffer(const Geo& g, const PackArgs& a, hipStream_t s);
 hipError_t launch_taa(const Geo& g, int storage, const void* filtered, const void* history, void* out, hipStream_t s);
 
 }  // namespace svgf

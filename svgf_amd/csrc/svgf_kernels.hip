@@ -987,6 +987,51 @@ __global__ __launch_bounds__(kBX* kBY) void taa_kernel(Geo g, const void* filter
     Store<ST>::st4(out, (size_t)(y - g.y0) * g.W + x, clamp01(o));        // :355 imageStore
 }
 
+// ------------------------------------------------------------------ G-buffer adapter -----------
+// What resources/shaders/GBuffer.frag:62-88 (+ GBuffer.vert:21-34) writes, from linear attribute planes.  All
+// arithmetic is unfused fp32 in a fixed order so that the CPU restatement reproduces it bit for bit.
+__device__ __forceinline__ float4 mat_mul_point(const float* m, float3 p) {       // column-major m * (p,1)
+    return make_float4(((m[0] * p.x + m[4] * p.y) + m[8] * p.z) + m[12], ((m[1] * p.x + m[5] * p.y) + m[9] * p.z) + m[13],
+                       ((m[2] * p.x + m[6] * p.y) + m[10] * p.z) + m[14], ((m[3] * p.x + m[7] * p.y) + m[11] * p.z) + m[15]);
+}
+__device__ __forceinline__ float depth_at(const PackArgs& a, size_t idx, bool& covered) {
+    const float4 n = a.normal[idx];
+    covered = !(n.x == 0.0f && n.y == 0.0f && n.z == 0.0f);
+    const float4 p = a.position[idx];
+    const float dx = a.cam[0] - p.x, dy = a.cam[1] - p.y, dz = a.cam[2] - p.z;
+    return sqrtf((dx * dx + dy * dy) + dz * dz);                                   // distance(), GBuffer.frag:70
+}
+__global__ __launch_bounds__(kBX* kBY) void pack_gbuffer_kernel(Geo g, PackArgs a) {
+    const int x = blockIdx.x * kBX + threadIdx.x;
+    const int y = g.yb + blockIdx.y * kBY + threadIdx.y;
+    if (x >= g.W || y >= g.ye) return;
+    const size_t idx = (size_t)(y - g.y0) * g.W + x;
+    bool covered;
+    const float depth = depth_at(a, idx, covered);
+    if (!covered) {                                                               // cleared texel (App.cu:383-384)
+        a.motion[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        a.normal_out[idx] = make_uint2(0u, 0u);
+        a.uv_out[idx] = make_uint2(0u, 0u);
+        return;
+    }
+    const float4 p = a.position[idx];
+    const float4 cur = mat_mul_point(a.vp, make_float3(p.x, p.y, p.z)), prev = mat_mul_point(a.pvp, make_float3(p.x, p.y, p.z));
+    const float mvx = (prev.x / prev.w - cur.x / cur.w) * (0.5f * (float)g.W);    // GBuffer.frag:65-67
+    const float mvy = (prev.y / prev.w - cur.y / cur.w) * (0.5f * (float)g.H);
+    // dFdx / dFdy: differences inside the 2x2 quad (GBuffer.frag:71)
+    const int xp = x ^ 1, yp = y ^ 1;
+    float ddx = 0.0f, ddy = 0.0f;
+    bool c2;
+    if (xp < g.W) { const float d2 = depth_at(a, (size_t)(y - g.y0) * g.W + xp, c2); if (c2) ddx = fabsf(d2 - depth); }
+    if (yp < g.H && yp - g.y0 >= 0 && yp - g.y0 < g.rows) { const float d2 = depth_at(a, (size_t)(yp - g.y0) * g.W + x, c2); if (c2) ddy = fabsf(d2 - depth); }
+    a.motion[idx] = make_float4(mvx, mvy, depth, fmaxf(ddx, ddy));
+    const float4 n = a.normal[idx];
+    const float len = sqrtf((n.x * n.x + n.y * n.y) + n.z * n.z);                 // normalize(), GBuffer.frag:62
+    a.normal_out[idx] = make_uint2(pack_h2(n.x / len, n.y / len), pack_h2(n.z / len, n.w));   // Vec4ToUVec4 (packHalf2x16), :48-60,87
+    const float4 b = a.bary[idx];
+    a.uv_out[idx] = make_uint2(pack_h2(b.x, b.y), pack_h2(b.z, b.w));
+}
+
 inline dim3 grid_for(const Geo& g) { return dim3((g.W + kBX - 1) / kBX, (g.ye - g.yb + kBY - 1) / kBY); }
 
 }  // namespace
@@ -1030,6 +1075,12 @@ hipError_t launch_atrous(const Geo& g, int storage, int variant, const AtrousArg
     const dim3 block(kBX, kBY), grid = grid_for(g);
     if (storage == 0) atrous_direct_kernel<0><<<grid, block, 0, s>>>(g, a);
     else atrous_direct_kernel<1><<<grid, block, 0, s>>>(g, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_gbuffer(const Geo& g, const PackArgs& a, hipStream_t s) {
+    if (g.ye <= g.yb) return hipSuccess;
+    pack_gbuffer_kernel<<<grid_for(g), dim3(kBX, kBY), 0, s>>>(g, a);
     return hipGetLastError();
 }
 

@@ -24,7 +24,7 @@ MAX_STEPS = 10
 EXPORTS = [
     "svgf_default_params", "svgf_status_string", "svgf_last_error", "svgf_abi_version", "svgf_create",
     "svgf_create_strip", "svgf_destroy", "svgf_set_params", "svgf_set_stream", "svgf_set_rows", "svgf_temporal",
-    "svgf_moments", "svgf_atrous", "svgf_taa", "svgf_denoise_frame", "svgf_reset_history", "svgf_state_plane",
+    "svgf_moments", "svgf_atrous", "svgf_taa", "svgf_pack_gbuffer", "svgf_denoise_frame", "svgf_reset_history", "svgf_state_plane",
     "svgf_state_pingpong", "svgf_plane_bytes", "svgf_timing_enable", "svgf_timing_read",
 ]
 
@@ -41,6 +41,10 @@ class ParamsC(C.Structure):
     _fields_ = [("steps", C.c_int), ("depth_threshold", C.c_float), ("normal_threshold", C.c_float),
                 ("history_base", C.c_int), ("phi_colour", C.c_float), ("phi_normal", C.c_float),
                 ("moments_radius", C.c_int), ("storage", C.c_int), ("mesh_id_test", C.c_int), ("variant", C.c_int)]
+
+
+class CameraC(C.Structure):
+    _fields_ = [("view_proj", C.c_float * 16), ("prev_view_proj", C.c_float * 16), ("position", C.c_float * 3)]
 
 
 class StripC(C.Structure):
@@ -109,6 +113,7 @@ def load_library():
     lib.svgf_moments.argtypes = [vp, vp, vp, vp, C.POINTER(GBufferC), vp]
     lib.svgf_atrous.argtypes = [vp, vp, vp, vp, C.POINTER(GBufferC), ip, ip]
     lib.svgf_taa.argtypes = [vp, vp, vp, vp]
+    lib.svgf_pack_gbuffer.argtypes = [vp, vp, vp, vp, C.POINTER(CameraC), vp, vp, vp]
     lib.svgf_denoise_frame.argtypes = [vp, vp, C.POINTER(GBufferC), C.POINTER(GBufferC), C.POINTER(vp)]
     lib.svgf_reset_history.argtypes = [vp]
     lib.svgf_state_plane.argtypes = [vp, ip, ip]
@@ -237,6 +242,19 @@ class Denoiser:
     def TAA(self, filtered, history, out):
         """application::TAA, src/App.cu:516-522 (history = the previous call's out)."""
         self._check(self.lib.svgf_taa(self._h, _ptr(filtered), _ptr(history), _ptr(out)), "svgf_taa")
+
+    def PackGBuffer(self, position, normal, bary, view_proj, prev_view_proj, camera_position):
+        """The G-buffer texels of resources/shaders/GBuffer.frag:62-88 from linear attribute planes; matrices are
+        16 floats column-major (glm).  Returns a GBuffer of new device planes."""
+        torch = self._torch
+        cam = CameraC((C.c_float * 16)(*[float(v) for v in view_proj]), (C.c_float * 16)(*[float(v) for v in prev_view_proj]),
+                      (C.c_float * 3)(*[float(v) for v in camera_position]))
+        motion = torch.empty((self.rows, self.W, 4), dtype=torch.float32, device=self.device)
+        nout = torch.empty((self.rows, self.W, 4), dtype=torch.int16, device=self.device)
+        uvout = torch.empty((self.rows, self.W, 4), dtype=torch.int16, device=self.device)
+        self._check(self.lib.svgf_pack_gbuffer(self._h, _ptr(position), _ptr(normal), _ptr(bary), C.byref(cam), _ptr(motion),
+                                               _ptr(nout), _ptr(uvout)), "svgf_pack_gbuffer")
+        return GBuffer(motion, nout, uvout)
 
     # -- whole frame on context-owned state --------------------------------------------------
     def Render(self, radiance, gb_cur: GBuffer, gb_prev: GBuffer | None = None):

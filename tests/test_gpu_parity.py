@@ -410,3 +410,52 @@ def test_frame_sizes_and_ten_iterations(G, oracle):
             got = hip.frame(fr[k]["radiance"], gbs[k], gbs[max(k - 1, 0)])
             assert np.array_equal(hip.taps["hist"], ref.taps["hist"]), (W, H, k)
             G.assert_colour_close(got, want, "f32", f"{W}x{H} steps {steps} frame {k}")
+
+
+def _look_at(eye, target, up=(0, 1, 0)):
+    e, t, u = (np.asarray(v, np.float64) for v in (eye, target, up))
+    f = t - e; f /= np.linalg.norm(f)
+    s = np.cross(f, u); s /= np.linalg.norm(s)
+    uu = np.cross(s, f)
+    m = np.eye(4); m[0, :3], m[1, :3], m[2, :3] = s, uu, -f
+    m[:3, 3] = -m[:3, :3] @ e
+    return m
+
+
+def _perspective(fovy, aspect, zn, zf):
+    t = 1.0 / np.tan(fovy / 2)
+    m = np.zeros((4, 4)); m[0, 0] = t / aspect; m[1, 1] = t; m[2, 2] = (zf + zn) / (zn - zf); m[2, 3] = 2 * zf * zn / (zn - zf); m[3, 2] = -1
+    return m
+
+
+def test_pack_gbuffer_adapter(G):
+    """The stage in front of the path: GBuffer.frag texels from linear attribute planes, bit for
+    bit against the NumPy restatement, then fed to the temporal stage: a camera that does not move must reproject
+    every covered pixel onto itself."""
+    from oracle import svgf_numpy as snp
+    from svgf_amd import filter as F
+    W, H = 301, 187
+    rng = np.random.default_rng(5)
+    eye0, eye1 = np.array([0.3, 0.4, 5.0]), np.array([0.35, 0.38, 5.02])
+    proj = _perspective(0.9, W / H, 0.1, 100.0)
+    vp, pvp = proj @ _look_at(eye1, (0, 0, 0)), proj @ _look_at(eye0, (0, 0, 0))
+    pos = np.concatenate([rng.uniform(-2, 2, (H, W, 3)), rng.integers(0, 900, (H, W, 1))], -1).astype(np.float32)
+    nrm = np.concatenate([rng.normal(size=(H, W, 3)), rng.integers(0, 20, (H, W, 1))], -1).astype(np.float32)
+    nrm[rng.uniform(size=(H, W)) < 0.1, :3] = 0                      # texels without geometry
+    bary = np.concatenate([rng.uniform(0, 1, (H, W, 3)), rng.integers(0, 50, (H, W, 1))], -1).astype(np.float32)
+    colmajor = lambda m: m.T.astype(np.float32).ravel()               # noqa: E731
+    want_m, want_n, want_uv = snp.pack_gbuffer(pos, nrm, bary, colmajor(vp), colmajor(pvp), eye1.astype(np.float32))
+    d = F.Denoiser(W, H, F.Params(storage="f32"))
+    gb = d.PackGBuffer(G.dev(pos), G.dev(nrm), G.dev(bary), colmajor(vp), colmajor(pvp), eye1)
+    got_m, got_n, got_uv = G.host(gb.motion), G.host(gb.normal).view(np.uint16), G.host(gb.uv).view(np.uint16)
+    assert np.array_equal(got_m.view(np.uint32), want_m.view(np.uint32))
+    assert np.array_equal(got_n, want_n) and np.array_equal(got_uv, want_uv)
+    assert np.all(got_m[(nrm[..., :3] == 0).all(-1)] == 0)
+    # static camera: zero motion on covered texels, and the filter accepts the reprojection everywhere but "sky"
+    gb0 = d.PackGBuffer(G.dev(pos), G.dev(nrm), G.dev(bary), colmajor(vp), colmajor(vp), eye1)
+    assert np.abs(G.host(gb0.motion)[..., :2]).max() == 0
+    col, hist, mom = d.new_colour(), d.new_history(), d.new_moments()
+    d.TemporalFilter(d.new_colour(), G.dev(rng.uniform(0, 1, (H, W, 4)).astype(np.float32)), col, gb0, gb0, G.dev(np.full((H, W), 5, np.uint8)),
+                     hist, mom, d.new_moments())
+    covered = ~(nrm[..., :3] == 0).all(-1)
+    assert np.all(G.host(hist)[covered] == 6) and np.all(G.host(hist)[~covered] == 1)
