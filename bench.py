@@ -95,7 +95,7 @@ def run_single(W, H, storage, iters, variant, steps, warmup, device, barrier=Non
     return dict(ms_per_step=(t1 - t0) * 1e3 / steps, stage_ms=[m / max(frames, 1) for m in stage_ms], frames=frames)
 
 
-def roofline_block(W, H, storage, iters, stage_ms):
+def roofline_block(W, H, storage, iters, stage_ms, variant="auto"):
     """Roofline of the dominant kernel (the LDS-streaming à-trous kernel, `iters` launches per frame)."""
     b = ALG_BYTES[storage]
     P = W * H
@@ -109,10 +109,10 @@ def roofline_block(W, H, storage, iters, stage_ms):
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get(f"{W}x{H}_{storage}", {}).get("atrous_bytes_per_launch")
+            traffic = json.load(open(tfile)).get(f"{W}x{H}_{storage}", {}).get("atrous_bytes_per_launch") if variant != "direct" else None
         except Exception:  # noqa: BLE001
             traffic = None
-    roof = {"bound": "hbm", "kernel": "atrous_lds_kernel", "launches_per_step": iters, "achieved": round(achieved, 1),
+    roof = {"bound": "hbm", "kernel": "atrous_direct_kernel" if variant == "direct" else "atrous_lds_kernel", "launches_per_step": iters, "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5), "traffic": traffic}
     names = ["temporal", "moments"] + [f"atrous_step{1 << i}" for i in range(iters)]
@@ -183,7 +183,7 @@ def main():
         r = run_single(W, H, storage, iters, args.variant, args.steps, args.warmup, device)
         ms = r["ms_per_step"]
         value = W * H / (ms * 1e-3) / 1e6
-        roof, stages = roofline_block(W, H, storage, iters, r["stage_ms"])
+        roof, stages = roofline_block(W, H, storage, iters, r["stage_ms"], args.variant)
         full_gbps = alg_bytes_full(storage, iters) * W * H / (ms * 1e-3) / 1e9
         line = {
             "metric": "Mpixels/s (and ms/frame) for full SVGF temporal+5 a-trous pass at 1080p/4K", "value": round(value, 1),
