@@ -14,6 +14,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace svgf {
 namespace {
@@ -286,7 +287,10 @@ __global__ __launch_bounds__(kBX* kBY) void atrous_direct_kernel(Geo g, AtrousAr
 constexpr int kRS = 2;                   // decimated rows produced per step
 constexpr int kRing = kRS + 4;
 constexpr int kRecBytes = 32;            // LDS bytes per staged pixel
-constexpr int kNarrowMaxStep = 4;           // steps up to this one use 128-column workgroups
+#ifndef SVGF_NARROW_MAX_STEP
+#define SVGF_NARROW_MAX_STEP 16
+#endif
+constexpr int kNarrowMaxStep = SVGF_NARROW_MAX_STEP;           // steps up to this one use 128-column workgroups
 constexpr int kDefaultKR = 1;            // outputs per thread of the kernel the library launches (see atrous_lds_kernel)
 constexpr unsigned kOob = 0xFFFFFF00u;   // byte offset no plane reaches (planes are < 4 GiB)
 
@@ -331,7 +335,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ float med01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }   // = min(max(v,0),1) for non-NaN v
 
 template <int ST, bool DZ>
-__device__ __forceinline__ void commit_px(const RawPx<ST, DZ>& r, f32x4* recA, f32x4* recB, int at) {
+__device__ __forceinline__ bool commit_px(const RawPx<ST, DZ>& r, f32x4* recA, f32x4* recB, int at, uint32_t ref01, uint32_t refz) {
     float4 c;
     if constexpr (ST == 0) c = make_float4(__uint_as_float(r.c.x), __uint_as_float(r.c.y), __uint_as_float(r.c.z), __uint_as_float(r.c.w));
     else { float2 lo = unpack_h2(r.c.x), hi = unpack_h2(r.c.y); c = make_float4(lo.x, lo.y, hi.x, hi.y); }
@@ -341,6 +345,8 @@ __device__ __forceinline__ void commit_px(const RawPx<ST, DZ>& r, f32x4* recA, f
     if (z == 0.0f) z = kSkyZ;                                           // GetDepth, :199-207
     recA[at] = (f32x4){c.x, c.y, c.z, c.w};
     recB[at] = (f32x4){lum_exact(c.x, c.y, c.z), z, __uint_as_float(r.n.x), unpack_h2(r.n.y).x};
+    // a texel without depth (sky, or outside the frame) has weight 0 through the depth term whatever its normal
+    return z != kSkyZ && (r.n.x != ref01 || (r.n.y & 0xffffu) != refz);
 }
 
 // log2 of the kernel weight K[|xx|]*K[|yy|] (:540,582), folded into the exponent
@@ -350,6 +356,9 @@ __device__ __forceinline__ constexpr float klog2(int axx, int ayy) {
          : (axx + ayy == 2) ? -2.5849626064300537f       // 1 * 1/6
          : (axx + ayy == 3) ? -3.1699249744415283f       // 2/3 * 1/6
          : -5.169925212860107f;                          // 1/6 * 1/6
+}
+__device__ __forceinline__ constexpr int kernel_class(int axx, int ayy) {   // index of klog2's five values
+    return (axx + ayy == 1) ? 0 : (axx == 1 && ayy == 1) ? 1 : (axx + ayy == 2) ? 2 : (axx + ayy == 3) ? 3 : 4;
 }
 __device__ __forceinline__ constexpr int len_class(int xx, int yy) {    // |(xx,yy)| in {1, sqrt2, 2, sqrt5, 2sqrt2}
     const int l2 = xx * xx + yy * yy;
@@ -385,6 +394,12 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* recA = (f32x4*)smem;
     f32x4* recB = recA + kRing * WL;
+    // Uniform-normal fast path: on planar geometry every texel of the ring carries the same normal bits; then
+    // n.n' is the centre's own |n|^2 for every tap and the dot product, its log2 and an FMA (22 of a tap's ~59 VALU
+    // cycles) leave the tap loop — with bit-identical results.  nflag[slot][wave] = "a texel of this ring row staged
+    // by this wave differs from the workgroup's reference normal" (depth-0 texels do not count: their weight is 0).
+    uint32_t* nflag = (uint32_t*)(recB + kRing * WL);              // [kRing][8]
+    uint32_t* nref = nflag + kRing * 8;                            // {(nx,ny) bits, nz bits}
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -440,12 +455,15 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
             else { raw_load<ST, true>(st.o[k], rs_none, vo_c, vo_m, vo_n, 0); raw_load<ST, false>(st.h[k], rs_none, vh_c, vh_m, vh_n, 0); }
         }
     };
+    uint32_t ref01 = 0, refz = 0;
     auto commit = [&](int sl, const Staged& st) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < KR; k++) {
             int so = sl + rg * KR + k; so = so >= kRing ? so - kRing : so;                   // scalar
-            commit_px<ST, true>(st.o[k], recA, recB, so * WL + oli);
-            if (has_halo) commit_px<ST, false>(st.h[k], recA, recB, so * WL + hli);
+            bool differs = commit_px<ST, true>(st.o[k], recA, recB, so * WL + oli, ref01, refz);
+            if (has_halo) differs = commit_px<ST, false>(st.h[k], recA, recB, so * WL + hli, ref01, refz) || differs;
+            const bool wave_differs = __ballot(differs) != 0ull;
+            if (lane == 0) nflag[so * 8 + wig] = wave_differs ? 1u : 0u;                     // a ring slot is always staged by the same waves
         }
     };
 
@@ -454,11 +472,19 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
     // time: that would wait for the prefetch it was issued with).
     float dq0[KR], dq1[KR];
     // prologue: two ring rows at a time (requesting all six at once measured the same: the launch is one resident
-    // round, so the first memory latency is paid once per kernel either way)
+    // round, so the first memory latency is paid once per kernel either way).  Rows j0, j0+1 (always inside the
+    // frame) go first: thread 0's pixel of row j0 is the workgroup's reference normal.
+    if (t < kRing * 8) nflag[t] = 0u;
 #pragma unroll 1
-    for (int r = 0; r < kRing; r += kRS) {
+    for (int rr = 0; rr < kRing; rr += kRS) {
+        const int r = rr == 0 ? 2 : (rr == 2 ? 0 : rr);
         Staged st;
         fetch(j0 - 2 + r, st);
+        if (rr == 0) {
+            if (t == 0) { nref[0] = st.o[0].n.x; nref[1] = st.o[0].n.y & 0xffffu; }
+            __syncthreads();
+            ref01 = nref[0]; refz = nref[1];
+        }
         commit(r, st);
 #pragma unroll
         for (int k = 0; k < KR; k++) {
@@ -515,6 +541,8 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
 
         // a wave whose centres are all sky (a band of cleared texels) has nothing to filter (:554-558)
         const bool wave_has_surface = __ballot(any_surface) != 0ull;
+        // every surface texel of the ring has the reference normal -> n.n' is each centre's own |n|^2
+        const bool uniform_normals = __ballot(lane < kRing * 8 && nflag[lane < kRing * 8 ? lane : 0] != 0u) == 0ull;
         // One ring row at a time (5 taps = 10 x ds_read_b128 in flight; KR = 2 reads the next row before it
         // consumes the current one).  The empty asm statements pin that order: left alone, instruction selection
         // sinks all arithmetic below all LDS reads of the unrolled loop (256 VGPRs + scratch spills).
@@ -523,7 +551,19 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
 #pragma unroll
             for (int c = 0; c < 5; c++) { tA[buf][c] = recA[rowbase[r] + c * S]; tB[buf][c] = recB[rowbase[r] + c * S]; }
         };
-        if (MODE != 1 && wave_has_surface) {
+        auto tap_rows = [&](auto uni_tag) __attribute__((always_inline)) {
+            constexpr bool UNI = decltype(uni_tag)::value;
+            // UNI: exponent of the normal term + kernel weight, per kernel-weight class, from the centre's own |n|^2 (the
+            // same expression the general path evaluates per tap, so the results are bit-identical)
+            float ebase[KR][5];
+            if constexpr (UNI) {
+#pragma unroll
+                for (int k = 0; k < KR; k++) {
+                    const float lg = hw_log2(clamp01(fmaf(ncz[k], ncz[k], dot2_h2(nc01[k], nc01[k]))));
+                    ebase[k][0] = fmaf(lg, phi_n, klog2(0, 1)); ebase[k][1] = fmaf(lg, phi_n, klog2(1, 1)); ebase[k][2] = fmaf(lg, phi_n, klog2(0, 2));
+                    ebase[k][3] = fmaf(lg, phi_n, klog2(1, 2)); ebase[k][4] = fmaf(lg, phi_n, klog2(2, 2));
+                }
+            }
             constexpr bool kDouble = true;        // KR = 2: double-buffer the ring rows (measured: 6 % faster than not)
             if (KR == 2 && kDouble) load_row(0, 0);
 #pragma unroll
@@ -539,9 +579,14 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
                         const int yy = r - 2 - k;
                         if (yy < -2 || yy > 2 || (xx == 0 && yy == 0)) continue;             // compile time; centre: weight 1, already in
                         const int axx = xx < 0 ? -xx : xx, ayy = yy < 0 ? -yy : yy;
-                        const float d = clamp01(fmaf(B.w, ncz[k], dot2_h2(__float_as_uint(B.z), nc01[k])));
                         const f32x2 dlz = (f32x2){B.x, B.y} - lzc[k];
-                        float e = fmaf(hw_log2(d), phi_n, klog2(axx, ayy));
+                        float e;
+                        if constexpr (UNI) {
+                            e = ebase[k][kernel_class(axx, ayy)];
+                        } else {
+                            const float d = clamp01(fmaf(B.w, ncz[k], dot2_h2(__float_as_uint(B.z), nc01[k])));
+                            e = fmaf(hw_log2(d), phi_n, klog2(axx, ayy));
+                        }
                         e = fmaf(-fabsf(dlz.x), il[k], e);
                         e = fmaf(-fabsf(dlz.y), iz[k][len_class(xx, yy)], e);
                         const float w = hw_exp2(e);
@@ -554,7 +599,13 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
 #pragma unroll
                 for (int k = 0; k < KR; k++) asm volatile("" : "+v"(sw[k]), "+v"(srg[k]), "+v"(sbv[k]) :: "memory");
             }
+        };
+        if (MODE != 1 && wave_has_surface) {
+            if (uniform_normals) tap_rows(std::true_type{}); else tap_rows(std::false_type{});
         }
+#ifdef SVGF_STAMPS
+        if (lane == 0) { atomicAdd(&g_stamps[10], 1ull); if (uniform_normals) atomicAdd(&g_stamps[11], 1ull); if (!wave_has_surface) atomicAdd(&g_stamps[12], 1ull); }
+#endif
         SVGF_STAMP(1);                             // centre setup + tap loop
 
         // Output values now, their stores AFTER the ring refill: hipcc's vmcnt bookkeeping cannot tell that the rows
@@ -636,7 +687,7 @@ inline int num_cus() {
 template <int ST, int S, int TX, int KR, int MODE = 0>
 hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     constexpr int WL = TX + 4 * S;
-    constexpr size_t lds = (size_t)kRing * WL * kRecBytes;
+    constexpr size_t lds = (size_t)kRing * WL * kRecBytes + (kRing * 8 + 2) * sizeof(uint32_t);
     constexpr int threads = TX * (kRS / KR);
     static bool attr_set = false;
     if (!attr_set) {
@@ -651,7 +702,13 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     const int nrows = g.ye - g.yb;
     const int njmax = (nrows + S - 1) / S;
     const int xtiles = (g.W + TX - 1) / TX;
-    int slots = per_cu * num_cus();
+    // 128-column workgroups: four times as many workgroups as resident slots, so that workgroups that take a fast
+    // path (all sky, uniform normals) make room for others instead of idling until the slowest one of a single round
+    // finishes (A/B on one device: 2x -3..5 %, 4x another -1.5 %, 6x worse; no gain for the 256-column kernels)
+#ifndef SVGF_OVERSUB
+#define SVGF_OVERSUB 4
+#endif
+    int slots = per_cu * num_cus() * (TX == 128 ? SVGF_OVERSUB : 1);
 #ifdef SVGF_DIAG
     slots = diag_env("SVGF_ATROUS_SLOTS", slots);
 #endif
@@ -677,10 +734,9 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
 
 template <int ST, int KR, int MODE>
 hipError_t launch_atrous_lds_step_kr(const Geo& g, const AtrousArgs& a, hipStream_t s) {
-    // Steps 1-4: 128-column workgroups (4 waves, 4 per CU).  Their 4S-column halo is small next to 128 columns, and
-    // twice the column blocks means bands twice as long for the same number of resident workgroups, so the 6-row
-    // ring prologue is amortised over more rows (measured 1-3 % per launch at 1080p and 4K; steps 8 and 16 are
-    // better off with 256 columns).
+    // 128-column workgroups (4 waves, 4 per CU) for every step: smaller tiles hit the uniform-normal fast path more
+    // often and balance better across the chip; with the oversubscribed grid below they beat 256 columns at every
+    // step (A/B on one device: 0.80 vs 0.82 ms per 4K frame), although the 4S-column halo costs 1.5x staging at S = 16.
     bool narrow = a.step <= kNarrowMaxStep;
 #ifdef SVGF_DIAG
     narrow = diag_env("SVGF_ATROUS_TX", narrow ? 128 : 256) == 128;

@@ -33,5 +33,6 @@ for step in (1, 4, 16):
     tot = sum(out[i] for i in range(6))
     waves = out[8]
     print(f"step {step}: waves {waves}, ticks per wave {tot / max(waves,1):.0f} (s_memtime ticks)")
+    print(f"   wave-steps {out[10]}, uniform-normal fast path {100.0 * out[11] / max(out[10], 1):.1f} %, all-sky skipped {100.0 * out[12] / max(out[10], 1):.1f} %")
     for i, n in enumerate(names):
         print(f"   {n:22s} {100.0 * out[i] / tot:5.1f} %   {out[i] / max(waves,1):9.0f} ticks/wave")
