@@ -384,6 +384,9 @@ __device__ __forceinline__ float dot2_h2(uint32_t a, uint32_t b) {
 //           have in common (30 LDS record pairs per 2 outputs instead of 50): on CDNA4 an LDS read's data return
 //           occupies the SIMD's register-file write path for ~16 cycles per ds_read_b128 and delays vector ALU
 //           issue by as much (tools/ubench/tap_lds.hip), so LDS bytes per output are paid for like instructions.
+#ifndef SVGF_UNI_B64
+#define SVGF_UNI_B64 1
+#endif
 template <int ST, int S, int TX, int KR, int MODE = 0>
 __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows) {
     constexpr int WL = TX + 4 * S;                 // staged columns per ring row
@@ -547,9 +550,14 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
         // consumes the current one).  The empty asm statements pin that order: left alone, instruction selection
         // sinks all arithmetic below all LDS reads of the unrolled loop (256 VGPRs + scratch spills).
         f32x4 tA[KR][5], tB[KR][5];
-        auto load_row = [&](int r, int buf) __attribute__((always_inline)) {
+        // uni: only {luminance, depth} of record B is needed when the normals are uniform (ds_read_b64 instead of b128)
+        auto load_row = [&](int r, int buf, bool uni) __attribute__((always_inline)) {
 #pragma unroll
-            for (int c = 0; c < 5; c++) { tA[buf][c] = recA[rowbase[r] + c * S]; tB[buf][c] = recB[rowbase[r] + c * S]; }
+            for (int c = 0; c < 5; c++) {
+                tA[buf][c] = recA[rowbase[r] + c * S];
+                if (uni && SVGF_UNI_B64) { const f32x2 lz = *(const f32x2*)&recB[rowbase[r] + c * S]; tB[buf][c] = (f32x4){lz.x, lz.y, 0.f, 0.f}; }
+                else tB[buf][c] = recB[rowbase[r] + c * S];
+            }
         };
         auto tap_rows = [&](auto uni_tag) __attribute__((always_inline)) {
             constexpr bool UNI = decltype(uni_tag)::value;
@@ -565,11 +573,11 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
                 }
             }
             constexpr bool kDouble = true;        // KR = 2: double-buffer the ring rows (measured: 6 % faster than not)
-            if (KR == 2 && kDouble) load_row(0, 0);
+            if (KR == 2 && kDouble) load_row(0, 0, UNI);
 #pragma unroll
             for (int r = 0; r < NR; r++) {
                 const int buf = (KR == 2 && kDouble) ? (r & 1) : 0;
-                if (KR == 2 && kDouble) { if (r + 1 < NR) load_row(r + 1, buf ^ 1); } else load_row(r, 0);
+                if (KR == 2 && kDouble) { if (r + 1 < NR) load_row(r + 1, buf ^ 1, UNI); } else load_row(r, 0, UNI);
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int xx = -2; xx <= 2; xx++) {
