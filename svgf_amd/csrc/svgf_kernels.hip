@@ -306,6 +306,7 @@ __device__ unsigned long long g_stamps[16];
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) f32x2 lds_f32x2;   // explicitly in LDS (a volatile access through a generic pointer would be a flat load)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // One staged pixel as it comes off the planes: colour (16 B fp32 / 8 B fp16), {depth, ddepth} (ddepth only for
@@ -335,7 +336,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ float med01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }   // = min(max(v,0),1) for non-NaN v
 
 template <int ST, bool DZ>
-__device__ __forceinline__ bool commit_px(const RawPx<ST, DZ>& r, f32x4* recA, f32x4* recB, int at, uint32_t ref01, uint32_t refz) {
+__device__ __forceinline__ bool commit_px(const RawPx<ST, DZ>& r, f32x4* recA, f32x2* recL, f32x2* recN, int at, uint32_t ref01, uint32_t refz) {
     float4 c;
     if constexpr (ST == 0) c = make_float4(__uint_as_float(r.c.x), __uint_as_float(r.c.y), __uint_as_float(r.c.z), __uint_as_float(r.c.w));
     else { float2 lo = unpack_h2(r.c.x), hi = unpack_h2(r.c.y); c = make_float4(lo.x, lo.y, hi.x, hi.y); }
@@ -344,7 +345,8 @@ __device__ __forceinline__ bool commit_px(const RawPx<ST, DZ>& r, f32x4* recA, f
     if constexpr (DZ) z = __uint_as_float(r.zd.x); else z = __uint_as_float(r.zd);
     if (z == 0.0f) z = kSkyZ;                                           // GetDepth, :199-207
     recA[at] = (f32x4){c.x, c.y, c.z, c.w};
-    recB[at] = (f32x4){lum_exact(c.x, c.y, c.z), z, __uint_as_float(r.n.x), unpack_h2(r.n.y).x};
+    recL[at] = (f32x2){lum_exact(c.x, c.y, c.z), z};
+    recN[at] = (f32x2){__uint_as_float(r.n.x), unpack_h2(r.n.y).x};
     // a texel without depth (sky, or outside the frame) has weight 0 through the depth term whatever its normal
     return z != kSkyZ && (r.n.x != ref01 || (r.n.y & 0xffffu) != refz);
 }
@@ -384,9 +386,6 @@ __device__ __forceinline__ float dot2_h2(uint32_t a, uint32_t b) {
 //           have in common (30 LDS record pairs per 2 outputs instead of 50): on CDNA4 an LDS read's data return
 //           occupies the SIMD's register-file write path for ~16 cycles per ds_read_b128 and delays vector ALU
 //           issue by as much (tools/ubench/tap_lds.hip), so LDS bytes per output are paid for like instructions.
-#ifndef SVGF_UNI_B64
-#define SVGF_UNI_B64 1
-#endif
 template <int ST, int S, int TX, int KR, int MODE = 0>
 __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows) {
     constexpr int WL = TX + 4 * S;                 // staged columns per ring row
@@ -396,12 +395,13 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
     static_assert(NH >= 1 && NH <= 64, "halo does not fit the row group's waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* recA = (f32x4*)smem;
-    f32x4* recB = recA + kRing * WL;
+    f32x2* recL = (f32x2*)(recA + kRing * WL);     // 8-byte records, contiguous: conflict-free ds_read_b64 (64 banks)
+    f32x2* recN = recL + kRing * WL;
     // Uniform-normal fast path: on planar geometry every texel of the ring carries the same normal bits; then
     // n.n' is the centre's own |n|^2 for every tap and the dot product, its log2 and an FMA (22 of a tap's ~59 VALU
     // cycles) leave the tap loop — with bit-identical results.  nflag[slot][wave] = "a texel of this ring row staged
     // by this wave differs from the workgroup's reference normal" (depth-0 texels do not count: their weight is 0).
-    uint32_t* nflag = (uint32_t*)(recB + kRing * WL);              // [kRing][8]
+    uint32_t* nflag = (uint32_t*)(recN + kRing * WL);              // [kRing][8]
     uint32_t* nref = nflag + kRing * 8;                            // {(nx,ny) bits, nz bits}
 
     const int t = threadIdx.x;
@@ -463,8 +463,8 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
 #pragma unroll
         for (int k = 0; k < KR; k++) {
             int so = sl + rg * KR + k; so = so >= kRing ? so - kRing : so;                   // scalar
-            bool differs = commit_px<ST, true>(st.o[k], recA, recB, so * WL + oli, ref01, refz);
-            if (has_halo) differs = commit_px<ST, false>(st.h[k], recA, recB, so * WL + hli, ref01, refz) || differs;
+            bool differs = commit_px<ST, true>(st.o[k], recA, recL, recN, so * WL + oli, ref01, refz);
+            if (has_halo) differs = commit_px<ST, false>(st.h[k], recA, recL, recN, so * WL + hli, ref01, refz) || differs;
             const bool wave_differs = __ballot(differs) != 0ull;
             if (lane == 0) nflag[so * 8 + wig] = wave_differs ? 1u : 0u;                     // a ring slot is always staged by the same waves
         }
@@ -525,7 +525,9 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
         bool any_surface = false;
 #pragma unroll
         for (int k = 0; k < KR; k++) {
-            const f32x4 A = recA[rowbase[2 + k] + 2 * S], B = recB[rowbase[2 + k] + 2 * S];
+            const f32x4 A = recA[rowbase[2 + k] + 2 * S];
+            const f32x2 L = recL[rowbase[2 + k] + 2 * S], N = recN[rowbase[2 + k] + 2 * S];
+            const f32x4 B = {L.x, L.y, N.x, N.y};
             cA[k] = A;
             const float cdz = B.y == kSkyZ ? 0.0f : dq0[k];                                  // GetDepth: sky -> ddepth 0
             lzc[k] = (f32x2){B.x, B.y};                                                      // centre luminance, depth
@@ -549,14 +551,16 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
         // One ring row at a time (5 taps = 10 x ds_read_b128 in flight; KR = 2 reads the next row before it
         // consumes the current one).  The empty asm statements pin that order: left alone, instruction selection
         // sinks all arithmetic below all LDS reads of the unrolled loop (256 VGPRs + scratch spills).
-        f32x4 tA[KR][5], tB[KR][5];
-        // uni: only {luminance, depth} of record B is needed when the normals are uniform (ds_read_b64 instead of b128)
+        f32x4 tA[KR][5];
+        f32x2 tL[KR][5], tN[KR][5];
+        // uni: the normal records are not read at all when the ring's normals are uniform
         auto load_row = [&](int r, int buf, bool uni) __attribute__((always_inline)) {
 #pragma unroll
             for (int c = 0; c < 5; c++) {
                 tA[buf][c] = recA[rowbase[r] + c * S];
-                if (uni && SVGF_UNI_B64) { const f32x2 lz = *(const f32x2*)&recB[rowbase[r] + c * S]; tB[buf][c] = (f32x4){lz.x, lz.y, 0.f, 0.f}; }
-                else tB[buf][c] = recB[rowbase[r] + c * S];
+                // volatile: keeps these as single ds_read_b64 (2 LDS cycles each); merged into ds_read2_b64 they take 8
+                tL[buf][c] = ((const volatile lds_f32x2*)recL)[rowbase[r] + c * S];
+                if (!uni) tN[buf][c] = ((const volatile lds_f32x2*)recN)[rowbase[r] + c * S];
             }
         };
         auto tap_rows = [&](auto uni_tag) __attribute__((always_inline)) {
@@ -581,18 +585,20 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int xx = -2; xx <= 2; xx++) {
-                    const f32x4 A = tA[buf][xx + 2], B = tB[buf][xx + 2];
+                    const f32x4 A = tA[buf][xx + 2];
+                    const f32x2 L = tL[buf][xx + 2];
 #pragma unroll
                     for (int k = 0; k < KR; k++) {
                         const int yy = r - 2 - k;
                         if (yy < -2 || yy > 2 || (xx == 0 && yy == 0)) continue;             // compile time; centre: weight 1, already in
                         const int axx = xx < 0 ? -xx : xx, ayy = yy < 0 ? -yy : yy;
-                        const f32x2 dlz = (f32x2){B.x, B.y} - lzc[k];
+                        const f32x2 dlz = L - lzc[k];
                         float e;
                         if constexpr (UNI) {
                             e = ebase[k][kernel_class(axx, ayy)];
                         } else {
-                            const float d = clamp01(fmaf(B.w, ncz[k], dot2_h2(__float_as_uint(B.z), nc01[k])));
+                            const f32x2 N = tN[buf][xx + 2];
+                            const float d = clamp01(fmaf(N.y, ncz[k], dot2_h2(__float_as_uint(N.x), nc01[k])));
                             e = fmaf(hw_log2(d), phi_n, klog2(axx, ayy));
                         }
                         e = fmaf(-fabsf(dlz.x), il[k], e);
