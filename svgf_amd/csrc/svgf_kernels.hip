@@ -286,6 +286,7 @@ __global__ __launch_bounds__(kBX* kBY) void atrous_direct_kernel(Geo g, AtrousAr
 // weight exactly 0, which is what skipping the tap (:579,584) does.
 constexpr int kRS = 2;                   // decimated rows produced per step
 constexpr int kRing = kRS + 4;
+constexpr int kXcds = 8;                 // MI355X: 8 accelerator dies, workgroup id i is dispatched to XCD i % 8
 constexpr int kRecBytes = 32;            // LDS bytes per staged pixel
 #ifndef SVGF_NARROW_MAX_STEP
 #define SVGF_NARROW_MAX_STEP 16
@@ -387,7 +388,7 @@ __device__ __forceinline__ float dot2_h2(uint32_t a, uint32_t b) {
 //           occupies the SIMD's register-file write path for ~16 cycles per ds_read_b128 and delays vector ALU
 //           issue by as much (tools/ubench/tap_lds.hip), so LDS bytes per output are paid for like instructions.
 template <int ST, int S, int TX, int KR, int MODE = 0>
-__global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows) {
+__global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup) {
     constexpr int WL = TX + 4 * S;                 // staged columns per ring row
     constexpr int CB = ST == 0 ? 16 : 8;           // bytes per colour texel
     constexpr int NH = 4 * S / (TX / 64);          // halo pixels each wave stages per row (lanes 0..NH-1)
@@ -409,9 +410,19 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
     const int col = t % TX;
     const int rg = __builtin_amdgcn_readfirstlane(t / TX);          // row group: wave-uniform -> scalar
     const int wig = __builtin_amdgcn_readfirstlane((t % TX) >> 6);  // wave index inside its row group
-    const int x0 = blockIdx.x * TX;
-    const int rv = blockIdx.y % S;                 // row residue (relative to g.yb) this workgroup owns
-    const int band = blockIdx.y / S;
+    // XCD-aware tile order.  The dispatcher deals consecutive workgroup ids to the 8 XCDs in turn, and each XCD has
+    // its own L2: with a plain (x, y) grid the two tiles that share a 2S-column halo, or two bands that share four
+    // ring rows, always sit on different XCDs and every halo texel comes from memory twice.  Here tile order is
+    // v = (residue, band, x tile) with x fastest, cut into groups of `xgroup` consecutive tiles, and group k goes to
+    // XCD k % 8: neighbours inside a group run on one XCD at about the same time and share their halos in its L2.
+    const int xtiles = (g.W + TX - 1) / TX;
+    const int ntiles = xtiles * nbands * S;
+    const int wid = blockIdx.x >> 3;               // index among the workgroups of this XCD
+    const int v = ((wid / xgroup) * kXcds + (blockIdx.x & (kXcds - 1))) * xgroup + wid % xgroup;
+    if (v >= ntiles) return;                       // padding of the last groups
+    const int x0 = (v % xtiles) * TX;
+    const int band = (v / xtiles) % nbands;
+    const int rv = v / (xtiles * nbands);          // row residue (relative to g.yb) this workgroup owns
     const int nrows = g.ye - g.yb;
     const int nj = (nrows - rv + S - 1) / S;       // decimated rows of this residue
     const int j0 = band * band_rows;
@@ -732,17 +743,29 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     if (band < 8) band = 8;
     band = (band + kRS - 1) / kRS * kRS;
     nbands = (njmax + band - 1) / band;
-    const dim3 grid(xtiles, S * nbands);
+    // m groups per XCD, 8 m groups in all (so that every XCD gets the same number of tiles)
+    int xm = S == 1 ? 16 : (S == 2 || S == 16) ? 2 : 1;    // A/B per step on one device (4K): tools/xgroup.sh
+#ifdef SVGF_DIAG
+    xm = diag_env("SVGF_ATROUS_XM", xm);
+    if (xm < 1) xm = 1;
+#endif
+    int xgroup = (xtiles * nbands * S + kXcds * xm - 1) / (kXcds * xm);
+#ifdef SVGF_DIAG
+    xgroup = diag_env("SVGF_ATROUS_XGROUP", xgroup);
+    if (xgroup < 1) xgroup = 1;
+#endif
+    const int ngroups = (xtiles * nbands * S + xgroup - 1) / xgroup;
+    const dim3 grid((unsigned)((ngroups + kXcds - 1) / kXcds) * kXcds * xgroup);
 #ifdef SVGF_DIAG
     static bool told = false;
     if (!told) {
         told = true;
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)atrous_lds_kernel<ST, S, TX, KR, MODE>, threads, lds);
-        fprintf(stderr, "[svgf diag] atrous_lds<ST=%d,S=%d,TX=%d,KR=%d,MODE=%d>: lds %zu B, occupancy %d blocks/CU (planned %d), grid %u x %u, band %d\n", ST, S, TX, KR, MODE, lds, nb, per_cu, grid.x, grid.y, band);
+        fprintf(stderr, "[svgf diag] atrous_lds<ST=%d,S=%d,TX=%d,KR=%d,MODE=%d>: lds %zu B, occupancy %d blocks/CU (planned %d), grid %u (x tiles %d, bands %d, xgroup %d), band %d\n", ST, S, TX, KR, MODE, lds, nb, per_cu, grid.x, xtiles, nbands, xgroup, band);
     }
 #endif
-    atrous_lds_kernel<ST, S, TX, KR, MODE><<<grid, dim3(threads), lds, s>>>(g, a, band);
+    atrous_lds_kernel<ST, S, TX, KR, MODE><<<grid, dim3(threads), lds, s>>>(g, a, band, nbands, xgroup);
     return hipGetLastError();
 }
 
