@@ -113,6 +113,15 @@ int svgf_temporal(svgf_ctx* ctx, const void* prev_colour, const void* radiance, 
 int svgf_moments(svgf_ctx* ctx, const void* colour, void* out, const void* moments,
                  const svgf_gbuffer* gbuf, const uint8_t* hist);
 
+/* Stages 1 + 2 fused, for hosts that own their planes (the strip runner): what svgf_denoise_frame does internally.
+ * The temporal launch also stores its result into `filter_out` — where history >= 4 FilterMoments is a copy
+ * (Filter.cuh:521) — and the moments launch then only re-filters the young pixels (history < 4) of global rows
+ * [moments_row_begin, moments_row_end) (a sub-range of the rows set by svgf_set_rows; -1,-1 = those rows).  Same
+ * results as svgf_temporal + svgf_moments on those rows, 32 B/px (fp32) less traffic in steady state. */
+int svgf_temporal_moments(svgf_ctx* ctx, const void* prev_colour, const void* radiance, void* colour_out, void* filter_out,
+                          const svgf_gbuffer* cur, const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur,
+                          void* moments_cur, const void* moments_prev, int moments_row_begin, int moments_row_end);
+
 /* Stage 3, one iteration — replaces one trip of the loop in application::WaveletFilter
  * (App.cu:497-507) launching filter::FilterKernel (Filter.cuh:527-624).  `feedback` is RenderOutput:
  * written (non-sky pixels only) iff iteration == 0 and it is non-null. */

@@ -388,7 +388,7 @@ __device__ __forceinline__ float dot2_h2(uint32_t a, uint32_t b) {
 //           occupies the SIMD's register-file write path for ~16 cycles per ds_read_b128 and delays vector ALU
 //           issue by as much (tools/ubench/tap_lds.hip), so LDS bytes per output are paid for like instructions.
 template <int ST, int S, int TX, int KR, int MODE = 0>
-__global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup) {
+__global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup, int xrot, int band_fastest) {
     constexpr int WL = TX + 4 * S;                 // staged columns per ring row
     constexpr int CB = ST == 0 ? 16 : 8;           // bytes per colour texel
     constexpr int NH = 4 * S / (TX / 64);          // halo pixels each wave stages per row (lanes 0..NH-1)
@@ -418,10 +418,13 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
     const int xtiles = (g.W + TX - 1) / TX;
     const int ntiles = xtiles * nbands * S;
     const int wid = blockIdx.x >> 3;               // index among the workgroups of this XCD
-    const int v = ((wid / xgroup) * kXcds + (blockIdx.x & (kXcds - 1))) * xgroup + wid % xgroup;
+    const int round = wid / xgroup;                // the XCD's round-th group; rotated so that an XCD's groups come from different parts of the frame
+    const int v = (round * kXcds + ((blockIdx.x + xrot * round) & (kXcds - 1))) * xgroup + wid % xgroup;
     if (v >= ntiles) return;                       // padding of the last groups
-    const int x0 = (v % xtiles) * TX;
-    const int band = (v / xtiles) % nbands;
+    // band_fastest: tile order (residue, x tile, band) instead — an XCD's consecutive workgroups walk down one column
+    // of tiles (every band halo shared, and each XCD's share of the frame is a set of vertical strips)
+    const int x0 = (band_fastest ? (v / nbands) % xtiles : v % xtiles) * TX;
+    const int band = band_fastest ? v % nbands : (v / xtiles) % nbands;
     const int rv = v / (xtiles * nbands);          // row residue (relative to g.yb) this workgroup owns
     const int nrows = g.ye - g.yb;
     const int nj = (nrows - rv + S - 1) / S;       // decimated rows of this residue
@@ -765,7 +768,12 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
         fprintf(stderr, "[svgf diag] atrous_lds<ST=%d,S=%d,TX=%d,KR=%d,MODE=%d>: lds %zu B, occupancy %d blocks/CU (planned %d), grid %u (x tiles %d, bands %d, xgroup %d), band %d\n", ST, S, TX, KR, MODE, lds, nb, per_cu, grid.x, xtiles, nbands, xgroup, band);
     }
 #endif
-    atrous_lds_kernel<ST, S, TX, KR, MODE><<<grid, dim3(threads), lds, s>>>(g, a, band, nbands, xgroup);
+    int xrot = 3, xorder = 0;
+#ifdef SVGF_DIAG
+    xorder = diag_env("SVGF_ATROUS_XORDER", xorder);
+    xrot = diag_env("SVGF_ATROUS_XROT", xrot);
+#endif
+    atrous_lds_kernel<ST, S, TX, KR, MODE><<<grid, dim3(threads), lds, s>>>(g, a, band, nbands, xgroup, xrot, xorder);
     return hipGetLastError();
 }
 

@@ -14,9 +14,11 @@ iteration of the group finds its halo locally:
     "grouped"        [[0,1,2],[3,4]]         2 à-trous exchanges per frame, <3 % redundant work   (default)
     "ghost"          [[0,1,2,3,4]]           no exchange between iterations, 62 ghost rows each side
 The temporal and moments stages are computed redundantly on the first group's halo, so a frame needs ONE more
-exchange, at its start: the previous frame's state (colour feedback, moments, history) on the rows the
-reprojection can reach.  Exchanges are posted before the rows that do not depend on them are computed
-(interior/boundary split), so the transfers overlap the interior kernels.
+exchange: its state (colour feedback, moments, history) on the rows the next frame's reprojection can reach.
+That state is final once iteration 0 has written the feedback colour, so it is posted right there and waited
+for at the start of the NEXT frame: the transfer runs beside iterations 1.. of the frame that produced it.
+The à-trous exchanges are posted before the rows that do not depend on them are computed (interior/boundary
+split), so those transfers overlap the interior kernels.
 """
 from __future__ import annotations
 
@@ -28,6 +30,7 @@ PLANS = {
     "ghost": lambda n: [list(range(n))] if n else [],
 }
 DEFAULT_PLAN = "grouped"
+AUTO_ORDER = ("ghost", "grouped", "per-iteration")
 
 
 def partition(H: int, world: int):
@@ -55,14 +58,25 @@ class Geometry:
     halo_max: int = 0
     y0: int = 0
     y1: int = 0
+    plan: object = None
 
     @staticmethod
     def make(W, H, rank, world, steps, plan=DEFAULT_PLAN, moments_radius=3, motion_reach=4):
         if plan == "auto":
-            plan = DEFAULT_PLAN
+            # the plan with the fewest exchanges whose halo still fits the strips: "ghost" needs one exchange per frame
+            # (the state, overlapped with iterations 1..), no transfer sits between two iterations
+            for cand in AUTO_ORDER:
+                try:
+                    g = Geometry.make(W, H, rank, world, steps, cand, moments_radius, motion_reach)
+                    g.plan = cand
+                    return g
+                except ValueError:
+                    continue
+            raise ValueError(f"{world} strips of a {H}-row frame are shorter than every halo plan")
         groups = PLANS[plan](steps) if isinstance(plan, str) else [list(g) for g in plan]
         assert [i for g in groups for i in g] == list(range(steps)), "plan must list the iterations in order"
         g = Geometry(W, H, rank, world, steps, moments_radius, motion_reach, groups)
+        g.plan = plan
         g.own = partition(H, world)[rank]
         g.ext_atrous = [0] * steps
         for grp in groups:
@@ -123,14 +137,21 @@ class LocalComm:
         parent = self
 
         class _C:
-            def start(self, sends, recvs):
-                for t, p in sends:
-                    parent.box.setdefault((rank, p), []).append(t.clone())
-                return recvs
+            """Exchanges are matched by their sequence number on the rank (every rank posts the same sequence), as RCCL
+            matches sends and receives of a peer pair in posting order, so handles may be finished in any order."""
+            seq = 0
 
-            def finish(self, recvs):
+            def start(self, sends, recvs):
+                n = self.seq
+                self.seq += 1
+                for t, p in sends:
+                    parent.box.setdefault((rank, p, n), []).append(t.clone())
+                return n, recvs
+
+            def finish(self, handle):
+                n, recvs = handle
                 for t, p in recvs:
-                    t.copy_(parent.box[(p, rank)].pop(0))
+                    t.copy_(parent.box[(p, rank, n)].pop(0))
         return _C()
 
 
@@ -154,6 +175,11 @@ class HipStages:
         self.d.set_rows(*rows)
         self.d.FilterMoments(colour, out, mom, gb, hist)
 
+    def temporal_moments(self, rows_t, rows_m, prev_colour, radiance, colour_out, filter_out, gb_cur, gb_prev, hist_prev, hist_cur, mom_cur, mom_prev):
+        """Both stages with the steady-state moments copy fused into the temporal launch (svgf_temporal_moments)."""
+        self.d.set_rows(*rows_t)
+        self.d.TemporalMoments(prev_colour, radiance, colour_out, filter_out, gb_cur, gb_prev, hist_prev, hist_cur, mom_cur, mom_prev, rows_m)
+
     def atrous(self, rows, src, dst, feedback, gb, step, iteration):
         self.d.set_rows(*rows)
         self.d.FilterKernel(src, dst, feedback, gb, step, iteration)
@@ -173,6 +199,7 @@ class StripRunner:
         self.filt = [z(4, dt), z(4, dt)]         # FilterBuffer[2]    App.h:140
         self.hist = [z(0, torch.uint8), z(0, torch.uint8)]
         self.P = 0
+        self.pending_state = None                # exchange of this frame's state, waited for by the next frame
 
     # -- halo plumbing -----------------------------------------------------------------------
     def _halo_ops(self, planes, h):
@@ -206,25 +233,18 @@ class StripRunner:
         g, st, P = self.geo, self.st, self.P
         if gb_prev is None:
             gb_prev = gb_cur
-        # previous-frame state halo: posted first, needed only by the rows near the strip edges
-        h = self.comm.start(*self._halo_ops([self.colour[1 - P], self.mom[1 - P], self.hist[1 - P]], g.halo_state)) if g.world > 1 else None
-        rows_t = g.rows(g.ext_temporal)
-
-        def temporal(rows):
-            st.temporal(rows, self.colour[1 - P], radiance, self.colour[P], gb_cur, gb_prev, self.hist[1 - P], self.hist[P],
-                        self.mom[P], self.mom[1 - P])
-        if h is not None:
-            inner, edges = self._split(g.own, g.motion_reach)
-            if inner:
-                temporal(inner)
-            yield
-            self.comm.finish(h)
-            done = [inner] if inner else []
-            for r in _subtract(rows_t, done):
-                temporal(r)
+        # previous-frame state halo (colour feedback, moments, history on the rows the reprojection can reach): posted by
+        # the PREVIOUS frame right after its iteration 0, so the transfer ran beside that frame's remaining iterations
+        if self.pending_state is not None:
+            self.comm.finish(self.pending_state)
+            self.pending_state = None
+        if hasattr(st, "temporal_moments"):
+            st.temporal_moments(g.rows(g.ext_temporal), g.rows(g.ext_moments), self.colour[1 - P], radiance, self.colour[P], self.filt[0],
+                                gb_cur, gb_prev, self.hist[1 - P], self.hist[P], self.mom[P], self.mom[1 - P])
         else:
-            temporal(rows_t)
-        st.moments(g.rows(g.ext_moments), self.colour[P], self.filt[0], self.mom[P], gb_cur, self.hist[P])
+            st.temporal(g.rows(g.ext_temporal), self.colour[1 - P], radiance, self.colour[P], gb_cur, gb_prev, self.hist[1 - P], self.hist[P],
+                        self.mom[P], self.mom[1 - P])
+            st.moments(g.rows(g.ext_moments), self.colour[P], self.filt[0], self.mom[P], gb_cur, self.hist[P])
         pp = 0
         for gi, grp in enumerate(g.groups):
             h = None
@@ -244,8 +264,17 @@ class StripRunner:
                 else:
                     st.atrous(rows, self.filt[pp], self.filt[1 - pp], fb, gb_cur, 1 << i, i)
                 pp ^= 1
+                if i == 0:
+                    self._post_state(P)            # this frame's state is final once iteration 0 has written the feedback colour
+        if not g.steps:
+            self._post_state(P)
         self.P ^= 1
         return self.filt[pp]
+
+    def _post_state(self, P):
+        g = self.geo
+        if g.world > 1:
+            self.pending_state = self.comm.start(*self._halo_ops([self.colour[P], self.mom[P], self.hist[P]], g.halo_state))
 
     def frame(self, radiance, gb_cur, gb_prev=None):
         it = self.frame_steps(radiance, gb_cur, gb_prev)
@@ -254,6 +283,12 @@ class StripRunner:
                 next(it)
         except StopIteration as e:
             return e.value
+
+    def flush(self):
+        """Wait for the exchange the last frame posted (call before tearing the process group down)."""
+        if self.pending_state is not None:
+            self.comm.finish(self.pending_state)
+            self.pending_state = None
 
     def owned(self, plane):
         g = self.geo
@@ -294,6 +329,11 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
     import torch.distributed as dist
     from . import filter as F
     rank, world = dist.get_rank(), dist.get_world_size()
+    # A high-priority side stream for the kernels: HIP maps a priority level to hardware queues of its own, so the RCCL
+    # send/recv kernels (torch's communication stream, normal priority) run BESIDE the filter kernels.  On one shared
+    # queue they run in line with them (tools/strip_sim.py: 0.66 vs 0.55 ms per 8K/8 strip).
+    side = torch.cuda.Stream(device=device, priority=-1)
+    torch.cuda.set_stream(side)
     params = F.Params(storage=storage, steps=iters, variant=variant)
     geo = Geometry.make(W, H, rank, world, iters, plan=plan, moments_radius=params.moments_radius, motion_reach=4)
     stages = HipStages(geo, params, device)
@@ -312,6 +352,7 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
     torch.cuda.synchronize(device)
     t1 = time.perf_counter()
     out = runner.frame(rads[0], gb, gb)
+    runner.flush()
     assert bool(torch.isfinite(runner.owned(out).float()).all())
     return dict(ms_per_step=(t1 - t0) * 1e3 / steps, rows_per_rank=geo.own[1] - geo.own[0],
-                plan=plan if plan != "auto" else DEFAULT_PLAN)
+                plan=geo.plan)

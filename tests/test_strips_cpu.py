@@ -94,6 +94,7 @@ def _gloo_worker(rank, world, port, W, H, N, plan, storage, q):
             tz = lambda f: {n: torch.from_numpy(f[n]) for n in ("motion", "normal", "uv")}      # noqa: E731
             out = runner.frame(torch.from_numpy(fr["radiance"].astype(CDT[storage])), tz(fr), tz(fp))
             outs.append(runner.owned(out).numpy().copy())
+        runner.flush()
         q.put((rank, outs))
     finally:
         dist.destroy_process_group()

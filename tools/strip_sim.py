@@ -1,0 +1,75 @@
+"""Diagnostic: what ONE middle strip of an N-strip frame costs per frame on ONE GPU (no 8-GPU node needed).
+
+The geometry is that of rank `--rank` of `--world` strips of a WxH frame; the halo exchanges are real RCCL
+send/recv batches, but both neighbours are this very rank (self send/recv), so the numbers hold the kernel
+time of a strip (with its halo rows and interior/boundary splits), the host-side dispatch cost and the
+RCCL launch cost — everything except the xGMI transfer time itself.  `--comm none` drops the exchanges.
+
+    python tools/strip_sim.py [--workload 8k] [--world 8] [--rank 3] [--plan grouped] [--comm self|none]
+"""
+import argparse
+import os
+import sys
+import time
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+sys.argv, argv = ["bench.py"], sys.argv
+import bench  # noqa: E402
+from svgf_amd import filter as F, strips  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="8k")
+ap.add_argument("--world", type=int, default=8)
+ap.add_argument("--rank", type=int, default=3)
+ap.add_argument("--plan", default="grouped")
+ap.add_argument("--comm", default="self")
+ap.add_argument("--storage", default="f32")
+ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--stream", default="own", help="own = a non-blocking side stream; own-hi = the same at high priority (its own hardware queue); null = the legacy default stream")
+ap.add_argument("--driver", default="python", help="python = StripRunner; native = svgf_strip_* C driver if present")
+args = ap.parse_args(argv[1:])
+
+W, H = bench.WORKLOADS[args.workload]
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29544")
+os.environ.setdefault("RANK", "0")
+os.environ.setdefault("WORLD_SIZE", "1")
+dist.init_process_group("nccl", device_id=dev)
+
+
+class SelfComm(strips.DistComm):
+    """Every peer is this rank."""
+    def start(self, sends, recvs):
+        if args.comm == "none":
+            return []
+        return super().start([(t, 0) for t, _ in sends], [(t, 0) for t, _ in recvs])
+
+
+side = torch.cuda.Stream(device=dev, priority=-1 if args.stream == "own-hi" else 0) if args.stream.startswith("own") else torch.cuda.default_stream(dev)
+torch.cuda.set_stream(side)
+params = F.Params(storage=args.storage, steps=5)
+geo = strips.Geometry.make(W, H, args.rank, args.world, 5, plan=args.plan, moments_radius=params.moments_radius, motion_reach=4)
+stages = strips.HipStages(geo, params, dev)
+runner = strips.make_runner(geo, stages, SelfComm(), storage=args.storage, device=dev, driver=args.driver) if hasattr(strips, "make_runner") \
+    else strips.StripRunner(geo, stages, SelfComm(), storage=args.storage, device=dev)
+gb, rads = bench.make_inputs(W, H, args.storage, dev, row_begin=geo.y0, row_end=geo.y1)
+for k in range(12):
+    runner.frame(rads[k % len(rads)], gb, gb)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for k in range(args.steps):
+    runner.frame(rads[k % len(rads)], gb, gb)
+t_host = time.perf_counter() - t0
+torch.cuda.synchronize()
+t = time.perf_counter() - t0
+own = geo.own[1] - geo.own[0]
+print(f"{W}x{H} strip {args.rank}/{args.world} ({own} rows, held {geo.y1 - geo.y0}), plan {args.plan}, comm {args.comm}, stream {args.stream}, driver {args.driver}: "
+      f"{t / args.steps * 1e3:.4f} ms/frame (host enqueue {t_host / args.steps * 1e3:.4f} ms) -> "
+      f"{W * own / (t / args.steps) / 1e6:.0f} Mpx/s per GPU, x{args.world} = {W * own * args.world / (t / args.steps) / 1e6:.0f} Mpx/s")
+dist.destroy_process_group()
