@@ -189,6 +189,34 @@ def test_frame_driver_equals_stage_calls(G, storage):
 
 
 @pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_temporal_moments_fused_equals_stage_calls(G, storage):
+    """svgf_temporal_moments (caller-owned planes; the strip runner's path) == svgf_temporal + svgf_moments, bitwise,
+    over the cold -> steady transition, with the moments rows a sub-range of the temporal rows."""
+    from svgf_amd import filter as F
+    W, H, N = 200, 120, 7
+    fr = frames(W, H, N, mv=(-2.5, 1.5))
+    hip = G.HipPipeline(W, H, storage, steps=0)
+    d = F.Denoiser(W, H, F.Params(storage=storage, steps=0))
+    colour, mom, hist = [d.new_colour() for _ in range(2)], [d.new_moments() for _ in range(2)], [d.new_history() for _ in range(2)]
+    filt = d.new_colour()
+    gbs = [G.gb_dev(f) for f in fr]
+    mrows = (8, H - 5)
+    for k in range(N):
+        P, kp = k & 1, max(k - 1, 0)
+        hip.frame(fr[k]["radiance"], gbs[k], gbs[kp])
+        rad = G.dev(fr[k]["radiance"].astype(G.NPDT[storage]))
+        d.TemporalMoments(colour[1 - P], rad, colour[P], filt, gbs[k], gbs[kp], hist[1 - P], hist[P], mom[P], mom[1 - P], mrows)
+        assert np.array_equal(G.host(colour[P]).view(np.uint8), hip.taps["temporal"].view(np.uint8)), k
+        assert np.array_equal(G.host(mom[P]).view(np.uint8), hip.taps["mom"].view(np.uint8)), k
+        assert np.array_equal(G.host(hist[P]), hip.taps["hist"]), k
+        assert np.array_equal(G.host(filt)[mrows[0]:mrows[1]].view(np.uint8), hip.taps["moments"][mrows[0]:mrows[1]].view(np.uint8)), k
+    with pytest.raises(F.SvgfError):
+        d.TemporalMoments(colour[0], rad, colour[1], colour[1], gbs[0], gbs[0], hist[0], hist[1], mom[1], mom[0])      # filter_out aliases colour_out
+    with pytest.raises(F.SvgfError):
+        d.TemporalMoments(colour[0], rad, colour[1], filt, gbs[0], gbs[0], hist[0], hist[1], mom[1], mom[0], (-3, H))     # rows outside
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
 def test_frame_driver_default_path(G, oracle, storage):
     """The default driver (LDS moments kernel while history < 4 everywhere, fused pass-through afterwards, LDS
     à-trous) against the oracle, free running over the cold -> steady transition."""
