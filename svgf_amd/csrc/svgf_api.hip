@@ -29,6 +29,7 @@ struct svgf_ctx {
     void* moments[2] = {nullptr, nullptr};
     void* filter[2] = {nullptr, nullptr};
     uint8_t* hist[2] = {nullptr, nullptr};
+    uint8_t* young_flags = nullptr;   // scratch: per (row, 64-column segment) "holds a pixel with history < 4", temporal -> moments
     int pingpong = 0;                   // PingPongInx, App.cu:374
     int frames_since_reset = 0;
     bool have_state = false;
@@ -89,6 +90,13 @@ hipEvent_t take_event(svgf_ctx* c) {
     hipEvent_t e = nullptr;
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
+}
+
+int alloc_flags(svgf_ctx* c) {
+    if (c->young_flags) return SVGF_OK;
+    SVGF_HIP(c, hipSetDevice(c->device));
+    SVGF_HIP(c, hipMalloc((void**)&c->young_flags, (size_t)c->strip.rows * ((c->W + 63) / 64)));
+    return SVGF_OK;
 }
 
 int alloc_state(svgf_ctx* c) {
@@ -175,6 +183,7 @@ void svgf_destroy(svgf_ctx* c) {
         if (c->filter[i]) (void)hipFree(c->filter[i]);
         if (c->hist[i]) (void)hipFree(c->hist[i]);
     }
+    if (c->young_flags) (void)hipFree(c->young_flags);
     for (auto& f : c->pending) for (auto e : f.ev) (void)hipEventDestroy(e);
     for (auto e : c->pool) (void)hipEventDestroy(e);
     delete c;
@@ -206,7 +215,7 @@ int svgf_set_rows(svgf_ctx* c, int rb, int re) {
 
 static int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, const svgf_gbuffer* cur,
                          const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur, void* moments_cur,
-                         const void* moments_prev, void* passthrough_out);
+                         const void* moments_prev, void* passthrough_out);   // passthrough_out != null: also fills c->young_flags
 static int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist, int cold_only, int dense);
 
 int svgf_temporal(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, const svgf_gbuffer* cur,
@@ -228,7 +237,8 @@ int svgf_temporal_moments(svgf_ctx* c, const void* prev_colour, const void* radi
     const int rb = c->rb, re = c->re;
     if (mrb == -1 && mre == -1) { mrb = rb; mre = re; }
     if (mrb < rb || mre > re || mrb > mre) return fail(c, SVGF_ERR_INVALID, "svgf_temporal_moments: moments rows outside the temporal rows");
-    int rc = temporal_impl(c, prev_colour, radiance, colour_out, cur, prev, hist_prev, hist_cur, moments_cur, moments_prev, filter_out);
+    int rc = alloc_flags(c);
+    if (rc == SVGF_OK) rc = temporal_impl(c, prev_colour, radiance, colour_out, cur, prev, hist_prev, hist_cur, moments_cur, moments_prev, filter_out);
     if (rc != SVGF_OK) return rc;
     c->rb = mrb; c->re = mre;
     rc = moments_impl(c, colour_out, filter_out, moments_cur, cur, hist_cur, 1, 0);
@@ -253,7 +263,7 @@ static int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radia
                          (const float4*)cur->motion, (const uint2*)cur->normal, (const uint2*)cur->uv,
                          (const float4*)prev->motion, (const uint2*)prev->normal, (const uint2*)prev->uv,
                          hist_prev, hist_cur, moments_cur, moments_prev,
-                         c->p.depth_threshold, c->p.normal_threshold, c->p.history_base, c->p.mesh_id_test, passthrough_out};
+                         c->p.depth_threshold, c->p.normal_threshold, c->p.history_base, c->p.mesh_id_test, passthrough_out, passthrough_out ? c->young_flags : nullptr, c->p.phi_normal > 0.0f};
     SVGF_HIP(c, svgf::launch_temporal(geo_of(c), c->p.storage, a, c->stream));
     return SVGF_OK;
 }
@@ -266,7 +276,7 @@ static int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* 
     if (rc == SVGF_OK) rc = check_halo(c, c->p.moments_radius, "svgf_moments");
     if (rc != SVGF_OK) return rc;
     svgf::MomentsArgs a{colour, out, moments, (const float4*)g->motion, (const uint2*)g->normal, hist,
-                        c->p.phi_colour, c->p.phi_normal, c->p.moments_radius, cold_only, dense};
+                        c->p.phi_colour, c->p.phi_normal, c->p.moments_radius, cold_only, dense, cold_only ? c->young_flags : nullptr};
     SVGF_HIP(c, svgf::launch_moments(geo_of(c), c->p.storage, a, c->stream));
     return SVGF_OK;
 }
@@ -334,6 +344,7 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     // the same result as the reference's rejection against its cleared previous framebuffer.
     if (!prev) prev = cur;
     rc = alloc_state(c);
+    if (rc == SVGF_OK) rc = alloc_flags(c);
     if (rc != SVGF_OK) return rc;
     const int P = c->pingpong;
 

@@ -15,12 +15,15 @@ struct TemporalArgs {
     const uint8_t* hist_prev; uint8_t* hist_cur; void* mom_cur; const void* mom_prev;
     float depth_thr, normal_thr; int history_base; int mesh_id_test;
     void* passthrough_out;   // frame driver only: where history >= 4 the moments stage is a copy (Filter.cuh:521) — write it here directly
+    uint8_t* young_flags;    // with passthrough_out: one byte per (local row, 64-column segment): some pixel of it needs the moments estimate
+    int sky_zero;            // with passthrough_out: PhiNormal > 0, so a young pixel with an all-zero normal filters to exactly 0 (written here)
 };
 struct MomentsArgs {
     const void* colour; void* out; const void* mom; const float4* motion; const uint2* normal; const uint8_t* hist;
     float phi_colour, phi_normal; int radius;
     int cold_only;           // 1: pixels with history >= 4 were already written by the temporal stage (passthrough_out)
     int dense;               // 1: (nearly) every pixel has history < 4 (first frames of a sequence): use the LDS-streaming kernel
+    const uint8_t* young_flags;   // with cold_only: TemporalArgs::young_flags of the same frame — only flagged segments are visited
 };
 struct AtrousArgs {
     const void* in; void* out; void* feedback; const float4* motion; const uint2* normal;

@@ -153,17 +153,26 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
     // Frame-driver fusion: for history >= 4 FilterMoments only copies this pixel into the filter buffer
     // (:521; store(load(x)) == x in both storage types), so it is written from here and the moments launch
     // touches nothing but the history byte of such pixels (-32 B/px of traffic in steady state).
-    if (a.passthrough_out && h >= 4) Store<ST>::st4(a.passthrough_out, idx, clamp01(o));
+    // A young pixel whose normal is exactly (0,0,0) — the G-buffer's cleared sky texels, which never pass the normal
+    // test and stay young for ever — filters to exactly (0,0,0,0) when PhiNormal > 0 (see moments_pixel): written here too.
+    const bool young = h < 4;
+    const bool zero_young = young && a.sky_zero && ((nc_raw.x & 0x7fff7fffu) | (nc_raw.y & 0x7fffu)) == 0u;
+    if (a.passthrough_out) {
+        if (!young) Store<ST>::st4(a.passthrough_out, idx, clamp01(o));
+        else if (zero_young) Store<ST>::st4(a.passthrough_out, idx, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    // ... and the moments launch is told where the remaining young pixels are: one flag per wave = 64-pixel row segment
+    if (a.young_flags) {
+        const bool any_young = __ballot(young && !zero_young) != 0ull;
+        if (threadIdx.x == 0) a.young_flags[(size_t)(y - g.y0) * ((g.W + kBX - 1) / kBX) + blockIdx.x] = any_young ? 1 : 0;
+    }
 }
 
 // ------------------------------------------------------------------ moments -------------------
 // Filter.cuh:430-525.  Steady state (h >= 4) is a plane copy; the (2R+1)^2 bilateral estimate runs
 // only for young pixels.
 template <int ST>
-__global__ __launch_bounds__(kBX* kBY) void moments_kernel(Geo g, MomentsArgs a) {
-    const int x = blockIdx.x * kBX + threadIdx.x;
-    const int y = g.yb + blockIdx.y * kBY + threadIdx.y;
-    if (x >= g.W || y >= g.ye) return;
+__device__ __forceinline__ void moments_pixel(const Geo& g, const MomentsArgs& a, int x, int y) {
     const size_t idx = (size_t)(y - g.y0) * g.W + x;
     const float h = (float)a.hist[idx];                               // :442
     if (a.cold_only && !(h < 4.0f)) return;                           // already written by temporal_kernel (passthrough_out)
@@ -211,6 +220,37 @@ __global__ __launch_bounds__(kBX* kBY) void moments_kernel(Geo g, MomentsArgs a)
     sm1 *= inv; sm2 *= inv;
     const float var = (sm2 - sm1 * sm1) * (4.0f / h);                 // :511-514
     Store<ST>::st4(a.out, idx, make_float4(sr * inv, sg * inv, sb * inv, var));   // :516 unclamped
+}
+
+template <int ST>
+__global__ __launch_bounds__(kBX* kBY) void moments_kernel(Geo g, MomentsArgs a) {
+    const int x = blockIdx.x * kBX + threadIdx.x;
+    const int y = g.yb + blockIdx.y * kBY + threadIdx.y;
+    if (x >= g.W || y >= g.ye) return;
+    moments_pixel<ST>(g, a, x, y);
+}
+
+// Steady state inside the frame driver: the temporal launch already copied every pixel with history >= 4 and left a
+// flag per 64-pixel row segment that holds a young one (disocclusions: sparse).  A small persistent grid scans the
+// flags, 64 per wave-load, and visits only flagged segments — instead of one thread per pixel reading a history byte.
+template <int ST>
+__global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int nseg = (g.W + kBX - 1) / kBX;
+    const int first = (g.yb - g.y0) * nseg, last = (g.ye - g.y0) * nseg;             // flag range of the launch rows
+    const int nwaves = gridDim.x * 4, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // flag (k*64 + lane)*nwaves + wave belongs to this wave: neighbouring segments (a patch of sky, a disocclusion
+    // edge) go to different waves
+    for (int k = 0; first + k * 64 * nwaves + wave < last; k++) {
+        const int sidx = first + (k * 64 + lane) * nwaves + wave;
+        unsigned long long m = __ballot(sidx < last && a.young_flags[sidx] != 0);
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const int seg = first + (k * 64 + b) * nwaves + wave, x = (seg % nseg) * kBX + lane, y = g.y0 + seg / nseg;
+            if (x < g.W) moments_pixel<ST>(g, a, x, y);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ a-trous (direct) ----------
@@ -571,6 +611,7 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
         auto load_row = [&](int r, int buf, bool uni) __attribute__((always_inline)) {
 #pragma unroll
             for (int c = 0; c < 5; c++) {
+                if (KR == 1 && r == 2 && c == 2) continue;                                        // the centre itself: already in registers
                 tA[buf][c] = recA[rowbase[r] + c * S];
                 // volatile: keeps these as single ds_read_b64 (2 LDS cycles each); merged into ds_read2_b64 they take 8
                 tL[buf][c] = ((const volatile lds_f32x2*)recL)[rowbase[r] + c * S];
@@ -1151,6 +1192,14 @@ hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, hipSt
     // radius and a non-degenerate PhiNormal (the fused exponent would see 0 * -inf)
     if (a.dense && a.radius == kMR && a.phi_normal != 0.0f)
         return storage == 0 ? launch_moments_lds<0>(g, a, s) : launch_moments_lds<1>(g, a, s);
+    if (a.cold_only && a.young_flags) {
+        const int nsegs = (g.ye - g.yb) * ((g.W + kBX - 1) / kBX);
+        int wgs = (nsegs + 255) / 256;                           // >= one flag per lane and load ...
+        if (wgs > 4 * num_cus()) wgs = 4 * num_cus();            // ... on at most one resident round
+        if (storage == 0) moments_young_kernel<0><<<wgs, 256, 0, s>>>(g, a);
+        else moments_young_kernel<1><<<wgs, 256, 0, s>>>(g, a);
+        return hipGetLastError();
+    }
     const dim3 block(kBX, kBY), grid = grid_for(g);
     if (storage == 0) moments_kernel<0><<<grid, block, 0, s>>>(g, a);
     else moments_kernel<1><<<grid, block, 0, s>>>(g, a);

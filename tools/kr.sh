@@ -1,5 +1,5 @@
 #!/bin/bash
-# KR (outputs per thread) A/B on 128-column tiles, diag build, interleaved on one device
+# KR (outputs per thread) A/B, diag build, interleaved on one device (KR = 2 runs the 256-column variant)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p build
 python3 -c "
