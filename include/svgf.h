@@ -168,7 +168,7 @@ size_t svgf_plane_bytes(const svgf_ctx* ctx, int plane);
 /* Per-stage device timing with HIP events on the context's stream (the reference only prints whole
  * frame time, App.cu:727-731).  Slots: 0 temporal, 1 moments, 2+i à-trous iteration i. */
 #define SVGF_MAX_STEPS 10                                              /* GUI range 0-10, GUI.cpp:988 */
-int svgf_timing_enable(svgf_ctx* ctx, int on);
+int svgf_timing_enable(svgf_ctx* ctx, int on);                                  /* 0 = off, n = time every n-th frame (events cost ~1 us each) */
 int svgf_timing_read(svgf_ctx* ctx, double* ms_sum, int* frames, int slots);   /* synchronises; resets sums */
 
 #ifdef __cplusplus

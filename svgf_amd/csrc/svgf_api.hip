@@ -34,7 +34,8 @@ struct svgf_ctx {
     int frames_since_reset = 0;
     bool have_state = false;
     // per-stage timing
-    bool timing = false;
+    int timing = 0;               // 0 = off, n = stage events on every n-th frame
+    int timing_phase = 0;
     struct FrameEvents { std::vector<hipEvent_t> ev; int nstage = 0; };
     std::vector<FrameEvents> pending;
     std::vector<hipEvent_t> pool;
@@ -349,8 +350,9 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     const int P = c->pingpong;
 
     svgf_ctx::FrameEvents fe;
+    const bool timed = c->timing > 0 && (c->timing_phase++ % c->timing) == 0;
     auto stamp = [&]() {
-        if (!c->timing) return;
+        if (!timed) return;
         hipEvent_t e = take_event(c);
         if (e && hipEventRecord(e, c->stream) == hipSuccess) fe.ev.push_back(e);
     };
@@ -373,7 +375,7 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
         stamp();
         pp ^= 1;
     }
-    if (c->timing) {
+    if (timed) {
         fe.nstage = 2 + c->p.steps;
         if ((int)fe.ev.size() == fe.nstage + 1) c->pending.push_back(std::move(fe));
         else for (auto e : fe.ev) c->pool.push_back(e);
@@ -409,7 +411,8 @@ size_t svgf_plane_bytes(const svgf_ctx* c, int plane) {
 
 int svgf_timing_enable(svgf_ctx* c, int on) {
     if (!c) return SVGF_ERR_INVALID;
-    c->timing = on != 0;
+    c->timing = on > 0 ? on : 0;
+    c->timing_phase = 0;
     return SVGF_OK;
 }
 

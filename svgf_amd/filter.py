@@ -302,6 +302,7 @@ class Denoiser:
 
     # -- timing -------------------------------------------------------------------------------
     def timing_enable(self, on=True):
+        """on: False/0 = off, True/1 = stage events on every frame, n = on every n-th frame."""
         self._check(self.lib.svgf_timing_enable(self._h, int(on)), "svgf_timing_enable")
 
     def timing_read(self):
