@@ -216,8 +216,8 @@ int svgf_set_rows(svgf_ctx* c, int rb, int re) {
 
 static int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, const svgf_gbuffer* cur,
                          const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur, void* moments_cur,
-                         const void* moments_prev, void* passthrough_out);   // passthrough_out != null: also fills c->young_flags
-static int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist, int cold_only, int dense);
+                         const void* moments_prev, void* passthrough_out, int sparse_colour = 0);   // passthrough_out != null: also fills c->young_flags
+static int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist, int cold_only, int dense, int sparse_colour = 0);
 
 int svgf_temporal(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, const svgf_gbuffer* cur,
                   const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur, void* moments_cur,
@@ -251,7 +251,7 @@ int svgf_temporal_moments(svgf_ctx* c, const void* prev_colour, const void* radi
 
 static int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, const svgf_gbuffer* cur,
                          const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur, void* moments_cur,
-                         const void* moments_prev, void* passthrough_out) {
+                         const void* moments_prev, void* passthrough_out, int sparse_colour) {
     if (!c) return SVGF_ERR_INVALID;
     if (!prev_colour || !radiance || !colour_out || !hist_prev || !hist_cur || !moments_cur || !moments_prev)
         return fail(c, SVGF_ERR_INVALID, "svgf_temporal: null plane");
@@ -264,12 +264,12 @@ static int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radia
                          (const float4*)cur->motion, (const uint2*)cur->normal, (const uint2*)cur->uv,
                          (const float4*)prev->motion, (const uint2*)prev->normal, (const uint2*)prev->uv,
                          hist_prev, hist_cur, moments_cur, moments_prev,
-                         c->p.depth_threshold, c->p.normal_threshold, c->p.history_base, c->p.mesh_id_test, passthrough_out, passthrough_out ? c->young_flags : nullptr, c->p.phi_normal > 0.0f};
+                         c->p.depth_threshold, c->p.normal_threshold, c->p.history_base, c->p.mesh_id_test, passthrough_out, passthrough_out ? c->young_flags : nullptr, sparse_colour, c->p.phi_normal > 0.0f};
     SVGF_HIP(c, svgf::launch_temporal(geo_of(c), c->p.storage, a, c->stream));
     return SVGF_OK;
 }
 
-static int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist, int cold_only, int dense) {
+static int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist, int cold_only, int dense, int sparse_colour) {
     if (!c) return SVGF_ERR_INVALID;
     if (!colour || !out || !moments || !hist) return fail(c, SVGF_ERR_INVALID, "svgf_moments: null plane");
     if (colour == out) return fail(c, SVGF_ERR_INVALID, "svgf_moments: in-place filtering is a race");
@@ -277,7 +277,7 @@ static int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* 
     if (rc == SVGF_OK) rc = check_halo(c, c->p.moments_radius, "svgf_moments");
     if (rc != SVGF_OK) return rc;
     svgf::MomentsArgs a{colour, out, moments, (const float4*)g->motion, (const uint2*)g->normal, hist,
-                        c->p.phi_colour, c->p.phi_normal, c->p.moments_radius, cold_only, dense, cold_only ? c->young_flags : nullptr};
+                        c->p.phi_colour, c->p.phi_normal, c->p.moments_radius, cold_only, dense, sparse_colour, cold_only ? c->young_flags : nullptr};
     SVGF_HIP(c, svgf::launch_moments(geo_of(c), c->p.storage, a, c->stream));
     return SVGF_OK;
 }
@@ -358,14 +358,17 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     };
 
     stamp();
+    // With at least one wavelet iteration the temporal result in colour[P] is dead where iteration 0's feedback will
+    // overwrite it (:619-622): it is only stored for young pixels (the moments estimate reads them) and depth-0 texels.
+    const int sparse = c->p.steps >= 1;
     // The temporal launch also writes the filter buffer where history >= 4 (there FilterMoments is a copy), the
     // moments launch then only works on young pixels: same planes, 32 B/px less traffic in steady state.
     rc = temporal_impl(c, c->colour[1 - P], radiance, c->colour[P], cur, prev, c->hist[1 - P], c->hist[P],
-                       c->moments[P], c->moments[1 - P], c->filter[0]);         // App.cu:552
+                       c->moments[P], c->moments[1 - P], c->filter[0], sparse);  // App.cu:552
     if (rc != SVGF_OK) return rc;
     stamp();
     // the first three frames after a reset have history <= 3 everywhere: the LDS-streaming moments kernel
-    rc = moments_impl(c, c->colour[P], c->filter[0], c->moments[P], cur, c->hist[P], 1, c->frames_since_reset < 3 && c->p.variant != SVGF_VARIANT_DIRECT);   // App.cu:554 (current moments: App. B #4)
+    rc = moments_impl(c, c->colour[P], c->filter[0], c->moments[P], cur, c->hist[P], 1, c->frames_since_reset < 3 && c->p.variant != SVGF_VARIANT_DIRECT, sparse);   // App.cu:554 (current moments: App. B #4)
     if (rc != SVGF_OK) return rc;
     stamp();
     int pp = 0;

@@ -16,6 +16,8 @@ struct TemporalArgs {
     float depth_thr, normal_thr; int history_base; int mesh_id_test;
     void* passthrough_out;   // frame driver only: where history >= 4 the moments stage is a copy (Filter.cuh:521) — write it here directly
     uint8_t* young_flags;    // with passthrough_out: one byte per (local row, 64-column segment): some pixel of it needs the moments estimate
+    int sparse_colour;       // with passthrough_out and >= 1 a-trous iteration: colour_out is only stored where the iteration-0 feedback
+                             // will not overwrite it or the moments estimate reads it (young pixels, depth-0 texels)
     int sky_zero;            // with passthrough_out: PhiNormal > 0, so a young pixel with an all-zero normal filters to exactly 0 (written here)
 };
 struct MomentsArgs {
@@ -23,6 +25,7 @@ struct MomentsArgs {
     float phi_colour, phi_normal; int radius;
     int cold_only;           // 1: pixels with history >= 4 were already written by the temporal stage (passthrough_out)
     int dense;               // 1: (nearly) every pixel has history < 4 (first frames of a sequence): use the LDS-streaming kernel
+    int sparse_colour;            // TemporalArgs::sparse_colour of the same frame: an old, non-sky neighbour's colour is in `out`
     const uint8_t* young_flags;   // with cold_only: TemporalArgs::young_flags of the same frame — only flagged segments are visited
 };
 struct AtrousArgs {

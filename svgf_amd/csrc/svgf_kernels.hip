@@ -148,7 +148,9 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
     const float4 o = make_float4(mix_exact(cp.x, c.x, alpha), mix_exact(cp.y, c.y, alpha), mix_exact(cp.z, c.z, alpha), var);
 
     a.hist_cur[idx] = (uint8_t)h;                                     // :400
-    Store<ST>::st4(a.colour_out, idx, clamp01(o));                    // :401 imageStore
+    // :401 imageStore.  sparse_colour (frame driver): iteration 0 of the wavelet filter overwrites this texel with its
+    // feedback (:619-622) unless it has no depth; until then only the moments estimate of young pixels reads it
+    if (!a.sparse_colour || h < 4 || mc.z == 0.0f) Store<ST>::st4(a.colour_out, idx, clamp01(o));
     Store<ST>::st2(a.mom_cur, idx, m);                                // :402
     // Frame-driver fusion: for history >= 4 FilterMoments only copies this pixel into the filter buffer
     // (:521; store(load(x)) == x in both storage types), so it is written from here and the moments launch
@@ -202,10 +204,13 @@ __device__ __forceinline__ void moments_pixel(const Geo& g, const MomentsArgs& a
             const int px = x + xx;
             if (px < 0 || px >= g.W) continue;
             const size_t p = (size_t)(py - g.y0) * g.W + px;
-            const float4 cp = Store<ST>::ld4(a.colour, p);            // :479 raw
+            const float4 mq = a.motion[p];
+            // sparse_colour: the temporal launch stored an old, non-sky texel only into `out` (same value)
+            const bool in_out = a.sparse_colour && mq.z != 0.0f && a.hist[p] >= 4;
+            const float4 cp = Store<ST>::ld4(in_out ? (const void*)a.out : a.colour, p);   // :479 raw
             const float2 mp = Store<ST>::ld2(a.mom, p);               // :480
             float zp, dzp;
-            depth_of(a.motion[p], zp, dzp);                           // :482
+            depth_of(mq, zp, dzp);                                    // :482
             const float3 np = normal_of(a.normal[p]);                 // :483
             const float len = sqrtf((float)(xx * xx + yy * yy));      // :488
             const float iz = (xx == 0 && yy == 0) ? 0.0f : hw_rcp(phi_d * len);   // phiDepth == 0 -> wZ = 0, :420
