@@ -101,6 +101,44 @@ def test_atrous(G, oracle, storage, step, variant):
     assert np.array_equal(G.host(out2).view(np.uint8), got.view(np.uint8))
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_tunables_and_sizes_vs_oracle(G, oracle, seed):
+    """Seeded sweep over the GUI ranges of the tunables (GUI.cpp:988-993) and over frame sizes: a-trous (LDS kernel) and
+    temporal from identical random inputs against the oracle."""
+    from svgf_amd import filter as F
+    rng = np.random.default_rng(100 + seed)
+    W, H = int(rng.integers(65, 420)), int(rng.integers(9, 200))
+    storage = ("f32", "f16")[seed & 1]
+    dt = CDT[storage]
+    step = int(2 ** rng.integers(0, 5))
+    phi_c, phi_n = float(rng.uniform(0.05, 40.0)), float(rng.uniform(0.5, 256.0))
+    dthr, nthr, hb = float(rng.uniform(0.0, 3.0)), float(rng.uniform(0.0, 1.0)), int(rng.integers(1, 256))
+    mv = (float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3)))
+    f0, f1 = synth.make_frame(W, H, seed, mv=mv), synth.make_frame(W, H, seed + 1, mv=mv)
+    # a-trous
+    src = np.concatenate([rng.uniform(-0.2, 1.3, (H, W, 3)), rng.uniform(-0.01, 0.2, (H, W, 1))], -1).astype(dt)
+    want = np.zeros_like(src); fbw = np.zeros_like(src)
+    oracle.atrous(W, H, storage, src, want, fbw, gbuf(f1), step=step, phi_colour=phi_c, phi_normal=phi_n, iteration=0)
+    d = F.Denoiser(W, H, F.Params(storage=storage, phi_colour=phi_c, phi_normal=phi_n, depth_threshold=dthr, normal_threshold=nthr,
+                                  history_base=hb, variant="lds"))
+    out, fb = d.new_colour(), d.new_colour()
+    d.FilterKernel(G.dev(src), out, fb, G.gb_dev(f1), step, 0)
+    G.assert_colour_close(G.host(out), want, storage, f"seed {seed}: {W}x{H} step {step} phi {phi_c:.2f}/{phi_n:.1f}")
+    # temporal: bit-exact whatever the thresholds
+    prev = rng.uniform(-0.1, 1.2, (H, W, 4)).astype(dt)
+    mom_prev = rng.uniform(0, 1, (H, W, 2)).astype(dt)
+    hist_prev = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    cur = rng.uniform(-0.1, 1.4, (H, W, 4)).astype(dt)
+    o = np.zeros_like(cur); hist = np.zeros((H, W), np.uint8); mom = np.zeros((H, W, 2), dt)
+    oracle.temporal(W, H, storage, prev, cur, o, gbuf(f1), gbuf(f0), hist_prev, hist, mom, mom_prev,
+                    depth_threshold=dthr, normal_threshold=nthr, history_base=hb, mesh_id_test=1)
+    o_col, o_hist, o_mom = d.new_colour(), d.new_history(), d.new_moments()
+    d.TemporalFilter(G.dev(prev), G.dev(cur), o_col, G.gb_dev(f1), G.gb_dev(f0), G.dev(hist_prev), o_hist, o_mom, G.dev(mom_prev))
+    assert np.array_equal(G.host(o_hist), hist)
+    assert np.array_equal(G.host(o_col).view(np.uint8), o.view(np.uint8))
+    assert np.array_equal(G.host(o_mom).view(np.uint8), mom.view(np.uint8))
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("storage", ["f32", "f16"])
 @pytest.mark.parametrize("mv", [(0.0, 0.0), (-2.5, 1.5)])
@@ -186,6 +224,31 @@ def test_frame_driver_equals_stage_calls(G, storage):
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), k
     assert d.pingpong() == N % 2
     assert np.array_equal(G.host(d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong())), hip.taps["hist"])
+
+
+@pytest.mark.parametrize("params", [
+    dict(steps=0), dict(steps=1), dict(steps=5, phi_normal=0.0), dict(steps=3, history_base=2), dict(steps=3, history_base=4),
+    dict(steps=2, mesh_id_test=0, normal_threshold=0.0), dict(steps=3, moments_radius=1), dict(steps=4, depth_threshold=0.0, phi_colour=0.5),
+])
+def test_frame_driver_fusions_hold_for_any_parameters(G, params):
+    """The driver's fusions (moments copy and exact sky zeros written by the temporal launch, young-segment flags, the
+    temporal result stored only where iteration 0's feedback will not overwrite it) are bit-identical to the plain stage
+    sequence whatever the tunables: no iteration at all, PhiNormal = 0 (no sky shortcut), a history cap below / at the
+    'young' limit of 4, thresholds that accept everything, the 3x3 estimate."""
+    from svgf_amd import filter as F
+    W, H, N = 203, 77, 7
+    fr = frames(W, H, N, mv=(-2.5, 1.5))
+    for storage in ("f32", "f16"):
+        hip = G.HipPipeline(W, H, storage, variant="direct", **params)
+        d = F.Denoiser(W, H, F.Params(storage=storage, variant="direct", **params))
+        gbs = [G.gb_dev(f) for f in fr]
+        for k in range(N):
+            kp = max(k - 1, 0)
+            a = hip.frame(fr[k]["radiance"], gbs[k], gbs[kp])
+            b = G.host(d.Render(G.dev(fr[k]["radiance"].astype(G.NPDT[storage])), gbs[k], gbs[kp] if k else None))
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (storage, k)
+        assert np.array_equal(G.host(d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong())), hip.taps["hist"])
+        assert np.array_equal(G.host(d.state_plane(F.PLANE_MOMENTS, 1 - d.pingpong())).view(np.uint8), hip.taps["mom"].view(np.uint8))
 
 
 @pytest.mark.parametrize("storage", ["f32", "f16"])
