@@ -117,10 +117,14 @@ int svgf_moments(svgf_ctx* ctx, const void* colour, void* out, const void* momen
  * The temporal launch also stores its result into `filter_out` — where history >= 4 FilterMoments is a copy
  * (Filter.cuh:521) — and the moments launch then only re-filters the young pixels (history < 4) of global rows
  * [moments_row_begin, moments_row_end) (a sub-range of the rows set by svgf_set_rows; -1,-1 = those rows).  Same
- * results as svgf_temporal + svgf_moments on those rows, 32 B/px (fp32) less traffic in steady state. */
+ * results as svgf_temporal + svgf_moments on those rows, 32 B/px (fp32) less traffic in steady state.
+ * feedback_follows != 0: the caller will run svgf_atrous iteration 0 with feedback = colour_out over every row of
+ * colour_out it goes on to use; then a texel that feedback overwrites (history >= 4, depth != 0: Filter.cuh:619-622) is
+ * not stored into colour_out at all by this call (another 16 B/px), only into filter_out. */
 int svgf_temporal_moments(svgf_ctx* ctx, const void* prev_colour, const void* radiance, void* colour_out, void* filter_out,
                           const svgf_gbuffer* cur, const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur,
-                          void* moments_cur, const void* moments_prev, int moments_row_begin, int moments_row_end);
+                          void* moments_cur, const void* moments_prev, int moments_row_begin, int moments_row_end,
+                          int feedback_follows);
 
 /* Stage 3, one iteration — replaces one trip of the loop in application::WaveletFilter
  * (App.cu:497-507) launching filter::FilterKernel (Filter.cuh:527-624).  `feedback` is RenderOutput:

@@ -232,17 +232,17 @@ int svgf_moments(svgf_ctx* c, const void* colour, void* out, const void* moments
 
 int svgf_temporal_moments(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, void* filter_out,
                           const svgf_gbuffer* cur, const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur,
-                          void* moments_cur, const void* moments_prev, int mrb, int mre) {
+                          void* moments_cur, const void* moments_prev, int mrb, int mre, int feedback_follows) {
     if (!c) return SVGF_ERR_INVALID;
     if (!filter_out || filter_out == colour_out) return fail(c, SVGF_ERR_INVALID, "svgf_temporal_moments: filter_out must be a plane of its own");
     const int rb = c->rb, re = c->re;
     if (mrb == -1 && mre == -1) { mrb = rb; mre = re; }
     if (mrb < rb || mre > re || mrb > mre) return fail(c, SVGF_ERR_INVALID, "svgf_temporal_moments: moments rows outside the temporal rows");
     int rc = alloc_flags(c);
-    if (rc == SVGF_OK) rc = temporal_impl(c, prev_colour, radiance, colour_out, cur, prev, hist_prev, hist_cur, moments_cur, moments_prev, filter_out);
+    if (rc == SVGF_OK) rc = temporal_impl(c, prev_colour, radiance, colour_out, cur, prev, hist_prev, hist_cur, moments_cur, moments_prev, filter_out, feedback_follows != 0);
     if (rc != SVGF_OK) return rc;
     c->rb = mrb; c->re = mre;
-    rc = moments_impl(c, colour_out, filter_out, moments_cur, cur, hist_cur, 1, 0);
+    rc = moments_impl(c, colour_out, filter_out, moments_cur, cur, hist_cur, 1, 0, feedback_follows != 0);
     c->rb = rb; c->re = re;
     return rc;
 }

@@ -110,7 +110,7 @@ def load_library():
     lib.svgf_set_stream.argtypes = [vp, vp]
     lib.svgf_set_rows.argtypes = [vp, ip, ip]
     lib.svgf_temporal.argtypes = [vp, vp, vp, vp, C.POINTER(GBufferC), C.POINTER(GBufferC), vp, vp, vp, vp]
-    lib.svgf_temporal_moments.argtypes = [vp, vp, vp, vp, vp, C.POINTER(GBufferC), C.POINTER(GBufferC), vp, vp, vp, vp, C.c_int, C.c_int]
+    lib.svgf_temporal_moments.argtypes = [vp, vp, vp, vp, vp, C.POINTER(GBufferC), C.POINTER(GBufferC), vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]
     lib.svgf_moments.argtypes = [vp, vp, vp, vp, C.POINTER(GBufferC), vp]
     lib.svgf_atrous.argtypes = [vp, vp, vp, vp, C.POINTER(GBufferC), ip, ip]
     lib.svgf_taa.argtypes = [vp, vp, vp, vp]
@@ -223,11 +223,11 @@ class Denoiser:
                                            _ptr(moments_prev)), "svgf_temporal")
 
     def TemporalMoments(self, prev_colour, radiance, colour_out, filter_out, gb_cur: GBuffer, gb_prev: GBuffer, hist_prev, hist_cur,
-                        moments_cur, moments_prev, moments_rows=(-1, -1)):
+                        moments_cur, moments_prev, moments_rows=(-1, -1), feedback_follows=False):
         """TemporalFilter + FilterMoments fused as in svgf_denoise_frame (src/App.cu:552-554), on caller-owned planes."""
         self._check(self.lib.svgf_temporal_moments(self._h, _ptr(prev_colour), _ptr(radiance), _ptr(colour_out), _ptr(filter_out),
                                                    gb_cur.c, gb_prev.c, _ptr(hist_prev), _ptr(hist_cur), _ptr(moments_cur),
-                                                   _ptr(moments_prev), int(moments_rows[0]), int(moments_rows[1])), "svgf_temporal_moments")
+                                                   _ptr(moments_prev), int(moments_rows[0]), int(moments_rows[1]), int(bool(feedback_follows))), "svgf_temporal_moments")
 
     def FilterMoments(self, colour, out, moments, gb: GBuffer, hist):
         """application::FilterMoments, src/App.cu:480-489."""

@@ -100,7 +100,7 @@ def _gloo_worker(rank, world, port, W, H, N, plan, storage, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("plan", ["per-iteration", "grouped"])
+@pytest.mark.parametrize("plan", ["per-iteration", "grouped", "ghost"])
 def test_gloo_world2_bit_identical(oracle, plan):
     import torch.multiprocessing as mp
     W, H, N, world, storage = 64, 200, 3, 2, "f32"

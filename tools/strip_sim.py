@@ -30,6 +30,8 @@ ap.add_argument("--comm", default="self")
 ap.add_argument("--storage", default="f32")
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--stream", default="own", help="own = a non-blocking side stream; own-hi = the same at high priority (its own hardware queue); null = the legacy default stream")
+ap.add_argument("--post", default="side", help="side = post RCCL batches from a stream of their own; inline = from the compute stream")
+ap.add_argument("--prefill", type=int, default=0, help="N 8192^3 bf16 GEMMs queued before the timed frames (GPU-event timing)")
 ap.add_argument("--driver", default="python", help="python = StripRunner; native = svgf_strip_* C driver if present")
 args = ap.parse_args(argv[1:])
 
@@ -45,6 +47,9 @@ dist.init_process_group("nccl", device_id=dev)
 
 class SelfComm(strips.DistComm):
     """Every peer is this rank."""
+    def __init__(self):
+        super().__init__(device=dev if args.post == "side" else None)
+
     def start(self, sends, recvs):
         if args.comm == "none":
             return []
@@ -62,14 +67,23 @@ gb, rads = bench.make_inputs(W, H, args.storage, dev, row_begin=geo.y0, row_end=
 for k in range(12):
     runner.frame(rads[k % len(rads)], gb, gb)
 torch.cuda.synchronize()
+if args.prefill:
+    # keep the GPU busy for a while so that the host gets far ahead: the frame time seen by GPU events is then free of any
+    # host-side launch latency (is a gap in the kernel trace the host's or the GPU's?)
+    xx = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    for _ in range(args.prefill):
+        xx @ xx
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 t0 = time.perf_counter()
+e0.record()
 for k in range(args.steps):
     runner.frame(rads[k % len(rads)], gb, gb)
+e1.record()
 t_host = time.perf_counter() - t0
 torch.cuda.synchronize()
-t = time.perf_counter() - t0
+t = e0.elapsed_time(e1) * 1e-3 if args.prefill else time.perf_counter() - t0
 own = geo.own[1] - geo.own[0]
-print(f"{W}x{H} strip {args.rank}/{args.world} ({own} rows, held {geo.y1 - geo.y0}), plan {args.plan}, comm {args.comm}, stream {args.stream}, driver {args.driver}: "
+print(f"{W}x{H} strip {args.rank}/{args.world} ({own} rows, held {geo.y1 - geo.y0}), plan {args.plan}, comm {args.comm}/{args.post}, stream {args.stream}, driver {args.driver}: "
       f"{t / args.steps * 1e3:.4f} ms/frame (host enqueue {t_host / args.steps * 1e3:.4f} ms) -> "
       f"{W * own / (t / args.steps) / 1e6:.0f} Mpx/s per GPU, x{args.world} = {W * own * args.world / (t / args.steps) / 1e6:.0f} Mpx/s")
 dist.destroy_process_group()
