@@ -224,7 +224,9 @@ def main():
             "stages": stages,
             "stages_note": "per-stage GB/s use the SURVEY 8(d) algorithmic bytes; svgf_denoise_frame fuses the steady-state moments copy into "
                            "the temporal kernel (second store) and the moments slot only re-filters segments flagged as young, so the "
-                           "two are rated together (temporal+moments); stage events are recorded on every 4th timed frame",
+                           "two are rated together (temporal+moments); a rate above the HBM peak means the fused driver moves fewer bytes than the "
+                           "per-stage accounting counts (no separate moments copy, temporal result stored only where it is read again); "
+                           "stage events are recorded on every 4th timed frame",
         }
         if r["cold_ms"]:
             line["cold_frames_ms"] = {"after_reset": r["cold_ms"], "note": "frames 0.. after svgf_reset_history, sum of stage events; "
