@@ -436,9 +436,10 @@ template <int ST, int S, int TX, int KR, int MODE = 0>
 __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup, int xrot, int band_fastest) {
     constexpr int WL = TX + 4 * S;                 // staged columns per ring row
     constexpr int CB = ST == 0 ? 16 : 8;           // bytes per colour texel
-    constexpr int NH = 4 * S / (TX / 64);          // halo pixels each wave stages per row (lanes 0..NH-1)
+    constexpr int NH = 4 * S;                      // halo pixels per ring row: all staged by wave 0 of the row group (lanes 0..NH-1);
+                                                   // spread over the waves, every wave paid the halo's ~20 VALU + 3 loads for a few lanes
     constexpr int NR = KR + 4;                     // ring rows a thread reads
-    static_assert(NH >= 1 && NH <= 64, "halo does not fit the row group's waves");
+    static_assert(NH >= 1 && NH <= 64, "halo does not fit one wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* recA = (f32x4*)smem;
     f32x2* recL = (f32x2*)(recA + kRing * WL);     // 8-byte records, contiguous: conflict-free ds_read_b64 (64 banks)
@@ -481,8 +482,9 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
     // per-lane constants
     const int gx = x0 + col;                       // own column
     const int oli = col + 2 * S;                   // its LDS column
-    const bool has_halo = lane < NH;               // this lane also stages one halo pixel per row of its row group
-    const int hh = wig * NH + lane;                // 0 .. 4S-1
+    const bool halo_wave = wig == 0;               // scalar
+    const bool has_halo = halo_wave && lane < NH;  // this lane also stages one halo pixel per row of its row group
+    const int hh = lane;                           // 0 .. 4S-1
     const int hx = (hh < 2 * S) ? x0 - 2 * S + hh : x0 + TX + hh - 2 * S;
     const int hli = (hh < 2 * S) ? hh : TX + hh;
     const bool own_ok = gx < g.W, halo_ok = has_halo && hx >= 0 && hx < g.W;
@@ -513,8 +515,8 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
             const int y = ybase + S * (jn + rg * KR + k), yl = y - g.y0;                    // scalar
             const bool rok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows;
             const int srow = rok ? yl * g.W : 0;
-            if (rok) { raw_load<ST, true>(st.o[k], rs, vo_c, vo_m, vo_n, srow); raw_load<ST, false>(st.h[k], rs, vh_c, vh_m, vh_n, srow); }
-            else { raw_load<ST, true>(st.o[k], rs_none, vo_c, vo_m, vo_n, 0); raw_load<ST, false>(st.h[k], rs_none, vh_c, vh_m, vh_n, 0); }
+            if (rok) { raw_load<ST, true>(st.o[k], rs, vo_c, vo_m, vo_n, srow); if (halo_wave) raw_load<ST, false>(st.h[k], rs, vh_c, vh_m, vh_n, srow); }
+            else { raw_load<ST, true>(st.o[k], rs_none, vo_c, vo_m, vo_n, 0); if (halo_wave) raw_load<ST, false>(st.h[k], rs_none, vh_c, vh_m, vh_n, 0); }
         }
     };
     uint32_t ref01 = 0, refz = 0;
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
         for (int k = 0; k < KR; k++) {
             int so = sl + rg * KR + k; so = so >= kRing ? so - kRing : so;                   // scalar
             bool differs = commit_px<ST, true>(st.o[k], recA, recL, recN, so * WL + oli, ref01, refz);
-            if (has_halo) differs = commit_px<ST, false>(st.h[k], recA, recL, recN, so * WL + hli, ref01, refz) || differs;
+            if (halo_wave) { if (has_halo) differs = commit_px<ST, false>(st.h[k], recA, recL, recN, so * WL + hli, ref01, refz) || differs; }
             const bool wave_differs = __ballot(differs) != 0ull;
             if (lane == 0) nflag[so * 8 + wig] = wave_differs ? 1u : 0u;                     // a ring slot is always staged by the same waves
         }
