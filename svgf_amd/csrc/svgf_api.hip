@@ -302,9 +302,9 @@ int svgf_taa(svgf_ctx* c, const void* filtered, const void* history, void* out) 
     if (!c) return SVGF_ERR_INVALID;
     if (!filtered || !history || !out) return fail(c, SVGF_ERR_INVALID, "svgf_taa: null plane");
     if (out == filtered || out == history) return fail(c, SVGF_ERR_INVALID, "svgf_taa: in-place filtering is a race");
-    int rc = check_halo(c, 2, "svgf_taa");
+    int rc = check_halo(c, 3, "svgf_taa");                                // samples sit 1-3 texels up-left of the pixel (fp32 rounding of uv*(N-1))
     if (rc != SVGF_OK) return rc;
-    SVGF_HIP(c, svgf::launch_taa(geo_of(c), c->p.storage, filtered, history, out, c->stream));
+    SVGF_HIP(c, svgf::launch_taa(geo_of(c), c->p.storage, filtered, history, out, c->p.variant == SVGF_VARIANT_DIRECT, c->stream));
     return SVGF_OK;
 }
 

@@ -1136,6 +1136,79 @@ __global__ __launch_bounds__(kBX* kBY) void taa_kernel(Geo g, const void* filter
     Store<ST>::st4(out, (size_t)(y - g.y0) * g.W + x, clamp01(o));        // :355 imageStore
 }
 
+// The same stage with the neighbourhood's YUV values computed ONCE per texel: a workgroup covers 64 x 8 pixels, encodes
+// the 68 x 12 filtered texels its samples can touch into LDS (the nearest-texel coordinates floor(uv*(N-1)) land one to
+// three texels up-left of the pixel, depending on fp32 rounding), and every pixel takes its nine neighbours from there
+// instead of nine gathers + nine YUV encodings.  Same functions on the same inputs: bit-identical to taa_kernel.
+constexpr int kTaaW = 68, kTaaH = 12, kTaaRows = 8;
+template <int ST>
+__global__ __launch_bounds__(kBX* kBY) void taa_lds_kernel(Geo g, const void* filtered, const void* history, void* out) {
+    __shared__ float4 yuv[kTaaH][kTaaW];                                  // 16-B records: one ds_read_b128 per neighbour
+    const int x0 = blockIdx.x * kBX, yb = g.yb + blockIdx.y * kTaaRows;
+    auto stage = [&](int lx, int ly) {
+        const int gx = x0 - 3 + lx, gy = yb - 3 + ly;
+        float3 e = make_float3(0.f, 0.f, 0.f);
+        if (gx >= 0 && gx < g.W && gy >= 0 && gy < g.H && gy >= g.y0 && gy < g.y0 + g.rows) {
+            const float4 c = clamp01(Store<ST>::ld4(filtered, (size_t)(gy - g.y0) * g.W + gx));
+            e = enc_yuv(make_float3(c.x, c.y, c.z));
+        }
+        yuv[ly][lx] = make_float4(e.x, e.y, e.z, 0.f);
+    };
+#pragma unroll
+    for (int k = 0; k < kTaaH / kBY; k++) stage(threadIdx.x, threadIdx.y + kBY * k);     // columns 0..63 of the 12 rows
+    {
+        const int id = threadIdx.y * kBX + threadIdx.x;                                   // columns 64..67
+        if (id < (kTaaW - kBX) * kTaaH) stage(kBX + (id & 3), id >> 2);
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x;
+    if (x >= g.W) return;
+    const float iw = 1.0f / (float)g.W, ih = 1.0f / (float)g.H;
+    const float u = (float)x * iw;                                        // :296
+    const int sx[3] = {tex_coord(u - iw, g.W), tex_coord(u, g.W), tex_coord(u + iw, g.W)};
+#pragma unroll
+    for (int r = 0; r < kTaaRows / kBY; r++) {
+        const int y = yb + threadIdx.y + kBY * r;
+        if (y >= g.ye) continue;
+        const float v = (float)y * ih;
+        const int sy[3] = {tex_coord(v - ih, g.H), tex_coord(v, g.H), tex_coord(v + ih, g.H)};
+        auto nb = [&](int ix, int iy) { const float4 e = yuv[sy[iy] - (yb - 3)][sx[ix] - (x0 - 3)]; return make_float3(e.x, e.y, e.z); };
+        const size_t ci = (size_t)(sy[1] - g.y0) * g.W + sx[1];
+        const float4 last = clamp01(Store<ST>::ld4(history, ci));         // :299
+        const float mix = fminf(last.w, 0.5f);                            // :302
+        const float4 c0 = clamp01(Store<ST>::ld4(filtered, ci));          // :305
+        float3 aa = make_float3(sqrtf(mix_exact(last.x * last.x, c0.x * c0.x, mix)), sqrtf(mix_exact(last.y * last.y, c0.y * c0.y, mix)),
+                                sqrtf(mix_exact(last.z * last.z, c0.z * c0.z, mix)));   // :307-308
+        float3 ya = enc_yuv(aa);                                          // :319
+        float3 mn, mx, mnd, mxd;
+        mn = nb(1, 1); mx = mn;
+        const int px[4] = {2, 0, 1, 1}, py[4] = {1, 1, 2, 0};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float3 yk = nb(px[k], py[k]);
+            mn = make_float3(fminf(mn.x, yk.x), fminf(mn.y, yk.y), fminf(mn.z, yk.z));
+            mx = make_float3(fmaxf(mx.x, yk.x), fmaxf(mx.y, yk.y), fmaxf(mx.z, yk.z));
+        }
+        mnd = mn; mxd = mx;
+        const int dx[4] = {2, 0, 2, 0}, dy[4] = {2, 2, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float3 yk = nb(dx[k], dy[k]);
+            mnd = make_float3(fminf(mnd.x, yk.x), fminf(mnd.y, yk.y), fminf(mnd.z, yk.z));
+            mxd = make_float3(fmaxf(mxd.x, yk.x), fmaxf(mxd.y, yk.y), fmaxf(mxd.z, yk.z));
+        }
+        mn = make_float3(mix_exact(mn.x, mnd.x, 0.5f), mix_exact(mn.y, mnd.y, 0.5f), mix_exact(mn.z, mnd.z, 0.5f));
+        mx = make_float3(mix_exact(mx.x, mxd.x, 0.5f), mix_exact(mx.y, mxd.y, 0.5f), mix_exact(mx.z, mxd.z, 0.5f));
+        ya = make_float3(fminf(fmaxf(ya.x, mn.x), mx.x), fminf(fmaxf(ya.y, mn.y), mx.y), fminf(fmaxf(ya.z, mn.z), mx.z));   // :338
+        float rr = sqrtf((ya.x * 1.0f + ya.y * 0.0f) + ya.z * 1.13983f);
+        float gg = sqrtf((ya.x * 1.0f + ya.y * -0.39465f) + ya.z * -0.58060f);
+        float bb = sqrtf((ya.x * 1.0f + ya.y * 2.03211f) + ya.z * 0.0f);
+        if (rr != rr || gg != gg || bb != bb) { rr = 0.f; gg = 0.f; bb = 0.f; }     // :351
+        const float4 o = make_float4(to_srgb(rr), to_srgb(gg), to_srgb(bb), 1.0f);  // :353
+        Store<ST>::st4(out, (size_t)(y - g.y0) * g.W + x, clamp01(o));    // :355 imageStore
+    }
+}
+
 // ------------------------------------------------------------------ G-buffer adapter -----------
 // What resources/shaders/GBuffer.frag:62-88 (+ GBuffer.vert:21-34) writes, from linear attribute planes.  All
 // arithmetic is unfused fp32 in a fixed order so that the CPU restatement reproduces it bit for bit.
@@ -1241,11 +1314,18 @@ hipError_t launch_pack_gbuffer(const Geo& g, const PackArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_taa(const Geo& g, int storage, const void* filtered, const void* history, void* out, hipStream_t s) {
+hipError_t launch_taa(const Geo& g, int storage, const void* filtered, const void* history, void* out, bool direct, hipStream_t s) {
     if (g.ye <= g.yb) return hipSuccess;
-    const dim3 block(kBX, kBY), grid = grid_for(g);
-    if (storage == 0) taa_kernel<0><<<grid, block, 0, s>>>(g, filtered, history, out);
-    else taa_kernel<1><<<grid, block, 0, s>>>(g, filtered, history, out);
+    const dim3 block(kBX, kBY);
+    if (direct) {
+        const dim3 grid = grid_for(g);
+        if (storage == 0) taa_kernel<0><<<grid, block, 0, s>>>(g, filtered, history, out);
+        else taa_kernel<1><<<grid, block, 0, s>>>(g, filtered, history, out);
+    } else {
+        const dim3 grid((g.W + kBX - 1) / kBX, (g.ye - g.yb + kTaaRows - 1) / kTaaRows);
+        if (storage == 0) taa_lds_kernel<0><<<grid, block, 0, s>>>(g, filtered, history, out);
+        else taa_lds_kernel<1><<<grid, block, 0, s>>>(g, filtered, history, out);
+    }
     return hipGetLastError();
 }
 

@@ -467,6 +467,15 @@ def test_taa(G, oracle, storage):
         hist, h_dev = want, G.dev(want)
     with pytest.raises(F.SvgfError, match="in-place"):
         d.TAA(h_dev, h_dev, h_dev)
+    # the LDS-tiled kernel (default) and the per-pixel kernel (variant direct) are bit-identical, also at a size where the
+    # fp32 rounding of uv*(N-1) moves some samples one more texel up-left
+    for (w2, h2) in ((W, H), (3840, 70), (517, 2160 // 8)):
+        a_, b_ = rng.uniform(-0.1, 1.2, (h2, w2, 4)).astype(dt), rng.uniform(0, 1, (h2, w2, 4)).astype(dt)
+        d1, d2 = F.Denoiser(w2, h2, F.Params(storage=storage)), F.Denoiser(w2, h2, F.Params(storage=storage, variant="direct"))
+        o1, o2 = d1.new_colour(), d2.new_colour()
+        d1.TAA(G.dev(a_), G.dev(b_), o1)
+        d2.TAA(G.dev(a_), G.dev(b_), o2)
+        assert np.array_equal(G.host(o1).view(np.uint8), G.host(o2).view(np.uint8)), (w2, h2)
 
 
 @pytest.mark.parametrize("storage", ["f32", "f16"])
