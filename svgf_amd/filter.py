@@ -93,6 +93,10 @@ def load_library():
                 raise SvgfError(f"libsvgf_mi355x.so is missing and could not be built: {e}") from e
     if not os.path.exists(path):
         raise SvgfError("libsvgf_mi355x.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    # torch ships a HIP runtime of its own (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's): it has to be the one
+    # already in the process when this library is opened, otherwise the process holds two runtimes and the one torch's
+    # tensors live in is not the one svgf_create talks to (hipGetDeviceCount fails -> "no usable gfx950 device").
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     vp, ip = C.c_void_p, C.c_int
     lib.svgf_default_params.argtypes = [C.POINTER(ParamsC)]
