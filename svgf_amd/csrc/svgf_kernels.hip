@@ -432,6 +432,9 @@ __device__ __forceinline__ float dot2_h2(uint32_t a, uint32_t b) {
 //           have in common (30 LDS record pairs per 2 outputs instead of 50): on CDNA4 an LDS read's data return
 //           occupies the SIMD's register-file write path for ~16 cycles per ds_read_b128 and delays vector ALU
 //           issue by as much (tools/ubench/tap_lds.hip), so LDS bytes per output are paid for like instructions.
+#ifndef SVGF_NO_FASTPATH
+#define SVGF_NO_FASTPATH 0          // 1: measure the kernel as it runs on geometry without planar regions (tools/ab.sh)
+#endif
 template <int ST, int S, int TX, int KR, int MODE = 0>
 __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup, int xrot, int band_fastest) {
     constexpr int WL = TX + 4 * S;                 // staged columns per ring row
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
             }
         };
         if (MODE != 1 && wave_has_surface) {
-            if (uniform_normals) tap_rows(std::true_type{}); else tap_rows(std::false_type{});
+            if (uniform_normals && !SVGF_NO_FASTPATH) tap_rows(std::true_type{}); else tap_rows(std::false_type{});
         }
 #ifdef SVGF_STAMPS
         if (lane == 0) { atomicAdd(&g_stamps[10], 1ull); if (uniform_normals) atomicAdd(&g_stamps[11], 1ull); if (!wave_has_surface) atomicAdd(&g_stamps[12], 1ull); }
