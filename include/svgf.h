@@ -155,6 +155,17 @@ typedef struct svgf_camera {
 int svgf_pack_gbuffer(svgf_ctx* ctx, const void* position, const void* normal, const void* bary, const svgf_camera* camera,
                       void* motion_out, void* normal_out, void* uv_out);
 
+/* Albedo demodulation / re-modulation around the filter.  The reference does not have it — "it's not doing
+ * albedo demodulation as described in the paper, so it doesn't really work with textured meshes" (README.md:14,172-174) —
+ * so there is no reference call site; the definition is the SVGF paper's:
+ *   svgf_demodulate: out.rgb = radiance.rgb / max(albedo.rgb, 1e-3), out.w = radiance.w       (before svgf_temporal)
+ *   svgf_modulate:   out.rgb = filtered.rgb * max(albedo.rgb, 1e-3), out.w = filtered.w       (after the last svgf_atrous)
+ * `albedo` is a {r,g,b,-} plane in the context's storage type; `out` may alias the first argument.  Note that the
+ * reference's imageLoad clamps colour to [0,1] (Filter.cuh:78-83): illumination above 1 is clipped by the temporal stage,
+ * so a caller with bright lights over dark albedo should pre-scale its radiance. */
+int svgf_demodulate(svgf_ctx* ctx, const void* radiance, const void* albedo, void* out);
+int svgf_modulate(svgf_ctx* ctx, const void* filtered, const void* albedo, void* out);
+
 /* Whole frame — replaces the sequence application::Render runs (App.cu:552-556) on context-owned
  * state (RenderBuffer[2], MomentsBuffer[2], FilterBuffer[2], history; App.h:138-141).
  * `prev` may be NULL on the first frame.  *result receives the device pointer of the final

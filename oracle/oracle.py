@@ -91,6 +91,12 @@ def taa(W, H, storage, filtered, history, out, *, geo=None, nthreads=1):
     assert rc == 0
 
 
+def albedo(mode, W, rows, storage, inp, alb, out):
+    """Albedo demodulation (mode 0) / re-modulation (mode 1): the build's own definition (the reference has none)."""
+    rc = lib().svgf_oracle_albedo(int(mode), W, rows, STORAGE[storage], _p(inp), _p(alb), _p(out))
+    assert rc == 0
+
+
 class Pipeline:
     """Whole-frame sequencing: TemporalFilter -> FilterMoments -> WaveletFilter (src/App.cu:552-556,
     469-514), with the host-side fixes SURVEY.md App. B lists (#1 history ping-pong, #4 current

@@ -269,3 +269,13 @@ def pack_gbuffer(position, normal, bary, view_proj, prev_view_proj, cam):
     uvout = bary.astype(np.float32).astype(np.float16).view(np.uint16).copy()
     uvout[~covered] = 0
     return motion, nout, uvout
+
+
+def albedo(mode, inp, alb):
+    """Albedo demodulation (mode 0) / re-modulation (mode 1), SURVEY.md 8f-4 (the build's own definition; the reference has
+    none, README.md:14).  inp, alb: (..., 4) arrays in the storage dtype; fp32 arithmetic, one rounding per operation."""
+    c, a = inp.astype(np.float32), alb.astype(np.float32)
+    d = np.maximum(a[..., :3], np.float32(1e-3))
+    o = c.copy()
+    o[..., :3] = (c[..., :3] / d) if mode == 0 else (c[..., :3] * d)
+    return o.astype(inp.dtype)

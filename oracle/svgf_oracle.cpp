@@ -365,6 +365,24 @@ void taa(const Geo& g, const void* input, const void* history, void* out, int nt
 }  // namespace
 
 // ---------------------------------------------------------------- C entry -----
+// Albedo demodulation / re-modulation around the filter.  NOT in the reference — its README says so
+// (README.md:14,172-174) — so this restates the build's own definition (include/svgf.h), not reference code:
+//   demodulate: illumination.rgb = radiance.rgb / max(albedo.rgb, 1e-3), .w = radiance.w      (IEEE division)
+//   modulate:   colour.rgb = illumination.rgb * max(albedo.rgb, 1e-3),   .w = illumination.w
+template <class T> void albedo_op(int mode, size_t n, const void* in, const void* albedo, void* out) {
+    for (size_t i = 0; i < n; i++) {
+        float c[4], al[4], o[4];
+        T::ld4(in, i, c);
+        T::ld4(albedo, i, al);
+        for (int k = 0; k < 3; k++) {
+            const float d = std::max(al[k], 1e-3f);
+            o[k] = mode == 0 ? c[k] / d : c[k] * d;
+        }
+        o[3] = c[3];
+        T::st4(out, i, o);
+    }
+}
+
 extern "C" {
 
 // storage: 0 = fp32 colour/moments, 1 = fp16 colour/moments (reference-native)
@@ -409,6 +427,14 @@ int svgf_oracle_taa(int W, int H, int y0, int rows, int yb, int ye, int storage,
     Geo g{W, H, y0, rows, yb, ye};
     if (storage == 0) taa<F32>(g, input, history, out, nthreads);
     else if (storage == 1) taa<F16>(g, input, history, out, nthreads);
+    else return -1;
+    return 0;
+}
+
+int svgf_oracle_albedo(int mode, int W, int rows, int storage, const void* in, const void* albedo, void* out) {
+    const size_t n = (size_t)W * rows;
+    if (storage == 0) albedo_op<F32>(mode, n, in, albedo, out);
+    else if (storage == 1) albedo_op<F16>(mode, n, in, albedo, out);
     else return -1;
     return 0;
 }

@@ -308,6 +308,16 @@ int svgf_taa(svgf_ctx* c, const void* filtered, const void* history, void* out) 
     return SVGF_OK;
 }
 
+static int albedo_impl(svgf_ctx* c, int mode, const void* in, const void* albedo, void* out, const char* what) {
+    if (!c) return SVGF_ERR_INVALID;
+    if (!in || !albedo || !out) return fail(c, SVGF_ERR_INVALID, std::string(what) + ": null plane");
+    if (albedo == out) return fail(c, SVGF_ERR_INVALID, std::string(what) + ": out must not alias the albedo plane");
+    SVGF_HIP(c, svgf::launch_albedo(geo_of(c), c->p.storage, mode, in, albedo, out, c->stream));
+    return SVGF_OK;
+}
+int svgf_demodulate(svgf_ctx* c, const void* radiance, const void* albedo, void* out) { return albedo_impl(c, 0, radiance, albedo, out, "svgf_demodulate"); }
+int svgf_modulate(svgf_ctx* c, const void* filtered, const void* albedo, void* out) { return albedo_impl(c, 1, filtered, albedo, out, "svgf_modulate"); }
+
 int svgf_pack_gbuffer(svgf_ctx* c, const void* position, const void* normal, const void* bary, const svgf_camera* cam,
                       void* motion_out, void* normal_out, void* uv_out) {
     if (!c) return SVGF_ERR_INVALID;

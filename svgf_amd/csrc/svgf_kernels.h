@@ -42,6 +42,7 @@ struct PackArgs {
     float4* motion; uint2* normal_out; uint2* uv_out;
 };
 hipError_t launch_pack_gbuffer(const Geo& g, const PackArgs& a, hipStream_t s);
+hipError_t launch_albedo(const Geo& g, int storage, int mode, const void* in, const void* albedo, void* out, hipStream_t s);
 hipError_t launch_taa(const Geo& g, int storage, const void* filtered, const void* history, void* out, bool direct, hipStream_t s);
 
 }  // namespace svgf

@@ -1311,6 +1311,27 @@ hipError_t launch_atrous(const Geo& g, int storage, int variant, const AtrousArg
     return hipGetLastError();
 }
 
+// Albedo demodulation (MODE 0) / re-modulation (MODE 1), SURVEY.md 8f-4: pointwise, IEEE division (bit-exact vs the oracle).
+template <int ST, int MODE>
+__global__ __launch_bounds__(kBX* kBY) void albedo_kernel(Geo g, const void* in, const void* albedo, void* out) {
+    const int x = blockIdx.x * kBX + threadIdx.x;
+    const int y = g.yb + blockIdx.y * kBY + threadIdx.y;
+    if (x >= g.W || y >= g.ye) return;
+    const size_t idx = (size_t)(y - g.y0) * g.W + x;
+    const float4 c = Store<ST>::ld4(in, idx), al = Store<ST>::ld4(albedo, idx);
+    const float dr = fmaxf(al.x, 1e-3f), dg = fmaxf(al.y, 1e-3f), db = fmaxf(al.z, 1e-3f);
+    const float4 o = MODE == 0 ? make_float4(c.x / dr, c.y / dg, c.z / db, c.w) : make_float4(c.x * dr, c.y * dg, c.z * db, c.w);
+    Store<ST>::st4(out, idx, o);
+}
+
+hipError_t launch_albedo(const Geo& g, int storage, int mode, const void* in, const void* albedo, void* out, hipStream_t s) {
+    if (g.ye <= g.yb) return hipSuccess;
+    const dim3 block(kBX, kBY), grid = grid_for(g);
+    if (storage == 0) { if (mode == 0) albedo_kernel<0, 0><<<grid, block, 0, s>>>(g, in, albedo, out); else albedo_kernel<0, 1><<<grid, block, 0, s>>>(g, in, albedo, out); }
+    else { if (mode == 0) albedo_kernel<1, 0><<<grid, block, 0, s>>>(g, in, albedo, out); else albedo_kernel<1, 1><<<grid, block, 0, s>>>(g, in, albedo, out); }
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_gbuffer(const Geo& g, const PackArgs& a, hipStream_t s) {
     if (g.ye <= g.yb) return hipSuccess;
     pack_gbuffer_kernel<<<grid_for(g), dim3(kBX, kBY), 0, s>>>(g, a);

@@ -23,7 +23,7 @@ MAX_STEPS = 10
 
 EXPORTS = [
     "svgf_default_params", "svgf_status_string", "svgf_last_error", "svgf_abi_version", "svgf_create",
-    "svgf_create_strip", "svgf_destroy", "svgf_set_params", "svgf_set_stream", "svgf_set_rows", "svgf_temporal", "svgf_temporal_moments",
+    "svgf_create_strip", "svgf_destroy", "svgf_set_params", "svgf_set_stream", "svgf_set_rows", "svgf_temporal", "svgf_temporal_moments", "svgf_demodulate", "svgf_modulate",
     "svgf_moments", "svgf_atrous", "svgf_taa", "svgf_pack_gbuffer", "svgf_denoise_frame", "svgf_reset_history", "svgf_state_plane",
     "svgf_state_pingpong", "svgf_plane_bytes", "svgf_timing_enable", "svgf_timing_read",
 ]
@@ -114,6 +114,8 @@ def load_library():
     lib.svgf_set_stream.argtypes = [vp, vp]
     lib.svgf_set_rows.argtypes = [vp, ip, ip]
     lib.svgf_temporal.argtypes = [vp, vp, vp, vp, C.POINTER(GBufferC), C.POINTER(GBufferC), vp, vp, vp, vp]
+    lib.svgf_demodulate.argtypes = [vp, vp, vp, vp]
+    lib.svgf_modulate.argtypes = [vp, vp, vp, vp]
     lib.svgf_temporal_moments.argtypes = [vp, vp, vp, vp, vp, C.POINTER(GBufferC), C.POINTER(GBufferC), vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]
     lib.svgf_moments.argtypes = [vp, vp, vp, vp, C.POINTER(GBufferC), vp]
     lib.svgf_atrous.argtypes = [vp, vp, vp, vp, C.POINTER(GBufferC), ip, ip]
@@ -254,6 +256,14 @@ class Denoiser:
     def TAA(self, filtered, history, out):
         """application::TAA, src/App.cu:516-522 (history = the previous call's out)."""
         self._check(self.lib.svgf_taa(self._h, _ptr(filtered), _ptr(history), _ptr(out)), "svgf_taa")
+
+    def Demodulate(self, radiance, albedo, out):
+        """radiance / max(albedo, 1e-3) — the SVGF paper's albedo demodulation, absent from the reference (README.md:14)."""
+        self._check(self.lib.svgf_demodulate(self._h, _ptr(radiance), _ptr(albedo), _ptr(out)), "svgf_demodulate")
+
+    def Modulate(self, filtered, albedo, out):
+        """filtered * max(albedo, 1e-3)."""
+        self._check(self.lib.svgf_modulate(self._h, _ptr(filtered), _ptr(albedo), _ptr(out)), "svgf_modulate")
 
     def PackGBuffer(self, position, normal, bary, view_proj, prev_view_proj, camera_position):
         """The G-buffer texels of resources/shaders/GBuffer.frag:62-88 from linear attribute planes; matrices are

@@ -647,3 +647,30 @@ def test_pack_gbuffer_adapter(G):
                      hist, mom, d.new_moments())
     covered = ~(nrm[..., :3] == 0).all(-1)
     assert np.all(G.host(hist)[covered] == 6) and np.all(G.host(hist)[~covered] == 1)
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_albedo_demodulation_bit_exact(G, oracle, storage):
+    """svgf_demodulate / svgf_modulate (an extension, the reference has none) against the oracle, bit for bit
+    (IEEE division), on a strip context too, in place, and the error paths."""
+    from svgf_amd import filter as F
+    rng = np.random.default_rng(78)
+    W, H = 333, 77
+    dt = CDT[storage]
+    x = rng.uniform(0, 1, (H, W, 4)).astype(dt)
+    alb = rng.uniform(-0.1, 1, (H, W, 4)).astype(dt)
+    want_d = np.zeros_like(x); want_m = np.zeros_like(x)
+    oracle.albedo(0, W, H, storage, x, alb, want_d)
+    oracle.albedo(1, W, H, storage, want_d, alb, want_m)
+    d = F.Denoiser(W, H, F.Params(storage=storage))
+    xd, ad, od = G.dev(x), G.dev(alb), d.new_colour()
+    d.Demodulate(xd, ad, od)
+    assert np.array_equal(G.host(od).view(np.uint8), want_d.view(np.uint8))
+    d.Modulate(od, ad, od)                                    # in place
+    assert np.array_equal(G.host(od).view(np.uint8), want_m.view(np.uint8))
+    ds = F.Denoiser(W, H, F.Params(storage=storage), strip=(16, 40, 24, 48))
+    os_ = ds.new_colour()
+    ds.Demodulate(G.dev(np.ascontiguousarray(x[16:56])), G.dev(np.ascontiguousarray(alb[16:56])), os_)
+    assert np.array_equal(G.host(os_)[8:32].view(np.uint8), want_d[24:48].view(np.uint8))
+    with pytest.raises(F.SvgfError, match="alias"):
+        d.Demodulate(xd, ad, ad)

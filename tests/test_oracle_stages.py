@@ -258,3 +258,25 @@ def test_pack_gbuffer_numpy_kat():
     assert np.all(n[1:, :, 2] == np.float16(1.0).view(np.uint16)) and np.all(n[1:, :, 3] == np.float16(7).view(np.uint16))
     assert np.all(uv[1:, :, 3] == np.float16(3).view(np.uint16)) and np.all(n[0, 0] == 0) and np.all(uv[0, 0] == 0)
     assert m[2, 3, 3] == 0 and m[0, 1, 3] == 0          # flat depth: zero derivative; partner without geometry: 0
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_albedo_demodulation_matches_numpy_and_round_trips(oracle, storage):
+    """SURVEY.md 8f-4 (an extension: the reference has no albedo demodulation, README.md:14): C++ oracle == NumPy
+    restatement bit for bit, and modulate(demodulate(x)) returns x to within the roundings of the two operations."""
+    from oracle import svgf_numpy as snp
+    rng = np.random.default_rng(77)
+    W, H = 53, 31
+    dt = CDT[storage]
+    x = rng.uniform(0, 1, (H, W, 4)).astype(dt)
+    alb = rng.uniform(-0.1, 1, (H, W, 4)).astype(dt)          # includes albedo below the 1e-3 floor
+    alb[0, :5, :3] = 0
+    d = np.zeros_like(x); m = np.zeros_like(x)
+    oracle.albedo(0, W, H, storage, x, alb, d)
+    assert np.array_equal(d.view(np.uint8), snp.albedo(0, x, alb).view(np.uint8))
+    oracle.albedo(1, W, H, storage, d, alb, m)
+    assert np.array_equal(m.view(np.uint8), snp.albedo(1, d, alb).view(np.uint8))
+    assert np.array_equal(m[..., 3], x[..., 3])
+    tol = 2e-7 if storage == "f32" else 2e-3
+    assert np.abs(m.astype(np.float64) - x.astype(np.float64))[..., :3].max() <= tol * 2
+    assert np.array_equal(d[0, :5, :3].astype(np.float32), (x[0, :5, :3].astype(np.float32) / np.float32(1e-3)).astype(dt).astype(np.float32))
