@@ -142,6 +142,10 @@ public:
     }
     // application::TAA (App.cu:516-522): Filtered -> Out with the previous Out as history
     void TAA(const void* Filtered, const void* History, void* Out) { check(svgf_taa(Ctx, Filtered, History, Out), "svgf_taa"); }
+    // Albedo demodulation / re-modulation (the SVGF paper's; the reference has none, README.md:14): in place on the frame's
+    // 1-spp radiance before TemporalFilter, and on the filtered plane after WaveletFilter.
+    void Demodulate(const void* Albedo) { check(svgf_demodulate(Ctx, Buffers.ColourBuffer->Data, Albedo, Buffers.ColourBuffer->Data), "svgf_demodulate"); }
+    void Modulate(void* Filtered, const void* Albedo) { check(svgf_modulate(Ctx, Filtered, Albedo, Filtered), "svgf_modulate"); }
     // application::EndFrame's share (App.cu:374): this frame's colour/moments/history become the previous frame's
     void EndFrame() {
         std::swap(Buffers.ColourBuffer, Buffers.HistoryBufferColour);
