@@ -588,7 +588,7 @@ def test_atrous_large_steps_and_degenerate_phis(G, oracle, storage):
 
 def test_frame_sizes_and_ten_iterations(G, oracle):
     """Odd sizes around the 256-column / 64-lane tiles, narrower than one tile, and the GUI's maximum of 10 iterations."""
-    for (W, H, steps) in [(64, 40, 3), (255, 33, 5), (257, 65, 5), (513, 130, 10)]:
+    for (W, H, steps) in [(1, 1, 2), (7, 3, 5), (17, 130, 5), (130, 2, 5), (64, 40, 3), (255, 33, 5), (257, 65, 5), (513, 130, 10)]:
         fr = frames(W, H, 3, mv=(1.0, 0.0))
         ref = oracle.Pipeline(W, H, "f32", steps=steps, nthreads=8)
         hip = G.HipPipeline(W, H, "f32", steps=steps)
@@ -598,6 +598,15 @@ def test_frame_sizes_and_ten_iterations(G, oracle):
             got = hip.frame(fr[k]["radiance"], gbs[k], gbs[max(k - 1, 0)])
             assert np.array_equal(hip.taps["hist"], ref.taps["hist"]), (W, H, k)
             G.assert_colour_close(got, want, "f32", f"{W}x{H} steps {steps} frame {k}")
+        # the frame driver (fused launches, flags per 64-pixel segment) on the same sizes
+        from svgf_amd import filter as F
+        d = F.Denoiser(W, H, F.Params(storage="f32", steps=steps))
+        ref2 = oracle.Pipeline(W, H, "f32", steps=steps, nthreads=8)
+        for k in range(3):
+            want = ref2.frame(fr[k]["radiance"], gbuf(fr[k]), gbuf(fr[max(k - 1, 0)]))
+            got = G.host(d.Render(G.dev(fr[k]["radiance"]), gbs[k], gbs[k - 1] if k else None))
+            assert np.array_equal(G.host(d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong())), ref2.taps["hist"]), (W, H, k)
+            assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= 2e-3, (W, H, k)
 
 
 def _look_at(eye, target, up=(0, 1, 0)):
