@@ -254,6 +254,15 @@ def main():
     t = torch.tensor([res["ms_per_step"]], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ms = float(t.item())
+    # roofline of the dominant kernel on rank 0's strip: its a-trous launches (halo rows included) between HIP events
+    ab = ALG_BYTES[storage]
+    n_l, ms_l, by_l = res["stages"].atrous_timing(ab["atrous_iter"], ab["atrous_feedback"])
+    roof = None
+    if n_l and ms_l > 0:
+        ach = by_l / (ms_l * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "atrous_lds_kernel", "scope": "rank 0, its strip incl. redundantly computed halo rows",
+                "launches_timed": n_l, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                "algorithmic_bytes_per_launch": int(by_l / n_l), "avg_launch_ms": round(ms_l / n_l, 5), "traffic": None}
     line = None
     if rank == 0:
         value = W * H / (ms * 1e-3) / 1e6
@@ -266,7 +275,7 @@ def main():
             "config": {"workload": f"{W}x{H} {storage} storage in {N} row strips ({res['rows_per_rank']} rows per GPU), halo exchange over "
                                    f"RCCL send/recv, plan {res['plan']}, temporal + moments + {iters} a-trous iterations, steady state",
                        "width": W, "height": H, "storage": storage, "atrous_iterations": iters, "halo_plan": res["plan"]},
-            "roofline": None,
+            "roofline": roof,
             "pass_roofline": {"algorithmic_bytes_per_px": alg_bytes_full(storage, iters), "achieved_GBps": round(full_gbps, 1),
                               "frac_of_aggregate_8TBps": round(full_gbps / (HBM_PEAK_GBPS * N), 4)},
         }

@@ -189,6 +189,7 @@ class HipStages:
         self.F, self.geo = F, geo
         self.d = F.Denoiser(geo.W, geo.H, params, device=device.index or 0, strip=(geo.y0, geo.y1 - geo.y0, geo.own[0], geo.own[1]))
         self.device = device
+        self.timing, self.events = False, []
 
     def gbuffer(self, motion, normal, uv):
         return self.F.GBuffer(motion, normal, uv)
@@ -210,7 +211,23 @@ class HipStages:
 
     def atrous(self, rows, src, dst, feedback, gb, step, iteration):
         self.d.set_rows(*rows)
-        self.d.FilterKernel(src, dst, feedback, gb, step, iteration)
+        if self.timing:                              # HIP events on the stream the kernel is launched on (torch's current one)
+            import torch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.d.FilterKernel(src, dst, feedback, gb, step, iteration)
+            e1.record()
+            self.events.append((e0, e1, (rows[1] - rows[0]) * self.geo.W, iteration))
+        else:
+            self.d.FilterKernel(src, dst, feedback, gb, step, iteration)
+
+    def atrous_timing(self, bytes_iter, bytes_feedback):
+        """-> (launches, total ms, total algorithmic bytes) of the a-trous launches recorded while self.timing was set."""
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.events)
+        by = sum(px * (bytes_iter + (bytes_feedback if it == 0 else 0)) for _, _, px, it in self.events)
+        n = len(self.events)
+        self.events = []
+        return n, ms, by
 
 
 class StripRunner:
@@ -391,7 +408,9 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for k in range(steps):
+        stages.timing = (k % 4) == 0             # a-trous launches of every 4th timed frame between HIP events
         runner.frame(rads[k % len(rads)], gb, gb)
+    stages.timing = False
     torch.cuda.synchronize(device)
     dist.barrier()
     torch.cuda.synchronize(device)
@@ -400,4 +419,4 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
     runner.flush()
     assert bool(torch.isfinite(runner.owned(out).float()).all())
     return dict(ms_per_step=(t1 - t0) * 1e3 / steps, rows_per_rank=geo.own[1] - geo.own[0],
-                plan=geo.plan)
+                plan=geo.plan, stages=stages)
