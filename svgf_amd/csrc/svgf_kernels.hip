@@ -309,18 +309,18 @@ __global__ __launch_bounds__(kBX* kBY) void atrous_direct_kernel(Geo g, AtrousAr
 
 // ------------------------------------------------------------------ a-trous (LDS streaming) ---
 // Filter.cuh:527-624 re-designed for CDNA4.  For step S a pixel only ever reads pixels of its own row residue
-// (y mod S), so a workgroup owns ONE residue of a band of rows and a TX = 256-pixel-wide column block, and
-// streams down the band: a ring of kRing = kRG+4 decimated rows (tile + 2S halo columns each side) lives in LDS
-// as fp32 records; every step the workgroup produces kRG = 2 vertically adjacent decimated rows from the ring
-// (waves 0-3 row j, waves 4-7 row j+1: one output per thread), while the rows of the next two steps are already
-// in flight from HBM into registers.  Global loads are always full-width row segments (16 B per lane, coalesced)
-// whatever the step; the y over-fetch is (band+4)/band and the x over-fetch (256+4S)/256 instead of the 25x
-// gather of a per-pixel kernel.
+// (y mod S), so a workgroup owns ONE residue of a band of rows and a TX-pixel-wide column block (TX = 128: 4 waves,
+// 4 workgroups per CU; the 256-column form is kept for diagnostics), and streams down the band: a ring of
+// kRing = kRS+4 decimated rows (tile + 2S halo columns each side) lives in LDS as fp32 records; every step the
+// workgroup produces kRS = 2 vertically adjacent decimated rows from the ring (waves 0-1 row j, waves 2-3 row j+1:
+// one output per thread), while the rows of the next two steps are already in flight from HBM into registers.
+// Global loads are always full-width row segments (16 B per lane, coalesced) whatever the step; the y over-fetch is
+// (band+4)/band and the x over-fetch (TX+4S)/TX instead of the 25x gather of a per-pixel kernel.
 //
-// LDS record per pixel (32 B): A = {r,g,b,variance} clamped (imageLoad :78-83), B = {luminance, depth (sky ->
-// 1e30), (nx,ny) as packed halfs, nz as float}.  The centre's ddepth is the only other per-pixel input: the
-// thread that stages a pixel of its own column is the thread that later filters it, so ddepth rides in a
-// three-register queue instead of LDS.
+// LDS record per pixel (32 B in three planes): A = {r,g,b,variance} clamped (imageLoad :78-83), L = {luminance,
+// depth (sky -> 1e30)}, N = {(nx,ny) as packed halfs, nz as float}.  The centre's ddepth is the only other per-pixel
+// input: the thread that stages a pixel of its own column is the thread that later filters it, so ddepth rides in
+// a two-register queue instead of LDS.
 //
 // Everything that is the same for all lanes of a wave — row offsets, ring slots, validity of a row — is kept in
 // scalar registers: planes are addressed as buffer resources with a per-thread constant byte offset (voffset)
