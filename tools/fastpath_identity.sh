@@ -1,0 +1,30 @@
+#!/bin/bash
+# The uniform-normal fast path must be bit-identical to the general path: run the same frames through a build with the fast
+# path compiled out (-DSVGF_NO_FASTPATH=1) and through the normal build, compare checksums of every output plane.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R; mkdir -p build
+python3 -c "
+from svgf_amd import build as b
+b.build_library(extra_flags=['-DSVGF_NO_FASTPATH=1'], out='$R/build/libsvgf_nofast.so')
+b.build_library(out='$R/build/libsvgf_fast.so', force=True)" 2>/dev/null
+cat > /tmp/fp_run.py <<'PY'
+import hashlib, os, sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+from svgf_amd import filter as F, synth
+for (W, H, storage, mv) in ((3840, 2160, "f32", (0.0, 0.0)), (1921, 1079, "f16", (-2.5, 1.5)), (517, 333, "f32", (1.0, 0.0))):
+    d = F.Denoiser(W, H, F.Params(storage=storage, steps=5))
+    npdt = np.float32 if storage == "f32" else np.float16
+    prev = None
+    for k in range(6):
+        fr = synth.make_frame(W, H, k, mv=mv)
+        gb = F.GBuffer(*(torch.from_numpy(fr[n]).cuda() for n in ("motion", "normal", "uv")))
+        out = d.Render(torch.from_numpy(fr["radiance"].astype(npdt)).cuda(), gb, prev)
+        torch.cuda.synchronize()
+        print(W, H, storage, k, hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest())
+        prev = gb
+PY
+SVGF_LIBRARY=$R/build/libsvgf_nofast.so python3 /tmp/fp_run.py 2>/dev/null > /tmp/fp_a.txt
+SVGF_LIBRARY=$R/build/libsvgf_fast.so python3 /tmp/fp_run.py 2>/dev/null > /tmp/fp_b.txt
+wc -l /tmp/fp_a.txt /tmp/fp_b.txt | head -2
+if cmp -s /tmp/fp_a.txt /tmp/fp_b.txt; then echo "fast path == general path: all $(wc -l < /tmp/fp_a.txt) frames bit-identical"; else echo "MISMATCH"; diff /tmp/fp_a.txt /tmp/fp_b.txt | head; fi
