@@ -47,9 +47,30 @@ def pipeline(W=64, H=48, N=8, mv=(-2.5, 1.5)):
     np.savez_compressed(os.path.join(HERE, "pipeline_64x48.npz"), W=W, H=H, N=N, mv=np.array(mv), **out)
 
 
+def config1(W=256, H=256):
+    """BASELINE.json configs[0] at full size: 256x256 synthetic G-buffer + noisy radiance, ONE a-trous iteration (step 1) through
+    the scalar C++ loop.  Only a strided sample of the output and its statistics are stored (the inputs are regenerated from
+    the seeded generator, whose planes are pinned by checksums)."""
+    f = synth.make_frame(W, H, 0)
+    rng = np.random.default_rng(256)
+    src = np.concatenate([f["radiance"][..., :3], rng.uniform(0.0, 0.05, (H, W, 1)).astype(np.float32)], -1)
+    gb = {k: f[k] for k in ("motion", "normal", "uv")}
+    out = {}
+    for st, dt in (("f32", np.float32), ("f16", np.float16)):
+        s = src.astype(dt)
+        o = np.zeros_like(s); fb = np.zeros_like(s)
+        orc.atrous(W, H, st, s, o, fb, gb, step=1, phi_colour=10.0, phi_normal=128.0, iteration=0)
+        out[f"sample_{st}"] = o[::8, ::8].copy()
+        out[f"mean_{st}"] = o.astype(np.float64).mean((0, 1))
+        out[f"fb_equal_{st}"] = np.array(np.array_equal(fb[f["region"] != synth.SKY], o[f["region"] != synth.SKY]))
+    sums = np.array([int(np.frombuffer(f[k].tobytes(), np.uint8).astype(np.uint64).sum()) for k in ("motion", "normal", "uv", "radiance")], np.uint64)
+    np.savez_compressed(os.path.join(HERE, "config1_256x256.npz"), input_sums=sums, **out)
+
+
 if __name__ == "__main__":
     atrous_single()
     pipeline()
+    config1()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

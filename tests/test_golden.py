@@ -26,6 +26,56 @@ def test_oracle_reproduces_atrous_golden(oracle):
             np.testing.assert_allclose(out.astype(np.float32), z[f"out_{st}_step{step}"].astype(np.float32), rtol=2e-6, atol=1e-7)
 
 
+def _config1_inputs():
+    W = H = 256
+    f = synth.make_frame(W, H, 0)
+    rng = np.random.default_rng(256)
+    src = np.concatenate([f["radiance"][..., :3], rng.uniform(0.0, 0.05, (H, W, 1)).astype(np.float32)], -1)
+    return W, H, f, src
+
+
+def test_baseline_config1_256x256_single_atrous_on_the_cpu_oracle(oracle):
+    """BASELINE.json configs[0]: 256x256 synthetic G-buffer + noisy radiance, a single a-trous iteration through the scalar
+    C++ loop (plumbing, no GPU) — against the committed sample, the NumPy restatement and the iteration-0 feedback rule."""
+    from oracle import svgf_numpy as snp
+    z = np.load(os.path.join(GOLD, "config1_256x256.npz"))
+    W, H, f, src = _config1_inputs()
+    sums = np.array([int(np.frombuffer(f[k].tobytes(), np.uint8).astype(np.uint64).sum()) for k in ("motion", "normal", "uv", "radiance")], np.uint64)
+    assert np.array_equal(sums, z["input_sums"]), "synthetic generator drifted"
+    for st, dt in (("f32", np.float32), ("f16", np.float16)):
+        s = src.astype(dt)
+        out = np.zeros_like(s); fb = np.full_like(s, 7)
+        oracle.atrous(W, H, st, s, out, fb, gbuf(f), step=1, phi_colour=10.0, phi_normal=128.0, iteration=0)
+        tol = 2e-6 if st == "f32" else 1e-3
+        assert np.abs(out[::8, ::8].astype(np.float32) - z[f"sample_{st}"].astype(np.float32)).max() <= tol
+        np.testing.assert_allclose(out.astype(np.float64).mean((0, 1)), z[f"mean_{st}"], rtol=1e-5)
+        sky = f["region"] == synth.SKY
+        assert np.array_equal(fb[~sky], out[~sky]) and np.all(fb[sky] == 7)            # Filter.cuh:619-622
+    want, fbmask = snp.atrous(src, gbuf(f), step=1, phi_colour=10.0, phi_normal=128.0)   # independent restatement, fp32
+    assert np.array_equal(fbmask, f["region"] != synth.SKY)
+    got = np.zeros_like(src)
+    oracle.atrous(W, H, "f32", src, got, None, gbuf(f), step=1, phi_colour=10.0, phi_normal=128.0, iteration=1)
+    assert np.abs(got - want).max() <= 5e-6
+
+
+@pytest.mark.gpu
+def test_hip_matches_config1_golden():
+    """The same configuration through the HIP kernels (both variants) against the committed sample."""
+    import torch
+    from svgf_amd import filter as F
+    z = np.load(os.path.join(GOLD, "config1_256x256.npz"))
+    W, H, f, src = _config1_inputs()
+    gb = F.GBuffer(*(torch.from_numpy(f[k]).cuda() for k in ("motion", "normal", "uv")))
+    for st, dt in (("f32", np.float32), ("f16", np.float16)):
+        for variant in ("lds", "direct"):
+            d = F.Denoiser(W, H, F.Params(storage=st, variant=variant))
+            out, fb = d.new_colour(), d.new_colour()
+            d.FilterKernel(torch.from_numpy(src.astype(dt)).cuda(), out, fb, gb, 1, 0)
+            got = out.cpu().numpy()
+            tol = 2e-5 if st == "f32" else 2e-3
+            assert np.abs(got[::8, ::8].astype(np.float32) - z[f"sample_{st}"].astype(np.float32)).max() <= tol, (st, variant)
+
+
 def test_oracle_reproduces_pipeline_golden(oracle):
     z = np.load(os.path.join(GOLD, "pipeline_64x48.npz"))
     W, H, N, mv = int(z["W"]), int(z["H"]), int(z["N"]), tuple(float(v) for v in z["mv"])
