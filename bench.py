@@ -236,6 +236,11 @@ def main():
             r2 = run_single(W2, H2, storage, iters, args.variant, max(args.steps, 20), args.warmup, device)
             line["also"] = {"1920x1080": {"ms_per_step": round(r2["ms_per_step"], 4),
                                           "Mpixels/s": round(W2 * H2 / (r2["ms_per_step"] * 1e-3) / 1e6, 1)}}
+            if storage == "f32" and wl == "4k":      # BASELINE configs[4]: the reference-native fp16 storage on the same frame
+                r3 = run_single(W, H, "f16", iters, args.variant, max(args.steps, 20), args.warmup, device)
+                line["also"]["3840x2160_f16"] = {"ms_per_step": round(r3["ms_per_step"], 4),
+                                                 "Mpixels/s": round(W * H / (r3["ms_per_step"] * 1e-3) / 1e6, 1),
+                                                 "frac_of_8TBps": round(alg_bytes_full("f16", iters) * W * H / (r3["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(storage, iters)
         if world > 1 or args.strips:
