@@ -29,7 +29,8 @@ ALG_BYTES = {
 }
 HBM_PEAK_GBPS = 8000.0        # MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 WORKLOADS = {"1080p": (1920, 1080), "4k": (3840, 2160), "8k": (7680, 4320)}
-PRIME_FRAMES = 8              # history must reach steady state (h >= 4) before anything is timed (§8d)
+PRIME_FRAMES = 40             # history must reach steady state (h >= 4) before anything is timed (§8d); 40 rather than 8 frames also
+                              # bring the device to its sustained clocks: with 8, a 5-step timed region read 0.80 instead of 0.73 ms
 
 
 def parse():
