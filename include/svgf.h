@@ -19,6 +19,9 @@
  *  - Calls enqueue work on the context's HIP stream and return without synchronising, like the
  *    reference's launches on the default stream (App.cu:471-505).  Errors are returned (0 = ok,
  *    negative = SVGF_ERR_*), never asserted (the reference asserts: App.cu:41-48).
+ *  - A context is not thread-safe (like the reference's single render thread, App.cu:692-734): one host thread at a
+ *    time per context; different contexts are independent and may share a device.  Resizing = a new context
+ *    (ResizeRenderTextures frees and reallocates everything, App.cu:742-778).
  *  - Strips: a context may hold only rows [y0, y0+rows) of a WxH frame (multi-GPU row strips);
  *    "inside the frame" tests always use the global frame, so strip results are bit-identical
  *    to the whole-frame result as long as the halo rows hold valid data.
