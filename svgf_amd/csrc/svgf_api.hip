@@ -278,7 +278,7 @@ static int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* 
     if (rc != SVGF_OK) return rc;
     svgf::MomentsArgs a{colour, out, moments, (const float4*)g->motion, (const uint2*)g->normal, hist,
                         c->p.phi_colour, c->p.phi_normal, c->p.moments_radius, cold_only, dense, sparse_colour, cold_only ? c->young_flags : nullptr};
-    SVGF_HIP(c, svgf::launch_moments(geo_of(c), c->p.storage, a, c->stream));
+    SVGF_HIP(c, svgf::launch_moments(geo_of(c), c->p.storage, a, c->p.variant == SVGF_VARIANT_DIRECT, c->stream));
     return SVGF_OK;
 }
 

@@ -34,7 +34,7 @@ struct AtrousArgs {
 };
 
 hipError_t launch_temporal(const Geo& g, int storage, const TemporalArgs& a, hipStream_t s);
-hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, hipStream_t s);
+hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, bool direct, hipStream_t s);
 hipError_t launch_atrous(const Geo& g, int storage, int variant, const AtrousArgs& a, hipStream_t s);
 struct PackArgs {
     const float4* position; const float4* normal; const float4* bary;

@@ -235,6 +235,94 @@ __global__ __launch_bounds__(kBX* kBY) void moments_kernel(Geo g, MomentsArgs a)
     moments_pixel<ST>(g, a, x, y);
 }
 
+// The 3x3 variant of the estimate (moments_radius = 1) with the neighbourhood shared through wave64 shuffles: a wave is
+// 64 consecutive pixels of a row; every lane loads its own column of rows y-1, y, y+1 once (coalesced) and takes the
+// columns x-1 / x+1 from its neighbour lanes (__shfl_up / __shfl_down); only lanes 0 and 63 fetch the column beyond the
+// wave.  3 row loads per plane instead of 9 gathers.  Same expressions in the same order as moments_pixel: bit-identical.
+struct MomTap { float cx, cy, cz, m1, m2, z; uint32_t n01, n2; };
+__device__ __forceinline__ MomTap shfl_tap(const MomTap& t, int dir) {
+    MomTap r;
+#define SVGF_SH(f) r.f = dir < 0 ? __shfl_up(t.f, 1) : __shfl_down(t.f, 1)
+    SVGF_SH(cx); SVGF_SH(cy); SVGF_SH(cz); SVGF_SH(m1); SVGF_SH(m2); SVGF_SH(z); SVGF_SH(n01); SVGF_SH(n2);
+#undef SVGF_SH
+    return r;
+}
+template <int ST>
+__device__ __forceinline__ MomTap load_tap(const Geo& g, const MomentsArgs& a, int px, int py) {
+    const size_t p = (size_t)(py - g.y0) * g.W + px;
+    const float4 c = Store<ST>::ld4(a.colour, p);                     // :479 raw
+    const float2 m = Store<ST>::ld2(a.mom, p);                        // :480
+    float z, dz;
+    depth_of(a.motion[p], z, dz);                                     // :482
+    const uint2 n = a.normal[p];                                      // :483
+    return MomTap{c.x, c.y, c.z, m.x, m.y, z, n.x, n.y};
+}
+template <int ST>
+__global__ __launch_bounds__(kBX* kBY) void moments3x3_shfl_kernel(Geo g, MomentsArgs a) {
+    const int lane = threadIdx.x;
+    const int x = blockIdx.x * kBX + lane;
+    const int y = g.yb + blockIdx.y * kBY + threadIdx.y;
+    if (y >= g.ye) return;                                            // the whole wave
+    const int xl = min(x, g.W - 1);                                   // lanes beyond the frame load a valid texel nobody uses
+    MomTap own[3], lft[3], rgt[3];
+    bool rowok[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int py = y + r - 1;
+        rowok[r] = py >= 0 && py < g.H;                               // :473 (wave-uniform)
+        if (!rowok[r]) continue;
+        own[r] = load_tap<ST>(g, a, xl, py);
+        lft[r] = shfl_tap(own[r], -1);
+        rgt[r] = shfl_tap(own[r], +1);
+        if (lane == 0 || lane == kBX - 1) {                           // the columns just outside the wave: one masked load
+            const int xe = lane == 0 ? x - 1 : x + 1;
+            if (xe >= 0 && xe < g.W) {
+                const MomTap e = load_tap<ST>(g, a, xe, py);
+                if (lane == 0) lft[r] = e; else rgt[r] = e;
+            }
+        }
+    }
+    if (x >= g.W) return;
+    const size_t idx = (size_t)(y - g.y0) * g.W + x;
+    const float h = (float)a.hist[idx];                               // :442
+    if (a.cold_only && !(h < 4.0f)) return;
+    if (!(h < 4.0f)) { Store<ST>::st4(a.out, idx, Store<ST>::ld4(a.colour, idx)); return; }   // :521
+    const MomTap& cc = own[1];
+    const float lc = lum_exact(cc.cx, cc.cy, cc.cz);
+    float zc, dzc;
+    depth_of(a.motion[idx], zc, dzc);
+    const float3 nc = normal_of(make_uint2(cc.n01, cc.n2));
+    if (((cc.n01 & 0x7fff7fffu) | (cc.n2 & 0x7fffu)) == 0u && a.phi_normal > 0.0f) {          // see moments_pixel
+        Store<ST>::st4(a.out, idx, make_float4(0.f, 0.f, 0.f, 0.f * (4.0f / h)));
+        return;
+    }
+    const float il = hw_rcp(a.phi_colour);                            // :460
+    const float phi_d = fmaxf(dzc, 1e-8f) * 3.0f;                     // :461
+    float sw = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sm1 = 0.f, sm2 = 0.f;
+#pragma unroll
+    for (int yy = -1; yy <= 1; yy++) {
+        if (!rowok[yy + 1]) continue;
+#pragma unroll
+        for (int xx = -1; xx <= 1; xx++) {
+            const int px = x + xx;
+            if (px < 0 || px >= g.W) continue;
+            const MomTap& t = xx < 0 ? lft[yy + 1] : (xx == 0 ? own[yy + 1] : rgt[yy + 1]);
+            const float3 np = normal_of(make_uint2(t.n01, t.n2));
+            const float len = sqrtf((float)(xx * xx + yy * yy));      // :488
+            const float iz = (xx == 0 && yy == 0) ? 0.0f : hw_rcp(phi_d * len);
+            const float w = edge_weight(fabsf(lc - lum_exact(t.cx, t.cy, t.cz)), il, fabsf(zc - t.z), iz, dot3_fma(nc, np), a.phi_normal);
+            sw += w;                                                  // :497-499
+            sr = fmaf(t.cx, w, sr); sg = fmaf(t.cy, w, sg); sb = fmaf(t.cz, w, sb);
+            sm1 = fmaf(t.m1, w, sm1); sm2 = fmaf(t.m2, w, sm2);
+        }
+    }
+    sw = fmaxf(sw, 1e-6f);                                            // :505
+    const float inv = 1.0f / sw;
+    sm1 *= inv; sm2 *= inv;
+    const float var = (sm2 - sm1 * sm1) * (4.0f / h);                 // :511-514
+    Store<ST>::st4(a.out, idx, make_float4(sr * inv, sg * inv, sb * inv, var));   // :516 unclamped
+}
+
 // Steady state inside the frame driver: the temporal launch already copied every pixel with history >= 4 and left a
 // flag per 64-pixel row segment that holds a young one (disocclusions: sparse).  A small persistent grid scans the
 // flags, 64 per wave-load, and visits only flagged segments — instead of one thread per pixel reading a history byte.
@@ -1269,12 +1357,19 @@ hipError_t launch_temporal(const Geo& g, int storage, const TemporalArgs& a, hip
     return hipGetLastError();
 }
 
-hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, hipStream_t s) {
+hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, bool direct, hipStream_t s) {
     if (g.ye <= g.yb) return hipSuccess;
     // dense: the caller knows (nearly) every pixel is young — the LDS-streaming kernel; it needs the reference's
     // radius and a non-degenerate PhiNormal (the fused exponent would see 0 * -inf)
     if (a.dense && a.radius == kMR && a.phi_normal != 0.0f)
         return storage == 0 ? launch_moments_lds<0>(g, a, s) : launch_moments_lds<1>(g, a, s);
+    // the 3x3 variant on a plane full of young pixels (stage call, or the first frames of a sequence): wave64 shuffles
+    if (a.radius == 1 && !direct && (a.dense || !a.cold_only)) {
+        const dim3 block(kBX, kBY), grid = grid_for(g);
+        if (storage == 0) moments3x3_shfl_kernel<0><<<grid, block, 0, s>>>(g, a);
+        else moments3x3_shfl_kernel<1><<<grid, block, 0, s>>>(g, a);
+        return hipGetLastError();
+    }
     if (a.cold_only && a.young_flags) {
         const int nsegs = (g.ye - g.yb) * ((g.W + kBX - 1) / kBX);
         int wgs = (nsegs + 255) / 256;                           // >= one flag per lane and load ...

@@ -74,6 +74,38 @@ def test_moments(G, oracle, storage, radius, variant):
         assert np.all(np.abs(g - w) <= 8e-5 + np.abs(w) * 2.0 ** -10)      # cancellation error + one half-ulp
 
 
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_moments_3x3_wave_shuffle_kernel_is_bit_identical(G, storage):
+    """moments_radius = 1: the wave64-shuffle kernel (default) against the per-pixel kernel (variant direct), bitwise, on
+    widths around the 64-lane wave (edge lanes fetch the column beyond the wave) and through the frame driver's cold frames."""
+    from svgf_amd import filter as F
+    rng = np.random.default_rng(5)
+    dt = CDT[storage]
+    for (W, H) in ((203, 67), (64, 9), (65, 5), (1, 3), (129, 2)):
+        f = synth.make_frame(W, H, 1)
+        col = rng.uniform(0, 1, (H, W, 4)).astype(dt)
+        mom = rng.uniform(0, 1, (H, W, 2)).astype(dt)
+        hist = rng.integers(1, 7, (H, W)).astype(np.uint8)
+        outs = []
+        for variant in ("auto", "direct"):
+            d = F.Denoiser(W, H, F.Params(storage=storage, moments_radius=1, variant=variant))
+            o = d.new_colour()
+            d.FilterMoments(G.dev(col), o, G.dev(mom), G.gb_dev(f), G.dev(hist))
+            outs.append(G.host(o))
+        assert np.array_equal(outs[0].view(np.uint8), outs[1].view(np.uint8)), (W, H)
+    W, H = 200, 90
+    fr = frames(W, H, 5, mv=(1.0, 0.0))
+    gbs = [G.gb_dev(f) for f in fr]
+    da = F.Denoiser(W, H, F.Params(storage=storage, steps=0, moments_radius=1))          # no iterations: the result IS the moments output
+    dd = F.Denoiser(W, H, F.Params(storage=storage, steps=0, moments_radius=1, variant="direct"))
+    for k in range(5):
+        rad = G.dev(fr[k]["radiance"].astype(G.NPDT[storage]))
+        a_ = G.host(da.Render(rad, gbs[k], gbs[k - 1] if k else None))
+        b_ = G.host(dd.Render(rad, gbs[k], gbs[k - 1] if k else None))
+        assert np.array_equal(a_.view(np.uint8), b_.view(np.uint8)), f"driver radius 1 frame {k}"
+        assert np.array_equal(G.host(da.state_plane(F.PLANE_HISTORY, 1 - da.pingpong())), G.host(dd.state_plane(F.PLANE_HISTORY, 1 - dd.pingpong())))
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("storage", ["f32", "f16"])
 @pytest.mark.parametrize("step", [1, 2, 4, 8, 16])
