@@ -582,19 +582,16 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
     const unsigned vo_c = own_ok ? (unsigned)gx * CB : kOob, vo_m = own_ok ? (unsigned)gx * 16u + 8u : kOob, vo_n = own_ok ? (unsigned)gx * 8u : kOob;
     const unsigned vh_c = halo_ok ? (unsigned)hx * CB : kOob, vh_m = halo_ok ? (unsigned)hx * 16u + 8u : kOob, vh_n = halo_ok ? (unsigned)hx * 8u : kOob;
 
-    PlaneRsrc rs, rs_none;
-    __amdgpu_buffer_rsrc_t rs_out, rs_fb;
-    {
-        const unsigned npx = (unsigned)g.rows * (unsigned)g.W;
-        rs.colour = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, (int)(npx * CB), 0x00020000);
-        rs.motion = __builtin_amdgcn_make_buffer_rsrc((void*)a.motion, 0, (int)(npx * 16u), 0x00020000);
-        rs.normal = __builtin_amdgcn_make_buffer_rsrc((void*)a.normal, 0, (int)(npx * 8u), 0x00020000);
-        rs_none.colour = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, 0, 0x00020000);   // zero records: every load returns 0
-        rs_none.motion = __builtin_amdgcn_make_buffer_rsrc((void*)a.motion, 0, 0, 0x00020000);
-        rs_none.normal = __builtin_amdgcn_make_buffer_rsrc((void*)a.normal, 0, 0, 0x00020000);
-        rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(npx * CB), 0x00020000);
-        rs_fb = __builtin_amdgcn_make_buffer_rsrc(a.feedback ? a.feedback : a.out, 0, a.feedback ? (int)(npx * CB) : 0, 0x00020000);
-    }
+    // Buffer resources are built where they are used (base pointer + a num_records word chosen by a scalar select) instead
+    // of being kept in 32 SGPRs for the whole kernel; a row outside the frame gets num_records = 0: every load returns 0.
+    const unsigned npx = (unsigned)g.rows * (unsigned)g.W;
+    auto plane_rsrc = [&](bool rok) __attribute__((always_inline)) {
+        PlaneRsrc r;
+        r.colour = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, rok ? (int)(npx * CB) : 0, 0x00020000);
+        r.motion = __builtin_amdgcn_make_buffer_rsrc((void*)a.motion, 0, rok ? (int)(npx * 16u) : 0, 0x00020000);
+        r.normal = __builtin_amdgcn_make_buffer_rsrc((void*)a.normal, 0, rok ? (int)(npx * 8u) : 0, 0x00020000);
+        return r;
+    };
 
     // A thread's share of one staged step: KR rows (jn + rg*KR + k): own pixel, and a halo pixel on lanes < NH
     typedef RawPx<ST, true> OwnPx;
@@ -606,8 +603,9 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
             const int y = ybase + S * (jn + rg * KR + k), yl = y - g.y0;                    // scalar
             const bool rok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows;
             const int srow = rok ? yl * g.W : 0;
-            if (rok) { raw_load<ST, true>(st.o[k], rs, vo_c, vo_m, vo_n, srow); if (halo_wave) raw_load<ST, false>(st.h[k], rs, vh_c, vh_m, vh_n, srow); }
-            else { raw_load<ST, true>(st.o[k], rs_none, vo_c, vo_m, vo_n, 0); if (halo_wave) raw_load<ST, false>(st.h[k], rs_none, vh_c, vh_m, vh_n, 0); }
+            const PlaneRsrc rs = plane_rsrc(rok);
+            raw_load<ST, true>(st.o[k], rs, vo_c, vo_m, vo_n, srow);
+            if (halo_wave) raw_load<ST, false>(st.h[k], rs, vh_c, vh_m, vh_n, srow);
         }
     };
     uint32_t ref01 = 0, refz = 0;
@@ -807,6 +805,8 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
             if (j + rg * KR + k < j1) {                                                            // scalar
                 const int srow = (ybase + S * (j + rg * KR + k) - g.y0) * g.W;
                 const bool sky = lzc[k].y == kSkyZ;
+                const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(npx * CB), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs_fb = __builtin_amdgcn_make_buffer_rsrc(a.feedback ? a.feedback : a.out, 0, a.feedback ? (int)(npx * CB) : 0, 0x00020000);
                 // columns outside the frame carry the out-of-range offset: the store is dropped by the range check
                 if constexpr (ST == 0) {
                     const u32x4 raw = {__float_as_uint(o[k].x), __float_as_uint(o[k].y), __float_as_uint(o[k].z), __float_as_uint(o[k].w)};
