@@ -886,7 +886,7 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     band = (band + kRS - 1) / kRS * kRS;
     nbands = (njmax + band - 1) / band;
     // m groups per XCD, 8 m groups in all (so that every XCD gets the same number of tiles)
-    int xm = S == 1 ? 16 : (S == 2 || S == 16) ? 2 : 1;    // A/B per step on one device (4K): tools/xgroup.sh
+    int xm = S <= 2 ? 16 : (S == 16 ? 2 : 1);              // A/B per step on one device (4K): tools/xgroup.sh
 #ifdef SVGF_DIAG
     xm = diag_env("SVGF_ATROUS_XM", xm);
     if (xm < 1) xm = 1;
