@@ -3,16 +3,24 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A "step" is one frame through the hot path (svgf_denoise_frame, or the strip runner for N > 1) with all
-inputs resident in HBM.  N = 1: 3840x2160 fp32 (BASELINE.json configs[2], the configuration the metric's
-roofline target is quoted on).  N > 1: one 7680x4320 fp32 frame cut into N row strips with halo exchange
-over RCCL (configs[3]); strong scaling.  One JSON line on stdout (rank 0).
+A "step" is one frame through the hot path (svgf_denoise_frame, or the strip driver for N > 1) with all inputs
+resident in HBM.  N = 1: 3840x2160 fp32 (BASELINE.json configs[2], the configuration the metric's roofline target is
+quoted on).  N > 1: one 7680x4320 fp32 frame cut into N row strips with halo exchange over RCCL (configs[3]); strong
+scaling; without WORLD_SIZE in the environment the N rank processes are started from here.  One JSON line on stdout.
+
+Inputs.  The current and the previous G-buffer are DISTINCT device planes, ping-ponged frame by frame as the reference
+binds two framebuffers (src/App.cu:471-474) — also with a static camera, where their contents are equal.  Two motions
+are timed: "static" (the headline, SURVEY.md 8d steady state) and "pan", a camera pan of mv = (-2.5, +1.5) pixels per
+frame (prev - cur, GBuffer.frag:67-69) over a pool of consecutive frames walked forth and back.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
+import math
 import os
+import subprocess
 import sys
 import time
 
@@ -27,10 +35,22 @@ ALG_BYTES = {
     "f32": dict(temporal=130, moments=33, atrous_iter=56, atrous_feedback=16, full5=459),
     "f16": dict(temporal=98, moments=17, atrous_iter=40, atrous_feedback=8, full5=323),
 }
+# Bytes the fused frame driver really moves per pixel in steady state, every plane it touches counted once (no cache
+# credit): the temporal launch reads radiance, both G-buffers (3 planes each), previous colour / moments / history and
+# writes history, moments and the filter buffer (the moments stage's copy, Filter.cuh:521, is folded into it and the
+# temporal colour itself is stored only where it is read again); an iteration reads colour, {depth, ddepth} texels and
+# normals and writes colour (+ the feedback colour in iteration 0).
+MOVED_BYTES = {
+    "f32": dict(temporal_moments=16 + 32 + 32 + 16 + 8 + 1 + 1 + 8 + 16, atrous_iter=56, atrous_feedback=16),
+    "f16": dict(temporal_moments=8 + 32 + 32 + 8 + 4 + 1 + 1 + 4 + 8, atrous_iter=40, atrous_feedback=8),
+}
 HBM_PEAK_GBPS = 8000.0        # MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 WORKLOADS = {"1080p": (1920, 1080), "4k": (3840, 2160), "8k": (7680, 4320)}
 PRIME_FRAMES = 40             # history must reach steady state (h >= 4) before anything is timed (§8d); 40 rather than 8 frames also
                               # bring the device to its sustained clocks: with 8, a 5-step timed region read 0.80 instead of 0.73 ms
+PAN_MV = (-2.5, 1.5)          # the pan that exercises the truncation of the reprojected coordinate
+PAN_POOL = 8                  # consecutive frames of the pan held in HBM (walked 0..7..0..)
+METRIC = "Mpixels/s (and ms/frame) for full SVGF temporal+5 a-trous pass at 1080p/4K"
 
 
 def parse():
@@ -43,9 +63,11 @@ def parse():
     ap.add_argument("--iters", type=int, default=5, help="à-trous iterations (BASELINE: 5)")
     ap.add_argument("--variant", default="auto")
     ap.add_argument("--halo-plan", default="auto")
+    ap.add_argument("--motion", choices=["static", "pan", "both"], default="both", help="N = 1: which camera motions are timed (value = static)")
+    ap.add_argument("--driver", choices=["native", "python"], default="native", help="N > 1: the C++ strip driver of the library, or svgf_amd/strips.py")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary (1080p) measurement")
-    ap.add_argument("--strips", action="store_true", help="run the strip runner even at N=1 (exercises the N>1 code path)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (pan, 1080p, fp16, cold frames)")
+    ap.add_argument("--strips", action="store_true", help="run the strip driver even at N=1 (exercises the N>1 code path)")
     return ap.parse_args()
 
 
@@ -54,8 +76,15 @@ def alg_bytes_full(storage, iters):
     return b["temporal"] + b["moments"] + iters * b["atrous_iter"] + (b["atrous_feedback"] if iters > 0 else 0)
 
 
+def moved_bytes_full(storage, iters):
+    b = MOVED_BYTES[storage]
+    return b["temporal_moments"] + iters * b["atrous_iter"] + (b["atrous_feedback"] if iters > 0 else 0)
+
+
+# ------------------------------------------------------------------ inputs ---------------------
 def make_inputs(W, H, storage, device, nframes=4, row_begin=0, row_end=None):
-    """Static camera: one G-buffer, a pool of `nframes` independent 1-spp radiance frames, all in HBM."""
+    """Static camera, rows [row_begin,row_end): ONE G-buffer and a pool of `nframes` independent 1-spp radiance frames in
+    HBM (the diagnostic tools and the strip runs use this; the strip runs upload the G-buffer twice)."""
     import torch
     from svgf_amd import filter as F
     from svgf_amd import synth
@@ -67,48 +96,145 @@ def make_inputs(W, H, storage, device, nframes=4, row_begin=0, row_end=None):
     return gb, rads
 
 
-def run_single(W, H, storage, iters, variant, steps, warmup, device, barrier=None, cold_frames=0):
-    """-> dict(ms_per_step, stage_ms[list], frames).  Timed region: barrier+sync, K frames, sync+barrier."""
+class Scene:
+    """Device-resident synthetic inputs of one frame size for both motions.  Two canvases a little larger than the frame are
+    generated once on the host (svgf_amd/synth.py; even and odd frames of the pan sit half a pixel apart) and every frame
+    of the pan is a window of one of them, copied into tight planes of its own on the device."""
+
+    def __init__(self, W, H, device, pool=PAN_POOL, mv=PAN_MV, nmasks=4):
+        import torch
+        from svgf_amd import synth
+        assert pool >= 2 and pool % 2 == 0 and all(float(2 * m).is_integer() for m in mv)
+        self.W, self.H, self.device, self.pool, self.mv = W, H, device, pool, mv
+        k = pool // 2 - 1
+        sx, sy = int(round(2 * mv[0])), int(round(2 * mv[1]))              # shift of the window per two frames
+        x0, x1 = min(0, sx * k), W + max(0, sx * k)
+        y0, y1 = min(0, sy * k), H + max(0, sy * k)
+        self.origin, self.shift = (x0, y0), (sx, sy)
+        self.canvas = []
+        for parity in (0, 1):
+            sc = synth.make_scene(W, H, parity, mv=mv, row_begin=y0, row_end=y1, col_begin=x0, col_end=x1)
+            self.canvas.append({n: torch.from_numpy(sc[n]).to(device) for n in ("motion", "normal", "uv", "base")})
+        ys, xs = np.arange(H, dtype=np.int64), np.arange(W, dtype=np.int64)
+        self.hit = [torch.from_numpy(synth.uniform01(synth.SEED, f + 1, ys, xs, 0) < np.float32(0.25)).to(device) for f in range(nmasks)]
+
+    def window(self, f):
+        """Planes of frame f of the pan (f = 0 is also the static frame): dict of tight device tensors."""
+        c = self.canvas[f & 1]
+        k = f // 2
+        xa, ya = k * self.shift[0] - self.origin[0], k * self.shift[1] - self.origin[1]
+        return {n: t[ya:ya + self.H, xa:xa + self.W].contiguous() for n, t in c.items()}
+
+    def radiance(self, base, mask, storage):
+        """1-spp style radiance {r,g,b,1}: a path either finds the light (p = 1/4, carrying 4x the radiance) or returns black."""
+        import torch
+        out = torch.ones((self.H, self.W, 4), dtype=torch.float32, device=self.device)
+        out[..., :3] = torch.where(self.hit[mask][..., None], base * 4.0, torch.zeros_like(base)).clamp_(0.0, 1.0)
+        return out if storage == "f32" else out.to(torch.float16)
+
+
+class FramePool:
+    """frame(n) -> (radiance, cur G-buffer, prev G-buffer) of the n-th frame of a sequence; everything lives in HBM."""
+
+    def __init__(self, scene: Scene, storage, motion):
+        from svgf_amd import filter as F
+        self.motion = motion
+        if motion == "static":
+            w = scene.window(0)
+            w["motion"][..., :2] = 0.0
+            # the same contents in two sets of planes: frame n reads set n & 1 as current and the other one as previous
+            self.gb = [F.GBuffer(w["motion"].clone(), w["normal"].clone(), w["uv"].clone()) for _ in range(2)]
+            self.rad = [scene.radiance(w["base"], m, storage) for m in range(len(scene.hit))]
+        else:
+            self.P = scene.pool
+            self.fwd, self.bwd, self.rad = [], [], []
+            for f in range(self.P):
+                w = scene.window(f)
+                back = w["motion"].clone()
+                back[..., :2] *= -1.0                     # walking the pool backwards, frame f's predecessor is frame f+1
+                self.fwd.append(F.GBuffer(w["motion"], w["normal"], w["uv"]))
+                self.bwd.append(F.GBuffer(back, w["normal"], w["uv"]))
+                self.rad.append(scene.radiance(w["base"], f % len(scene.hit), storage))
+            self.prev = None
+
+    def frame(self, n):
+        if self.motion == "static":
+            return self.rad[n % len(self.rad)], self.gb[n & 1], self.gb[(n & 1) ^ 1]
+        period = 2 * (self.P - 1)
+        m = n % period
+        idx, forward = (m, True) if m < self.P else (period - m, False)
+        if m == 0 and n > 0:
+            forward = False
+        cur = (self.fwd if forward else self.bwd)[idx]
+        prev = self.prev if n > 0 and self.prev is not None else cur
+        self.prev = cur
+        return self.rad[idx], cur, prev
+
+
+# ------------------------------------------------------------------ single GPU -----------------
+def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, device, cold_frames=0):
+    """-> dict(ms_per_step, stage_ms[list], frames).  Timed region: sync, K frames, sync."""
     import torch
     from svgf_amd import filter as F
     d = F.Denoiser(W, H, F.Params(storage=storage, steps=iters, variant=variant), device=device.index or 0)
-    gb, rads = make_inputs(W, H, storage, device)
-    for k in range(PRIME_FRAMES):
-        d.Render(rads[k % len(rads)], gb, gb)
-    for k in range(warmup):
-        d.Render(rads[k % len(rads)], gb, gb)
+    n = 0
+    for _ in range(PRIME_FRAMES + warmup):
+        d.Render(*pool.frame(n))
+        n += 1
     d.timing_enable(4)         # HIP events between the stages of every 4th timed frame, on the stream the kernels are launched on
     torch.cuda.synchronize(device)
-    if barrier:
-        barrier()
     t0 = time.perf_counter()
-    for k in range(steps):
-        d.Render(rads[k % len(rads)], gb, gb)
+    for _ in range(steps):
+        d.Render(*pool.frame(n))
+        n += 1
     torch.cuda.synchronize(device)
-    if barrier:
-        barrier()
     t1 = time.perf_counter()
     stage_ms, frames = d.timing_read()
     d.timing_enable(False)
-    out = d.Render(rads[0], gb, gb)
+    out = d.Render(*pool.frame(n))
     assert bool(torch.isfinite(out.float()).all()), "non-finite output"
+    hist = d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong())
+    young = float((hist < 4).float().mean().item())
     cold = []
     if cold_frames:                          # §8d: cold frames (history < 4: the 7x7 moments estimate runs everywhere) reported apart
         d.reset_history()
         torch.cuda.synchronize(device)
         d.timing_enable(True)
         for k in range(cold_frames):
-            d.Render(rads[k % len(rads)], gb, gb if k else None)
+            rad, cur, prev = pool.frame(k)
+            d.Render(rad, cur, prev if k else None)
             ms_k, _ = d.timing_read()        # synchronises
             cold.append(round(sum(ms_k), 4))
         d.timing_enable(False)
     d.close()
-    return dict(ms_per_step=(t1 - t0) * 1e3 / steps, stage_ms=[m / max(frames, 1) for m in stage_ms], frames=frames, cold_ms=cold)
+    return dict(ms_per_step=(t1 - t0) * 1e3 / steps, stage_ms=[m / max(frames, 1) for m in stage_ms], frames=frames, cold_ms=cold,
+                young_fraction=young)
+
+
+def kernel_source_sha():
+    h = hashlib.sha256()
+    for f in ("svgf_kernels.hip", "svgf_api.hip", "svgf_kernels.h"):
+        with open(os.path.join(ROOT, "svgf_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(W, H, storage, kernel):
+    """HBM bytes per launch from the rocprofv3 PMC passes of tools/prof.sh, as recorded in profiles/hbm_traffic.json — used only
+    if that file was produced from THESE kernel sources (it records their hash); otherwise null."""
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        rec = json.load(open(tfile))
+        if rec.get("kernel_source_sha16") != kernel_source_sha():
+            return None
+        return rec.get(f"{W}x{H}_{storage}", {}).get(kernel)
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def roofline_block(W, H, storage, iters, stage_ms, variant="auto"):
-    """Roofline of the dominant kernel (the LDS-streaming à-trous kernel, `iters` launches per frame)."""
-    b = ALG_BYTES[storage]
+    """Roofline of the dominant kernel (the LDS-streaming à-trous kernel, `iters` launches per frame) + per-stage table."""
+    b, mv = ALG_BYTES[storage], MOVED_BYTES[storage]
     P = W * H
     at_ms = stage_ms[2:2 + iters]
     if not at_ms or sum(at_ms) <= 0:
@@ -116,25 +242,34 @@ def roofline_block(W, H, storage, iters, stage_ms, variant="auto"):
     bytes_per_launch = (iters * b["atrous_iter"] + b["atrous_feedback"]) * P / iters
     avg_ms = sum(at_ms) / iters
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tfile):
-        try:
-            traffic = json.load(open(tfile)).get(f"{W}x{H}_{storage}", {}).get("atrous_bytes_per_launch") if variant != "direct" else None
-        except Exception:  # noqa: BLE001
-            traffic = None
-    roof = {"bound": "hbm", "kernel": "atrous_direct_kernel" if variant == "direct" else "atrous_lds_kernel", "launches_per_step": iters, "achieved": round(achieved, 1),
+    kname = "atrous_direct_kernel" if variant == "direct" else "atrous_lds_kernel"
+    roof = {"bound": "hbm", "kernel": kname, "launches_per_step": iters, "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5), "traffic": traffic}
-    names = ["temporal", "moments"] + [f"atrous_step{1 << i}" for i in range(iters)]
-    per_px = [b["temporal"], b["moments"]] + [b["atrous_iter"] + (b["atrous_feedback"] if i == 0 else 0) for i in range(iters)]
-    stages = {n: {"ms": round(ms, 5), "GBps": round(px * P / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
-              for n, ms, px in zip(names, stage_ms, per_px)}
-    # the frame driver folds the steady-state moments copy into the temporal launch: rate the two stages together
+            "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5),
+            "traffic": measured_traffic(W, H, storage, "atrous_bytes_per_launch") if variant != "direct" else None}
+
+    def rate(px_bytes, ms):
+        return round(px_bytes * P / (ms * 1e-3) / 1e9, 1) if ms > 0 else None
     tm = stage_ms[0] + stage_ms[1]
-    stages["moments"]["GBps"] = None
-    stages["temporal+moments"] = {"ms": round(tm, 5), "GBps": round((b["temporal"] + b["moments"]) * P / (tm * 1e-3) / 1e9, 1) if tm > 0 else None}
+    stages = {"temporal+moments": {"ms": round(tm, 5), "temporal_ms": round(stage_ms[0], 5), "moments_ms": round(stage_ms[1], 5),
+                                   "algorithmic_B_per_px": b["temporal"] + b["moments"], "moved_B_per_px": mv["temporal_moments"],
+                                   "algorithmic_equivalent_GBps": rate(b["temporal"] + b["moments"], tm), "moved_GBps": rate(mv["temporal_moments"], tm),
+                                   "measured_hbm_bytes": measured_traffic(W, H, storage, "temporal_bytes_per_launch")}}
+    for i in range(iters):
+        px = b["atrous_iter"] + (b["atrous_feedback"] if i == 0 else 0)
+        stages[f"atrous_step{1 << i}"] = {"ms": round(stage_ms[2 + i], 5), "algorithmic_B_per_px": px, "moved_B_per_px": px, "moved_GBps": rate(px, stage_ms[2 + i])}
     return roof, stages
+
+
+def pass_block(W, H, storage, iters, ms):
+    alg, mov = alg_bytes_full(storage, iters), moved_bytes_full(storage, iters)
+    g = lambda bpp: bpp * W * H / (ms * 1e-3) / 1e9   # noqa: E731
+    return {"algorithmic_bytes_per_px": alg, "algorithmic_equivalent_GBps": round(g(alg), 1), "frac_of_8TBps": round(g(alg) / HBM_PEAK_GBPS, 4),
+            "frac_of_6.29TBps_copy": round(g(alg) / 6290.0, 4),
+            "moved_bytes_per_px": mov, "moved_GBps": round(g(mov), 1), "moved_frac_of_8TBps": round(g(mov) / HBM_PEAK_GBPS, 4),
+            "note": "frac_of_8TBps rates the SURVEY 8(d) algorithmic bytes (the contract's figure, 459 B/px fp32) against the frame time; the fused "
+                    "driver moves fewer bytes (moved_bytes_per_px: no separate moments copy, temporal colour stored only where it is read again), "
+                    "so moved_frac_of_8TBps is the share of the HBM peak the frame really uses"}
 
 
 def cpu_baseline(storage, iters):
@@ -182,8 +317,40 @@ def emit(line):
     print(json.dumps(line), flush=True)
 
 
+# ------------------------------------------------------------------ launcher for N > 1 ---------
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (fresh interpreters, before anything in
+    this process has touched the GPU), hand rank 0's JSON line through, fail if any rank fails."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()          # does not initialise the GPU
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} device(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = [p.wait() for p in procs]
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if any(codes) or not lines:
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main():
     args = parse()
+    N = args.gpus
+    if N > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -192,7 +359,6 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    N = args.gpus
     if world > 1 or args.strips:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -206,42 +372,62 @@ def main():
     if N == 1 and not args.strips:
         wl = args.workload or "4k"
         W, H = WORKLOADS[wl]
-        r = run_single(W, H, storage, iters, args.variant, args.steps, args.warmup, device, cold_frames=0 if args.no_extra else 5)
+        scene = Scene(W, H, device)
+        motions = ["static", "pan"] if args.motion == "both" and not args.no_extra else [args.motion if args.motion != "both" else "static"]
+        res = {}
+        for m in motions:
+            res[m] = run_single(FramePool(scene, storage, m), W, H, storage, iters, args.variant, args.steps, args.warmup, device,
+                                cold_frames=5 if (m == "static" and not args.no_extra) else 0)
+        head = motions[0]
+        r = res[head]
         ms = r["ms_per_step"]
         value = W * H / (ms * 1e-3) / 1e6
         roof, stages = roofline_block(W, H, storage, iters, r["stage_ms"], args.variant)
-        full_gbps = alg_bytes_full(storage, iters) * W * H / (ms * 1e-3) / 1e9
         line = {
-            "metric": "Mpixels/s (and ms/frame) for full SVGF temporal+5 a-trous pass at 1080p/4K", "value": round(value, 1),
+            "metric": METRIC, "value": round(value, 1),
             "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if storage == "f32" else "f16",
             "data": "synthetic",
-            "config": {"workload": f"{W}x{H} {storage} storage, temporal + moments + {iters} a-trous iterations (steps 1..{1 << (iters - 1)}), "
-                                   f"steady state (history >= 4), static camera, 1-spp noise, seed 0x5356474600000001",
-                       "width": W, "height": H, "storage": storage, "atrous_iterations": iters, "variant": args.variant},
+            "config": {"workload": f"{W}x{H} {storage} storage, temporal + moments + {iters} a-trous iterations (steps 1..{1 << max(iters - 1, 0)}), "
+                                   f"steady state (history >= 4), {'static camera' if head == 'static' else 'camera pan ' + str(PAN_MV)}, current and previous "
+                                   f"G-buffer in distinct planes (ping-ponged), 1-spp noise, seed 0x5356474600000001",
+                       "width": W, "height": H, "storage": storage, "atrous_iterations": iters, "variant": args.variant, "motion": head},
             "roofline": roof,
-            "pass_roofline": {"algorithmic_bytes_per_px": alg_bytes_full(storage, iters), "achieved_GBps": round(full_gbps, 1),
-                              "frac_of_8TBps": round(full_gbps / HBM_PEAK_GBPS, 4), "frac_of_6.29TBps_copy": round(full_gbps / 6290.0, 4)},
+            "pass_roofline": pass_block(W, H, storage, iters, ms),
             "stages": stages,
-            "stages_note": "per-stage GB/s use the SURVEY 8(d) algorithmic bytes; svgf_denoise_frame fuses the steady-state moments copy into "
-                           "the temporal kernel (second store) and the moments slot only re-filters segments flagged as young, so the "
-                           "two are rated together (temporal+moments); a rate above the HBM peak means the fused driver moves fewer bytes than the "
-                           "per-stage accounting counts (no separate moments copy, temporal result stored only where it is read again); "
-                           "stage events are recorded on every 4th timed frame",
+            "stages_note": "stage times from HIP events recorded by the library on its launch stream, on every 4th timed frame; svgf_denoise_frame folds "
+                           "the steady-state moments copy into the temporal launch and the moments slot only re-filters the 64-pixel segments flagged "
+                           "as young, so the two stages are rated together: algorithmic_* uses the SURVEY 8(d) bytes, moved_* the bytes the fused "
+                           "launches really touch; measured_hbm_bytes / roofline.traffic come from rocprofv3 PMC passes of the same sources "
+                           "(profiles/hbm_traffic.json) or are null",
+            "young_fraction": round(r["young_fraction"], 5),
         }
+        if "pan" in res and head != "pan":
+            p = res["pan"]
+            _, pst = roofline_block(W, H, storage, iters, p["stage_ms"], args.variant)
+            line["pan"] = {"mv": list(PAN_MV), "pool_frames": PAN_POOL, "ms_per_step": round(p["ms_per_step"], 4),
+                           "Mpixels/s": round(W * H / (p["ms_per_step"] * 1e-3) / 1e6, 1),
+                           "frac_of_8TBps": pass_block(W, H, storage, iters, p["ms_per_step"])["frac_of_8TBps"],
+                           "young_fraction": round(p["young_fraction"], 5),
+                           "stage_ms": {k: v["ms"] for k, v in pst.items()}}
         if r["cold_ms"]:
             line["cold_frames_ms"] = {"after_reset": r["cold_ms"], "note": "frames 0.. after svgf_reset_history, sum of stage events; "
                                       "history < 4 on frames 0-2 (7x7 moments estimate everywhere)"}
         if not args.no_extra and wl != "1080p":
             W2, H2 = WORKLOADS["1080p"]
-            r2 = run_single(W2, H2, storage, iters, args.variant, max(args.steps, 20), args.warmup, device)
+            sc2 = Scene(W2, H2, device, pool=2)
+            r2 = run_single(FramePool(sc2, storage, "static"), W2, H2, storage, iters, args.variant, max(args.steps, 20), args.warmup, device)
             line["also"] = {"1920x1080": {"ms_per_step": round(r2["ms_per_step"], 4),
                                           "Mpixels/s": round(W2 * H2 / (r2["ms_per_step"] * 1e-3) / 1e6, 1)}}
+            del sc2
             if storage == "f32" and wl == "4k":      # BASELINE configs[4]: the reference-native fp16 storage on the same frame
-                r3 = run_single(W, H, "f16", iters, args.variant, max(args.steps, 20), args.warmup, device)
+                r3 = run_single(FramePool(scene, "f16", "static"), W, H, "f16", iters, args.variant, max(args.steps, 20), args.warmup, device)
+                roof3, _ = roofline_block(W, H, "f16", iters, r3["stage_ms"], args.variant)
                 line["also"]["3840x2160_f16"] = {"ms_per_step": round(r3["ms_per_step"], 4),
                                                  "Mpixels/s": round(W * H / (r3["ms_per_step"] * 1e-3) / 1e6, 1),
-                                                 "frac_of_8TBps": round(alg_bytes_full("f16", iters) * W * H / (r3["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+                                                 "frac_of_8TBps": pass_block(W, H, "f16", iters, r3["ms_per_step"])["frac_of_8TBps"],
+                                                 "atrous_avg_launch_ms": roof3["avg_launch_ms"] if roof3 else None,
+                                                 "atrous_roofline_frac": roof3["frac"] if roof3 else None}
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(storage, iters)
         if world > 1 or args.strips:
@@ -256,13 +442,13 @@ def main():
     wl = args.workload or "8k"
     W, H = WORKLOADS[wl]
     res = strips.bench_strips(W, H, storage, iters, args.variant, args.steps, args.warmup, device, plan=args.halo_plan,
-                              make_inputs=make_inputs, prime_frames=PRIME_FRAMES)
+                              make_inputs=make_inputs, prime_frames=PRIME_FRAMES, driver=args.driver)
     t = torch.tensor([res["ms_per_step"]], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ms = float(t.item())
     # roofline of the dominant kernel on rank 0's strip: its a-trous launches (halo rows included) between HIP events
     ab = ALG_BYTES[storage]
-    n_l, ms_l, by_l = res["stages"].atrous_timing(ab["atrous_iter"], ab["atrous_feedback"])
+    n_l, ms_l, by_l = res["atrous_timing"](ab["atrous_iter"], ab["atrous_feedback"])
     roof = None
     if n_l and ms_l > 0:
         ach = by_l / (ms_l * 1e-3) / 1e9
@@ -274,16 +460,18 @@ def main():
         value = W * H / (ms * 1e-3) / 1e6
         full_gbps = alg_bytes_full(storage, iters) * W * H / (ms * 1e-3) / 1e9
         line = {
-            "metric": "Mpixels/s (and ms/frame) for full SVGF temporal+5 a-trous pass at 1080p/4K", "value": round(value, 1),
+            "metric": METRIC, "value": round(value, 1),
             "unit": "Mpixels/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if storage == "f32" else "f16",
             "data": "synthetic",
             "config": {"workload": f"{W}x{H} {storage} storage in {N} row strips ({res['rows_per_rank']} rows per GPU), halo exchange over "
-                                   f"RCCL send/recv, plan {res['plan']}, temporal + moments + {iters} a-trous iterations, steady state",
-                       "width": W, "height": H, "storage": storage, "atrous_iterations": iters, "halo_plan": res["plan"]},
+                                   f"RCCL send/recv ({res['driver']} driver), plan {res['plan']}, temporal + moments + {iters} a-trous iterations, steady state, "
+                                   f"static camera (motion reach {res['motion_reach']} rows, from the inputs), current and previous G-buffer in distinct planes",
+                       "width": W, "height": H, "storage": storage, "atrous_iterations": iters, "halo_plan": res["plan"], "driver": res["driver"]},
             "roofline": roof,
             "pass_roofline": {"algorithmic_bytes_per_px": alg_bytes_full(storage, iters), "achieved_GBps": round(full_gbps, 1),
                               "frac_of_aggregate_8TBps": round(full_gbps / (HBM_PEAK_GBPS * N), 4)},
+            "host_enqueue_ms_per_frame": res.get("host_ms"),
         }
     dist.barrier()
     dist.destroy_process_group()

@@ -20,8 +20,18 @@
  *    reference's launches on the default stream (App.cu:471-505).  Errors are returned (0 = ok,
  *    negative = SVGF_ERR_*), never asserted (the reference asserts: App.cu:41-48).
  *  - A context is not thread-safe (like the reference's single render thread, App.cu:692-734): one host thread at a
- *    time per context; different contexts are independent and may share a device.  Resizing = a new context
- *    (ResizeRenderTextures frees and reallocates everything, App.cu:742-778).
+ *    time per context; different contexts are independent, may share a device or live on different devices of one
+ *    process (every entry point makes the context's device current and restores the caller's).  svgf_resize is
+ *    ResizeRenderTextures (App.cu:742-778): everything is freed and reallocated, the accumulation restarts.
+ *  - mesh_id_test.  Filter.cuh:245-247 fetches the RGBA16UI barycentric/instance texture through tex2D<float4>: the
+ *    half bits come back as denormal floats and int(...) of both sides is 0, so in the reference's BINARY the
+ *    instance-ID test never rejects.  svgf_default_params sets mesh_id_test = 1, the comparison the
+ *    source intends (decode the half, compare the IDs); a host that wants the reference's de-facto accept/reject mask sets
+ *    mesh_id_test = 0.  Both are covered by the bit-exact temporal tests.
+ *  - Sky.  A texel whose GetDepth() is the sentinel (depth 0, Filter.cuh:199-207 — a depth of literally 1e30f reads the
+ *    same) is "sky": the wavelet filter copies it and skips its feedback store.  The kernels rely on a sky TAP having
+ *    weight exactly 0, which holds while ddepth * step < ~1e22 (|1e30 - z| / phi_z overflows the exponent of exp to -inf
+ *    or beyond -150): any real depth derivative.
  *  - Strips: a context may hold only rows [y0, y0+rows) of a WxH frame (multi-GPU row strips);
  *    "inside the frame" tests always use the global frame, so strip results are bit-identical
  *    to the whole-frame result as long as the halo rows hold valid data.
@@ -36,15 +46,17 @@
 extern "C" {
 #endif
 
-#define SVGF_ABI_VERSION 1
+#define SVGF_ABI_VERSION 2
 
 enum svgf_status {
     SVGF_OK = 0,
     SVGF_ERR_INVALID = -1,    /* bad argument (null plane, bad size, bad row range, step < 1 ...)   */
     SVGF_ERR_HIP = -2,        /* a HIP runtime call failed; see svgf_last_error()                   */
     SVGF_ERR_NO_DEVICE = -3,  /* no usable gfx950 device                                            */
-    SVGF_ERR_HALO = -4,       /* requested rows need taps outside the rows this strip holds         */
-    SVGF_ERR_ALLOC = -5
+    SVGF_ERR_HALO = -4,       /* requested rows need taps outside the rows this strip holds, or (svgf_sync / svgf_strips_sync)
+                                 a strip's temporal stage reprojected into rows it does not hold                         */
+    SVGF_ERR_ALLOC = -5,
+    SVGF_ERR_COMM = -6        /* an RCCL call failed, or librccl could not be opened                */
 };
 
 enum svgf_storage { SVGF_F32 = 0, SVGF_F16 = 1 };
@@ -101,6 +113,18 @@ int  svgf_set_stream(svgf_ctx* ctx, void* hip_stream);
 /* Restrict the following stage calls to global rows [row_begin,row_end) (interior/boundary split of
  * a strip); (-1,-1) restores the owned rows. */
 int  svgf_set_rows(svgf_ctx* ctx, int row_begin, int row_end);
+/* application::ResizeRenderTextures (App.cu:742-778): new render size (svgf_resize: whole frame; svgf_resize_strip: a strip
+ * of the new frame).  Synchronises the stream, frees every state plane; the next svgf_denoise_frame allocates them again
+ * (exact size, zeroed: ResetRender, App.cu:777).  Tunables, stream, device, debug mode and timing settings stay. */
+int  svgf_resize(svgf_ctx* ctx, int width, int height);
+int  svgf_resize_strip(svgf_ctx* ctx, int width, int height, const svgf_strip* strip);
+int  svgf_get_size(const svgf_ctx* ctx, int* width, int* height, svgf_strip* strip);     /* any pointer may be NULL */
+/* Wait for the context's stream.  Returns SVGF_ERR_HALO if, since the last call, the temporal stage of a STRIP context
+ * reprojected a pixel to a row inside the frame that the strip does not hold (motion larger than its state halo): such a
+ * pixel was treated as a rejection, so the strip is no longer bit-identical to the whole frame.  svgf_halo_violations
+ * returns the count (and zeroes it if clear != 0) without turning it into an error. */
+int  svgf_sync(svgf_ctx* ctx);
+int  svgf_halo_violations(svgf_ctx* ctx, unsigned long long* count, int clear);
 
 /* Stage 1 — replaces application::TemporalFilter (App.cu:469-478) launching filter::TemporalFilter
  * (Filter.cuh:359-404, LoadPreviousData :225-258).  `radiance` (1-spp input, clamped on load) and
@@ -176,6 +200,24 @@ int svgf_modulate(svgf_ctx* ctx, const void* filtered, const void* albedo, void*
 int svgf_denoise_frame(svgf_ctx* ctx, const void* radiance, const svgf_gbuffer* cur,
                        const svgf_gbuffer* prev, const void** result);
 int svgf_reset_history(svgf_ctx* ctx);                                 /* zero all state planes (ResetRender) */
+/* The sequences application::Render runs in its debug views (SVGFDebugOutput, App.cu:545-649) on the same state:
+ *   SVGF_DEBUG_FINAL     TemporalFilter, FilterMoments, WaveletFilter (App.cu:552-556)                  — the default
+ *   SVGF_DEBUG_TEMPORAL  TemporalFilter only; *result = the temporally accumulated colour (App.cu:602-609)
+ *   SVGF_DEBUG_ATROUS    TemporalFilter, then WaveletFilter WITHOUT FilterMoments (App.cu:611-620; also the Depth view,
+ *                        :632-638): the filter's input is whatever FilterBuffer[0] holds — the previous frame's result
+ *                         — and iteration 0 still feeds RenderBuffer back. */
+enum svgf_debug_mode { SVGF_DEBUG_FINAL = 0, SVGF_DEBUG_TEMPORAL = 1, SVGF_DEBUG_ATROUS = 2 };
+int svgf_set_debug_mode(svgf_ctx* ctx, int mode);
+
+/* Texture / pitched adapters — what the reference gets from its CUDA <-> OpenGL mappings (CreateMapping, CudaUtil.h:68-99;
+ * render targets Framebuffer.cpp:7-49): the G-buffer planes arrive as array-backed textures or pitched surfaces and are
+ * copied (device to device, on the context's stream) into the tight linear planes the filter reads; the filtered plane
+ * goes back into the display texture's array (cudaMemcpyToArray, App.cu:561).  `dst` / `plane_data` hold the context's
+ * rows [y0, y0+rows); an array holds the whole frame.  Texel formats as in svgf_gbuffer. */
+enum svgf_gbuffer_plane { SVGF_GBUF_MOTION = 0, SVGF_GBUF_NORMAL = 1, SVGF_GBUF_UV = 2 };
+int svgf_import_gbuffer_pitched(svgf_ctx* ctx, int plane, const void* src, size_t src_pitch_bytes, void* dst);
+int svgf_import_gbuffer_array(svgf_ctx* ctx, int plane, const void* hip_array /* hipArray_const_t */, void* dst);
+int svgf_export_to_array(svgf_ctx* ctx, const void* plane_data, void* hip_array /* hipArray_t */);
 
 /* Debug taps / state access (the reference's SVGFDebugOutput modes read these, App.cu:567-649). */
 enum svgf_plane { SVGF_PLANE_COLOUR = 0, SVGF_PLANE_MOMENTS = 1, SVGF_PLANE_FILTER = 2, SVGF_PLANE_HISTORY = 3 };
@@ -188,6 +230,53 @@ size_t svgf_plane_bytes(const svgf_ctx* ctx, int plane);
 #define SVGF_MAX_STEPS 10                                              /* GUI range 0-10, GUI.cpp:988 */
 int svgf_timing_enable(svgf_ctx* ctx, int on);                                  /* 0 = off, n = time every n-th frame (events cost ~1 us each) */
 int svgf_timing_read(svgf_ctx* ctx, double* ms_sum, int* frames, int slots);   /* synchronises; resets sums */
+
+/* ---- Multi-GPU: row strips with RCCL halo exchange (the reference is single-GPU) ------------------------
+ * The frame is cut into `world` contiguous row strips, one per GPU, and application::Render's filter sequence
+ * (App.cu:552-556) runs on every strip; rows a strip needs from its neighbours travel as RCCL send/recv groups over xGMI,
+ * posted from a communication stream of the driver's own and tied to the filter stream by HIP events.  Results are
+ * bit-identical to the single-GPU frame.  A driver holds the strips of the ranks of THIS process: one per process (one
+ * process per GPU), several on several devices, or — for tests — several virtual ranks on one device sharing ONE
+ * loop-back communicator (loopback != 0: every peer is communicator rank 0).  See svgf_amd/csrc/svgf_strip.hip.
+ * librccl is opened at run time (the one already in the process, else ROCm's; SVGF_RCCL_LIBRARY overrides). */
+enum svgf_halo_plan { SVGF_PLAN_AUTO = 0, SVGF_PLAN_GHOST = 1, SVGF_PLAN_GROUPED = 2, SVGF_PLAN_PER_ITERATION = 3 };
+typedef struct svgf_strips svgf_strips;
+typedef struct svgf_strip_layout {
+    int plan;                             /* the plan in force (AUTO resolved: the fewest exchanges whose halo fits the strips) */
+    svgf_strip strip;                     /* rows the rank's planes hold / own                                               */
+    int ext_atrous[SVGF_MAX_STEPS];       /* rows beyond the owned ones iteration i is computed on                           */
+    int ngroups, group_first[SVGF_MAX_STEPS], halo_group[SVGF_MAX_STEPS];   /* iteration groups and their input halos          */
+    int ext_moments, ext_temporal;        /* the same for the moments and temporal stages                                    */
+    int halo_state;                       /* previous-frame state rows needed beyond the owned ones (ext_temporal + motion_reach) */
+    int halo_max;
+} svgf_strip_layout;
+/* Pure geometry: what rank `rank` of `world` holds and computes.  SVGF_ERR_HALO if the strips are shorter than the halo. */
+int svgf_strips_plan(int width, int height, int rank, int world, int steps, int plan, int moments_radius, int motion_reach,
+                     svgf_strip_layout* out);
+/* Bootstrap helpers around ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy (id128: 128 bytes, produced on one rank and
+ * handed to the others by whatever the host has — MPI, a socket, torch.distributed). */
+int svgf_rccl_unique_id(void* id128);
+int svgf_rccl_comm_init(void** comm, int world, int rank, const void* id128, int device);
+int svgf_rccl_comm_destroy(void* comm);
+/* ranks / devices / compute_streams (hipStream_t, NULL entries = the null stream) / comms (ncclComm_t; loopback: comms[0] only;
+ * may be NULL when world == 1) describe the nlocal ranks of this process.  motion_reach = the largest |mv.y| (rows) the
+ * temporal reprojection may need beyond what a strip computes itself; exceeding it is reported by svgf_strips_sync. */
+int svgf_strips_create(svgf_strips** out, int width, int height, int world, const svgf_params* params, int plan, int motion_reach,
+                       int nlocal, const int* ranks, const int* devices, void* const* compute_streams, void* const* comms, int loopback);
+void svgf_strips_destroy(svgf_strips* s);
+const char* svgf_strips_last_error(const svgf_strips* s);
+svgf_ctx* svgf_strips_context(svgf_strips* s, int local_index);            /* the strip's context (state planes, svgf_get_size ...) */
+int svgf_strips_layout(const svgf_strips* s, int local_index, svgf_strip_layout* out);
+/* One frame on every local strip.  radiance[k], cur[k], prev[k] are device planes of local rank k holding ITS rows
+ * [strip.y0, strip.y0 + strip.rows) (prev may be NULL, or prev[k].motion NULL, on the first frame); results[k] receives the
+ * plane whose OWNED rows hold the result.  Enqueues and returns. */
+int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gbuffer* cur, const svgf_gbuffer* prev, const void** results);
+/* Wait for the last frame's state exchange and the streams; SVGF_ERR_HALO if a reprojection left a strip (see svgf_sync). */
+int svgf_strips_sync(svgf_strips* s);
+/* HIP events around the a-trous launches of the first local rank on every n-th frame (0 = off); read: launches, their summed
+ * ms, the pixels they covered in all iterations and in iteration 0 (for the roofline's algorithmic bytes). */
+int svgf_strips_timing_enable(svgf_strips* s, int every);
+int svgf_strips_timing_read(svgf_strips* s, int* launches, double* ms, double* px_all, double* px_iter0);
 
 #ifdef __cplusplus
 }

@@ -8,8 +8,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsvgf_mi355x.so")
-SOURCES = ["svgf_kernels.hip", "svgf_api.hip"]
-HEADERS = ["svgf_kernels.h", os.path.join("..", "..", "include", "svgf.h")]
+SOURCES = ["svgf_kernels.hip", "svgf_api.hip", "svgf_strip.hip"]
+HEADERS = ["svgf_kernels.h", "svgf_ctx.h", os.path.join("..", "..", "include", "svgf.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
@@ -19,6 +19,14 @@ def hipcc() -> str:
         if cand and os.path.exists(cand):
             return cand
     raise RuntimeError("hipcc not found: libsvgf_mi355x.so cannot be built (there is no CPU fallback)")
+
+
+def have_hipcc() -> bool:
+    try:
+        hipcc()
+        return True
+    except RuntimeError:
+        return False
 
 
 def stale() -> bool:

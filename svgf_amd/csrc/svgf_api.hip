@@ -5,45 +5,14 @@
 // There is deliberately NO CPU path here: every entry point either launches the gfx950 kernels
 // or returns an error.
 
-#include "../../include/svgf.h"
-#include "svgf_kernels.h"
+#include "svgf_ctx.h"
 
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <new>
-#include <string>
-#include <vector>
 
-struct svgf_ctx {
-    int W = 0, H = 0;
-    svgf_strip strip{};
-    int rb = 0, re = 0;                 // active compute rows (global)
-    svgf_params p{};
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-    // context-owned state (frame driver): RenderBuffer[2], MomentsBuffer[2], FilterBuffer[2] (App.h:138-140)
-    // and the ping-ponged history plane (App.h:141 + SURVEY App. B #1)
-    void* colour[2] = {nullptr, nullptr};
-    void* moments[2] = {nullptr, nullptr};
-    void* filter[2] = {nullptr, nullptr};
-    uint8_t* hist[2] = {nullptr, nullptr};
-    uint8_t* young_flags = nullptr;   // scratch: per (row, 64-column segment) "holds a pixel with history < 4", temporal -> moments
-    int pingpong = 0;                   // PingPongInx, App.cu:374
-    int frames_since_reset = 0;
-    bool have_state = false;
-    // per-stage timing
-    int timing = 0;               // 0 = off, n = stage events on every n-th frame
-    int timing_phase = 0;
-    struct FrameEvents { std::vector<hipEvent_t> ev; int nstage = 0; };
-    std::vector<FrameEvents> pending;
-    std::vector<hipEvent_t> pool;
-    double ms_sum[2 + SVGF_MAX_STEPS] = {0};
-    int timed_frames = 0;
-};
-
-namespace {
+namespace svgf_host {
 
 int fail(svgf_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg;
@@ -52,11 +21,6 @@ int fail(svgf_ctx* c, int code, const std::string& msg) {
 int hip_fail(svgf_ctx* c, hipError_t e, const char* what) {
     return fail(c, SVGF_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
-#define SVGF_HIP(c, call)                                         \
-    do {                                                          \
-        hipError_t e_ = (call);                                   \
-        if (e_ != hipSuccess) return hip_fail((c), e_, #call);    \
-    } while (0)
 
 size_t colour_bytes(const svgf_ctx* c) { return (size_t)c->strip.rows * c->W * (c->p.storage == SVGF_F16 ? 8 : 16); }
 size_t moments_bytes(const svgf_ctx* c) { return (size_t)c->strip.rows * c->W * (c->p.storage == SVGF_F16 ? 4 : 8); }
@@ -68,6 +32,17 @@ int check_params(svgf_ctx* c, const svgf_params* p) {
     if (p->storage != SVGF_F32 && p->storage != SVGF_F16) return fail(c, SVGF_ERR_INVALID, "storage must be SVGF_F32 or SVGF_F16");
     if (p->moments_radius < 0 || p->moments_radius > 3) return fail(c, SVGF_ERR_INVALID, "moments_radius must be in [0,3]");
     if (p->variant < SVGF_VARIANT_AUTO || p->variant > SVGF_VARIANT_LDS) return fail(c, SVGF_ERR_INVALID, "unknown variant");
+    return SVGF_OK;
+}
+
+// Geometry checks shared by svgf_create_strip and svgf_resize.  The kernels address a plane with 32-bit byte offsets
+// (buffer resources: row offset in an SGPR, column offset in a VGPR), so the widest plane (16 B per pixel) of the strip
+// must stay below 2 GiB.
+int check_geometry(int width, int height, const svgf_strip* strip) {
+    if (width <= 0 || height <= 0 || !strip) return SVGF_ERR_INVALID;
+    if (strip->y0 < 0 || strip->rows <= 0 || strip->y0 + strip->rows > height) return SVGF_ERR_INVALID;
+    if (strip->own_begin < strip->y0 || strip->own_end > strip->y0 + strip->rows || strip->own_begin > strip->own_end) return SVGF_ERR_INVALID;
+    if ((unsigned long long)strip->rows * (unsigned long long)width * 16ull >= (1ull << 31)) return SVGF_ERR_INVALID;
     return SVGF_OK;
 }
 
@@ -95,14 +70,22 @@ hipEvent_t take_event(svgf_ctx* c) {
 
 int alloc_flags(svgf_ctx* c) {
     if (c->young_flags) return SVGF_OK;
-    SVGF_HIP(c, hipSetDevice(c->device));
     SVGF_HIP(c, hipMalloc((void**)&c->young_flags, (size_t)c->strip.rows * ((c->W + 63) / 64)));
+    return SVGF_OK;
+}
+
+bool is_strip(const svgf_ctx* c) { return c->strip.y0 != 0 || c->strip.rows != c->H; }
+
+// the violation counter of a strip context (a whole-frame context cannot lose a reprojection: it holds every row)
+int alloc_halo_counter(svgf_ctx* c) {
+    if (c->halo_violations || !is_strip(c)) return SVGF_OK;
+    SVGF_HIP(c, hipMalloc((void**)&c->halo_violations, sizeof(unsigned)));
+    SVGF_HIP(c, hipMemsetAsync(c->halo_violations, 0, sizeof(unsigned), c->stream));
     return SVGF_OK;
 }
 
 int alloc_state(svgf_ctx* c) {
     if (c->have_state) return SVGF_OK;
-    SVGF_HIP(c, hipSetDevice(c->device));
     for (int i = 0; i < 2; i++) {
         SVGF_HIP(c, hipMalloc(&c->colour[i], colour_bytes(c)));
         SVGF_HIP(c, hipMalloc(&c->moments[i], moments_bytes(c)));
@@ -110,10 +93,115 @@ int alloc_state(svgf_ctx* c) {
         SVGF_HIP(c, hipMalloc((void**)&c->hist[i], hist_bytes(c)));
     }
     c->have_state = true;
-    return svgf_reset_history(c);
+    return reset_history(c);
 }
 
-}  // namespace
+void free_state(svgf_ctx* c) {
+    for (int i = 0; i < 2; i++) {
+        if (c->colour[i]) (void)hipFree(c->colour[i]);
+        if (c->moments[i]) (void)hipFree(c->moments[i]);
+        if (c->filter[i]) (void)hipFree(c->filter[i]);
+        if (c->hist[i]) (void)hipFree(c->hist[i]);
+        c->colour[i] = c->moments[i] = c->filter[i] = nullptr;
+        c->hist[i] = nullptr;
+    }
+    if (c->young_flags) (void)hipFree(c->young_flags);
+    c->young_flags = nullptr;
+    c->have_state = false;
+}
+
+int reset_history(svgf_ctx* c) {
+    if (!c->have_state) return SVGF_OK;
+    for (int i = 0; i < 2; i++) {
+        SVGF_HIP(c, hipMemsetAsync(c->colour[i], 0, colour_bytes(c), c->stream));
+        SVGF_HIP(c, hipMemsetAsync(c->moments[i], 0, moments_bytes(c), c->stream));
+        SVGF_HIP(c, hipMemsetAsync(c->filter[i], 0, colour_bytes(c), c->stream));
+        SVGF_HIP(c, hipMemsetAsync(c->hist[i], 0, hist_bytes(c), c->stream));
+    }
+    c->pingpong = 0;
+    c->frames_since_reset = 0;
+    c->result_index = 0;
+    return SVGF_OK;
+}
+
+// The violations counted so far (the stream is synchronised first); clear != 0 zeroes the counter.
+int read_halo_violations(svgf_ctx* c, unsigned long long* count, int clear) {
+    *count = 0;
+    if (!c->halo_violations) return SVGF_OK;
+    unsigned v = 0;
+    SVGF_HIP(c, hipMemcpyAsync(&v, c->halo_violations, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    SVGF_HIP(c, hipStreamSynchronize(c->stream));
+    if (clear && v) SVGF_HIP(c, hipMemsetAsync(c->halo_violations, 0, sizeof(unsigned), c->stream));
+    *count = v;
+    return SVGF_OK;
+}
+
+int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, const svgf_gbuffer* cur,
+                  const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur, void* moments_cur,
+                  const void* moments_prev, void* passthrough_out, int sparse_colour) {
+    if (!prev_colour || !radiance || !colour_out || !hist_prev || !hist_cur || !moments_cur || !moments_prev)
+        return fail(c, SVGF_ERR_INVALID, "svgf_temporal: null plane");
+    int rc = check_gbuf(c, cur, true, "svgf_temporal(cur)");
+    if (rc == SVGF_OK) rc = check_gbuf(c, prev, true, "svgf_temporal(prev)");
+    if (rc == SVGF_OK) rc = alloc_halo_counter(c);
+    if (rc != SVGF_OK) return rc;
+    if (prev_colour == colour_out || hist_prev == hist_cur || moments_prev == moments_cur)
+        return fail(c, SVGF_ERR_INVALID, "svgf_temporal: previous and current state planes must differ (App. B #1)");
+    svgf::TemporalArgs a{prev_colour, radiance, colour_out,
+                         (const float4*)cur->motion, (const uint2*)cur->normal, (const uint2*)cur->uv,
+                         (const float4*)prev->motion, (const uint2*)prev->normal, (const uint2*)prev->uv,
+                         hist_prev, hist_cur, moments_cur, moments_prev,
+                         c->p.depth_threshold, c->p.normal_threshold, c->p.history_base, c->p.mesh_id_test, passthrough_out,
+                         passthrough_out ? c->young_flags : nullptr, sparse_colour, c->p.phi_normal > 0.0f, c->halo_violations};
+    SVGF_HIP(c, svgf::launch_temporal(geo_of(c), c->p.storage, a, c->stream));
+    return SVGF_OK;
+}
+
+int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist, int cold_only,
+                 int dense, int sparse_colour) {
+    if (!colour || !out || !moments || !hist) return fail(c, SVGF_ERR_INVALID, "svgf_moments: null plane");
+    if (colour == out) return fail(c, SVGF_ERR_INVALID, "svgf_moments: in-place filtering is a race");
+    int rc = check_gbuf(c, g, false, "svgf_moments");
+    if (rc == SVGF_OK) rc = check_halo(c, c->p.moments_radius, "svgf_moments");
+    if (rc != SVGF_OK) return rc;
+    svgf::MomentsArgs a{colour, out, moments, (const float4*)g->motion, (const uint2*)g->normal, hist,
+                        c->p.phi_colour, c->p.phi_normal, c->p.moments_radius, cold_only, dense, sparse_colour, cold_only ? c->young_flags : nullptr};
+    SVGF_HIP(c, svgf::launch_moments(geo_of(c), c->p.storage, a, c->p.variant == SVGF_VARIANT_DIRECT, c->stream));
+    return SVGF_OK;
+}
+
+int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration) {
+    if (!in || !out) return fail(c, SVGF_ERR_INVALID, "svgf_atrous: null plane");
+    if (in == out || in == feedback) return fail(c, SVGF_ERR_INVALID, "svgf_atrous: in-place filtering is a race");
+    if (step < 1 || step > (1 << SVGF_MAX_STEPS)) return fail(c, SVGF_ERR_INVALID, "svgf_atrous: step out of range");
+    int rc = check_gbuf(c, g, false, "svgf_atrous");
+    if (rc == SVGF_OK) rc = check_halo(c, 2 * step, "svgf_atrous");
+    if (rc != SVGF_OK) return rc;
+    svgf::AtrousArgs a{in, out, iteration == 0 ? feedback : nullptr, (const float4*)g->motion, (const uint2*)g->normal,
+                       step, c->p.phi_colour, c->p.phi_normal};
+    SVGF_HIP(c, svgf::launch_atrous(geo_of(c), c->p.storage, c->p.variant, a, c->stream));
+    return SVGF_OK;
+}
+
+int temporal_moments_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, void* filter_out,
+                          const svgf_gbuffer* cur, const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur,
+                          void* moments_cur, const void* moments_prev, int mrb, int mre, int feedback_follows) {
+    if (!filter_out || filter_out == colour_out) return fail(c, SVGF_ERR_INVALID, "svgf_temporal_moments: filter_out must be a plane of its own");
+    const int rb = c->rb, re = c->re;
+    if (mrb == -1 && mre == -1) { mrb = rb; mre = re; }
+    if (mrb < rb || mre > re || mrb > mre) return fail(c, SVGF_ERR_INVALID, "svgf_temporal_moments: moments rows outside the temporal rows");
+    int rc = alloc_flags(c);
+    if (rc == SVGF_OK) rc = temporal_impl(c, prev_colour, radiance, colour_out, cur, prev, hist_prev, hist_cur, moments_cur, moments_prev, filter_out, feedback_follows != 0);
+    if (rc != SVGF_OK) return rc;
+    c->rb = mrb; c->re = mre;
+    rc = moments_impl(c, colour_out, filter_out, moments_cur, cur, hist_cur, 1, 0, feedback_follows != 0);
+    c->rb = rb; c->re = re;
+    return rc;
+}
+
+}  // namespace svgf_host
+
+using namespace svgf_host;
 
 extern "C" {
 
@@ -127,7 +215,7 @@ void svgf_default_params(svgf_params* p) {
     p->phi_normal = 128.0f;       // App.h:114
     p->moments_radius = 3;        // Filter.cuh:465
     p->storage = SVGF_F16;        // Filter.cuh:15-16
-    p->mesh_id_test = 1;
+    p->mesh_id_test = 1;          // the test Filter.cuh:245-247 intends; 0 = what the reference's binary does (see svgf.h)
     p->variant = SVGF_VARIANT_AUTO;
 }
 
@@ -139,6 +227,7 @@ const char* svgf_status_string(int s) {
         case SVGF_ERR_NO_DEVICE: return "no usable gfx950 device";
         case SVGF_ERR_HALO: return "strip halo too small";
         case SVGF_ERR_ALLOC: return "allocation failed";
+        case SVGF_ERR_COMM: return "RCCL error";
         default: return "unknown status";
     }
 }
@@ -150,16 +239,16 @@ int svgf_create_strip(svgf_ctx** out, int width, int height, const svgf_strip* s
                       int device, void* hip_stream) {
     if (!out) return SVGF_ERR_INVALID;
     *out = nullptr;
-    if (width <= 0 || height <= 0 || !strip || !params) return SVGF_ERR_INVALID;
-    if (strip->y0 < 0 || strip->rows <= 0 || strip->y0 + strip->rows > height) return SVGF_ERR_INVALID;
-    if (strip->own_begin < strip->y0 || strip->own_end > strip->y0 + strip->rows || strip->own_begin > strip->own_end) return SVGF_ERR_INVALID;
+    if (!params) return SVGF_ERR_INVALID;
+    int rc = check_geometry(width, height, strip);
+    if (rc != SVGF_OK) return rc;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return SVGF_ERR_NO_DEVICE;
     svgf_ctx* c = new (std::nothrow) svgf_ctx();
     if (!c) return SVGF_ERR_ALLOC;
     c->W = width; c->H = height; c->strip = *strip; c->rb = strip->own_begin; c->re = strip->own_end;
     c->device = device; c->stream = (hipStream_t)hip_stream;
-    int rc = check_params(c, params);
+    rc = check_params(c, params);
     if (rc != SVGF_OK) { delete c; return rc; }
     c->p = *params;
     c->p.history_base = std::min(std::max(c->p.history_base, 1), 255);
@@ -174,20 +263,35 @@ int svgf_create(svgf_ctx** out, int width, int height, const svgf_params* params
 
 void svgf_destroy(svgf_ctx* c) {
     if (!c) return;
-    if (c->have_state || !c->pool.empty() || !c->pending.empty()) {
-        (void)hipSetDevice(c->device);
-        (void)hipStreamSynchronize(c->stream);
-    }
-    for (int i = 0; i < 2; i++) {
-        if (c->colour[i]) (void)hipFree(c->colour[i]);
-        if (c->moments[i]) (void)hipFree(c->moments[i]);
-        if (c->filter[i]) (void)hipFree(c->filter[i]);
-        if (c->hist[i]) (void)hipFree(c->hist[i]);
-    }
-    if (c->young_flags) (void)hipFree(c->young_flags);
+    DeviceGuard dg(c->device);
+    if (c->have_state || !c->pool.empty() || !c->pending.empty() || c->halo_violations || c->strip_drv) (void)hipStreamSynchronize(c->stream);
+    strip_driver_destroy(c);
+    free_state(c);
+    if (c->halo_violations) (void)hipFree(c->halo_violations);
     for (auto& f : c->pending) for (auto e : f.ev) (void)hipEventDestroy(e);
     for (auto e : c->pool) (void)hipEventDestroy(e);
     delete c;
+}
+
+// application::ResizeRenderTextures (App.cu:742-778): the render size changed, every filter buffer is reallocated and the
+// accumulation restarts (ResetRender, App.cu:777).  State planes are freed here and come back — exact size, zeroed — with the
+// next svgf_denoise_frame; tunables, stream, device and timing settings stay.
+int svgf_resize_strip(svgf_ctx* c, int width, int height, const svgf_strip* strip) {
+    if (!c) return SVGF_ERR_INVALID;
+    if (check_geometry(width, height, strip) != SVGF_OK) return fail(c, SVGF_ERR_INVALID, "svgf_resize: bad frame size or strip");
+    if (c->strip_drv) return fail(c, SVGF_ERR_INVALID, "svgf_resize: a strip driver is attached to this context (svgf_strip_detach first)");
+    DeviceGuard dg(c->device);
+    SVGF_HIP(c, hipStreamSynchronize(c->stream));        // cudaDeviceSynchronize() in the reference (App.cu:758)
+    free_state(c);
+    if (c->halo_violations) { (void)hipFree(c->halo_violations); c->halo_violations = nullptr; }
+    c->W = width; c->H = height; c->strip = *strip; c->rb = strip->own_begin; c->re = strip->own_end;
+    c->pingpong = 0; c->frames_since_reset = 0; c->result_index = 0;
+    return SVGF_OK;
+}
+
+int svgf_resize(svgf_ctx* c, int width, int height) {
+    svgf_strip s{0, height, 0, height};
+    return svgf_resize_strip(c, width, height, &s);
 }
 
 int svgf_set_params(svgf_ctx* c, const svgf_params* p) {
@@ -214,88 +318,40 @@ int svgf_set_rows(svgf_ctx* c, int rb, int re) {
     return SVGF_OK;
 }
 
-static int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, const svgf_gbuffer* cur,
-                         const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur, void* moments_cur,
-                         const void* moments_prev, void* passthrough_out, int sparse_colour = 0);   // passthrough_out != null: also fills c->young_flags
-static int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist, int cold_only, int dense, int sparse_colour = 0);
+int svgf_set_debug_mode(svgf_ctx* c, int mode) {
+    if (!c) return SVGF_ERR_INVALID;
+    if (mode < SVGF_DEBUG_FINAL || mode > SVGF_DEBUG_ATROUS) return fail(c, SVGF_ERR_INVALID, "unknown debug mode");
+    c->debug_mode = mode;
+    return SVGF_OK;
+}
 
 int svgf_temporal(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, const svgf_gbuffer* cur,
                   const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur, void* moments_cur,
                   const void* moments_prev) {
-    return temporal_impl(c, prev_colour, radiance, colour_out, cur, prev, hist_prev, hist_cur, moments_cur, moments_prev, nullptr);
+    if (!c) return SVGF_ERR_INVALID;
+    DeviceGuard dg(c->device);
+    return temporal_impl(c, prev_colour, radiance, colour_out, cur, prev, hist_prev, hist_cur, moments_cur, moments_prev, nullptr, 0);
 }
 
 int svgf_moments(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist) {
+    if (!c) return SVGF_ERR_INVALID;
+    DeviceGuard dg(c->device);
     // stage call: history is unknown to the host, so the per-pixel kernel — unless the caller asks for the LDS variant
-    return moments_impl(c, colour, out, moments, g, hist, 0, c && c->p.variant == SVGF_VARIANT_LDS);
+    return moments_impl(c, colour, out, moments, g, hist, 0, c->p.variant == SVGF_VARIANT_LDS, 0);
 }
 
 int svgf_temporal_moments(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, void* filter_out,
                           const svgf_gbuffer* cur, const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur,
                           void* moments_cur, const void* moments_prev, int mrb, int mre, int feedback_follows) {
     if (!c) return SVGF_ERR_INVALID;
-    if (!filter_out || filter_out == colour_out) return fail(c, SVGF_ERR_INVALID, "svgf_temporal_moments: filter_out must be a plane of its own");
-    const int rb = c->rb, re = c->re;
-    if (mrb == -1 && mre == -1) { mrb = rb; mre = re; }
-    if (mrb < rb || mre > re || mrb > mre) return fail(c, SVGF_ERR_INVALID, "svgf_temporal_moments: moments rows outside the temporal rows");
-    int rc = alloc_flags(c);
-    if (rc == SVGF_OK) rc = temporal_impl(c, prev_colour, radiance, colour_out, cur, prev, hist_prev, hist_cur, moments_cur, moments_prev, filter_out, feedback_follows != 0);
-    if (rc != SVGF_OK) return rc;
-    c->rb = mrb; c->re = mre;
-    rc = moments_impl(c, colour_out, filter_out, moments_cur, cur, hist_cur, 1, 0, feedback_follows != 0);
-    c->rb = rb; c->re = re;
-    return rc;
+    DeviceGuard dg(c->device);
+    return temporal_moments_impl(c, prev_colour, radiance, colour_out, filter_out, cur, prev, hist_prev, hist_cur, moments_cur, moments_prev, mrb, mre, feedback_follows);
 }
-
-}  // extern "C"
-
-static int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, const svgf_gbuffer* cur,
-                         const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur, void* moments_cur,
-                         const void* moments_prev, void* passthrough_out, int sparse_colour) {
-    if (!c) return SVGF_ERR_INVALID;
-    if (!prev_colour || !radiance || !colour_out || !hist_prev || !hist_cur || !moments_cur || !moments_prev)
-        return fail(c, SVGF_ERR_INVALID, "svgf_temporal: null plane");
-    int rc = check_gbuf(c, cur, true, "svgf_temporal(cur)");
-    if (rc == SVGF_OK) rc = check_gbuf(c, prev, true, "svgf_temporal(prev)");
-    if (rc != SVGF_OK) return rc;
-    if (prev_colour == colour_out || hist_prev == hist_cur || moments_prev == moments_cur)
-        return fail(c, SVGF_ERR_INVALID, "svgf_temporal: previous and current state planes must differ (App. B #1)");
-    svgf::TemporalArgs a{prev_colour, radiance, colour_out,
-                         (const float4*)cur->motion, (const uint2*)cur->normal, (const uint2*)cur->uv,
-                         (const float4*)prev->motion, (const uint2*)prev->normal, (const uint2*)prev->uv,
-                         hist_prev, hist_cur, moments_cur, moments_prev,
-                         c->p.depth_threshold, c->p.normal_threshold, c->p.history_base, c->p.mesh_id_test, passthrough_out, passthrough_out ? c->young_flags : nullptr, sparse_colour, c->p.phi_normal > 0.0f};
-    SVGF_HIP(c, svgf::launch_temporal(geo_of(c), c->p.storage, a, c->stream));
-    return SVGF_OK;
-}
-
-static int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist, int cold_only, int dense, int sparse_colour) {
-    if (!c) return SVGF_ERR_INVALID;
-    if (!colour || !out || !moments || !hist) return fail(c, SVGF_ERR_INVALID, "svgf_moments: null plane");
-    if (colour == out) return fail(c, SVGF_ERR_INVALID, "svgf_moments: in-place filtering is a race");
-    int rc = check_gbuf(c, g, false, "svgf_moments");
-    if (rc == SVGF_OK) rc = check_halo(c, c->p.moments_radius, "svgf_moments");
-    if (rc != SVGF_OK) return rc;
-    svgf::MomentsArgs a{colour, out, moments, (const float4*)g->motion, (const uint2*)g->normal, hist,
-                        c->p.phi_colour, c->p.phi_normal, c->p.moments_radius, cold_only, dense, sparse_colour, cold_only ? c->young_flags : nullptr};
-    SVGF_HIP(c, svgf::launch_moments(geo_of(c), c->p.storage, a, c->p.variant == SVGF_VARIANT_DIRECT, c->stream));
-    return SVGF_OK;
-}
-
-extern "C" {
 
 int svgf_atrous(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration) {
     if (!c) return SVGF_ERR_INVALID;
-    if (!in || !out) return fail(c, SVGF_ERR_INVALID, "svgf_atrous: null plane");
-    if (in == out || in == feedback) return fail(c, SVGF_ERR_INVALID, "svgf_atrous: in-place filtering is a race");
-    if (step < 1 || step > (1 << SVGF_MAX_STEPS)) return fail(c, SVGF_ERR_INVALID, "svgf_atrous: step out of range");
-    int rc = check_gbuf(c, g, false, "svgf_atrous");
-    if (rc == SVGF_OK) rc = check_halo(c, 2 * step, "svgf_atrous");
-    if (rc != SVGF_OK) return rc;
-    svgf::AtrousArgs a{in, out, iteration == 0 ? feedback : nullptr, (const float4*)g->motion, (const uint2*)g->normal,
-                       step, c->p.phi_colour, c->p.phi_normal};
-    SVGF_HIP(c, svgf::launch_atrous(geo_of(c), c->p.storage, c->p.variant, a, c->stream));
-    return SVGF_OK;
+    DeviceGuard dg(c->device);
+    return atrous_impl(c, in, out, feedback, g, step, iteration);
 }
 
 int svgf_taa(svgf_ctx* c, const void* filtered, const void* history, void* out) {
@@ -304,6 +360,7 @@ int svgf_taa(svgf_ctx* c, const void* filtered, const void* history, void* out) 
     if (out == filtered || out == history) return fail(c, SVGF_ERR_INVALID, "svgf_taa: in-place filtering is a race");
     int rc = check_halo(c, 3, "svgf_taa");                                // samples sit 1-3 texels up-left of the pixel (fp32 rounding of uv*(N-1))
     if (rc != SVGF_OK) return rc;
+    DeviceGuard dg(c->device);
     SVGF_HIP(c, svgf::launch_taa(geo_of(c), c->p.storage, filtered, history, out, c->p.variant == SVGF_VARIANT_DIRECT, c->stream));
     return SVGF_OK;
 }
@@ -312,6 +369,7 @@ static int albedo_impl(svgf_ctx* c, int mode, const void* in, const void* albedo
     if (!c) return SVGF_ERR_INVALID;
     if (!in || !albedo || !out) return fail(c, SVGF_ERR_INVALID, std::string(what) + ": null plane");
     if (albedo == out) return fail(c, SVGF_ERR_INVALID, std::string(what) + ": out must not alias the albedo plane");
+    DeviceGuard dg(c->device);
     SVGF_HIP(c, svgf::launch_albedo(geo_of(c), c->p.storage, mode, in, albedo, out, c->stream));
     return SVGF_OK;
 }
@@ -328,22 +386,48 @@ int svgf_pack_gbuffer(svgf_ctx* c, const void* position, const void* normal, con
     a.position = (const float4*)position; a.normal = (const float4*)normal; a.bary = (const float4*)bary;
     std::memcpy(a.vp, cam->view_proj, sizeof(a.vp)); std::memcpy(a.pvp, cam->prev_view_proj, sizeof(a.pvp)); std::memcpy(a.cam, cam->position, sizeof(a.cam));
     a.motion = (float4*)motion_out; a.normal_out = (uint2*)normal_out; a.uv_out = (uint2*)uv_out;
+    DeviceGuard dg(c->device);
     SVGF_HIP(c, svgf::launch_pack_gbuffer(geo_of(c), a, c->stream));
+    return SVGF_OK;
+}
+
+// ---- texture / pitched adapters: what the reference gets from its CUDA <-> OpenGL mappings (CudaUtil.h:68-99) ---------------
+static size_t texel_bytes(int plane) { return plane == SVGF_GBUF_MOTION ? 16 : 8; }
+
+int svgf_import_gbuffer_pitched(svgf_ctx* c, int plane, const void* src, size_t src_pitch_bytes, void* dst) {
+    if (!c) return SVGF_ERR_INVALID;
+    if (plane < SVGF_GBUF_MOTION || plane > SVGF_GBUF_UV || !src || !dst) return fail(c, SVGF_ERR_INVALID, "svgf_import_gbuffer_pitched: bad argument");
+    const size_t row = (size_t)c->W * texel_bytes(plane);
+    if (src_pitch_bytes < row) return fail(c, SVGF_ERR_INVALID, "svgf_import_gbuffer_pitched: pitch smaller than a row");
+    DeviceGuard dg(c->device);
+    SVGF_HIP(c, hipMemcpy2DAsync(dst, row, src, src_pitch_bytes, row, (size_t)c->strip.rows, hipMemcpyDeviceToDevice, c->stream));
+    return SVGF_OK;
+}
+
+int svgf_import_gbuffer_array(svgf_ctx* c, int plane, const void* hip_array, void* dst) {
+    if (!c) return SVGF_ERR_INVALID;
+    if (plane < SVGF_GBUF_MOTION || plane > SVGF_GBUF_UV || !hip_array || !dst) return fail(c, SVGF_ERR_INVALID, "svgf_import_gbuffer_array: bad argument");
+    const size_t row = (size_t)c->W * texel_bytes(plane);
+    DeviceGuard dg(c->device);
+    // the array holds the WHOLE frame (a render target); the strip's rows start at array row y0
+    SVGF_HIP(c, hipMemcpy2DFromArrayAsync(dst, row, (hipArray_const_t)hip_array, 0, (size_t)c->strip.y0, row, (size_t)c->strip.rows, hipMemcpyDeviceToDevice, c->stream));
+    return SVGF_OK;
+}
+
+int svgf_export_to_array(svgf_ctx* c, const void* plane_data, void* hip_array) {
+    if (!c) return SVGF_ERR_INVALID;
+    if (!plane_data || !hip_array) return fail(c, SVGF_ERR_INVALID, "svgf_export_to_array: null argument");
+    const size_t row = (size_t)c->W * (c->p.storage == SVGF_F16 ? 8 : 16);
+    DeviceGuard dg(c->device);
+    // cudaMemcpyToArray(RenderTextureMapping->CudaTextureArray, 0, 0, FilterBuffer[1]->Data, ...) — App.cu:561
+    SVGF_HIP(c, hipMemcpy2DToArrayAsync((hipArray_t)hip_array, 0, (size_t)c->strip.y0, plane_data, row, row, (size_t)c->strip.rows, hipMemcpyDeviceToDevice, c->stream));
     return SVGF_OK;
 }
 
 int svgf_reset_history(svgf_ctx* c) {
     if (!c) return SVGF_ERR_INVALID;
-    if (!c->have_state) return SVGF_OK;
-    for (int i = 0; i < 2; i++) {
-        SVGF_HIP(c, hipMemsetAsync(c->colour[i], 0, colour_bytes(c), c->stream));
-        SVGF_HIP(c, hipMemsetAsync(c->moments[i], 0, moments_bytes(c), c->stream));
-        SVGF_HIP(c, hipMemsetAsync(c->filter[i], 0, colour_bytes(c), c->stream));
-        SVGF_HIP(c, hipMemsetAsync(c->hist[i], 0, hist_bytes(c), c->stream));
-    }
-    c->pingpong = 0;
-    c->frames_since_reset = 0;
-    return SVGF_OK;
+    DeviceGuard dg(c->device);
+    return reset_history(c);
 }
 
 int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cur, const svgf_gbuffer* prev, const void** result) {
@@ -351,6 +435,7 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     if (!radiance) return fail(c, SVGF_ERR_INVALID, "svgf_denoise_frame: null radiance");
     int rc = check_gbuf(c, cur, true, "svgf_denoise_frame(cur)");
     if (rc != SVGF_OK) return rc;
+    DeviceGuard dg(c->device);
     // First frame: state is zero, so reprojecting onto the current G-buffer gives h = 1, alpha = 1 —
     // the same result as the reference's rejection against its cleared previous framebuffer.
     if (!prev) prev = cur;
@@ -365,9 +450,43 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
         if (!timed) return;
         hipEvent_t e = take_event(c);
         if (e && hipEventRecord(e, c->stream) == hipSuccess) fe.ev.push_back(e);
+        else if (e) c->pool.push_back(e);
+    };
+    auto bail = [&](int code) {                     // an error path hands the events already taken back to the pool
+        for (auto e : fe.ev) c->pool.push_back(e);
+        fe.ev.clear();
+        return code;
     };
 
     stamp();
+    if (c->debug_mode != SVGF_DEBUG_FINAL) {
+        // SVGFDebugOutput::TemporalFilter (App.cu:602-609): the temporal stage alone, its result is the frame.
+        // SVGFDebugOutput::ATrousWaveletFilter / Depth (App.cu:611-620, 632-638): temporal, then the wavelet filter WITHOUT
+        // FilterMoments — FilterBuffer[0] still holds the previous frame's result (App. B #11), which is what gets filtered.
+        rc = temporal_impl(c, c->colour[1 - P], radiance, c->colour[P], cur, prev, c->hist[1 - P], c->hist[P], c->moments[P], c->moments[1 - P], nullptr, 0);
+        if (rc != SVGF_OK) return bail(rc);
+        stamp(); stamp();
+        const void* res = c->colour[P];
+        if (c->debug_mode == SVGF_DEBUG_ATROUS) {
+            int pp = c->result_index;
+            for (int i = 0; i < c->p.steps; i++) {
+                rc = atrous_impl(c, c->filter[pp], c->filter[1 - pp], c->colour[P], cur, 1 << i, i);
+                if (rc != SVGF_OK) return bail(rc);
+                stamp();
+                pp ^= 1;
+            }
+            c->result_index = pp;
+            res = c->filter[pp];
+        }
+        if (timed) {
+            fe.nstage = (int)fe.ev.size() - 1;
+            if (fe.nstage >= 2) c->pending.push_back(std::move(fe)); else bail(0);
+        }
+        if (result) *result = res;
+        c->pingpong ^= 1;
+        if (c->frames_since_reset < (1 << 30)) c->frames_since_reset++;
+        return SVGF_OK;
+    }
     // With at least one wavelet iteration the temporal result in colour[P] is dead where iteration 0's feedback will
     // overwrite it (:619-622): it is only stored for young pixels (the moments estimate reads them) and depth-0 texels.
     const int sparse = c->p.steps >= 1;
@@ -375,25 +494,26 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     // moments launch then only works on young pixels: same planes, 32 B/px less traffic in steady state.
     rc = temporal_impl(c, c->colour[1 - P], radiance, c->colour[P], cur, prev, c->hist[1 - P], c->hist[P],
                        c->moments[P], c->moments[1 - P], c->filter[0], sparse);  // App.cu:552
-    if (rc != SVGF_OK) return rc;
+    if (rc != SVGF_OK) return bail(rc);
     stamp();
     // the first three frames after a reset have history <= 3 everywhere: the LDS-streaming moments kernel
     rc = moments_impl(c, c->colour[P], c->filter[0], c->moments[P], cur, c->hist[P], 1, c->frames_since_reset < 3 && c->p.variant != SVGF_VARIANT_DIRECT, sparse);   // App.cu:554 (current moments: App. B #4)
-    if (rc != SVGF_OK) return rc;
+    if (rc != SVGF_OK) return bail(rc);
     stamp();
     int pp = 0;
     for (int i = 0; i < c->p.steps; i++) {                                      // App.cu:497-507
-        rc = svgf_atrous(c, c->filter[pp], c->filter[1 - pp], c->colour[P], cur, 1 << i, i);
-        if (rc != SVGF_OK) return rc;
+        rc = atrous_impl(c, c->filter[pp], c->filter[1 - pp], c->colour[P], cur, 1 << i, i);
+        if (rc != SVGF_OK) return bail(rc);
         stamp();
         pp ^= 1;
     }
     if (timed) {
         fe.nstage = 2 + c->p.steps;
         if ((int)fe.ev.size() == fe.nstage + 1) c->pending.push_back(std::move(fe));
-        else for (auto e : fe.ev) c->pool.push_back(e);
+        else bail(0);
     }
     if (result) *result = c->filter[pp];
+    c->result_index = pp;
     c->pingpong ^= 1;                                                           // App.cu:374
     if (c->frames_since_reset < (1 << 30)) c->frames_since_reset++;
     return SVGF_OK;
@@ -422,6 +542,34 @@ size_t svgf_plane_bytes(const svgf_ctx* c, int plane) {
     }
 }
 
+int svgf_get_size(const svgf_ctx* c, int* width, int* height, svgf_strip* strip) {
+    if (!c) return SVGF_ERR_INVALID;
+    if (width) *width = c->W;
+    if (height) *height = c->H;
+    if (strip) *strip = c->strip;
+    return SVGF_OK;
+}
+
+int svgf_halo_violations(svgf_ctx* c, unsigned long long* count, int clear) {
+    if (!c || !count) return SVGF_ERR_INVALID;
+    DeviceGuard dg(c->device);
+    return read_halo_violations(c, count, clear);
+}
+
+// Wait for everything enqueued on the context's stream and report what the kernels could only count: a strip whose
+// temporal stage reprojected into rows it does not hold (motion beyond the state halo) is no longer the whole frame's result.
+int svgf_sync(svgf_ctx* c) {
+    if (!c) return SVGF_ERR_INVALID;
+    DeviceGuard dg(c->device);
+    unsigned long long n = 0;
+    int rc = read_halo_violations(c, &n, 1);
+    if (rc != SVGF_OK) return rc;
+    if (!c->halo_violations) SVGF_HIP(c, hipStreamSynchronize(c->stream));
+    if (n) return fail(c, SVGF_ERR_HALO, "temporal stage: " + std::to_string(n) + " reprojection(s) landed inside the frame but outside the rows this strip holds "
+                                                                                "(motion larger than the state halo): the strip differs from the whole frame there");
+    return SVGF_OK;
+}
+
 int svgf_timing_enable(svgf_ctx* c, int on) {
     if (!c) return SVGF_ERR_INVALID;
     c->timing = on > 0 ? on : 0;
@@ -431,6 +579,7 @@ int svgf_timing_enable(svgf_ctx* c, int on) {
 
 int svgf_timing_read(svgf_ctx* c, double* ms_sum, int* frames, int slots) {
     if (!c || !ms_sum || slots <= 0) return SVGF_ERR_INVALID;
+    DeviceGuard dg(c->device);
     for (auto& f : c->pending) {
         SVGF_HIP(c, hipEventSynchronize(f.ev.back()));
         for (int i = 0; i < f.nstage; i++) {

@@ -1,0 +1,84 @@
+// Internal: the context behind the C ABI and the helpers shared by svgf_api.hip (stages, frame driver, lifecycle) and
+// svgf_strip.hip (the multi-GPU strip driver).
+#pragma once
+#include "../../include/svgf.h"
+#include "svgf_kernels.h"
+
+#include <string>
+#include <vector>
+
+struct svgf_strip_driver;
+
+struct svgf_ctx {
+    int W = 0, H = 0;
+    svgf_strip strip{};
+    int rb = 0, re = 0;                 // active compute rows (global)
+    svgf_params p{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // context-owned state (frame driver): RenderBuffer[2], MomentsBuffer[2], FilterBuffer[2] (App.h:138-140)
+    // and the ping-ponged history plane (App.h:141 + SURVEY App. B #1)
+    void* colour[2] = {nullptr, nullptr};
+    void* moments[2] = {nullptr, nullptr};
+    void* filter[2] = {nullptr, nullptr};
+    uint8_t* hist[2] = {nullptr, nullptr};
+    uint8_t* young_flags = nullptr;        // scratch: per (row, 64-column segment) "holds a pixel with history < 4", temporal -> moments
+    unsigned* halo_violations = nullptr;   // strips: device counter of reprojections that left the rows this strip holds (temporal_kernel)
+    int pingpong = 0;                      // PingPongInx, App.cu:374
+    int frames_since_reset = 0;
+    int result_index = 0;                  // which filter plane holds the last result (the reference copies it back into FilterBuffer[0], App.cu:510-513)
+    int debug_mode = SVGF_DEBUG_FINAL;     // SVGFDebugOutput, App.cu:545-649
+    bool have_state = false;
+    svgf_strip_driver* strip_drv = nullptr;
+    // per-stage timing
+    int timing = 0;               // 0 = off, n = stage events on every n-th frame
+    int timing_phase = 0;
+    struct FrameEvents { std::vector<hipEvent_t> ev; int nstage = 0; };
+    std::vector<FrameEvents> pending;
+    std::vector<hipEvent_t> pool;
+    double ms_sum[2 + SVGF_MAX_STEPS] = {0};
+    int timed_frames = 0;
+};
+
+namespace svgf_host {
+
+// Every entry point runs with the context's device current and restores the caller's on the way out: a host that drives
+// several devices from one thread (or whose current device is not the context's) finds its own device unchanged.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+int fail(svgf_ctx* c, int code, const std::string& msg);
+int hip_fail(svgf_ctx* c, hipError_t e, const char* what);
+#define SVGF_HIP(c, call)                                                    \
+    do {                                                                     \
+        hipError_t e_ = (call);                                              \
+        if (e_ != hipSuccess) return svgf_host::hip_fail((c), e_, #call);    \
+    } while (0)
+
+size_t colour_bytes(const svgf_ctx* c);
+size_t moments_bytes(const svgf_ctx* c);
+size_t hist_bytes(const svgf_ctx* c);
+bool is_strip(const svgf_ctx* c);
+int reset_history(svgf_ctx* c);
+int alloc_state(svgf_ctx* c);
+int alloc_flags(svgf_ctx* c);
+int read_halo_violations(svgf_ctx* c, unsigned long long* count, int clear);
+
+// the stages on caller- or driver-owned planes, rows [c->rb, c->re); the device is already current
+int temporal_moments_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, void* filter_out,
+                          const svgf_gbuffer* cur, const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur,
+                          void* moments_cur, const void* moments_prev, int mrb, int mre, int feedback_follows);
+int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration);
+
+void strip_driver_destroy(svgf_ctx* c);     // svgf_strip.hip
+
+}  // namespace svgf_host

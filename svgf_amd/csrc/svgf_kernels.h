@@ -19,6 +19,7 @@ struct TemporalArgs {
     int sparse_colour;       // with passthrough_out and >= 1 a-trous iteration: colour_out is only stored where the iteration-0 feedback
                              // will not overwrite it or the moments estimate reads it (young pixels, depth-0 texels)
     int sky_zero;            // with passthrough_out: PhiNormal > 0, so a young pixel with an all-zero normal filters to exactly 0 (written here)
+    unsigned* halo_violations;   // strips only: counts reprojections that land inside the frame but outside the rows the strip holds
 };
 struct MomentsArgs {
     const void* colour; void* out; const void* mom; const float4* motion; const uint2* normal; const uint8_t* hist;

@@ -12,9 +12,24 @@
 
 #include "svgf_kernels.h"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+
+// measurement switches of the a-trous kernel (tools/abn.sh builds twins of the library with other values)
+#ifndef SVGF_COLOUR_LD_AUX
+#define SVGF_COLOUR_LD_AUX 0        // cache policy bits of the a-trous colour loads / stores and G-buffer loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
+#ifndef SVGF_COLOUR_ST_AUX
+#define SVGF_COLOUR_ST_AUX 0
+#endif
+#ifndef SVGF_GB_LD_AUX
+#define SVGF_GB_LD_AUX 0
+#endif
+#ifndef SVGF_REVERSE_MASK
+#define SVGF_REVERSE_MASK 0         // bit i set: iteration with step 2^i walks the frame bottom-up (what the previous launch touched last is read first)
+#endif
 
 namespace svgf {
 namespace {
@@ -109,7 +124,15 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
     const int qx = x + (int)mc.x, qy = y + (int)mc.y;                 // :232, truncation toward zero
     bool ok = qx >= 0 && qx < g.W && qy >= 0 && qy < g.H;             // :235
     const int ql = qy - g.y0;
-    ok = ok && ql >= 0 && ql < g.rows;                                // strip guard: never read outside the local planes
+    // Strip guard: never read outside the local planes.  A reprojection that lands inside the FRAME but outside the rows
+    // this strip holds would silently turn into a rejection (history reset) and the strip would no longer equal the whole
+    // frame: it is counted, and the host reports SVGF_ERR_HALO at its next synchronising call (svgf_sync).
+    const bool in_strip = ql >= 0 && ql < g.rows;
+    if (a.halo_violations) {
+        const unsigned long long lost = __ballot(ok && !in_strip);
+        if (lost != 0ull && threadIdx.x == (unsigned)__builtin_ctzll(lost)) atomicAdd(a.halo_violations, (unsigned)__builtin_popcountll(lost));
+    }
+    ok = ok && in_strip;
     const size_t q = ok ? (size_t)ql * g.W + qx : idx;
 
     const float4 c = clamp01(Store<ST>::ld4(a.radiance, idx));        // :370 imageLoad
@@ -150,7 +173,8 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
     a.hist_cur[idx] = (uint8_t)h;                                     // :400
     // :401 imageStore.  sparse_colour (frame driver): iteration 0 of the wavelet filter overwrites this texel with its
     // feedback (:619-622) unless it has no depth; until then only the moments estimate of young pixels reads it
-    if (!a.sparse_colour || h < 4 || mc.z == 0.0f) Store<ST>::st4(a.colour_out, idx, clamp01(o));
+    // (the same predicate as the feedback store of atrous_*_kernel: GetDepth() == sentinel, i.e. depth 0 or literally 1e30f)
+    if (!a.sparse_colour || h < 4 || zc == kSkyZ) Store<ST>::st4(a.colour_out, idx, clamp01(o));
     Store<ST>::st2(a.mom_cur, idx, m);                                // :402
     // Frame-driver fusion: for history >= 4 FilterMoments only copies this pixel into the filter buffer
     // (:521; store(load(x)) == x in both storage types), so it is written from here and the moments launch
@@ -206,7 +230,7 @@ __device__ __forceinline__ void moments_pixel(const Geo& g, const MomentsArgs& a
             const size_t p = (size_t)(py - g.y0) * g.W + px;
             const float4 mq = a.motion[p];
             // sparse_colour: the temporal launch stored an old, non-sky texel only into `out` (same value)
-            const bool in_out = a.sparse_colour && mq.z != 0.0f && a.hist[p] >= 4;
+            const bool in_out = a.sparse_colour && mq.z != 0.0f && mq.z != kSkyZ && a.hist[p] >= 4;
             const float4 cp = Store<ST>::ld4(in_out ? (const void*)a.out : a.colour, p);   // :479 raw
             const float2 mp = Store<ST>::ld2(a.mom, p);               // :480
             float zp, dzp;
@@ -458,11 +482,19 @@ struct PlaneRsrc { __amdgpu_buffer_rsrc_t colour, motion, normal; };
 template <int ST, bool DZ>
 __device__ __forceinline__ void raw_load(RawPx<ST, DZ>& r, const PlaneRsrc& rs, unsigned voff_c, unsigned voff_m, unsigned voff_n, int srow) {
     constexpr int cb = ST == 0 ? 16 : 8;
-    if constexpr (ST == 0) r.c = __builtin_amdgcn_raw_buffer_load_b128(rs.colour, voff_c, srow * cb, 0);
-    else r.c = __builtin_amdgcn_raw_buffer_load_b64(rs.colour, voff_c, srow * cb, 0);
-    if constexpr (DZ) r.zd = __builtin_amdgcn_raw_buffer_load_b64(rs.motion, voff_m, srow * 16, 0);      // {depth, ddepth}
-    else r.zd = __builtin_amdgcn_raw_buffer_load_b32(rs.motion, voff_m, srow * 16, 0);                   // depth
-    r.n = __builtin_amdgcn_raw_buffer_load_b64(rs.normal, voff_n, srow * 8, 0);
+    if constexpr (ST == 0) r.c = __builtin_amdgcn_raw_buffer_load_b128(rs.colour, voff_c, srow * cb, SVGF_COLOUR_LD_AUX);
+    else r.c = __builtin_amdgcn_raw_buffer_load_b64(rs.colour, voff_c, srow * cb, SVGF_COLOUR_LD_AUX);
+#ifdef SVGF_DIAG_SKIP_MOTION
+    if constexpr (DZ) r.zd = (u32x2){0x40a00000u, 0x3c23d70au}; else r.zd = 0x40a00000u;               // bandwidth probe only
+#else
+    if constexpr (DZ) r.zd = __builtin_amdgcn_raw_buffer_load_b64(rs.motion, voff_m, srow * 16, SVGF_GB_LD_AUX);      // {depth, ddepth}
+    else r.zd = __builtin_amdgcn_raw_buffer_load_b32(rs.motion, voff_m, srow * 16, SVGF_GB_LD_AUX);                   // depth
+#endif
+#ifdef SVGF_DIAG_SKIP_NORMAL
+    r.n = (u32x2){0x3c00u, 0xbc00u};      // bandwidth probe only (results are wrong)
+#else
+    r.n = __builtin_amdgcn_raw_buffer_load_b64(rs.normal, voff_n, srow * 8, SVGF_GB_LD_AUX);
+#endif
 }
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -523,8 +555,23 @@ __device__ __forceinline__ float dot2_h2(uint32_t a, uint32_t b) {
 #ifndef SVGF_NO_FASTPATH
 #define SVGF_NO_FASTPATH 0          // 1: measure the kernel as it runs on geometry without planar regions (tools/ab.sh)
 #endif
+#ifndef SVGF_TAP_DEPTH
+#define SVGF_TAP_DEPTH 0            // > 0: taps as one rolling pipeline, LDS reads this many taps ahead (see tap_roll)
+#endif
+#ifndef SVGF_MIN_WAVES
+#define SVGF_MIN_WAVES 4            // waves per SIMD the register allocation is asked to leave room for (KR = 1)
+#endif
+#ifndef SVGF_KR2_WAVES
+#define SVGF_KR2_WAVES 2            // the same for KR = 2
+#endif
+#ifndef SVGF_FORCE_MODE
+#define SVGF_FORCE_MODE 0           // diagnostic builds: 1 = streaming only, 2 = arithmetic only (see MODE), for the kernels the library launches
+#endif
+#ifndef SVGF_WAVE_TILE
+#define SVGF_WAVE_TILE 0            // 1: single-wave workgroups (64 columns, KR = 2): no barrier, no sibling wave to wait for
+#endif
 template <int ST, int S, int TX, int KR, int MODE = 0>
-__global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup, int xrot, int band_fastest) {
+__global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? SVGF_MIN_WAVES : SVGF_KR2_WAVES) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup, int xrot, int band_fastest) {
     constexpr int WL = TX + 4 * S;                 // staged columns per ring row
     constexpr int CB = ST == 0 ? 16 : 8;           // bytes per colour texel
     constexpr int NH = 4 * S;                      // halo pixels per ring row: all staged by wave 0 of the row group (lanes 0..NH-1);
@@ -556,8 +603,9 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
     const int ntiles = xtiles * nbands * S;
     const int wid = blockIdx.x >> 3;               // index among the workgroups of this XCD
     const int round = wid / xgroup;                // the XCD's round-th group; rotated so that an XCD's groups come from different parts of the frame
-    const int v = (round * kXcds + ((blockIdx.x + xrot * round) & (kXcds - 1))) * xgroup + wid % xgroup;
+    int v = (round * kXcds + ((blockIdx.x + xrot * round) & (kXcds - 1))) * xgroup + wid % xgroup;
     if (v >= ntiles) return;                       // padding of the last groups
+    if ((SVGF_REVERSE_MASK / S) & 1) v = ntiles - 1 - v;
     // band_fastest: tile order (residue, x tile, band) instead — an XCD's consecutive workgroups walk down one column
     // of tiles (every band halo shared, and each XCD's share of the frame is a set of vertical strips)
     const int x0 = (band_fastest ? (v / nbands) % xtiles : v % xtiles) * TX;
@@ -649,6 +697,8 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
 
     const float phi_n = a.phi_normal;              // != 0 (launcher)
     int slot0 = 0;
+    // a workgroup of ONE wave needs no barrier: the LDS operations of a wave execute in order
+    auto wg_barrier = [&]() __attribute__((always_inline)) { if constexpr (TX * (kRS / KR) > 64) lds_barrier(); else asm volatile("" ::: "memory"); };
 #ifdef SVGF_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t) :: "memory");
@@ -765,8 +815,74 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
                 for (int k = 0; k < KR; k++) asm volatile("" : "+v"(sw[k]), "+v"(srg[k]), "+v"(sbv[k]) :: "memory");
             }
         };
+        // KR = 1, SVGF_TAP_DEPTH = D > 0: the 24 taps as ONE rolling software pipeline — the LDS reads of tap t+D are issued
+        // before tap t is consumed, across row boundaries (row-at-a-time, every ring row started with no read in flight:
+        // five LDS round trips per step exposed to the wave), and only D+1 taps' records are live instead of a row's five.
+        auto tap_roll = [&](auto uni_tag) __attribute__((always_inline)) {
+            constexpr bool UNI = decltype(uni_tag)::value;
+            constexpr int D = SVGF_TAP_DEPTH > 0 ? SVGF_TAP_DEPTH : 1;
+            constexpr int NT = 5 * NR;                       // records of the thread's NR ring rows, row-major
+            float ebase[KR][5];
+            if constexpr (UNI) {
+#pragma unroll
+                for (int k = 0; k < KR; k++) {
+                    const float lg = hw_log2(clamp01(fmaf(ncz[k], ncz[k], dot2_h2(nc01[k], nc01[k]))));
+                    ebase[k][0] = fmaf(lg, phi_n, klog2(0, 1)); ebase[k][1] = fmaf(lg, phi_n, klog2(1, 1)); ebase[k][2] = fmaf(lg, phi_n, klog2(0, 2));
+                    ebase[k][3] = fmaf(lg, phi_n, klog2(1, 2)); ebase[k][4] = fmaf(lg, phi_n, klog2(2, 2));
+                }
+            }
+            f32x4 qA[NT];
+            f32x2 qL[NT], qN[NT];
+            auto skip = [](int t) constexpr { return KR == 1 && t == 12; };                       // KR = 1: the centre itself is no tap
+            auto issue = [&](int t) __attribute__((always_inline)) {
+                if (skip(t)) return;
+                const int r = t / 5, c = t % 5;
+                qA[t] = recA[rowbase[r] + c * S];
+                qL[t] = ((const volatile lds_f32x2*)recL)[rowbase[r] + c * S];
+                if (!UNI) qN[t] = ((const volatile lds_f32x2*)recN)[rowbase[r] + c * S];
+            };
+#pragma unroll
+            for (int t = 0; t < D; t++) issue(t);
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                if (t + D < NT) issue(t + D);
+                asm volatile("" ::: "memory");
+                if (skip(t)) continue;
+                const int r = t / 5, xx = t % 5 - 2;
+                const f32x4 A = qA[t];
+                const f32x2 L = qL[t];
+#pragma unroll
+                for (int k = 0; k < KR; k++) {
+                    const int yy = r - 2 - k;
+                    if (yy < -2 || yy > 2 || (xx == 0 && yy == 0)) continue;                     // compile time
+                    const int axx = xx < 0 ? -xx : xx, ayy = yy < 0 ? -yy : yy;
+                    const f32x2 dlz = L - lzc[k];
+                    float e;
+                    if constexpr (UNI) {
+                        e = ebase[k][kernel_class(axx, ayy)];
+                    } else {
+                        const f32x2 N = qN[t];
+                        const float d = clamp01(fmaf(N.y, ncz[k], dot2_h2(__float_as_uint(N.x), nc01[k])));
+                        e = fmaf(hw_log2(d), phi_n, klog2(axx, ayy));
+                    }
+                    e = fmaf(-fabsf(dlz.x), il[k], e);
+                    e = fmaf(-fabsf(dlz.y), iz[k][len_class(xx, yy)], e);
+                    const float w = hw_exp2(e);
+                    const f32x2 ww = {w, w * w};
+                    sw[k] += w;
+                    srg[k] = __builtin_elementwise_fma((f32x2){w, w}, (f32x2){A.x, A.y}, srg[k]);
+                    sbv[k] = __builtin_elementwise_fma(ww, (f32x2){A.z, A.w}, sbv[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < KR; k++) asm volatile("" : "+v"(sw[k]), "+v"(srg[k]), "+v"(sbv[k]) :: "memory");
+            }
+        };
         if (MODE != 1 && wave_has_surface) {
-            if (uniform_normals && !SVGF_NO_FASTPATH) tap_rows(std::true_type{}); else tap_rows(std::false_type{});
+            if constexpr (SVGF_TAP_DEPTH > 0) {
+                if (uniform_normals && !SVGF_NO_FASTPATH) tap_roll(std::true_type{}); else tap_roll(std::false_type{});
+            } else {
+                if (uniform_normals && !SVGF_NO_FASTPATH) tap_rows(std::true_type{}); else tap_rows(std::false_type{});
+            }
         }
 #ifdef SVGF_STAMPS
         if (lane == 0) { atomicAdd(&g_stamps[10], 1ull); if (uniform_normals) atomicAdd(&g_stamps[11], 1ull); if (!wave_has_surface) atomicAdd(&g_stamps[12], 1ull); }
@@ -790,14 +906,14 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
             // Raw barriers: __syncthreads() would also wait for vmcnt(0), i.e. for the prefetch issued at the
             // start of this step — exactly the latency the two-step prefetch exists to hide.  Only this wave's
             // LDS reads/writes have to be done.
-            lds_barrier();                         // every wave is done reading the kRS oldest ring rows
+            wg_barrier();                          // every wave is done reading the kRS oldest ring rows
             SVGF_STAMP(3);                         // barrier 1
             commit(slot0, cs);
 #pragma unroll
             for (int k = 0; k < KR; k++) { dq0[k] = dq1[k]; dq1[k] = __uint_as_float(cs.o[k].zd.y); }   // rows j+4+..: the centres two steps on
             slot0 += kRS; if (slot0 >= kRing) slot0 -= kRing;
             SVGF_STAMP(4);                         // wait for the staged rows + convert + LDS writes
-            lds_barrier();
+            wg_barrier();
             SVGF_STAMP(5);                         // barrier 2
         }
 #pragma unroll
@@ -810,11 +926,11 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
                 // columns outside the frame carry the out-of-range offset: the store is dropped by the range check
                 if constexpr (ST == 0) {
                     const u32x4 raw = {__float_as_uint(o[k].x), __float_as_uint(o[k].y), __float_as_uint(o[k].z), __float_as_uint(o[k].w)};
-                    __builtin_amdgcn_raw_buffer_store_b128(raw, rs_out, vo_c, srow * CB, 0);                   // :618
+                    __builtin_amdgcn_raw_buffer_store_b128(raw, rs_out, vo_c, srow * CB, SVGF_COLOUR_ST_AUX);                   // :618
                     __builtin_amdgcn_raw_buffer_store_b128(raw, rs_fb, sky ? kOob : vo_c, srow * CB, 0);      // :619-622 (not for sky)
                 } else {
                     const u32x2 raw = {pack_h2(o[k].x, o[k].y), pack_h2(o[k].z, o[k].w)};
-                    __builtin_amdgcn_raw_buffer_store_b64(raw, rs_out, vo_c, srow * CB, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(raw, rs_out, vo_c, srow * CB, SVGF_COLOUR_ST_AUX);
                     __builtin_amdgcn_raw_buffer_store_b64(raw, rs_fb, sky ? kOob : vo_c, srow * CB, 0);
                 }
             }
@@ -840,15 +956,34 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? 4 : 2) void atrous_lds_k
 inline int diag_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 #endif
 
+// Per-device launch facts, cached without a lock: contexts on different devices (or host threads) may launch concurrently.
+constexpr int kMaxDevices = 64;
+inline int current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess && dev >= 0 ? dev : 0;
+}
 inline int num_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (cus <= 0) cus = 256;
+    static std::atomic<int> cus[kMaxDevices];
+    const int dev = current_device();
+    int n = dev < kMaxDevices ? cus[dev].load(std::memory_order_relaxed) : 0;
+    if (n <= 0) {
+        n = 256;
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (n <= 0) n = 256;
+        if (dev < kMaxDevices) cus[dev].store(n, std::memory_order_relaxed);
     }
-    return cus;
+    return n;
+}
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the (kernel, device) pair: set once per device.  Setting it twice is
+// harmless, so a relaxed flag per device is enough for concurrent first launches.
+template <typename K>
+hipError_t allow_dynamic_lds(K kernel, size_t bytes, std::atomic<unsigned long long>& done) {
+    const int dev = current_device();
+    const unsigned long long bit = dev < kMaxDevices ? 1ull << dev : 0ull;
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && bit) done.fetch_or(bit, std::memory_order_release);
+    return e;
 }
 
 template <int ST, int S, int TX, int KR, int MODE = 0>
@@ -856,15 +991,11 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     constexpr int WL = TX + 4 * S;
     constexpr size_t lds = (size_t)kRing * WL * kRecBytes + (kRing * 8 + 2) * sizeof(uint32_t);
     constexpr int threads = TX * (kRS / KR);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)atrous_lds_kernel<ST, S, TX, KR, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (hipError_t e = allow_dynamic_lds(atrous_lds_kernel<ST, S, TX, KR, MODE>, lds, attr_done); e != hipSuccess) return e;
     // One round of workgroups: bands are sized so that (x tiles) x (S residues) x (bands) fills the resident
     // slots of the chip once (LDS: 160 KiB per CU; registers: 4 / 2 waves per SIMD) instead of leaving a partial round.
-    constexpr int per_cu_lds = (int)((160 * 1024) / lds), per_cu_waves = (KR == 1 ? 16 : 8) / (threads / 64);
+    constexpr int per_cu_lds = (int)((160 * 1024) / lds), per_cu_waves = (KR == 1 ? 4 * SVGF_MIN_WAVES : 4 * SVGF_KR2_WAVES) / (threads / 64);
     constexpr int per_cu = per_cu_lds < per_cu_waves ? per_cu_lds : per_cu_waves;
     const int nrows = g.ye - g.yb;
     const int njmax = (nrows + S - 1) / S;
@@ -875,7 +1006,7 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
 #ifndef SVGF_OVERSUB
 #define SVGF_OVERSUB 4
 #endif
-    int slots = per_cu * num_cus() * (TX == 128 ? SVGF_OVERSUB : 1);
+    int slots = per_cu * num_cus() * (TX <= 128 ? SVGF_OVERSUB : 1);
 #ifdef SVGF_DIAG
     slots = diag_env("SVGF_ATROUS_SLOTS", slots);
 #endif
@@ -925,12 +1056,20 @@ hipError_t launch_atrous_lds_step_kr(const Geo& g, const AtrousArgs& a, hipStrea
 #ifdef SVGF_DIAG
     narrow = diag_env("SVGF_ATROUS_TX", narrow ? 128 : 256) == 128;
 #endif
+    if (SVGF_WAVE_TILE && MODE == 0) switch (a.step) {
+        case 1: return launch_atrous_lds<ST, 1, 64, 2, SVGF_FORCE_MODE>(g, a, s);
+        case 2: return launch_atrous_lds<ST, 2, 64, 2, SVGF_FORCE_MODE>(g, a, s);
+        case 4: return launch_atrous_lds<ST, 4, 64, 2, SVGF_FORCE_MODE>(g, a, s);
+        case 8: return launch_atrous_lds<ST, 8, 64, 2, SVGF_FORCE_MODE>(g, a, s);
+        case 16: return launch_atrous_lds<ST, 16, 64, 2, SVGF_FORCE_MODE>(g, a, s);
+        default: return hipErrorInvalidValue;
+    }
     if (KR == 1 && MODE == 0 && narrow) switch (a.step) {
-        case 1: return launch_atrous_lds<ST, 1, 128, 1, 0>(g, a, s);
-        case 2: return launch_atrous_lds<ST, 2, 128, 1, 0>(g, a, s);
-        case 4: return launch_atrous_lds<ST, 4, 128, 1, 0>(g, a, s);
-        case 8: return launch_atrous_lds<ST, 8, 128, 1, 0>(g, a, s);
-        case 16: return launch_atrous_lds<ST, 16, 128, 1, 0>(g, a, s);
+        case 1: return launch_atrous_lds<ST, 1, 128, 1, SVGF_FORCE_MODE>(g, a, s);
+        case 2: return launch_atrous_lds<ST, 2, 128, 1, SVGF_FORCE_MODE>(g, a, s);
+        case 4: return launch_atrous_lds<ST, 4, 128, 1, SVGF_FORCE_MODE>(g, a, s);
+        case 8: return launch_atrous_lds<ST, 8, 128, 1, SVGF_FORCE_MODE>(g, a, s);
+        case 16: return launch_atrous_lds<ST, 16, 128, 1, SVGF_FORCE_MODE>(g, a, s);
         default: return hipErrorInvalidValue;
     }
     switch (a.step) {
@@ -1139,12 +1278,8 @@ template <int ST>
 hipError_t launch_moments_lds(const Geo& g, const MomentsArgs& a, hipStream_t s) {
     constexpr int WL = kMTX + 2 * kMR;
     constexpr size_t lds = (size_t)kMRing * WL * 36;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)moments_lds_kernel<ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (hipError_t e = allow_dynamic_lds(moments_lds_kernel<ST>, lds, attr_done); e != hipSuccess) return e;
     const int nrows = g.ye - g.yb, xtiles = (g.W + kMTX - 1) / kMTX;
     int nbands = 2 * num_cus() / xtiles;                  // one resident round: 2 workgroups per CU (LDS)
     if (nbands < 1) nbands = 1;

@@ -1,0 +1,522 @@
+// svgf_strip.hip — multi-GPU row strips behind the C ABI (include/svgf.h, "Multi-GPU").
+//
+// The reference is single-GPU: application::Render runs TemporalFilter / FilterMoments / WaveletFilter on the whole frame
+// (src/App.cu:552-556).  Here the frame is cut into `world` contiguous row strips and the same sequence runs on every strip,
+// with the rows a strip needs from its neighbours travelling as RCCL point-to-point transfers
+// (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd over xGMI), posted from a communication stream of their own and tied to
+// the filter stream by HIP events only.  There is no collective in the data path and no reduction: every stage is a
+// bounded-reach gather, so the strips are bit-identical to the single-GPU frame.
+//
+// Halo plan.  À-trous iteration i reaches 2*2^i rows.  A plan groups the iterations; a group's input halo (the
+// sum of its iterations' reaches) is exchanged once, before the group, and inside the group iteration i runs on `ext_i` extra
+// rows each side (redundantly with the neighbour, bit-identically) so that the next iteration finds its halo locally.
+//   ghost          [[0,1,2,3,4]]            no transfer between iterations
+//   grouped        [[0,1,2],[3,4]]          one transfer between iterations
+//   per-iteration  [[0],[1],[2],[3],[4]]    the literal "halo exchange between à-trous iterations"
+// The temporal and moments stages run redundantly on the first group's halo, so a frame needs one more exchange: its STATE
+// (colour feedback, moments, history) on the rows the next frame's reprojection can reach.  That state is final once
+// iteration 0 has written the feedback colour: it is posted right there and waited for at the start of the NEXT frame — the
+// transfer runs beside iterations 1.. of the frame that produced it.
+//
+// A driver object holds the strips of the ranks that live in THIS process: one (a rank per process, the bench.py layout),
+// several on several devices (one host process driving the node, ncclCommInitAll-style), or several virtual ranks on one
+// device sharing one loop-back communicator (tests: every peer is communicator rank 0).  Frames run in lock step over the
+// local ranks so that each exchange is ONE RCCL group holding every local rank's transfers.
+//
+// RCCL is opened at run time (dlopen of the librccl the process already has — torch brings one — or of ROCm's): hosts that
+// never attach a strip driver do not need it.
+
+#include "svgf_ctx.h"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <new>
+
+using namespace svgf_host;
+
+namespace {
+
+// ------------------------------------------------------------------ RCCL, resolved at run time ----------
+typedef struct ncclComm* ncclComm_t;
+struct ncclUniqueId { char internal[128]; };
+enum { ncclSuccess = 0 };
+enum { ncclInt8 = 0 };
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* env = getenv("SVGF_RCCL_LIBRARY");
+        const char* loaded[] = {"librccl.so", "librccl.so.1"};
+        if (env) r.lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+        for (const char* n : loaded) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // the one already in the process (torch's)
+        const char* fresh[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* n : fresh) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) { r.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return; }
+#define SVGF_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name)); if (!r.field) r.why = std::string("librccl lacks ") + name
+        SVGF_SYM(GetUniqueId, "ncclGetUniqueId"); SVGF_SYM(CommInitRank, "ncclCommInitRank"); SVGF_SYM(CommDestroy, "ncclCommDestroy");
+        SVGF_SYM(GroupStart, "ncclGroupStart"); SVGF_SYM(GroupEnd, "ncclGroupEnd"); SVGF_SYM(Send, "ncclSend"); SVGF_SYM(Recv, "ncclRecv");
+        SVGF_SYM(GetErrorString, "ncclGetErrorString");
+#undef SVGF_SYM
+    });
+    return &r;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ the driver -----------------------------
+struct svgf_strip_plan_geo {
+    int own0 = 0, own1 = 0;
+    std::vector<std::vector<int>> groups;
+    std::vector<int> ext_atrous, halo_group;
+    int ext_moments = 0, ext_temporal = 0, halo_state = 0, halo_max = 0, y0 = 0, y1 = 0;
+};
+
+struct svgf_strips {
+    int W = 0, H = 0, world = 1, steps = 0, plan = SVGF_PLAN_AUTO, motion_reach = 0, moments_radius = 3, storage = SVGF_F32;
+    bool loopback = false;
+    struct Local {
+        int rank = 0, device = 0;
+        svgf_ctx* ctx = nullptr;
+        ncclComm_t comm = nullptr;
+        hipStream_t compute = nullptr, comm_stream = nullptr;
+        bool own_comm_stream = false;
+        hipEvent_t ready = nullptr, halo_done = nullptr, state_done = nullptr;
+        bool state_pending = false;
+        svgf_strip_plan_geo g;
+        // timing of the a-trous launches (bench.py's roofline block at N > 1)
+        std::vector<hipEvent_t> tev;           // pairs
+        std::vector<double> tbytes_px;         // pixels x (1 + feedback) weight per pair: (rows*W, iteration)
+        std::vector<int> titer;
+    };
+    std::vector<Local> local;
+    int timing_every = 0, frame_no = 0;
+    double t_ms = 0, t_px_iter = 0, t_px_fb = 0;
+    int t_launches = 0;
+    std::string err;
+};
+
+namespace {
+
+int sfail(svgf_strips* s, int code, const std::string& m) { if (s) s->err = m; return code; }
+#define SVGF_SHIP(s, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return sfail((s), SVGF_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+#define SVGF_NCCL(s, call) do { int e_ = (call); if (e_ != ncclSuccess) return sfail((s), SVGF_ERR_COMM, std::string(#call) + ": " + rccl()->GetErrorString(e_)); } while (0)
+
+std::vector<std::vector<int>> plan_groups(int plan, int n) {
+    std::vector<std::vector<int>> g;
+    if (n <= 0) return g;
+    if (plan == SVGF_PLAN_GHOST) { g.emplace_back(); for (int i = 0; i < n; i++) g[0].push_back(i); }
+    else if (plan == SVGF_PLAN_GROUPED) {
+        g.emplace_back(); for (int i = 0; i < std::min(3, n); i++) g[0].push_back(i);
+        if (n > 3) { g.emplace_back(); for (int i = 3; i < n; i++) g[1].push_back(i); }
+    } else for (int i = 0; i < n; i++) g.push_back({i});
+    return g;
+}
+
+// svgf_amd/strips.py:Geometry.make restated (the CPU tests compare the two)
+bool make_geo(int W, int H, int rank, int world, int steps, int plan, int moments_radius, int motion_reach, svgf_strip_plan_geo& g) {
+    (void)W;
+    g = svgf_strip_plan_geo();
+    g.groups = plan_groups(plan, steps);
+    g.own0 = (int)((long long)H * rank / world); g.own1 = (int)((long long)H * (rank + 1) / world);
+    g.ext_atrous.assign(steps, 0);
+    for (auto& grp : g.groups) {
+        int hsum = 0;
+        for (int i : grp) { int e = 0; for (int k : grp) if (k > i) e += 2 << k; g.ext_atrous[i] = e; hsum += 2 << i; }
+        g.halo_group.push_back(hsum);
+    }
+    g.ext_moments = g.groups.empty() ? 0 : g.halo_group[0];
+    g.ext_temporal = g.ext_moments + moments_radius;
+    g.halo_state = g.ext_temporal + motion_reach;
+    g.halo_max = g.halo_state;
+    for (int h : g.halo_group) g.halo_max = std::max(g.halo_max, h);
+    g.y0 = std::max(0, g.own0 - g.halo_max); g.y1 = std::min(H, g.own1 + g.halo_max);
+    int smallest = H;
+    for (int r = 0; r < world; r++) smallest = std::min(smallest, (int)((long long)H * (r + 1) / world) - (int)((long long)H * r / world));
+    return world <= 1 || smallest >= g.halo_max;
+}
+
+struct Rows { int a, b; };
+Rows grown(const svgf_strip_plan_geo& g, int H, int ext) { return Rows{std::max(0, g.own0 - ext), std::min(H, g.own1 + ext)}; }
+
+// One transfer of an exchange: rows [lo,hi) at distance from the boundary between rank `b` and `b + 1`, of one plane.
+struct Msg { int src, dst; size_t src_off, dst_off, bytes; int plane; };
+
+}  // namespace
+
+namespace svgf_host {
+void strip_driver_destroy(svgf_ctx* c) { c->strip_drv = nullptr; }      // the driver owns its contexts, never the other way round
+}
+
+namespace {
+
+size_t row_bytes(const svgf_strips* s, int plane) {
+    const size_t px = (size_t)s->W;
+    switch (plane) {
+        case SVGF_PLANE_COLOUR: case SVGF_PLANE_FILTER: return px * (s->storage == SVGF_F16 ? 8 : 16);
+        case SVGF_PLANE_MOMENTS: return px * (s->storage == SVGF_F16 ? 4 : 8);
+        default: return px;
+    }
+}
+
+// Post ONE exchange for all local ranks: rows at distance [lo, h) from each strip boundary of the given planes.
+// planes[k] = {plane kind, index}; done_is_state selects which event the filter stream will wait for.
+int post_exchange(svgf_strips* s, const std::vector<std::pair<int, int>>& planes, const std::vector<int>& held, int h, bool is_state) {
+    Rccl* R = rccl();
+    if (!R->Send) return sfail(s, SVGF_ERR_COMM, R->why.empty() ? "librccl not available" : R->why);
+    auto find_local = [&](int rank) -> svgf_strips::Local* { for (auto& l : s->local) if (l.rank == rank) return &l; return nullptr; };
+    // The transfers of a rank start when its filter stream has produced the rows it sends and is done with the halo rows it
+    // receives into.  Loop-back: every virtual rank shares one communication stream, which then waits for all of them.
+    for (auto& l : s->local) {
+        DeviceGuard dg(l.device);
+        SVGF_SHIP(s, hipEventRecord(l.ready, l.compute));
+    }
+    for (auto& l : s->local) {
+        DeviceGuard dg(l.device);
+        if (!s->loopback) SVGF_SHIP(s, hipStreamWaitEvent(l.comm_stream, l.ready, 0));
+        else if (&l == &s->local[0]) for (auto& m : s->local) SVGF_SHIP(s, hipStreamWaitEvent(l.comm_stream, m.ready, 0));
+    }
+    SVGF_NCCL(s, R->GroupStart());
+    for (size_t k = 0; k < planes.size(); k++) {
+        const int lo = held[k];
+        if (h <= lo) continue;
+        const size_t rb = row_bytes(s, planes[k].first);
+        for (int b = 0; b + 1 < s->world; b++) {
+            svgf_strips::Local* up = find_local(b);
+            svgf_strips::Local* dn = find_local(b + 1);
+            // message 1: rank b's bottom rows [own1-h, own1-lo) -> rank b+1's halo rows of the same global index
+            // message 2: rank b+1's top rows [own0+lo, own0+h) -> rank b's halo
+            for (int dir = 0; dir < 2; dir++) {
+                svgf_strips::Local* src = dir == 0 ? up : dn;
+                svgf_strips::Local* dst = dir == 0 ? dn : up;
+                const int src_rank = dir == 0 ? b : b + 1, dst_rank = dir == 0 ? b + 1 : b;
+                // global rows of the message, from the owner's geometry (own ranges are a pure function of (H, world, rank))
+                const int o0 = (int)((long long)s->H * src_rank / s->world), o1 = (int)((long long)s->H * (src_rank + 1) / s->world);
+                const int g0 = dir == 0 ? o1 - h : o0 + lo, g1 = dir == 0 ? o1 - lo : o0 + h;
+                if (src) {
+                    char* base = (char*)svgf_state_plane(src->ctx, planes[k].first, planes[k].second);
+                    SVGF_NCCL(s, R->Send(base + (size_t)(g0 - src->g.y0) * rb, (size_t)(g1 - g0) * rb, ncclInt8, s->loopback ? 0 : dst_rank, src->comm, src->comm_stream));
+                }
+                if (dst) {
+                    char* base = (char*)svgf_state_plane(dst->ctx, planes[k].first, planes[k].second);
+                    SVGF_NCCL(s, R->Recv(base + (size_t)(g0 - dst->g.y0) * rb, (size_t)(g1 - g0) * rb, ncclInt8, s->loopback ? 0 : src_rank, dst->comm, dst->comm_stream));
+                }
+            }
+        }
+    }
+    SVGF_NCCL(s, R->GroupEnd());
+    for (auto& l : s->local) {
+        DeviceGuard dg(l.device);
+        SVGF_SHIP(s, hipEventRecord(is_state ? l.state_done : l.halo_done, l.comm_stream));
+        if (is_state) l.state_pending = true;
+    }
+    return SVGF_OK;
+}
+
+int wait_exchange(svgf_strips* s, svgf_strips::Local& l, bool is_state) {
+    DeviceGuard dg(l.device);
+    SVGF_SHIP(s, hipStreamWaitEvent(l.compute, is_state ? l.state_done : l.halo_done, 0));
+    if (is_state) l.state_pending = false;
+    return SVGF_OK;
+}
+
+int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src, int dst, int P, const svgf_gbuffer* cur, int i) {
+    if (rows.b <= rows.a) return SVGF_OK;
+    svgf_ctx* c = l.ctx;
+    DeviceGuard dg(l.device);
+    c->rb = rows.a; c->re = rows.b;
+    const bool timed = s->timing_every > 0 && (s->frame_no % s->timing_every) == 0 && l.rank == s->local[0].rank;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) {
+        SVGF_SHIP(s, hipEventCreate(&e0)); SVGF_SHIP(s, hipEventCreate(&e1));
+        SVGF_SHIP(s, hipEventRecord(e0, l.compute));
+    }
+    int rc = atrous_impl(c, c->filter[src], c->filter[dst], i == 0 ? c->colour[P] : nullptr, cur, 1 << i, i);
+    if (rc != SVGF_OK) return sfail(s, rc, c->err);
+    if (timed) {
+        SVGF_SHIP(s, hipEventRecord(e1, l.compute));
+        l.tev.push_back(e0); l.tev.push_back(e1);
+        l.tbytes_px.push_back((double)(rows.b - rows.a) * s->W);
+        l.titer.push_back(i);
+    }
+    return SVGF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int svgf_rccl_unique_id(void* id128) {
+    Rccl* R = rccl();
+    if (!id128 || !R->GetUniqueId) return SVGF_ERR_COMM;
+    ncclUniqueId id;
+    if (R->GetUniqueId(&id) != ncclSuccess) return SVGF_ERR_COMM;
+    std::memcpy(id128, &id, sizeof(id));
+    return SVGF_OK;
+}
+
+int svgf_rccl_comm_init(void** comm, int world, int rank, const void* id128, int device) {
+    Rccl* R = rccl();
+    if (!comm || !id128 || !R->CommInitRank) return SVGF_ERR_COMM;
+    DeviceGuard dg(device);
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    if (R->CommInitRank(&c, world, id, rank) != ncclSuccess) return SVGF_ERR_COMM;
+    *comm = c;
+    return SVGF_OK;
+}
+
+int svgf_rccl_comm_destroy(void* comm) {
+    Rccl* R = rccl();
+    if (!comm || !R->CommDestroy) return SVGF_ERR_COMM;
+    return R->CommDestroy((ncclComm_t)comm) == ncclSuccess ? SVGF_OK : SVGF_ERR_COMM;
+}
+
+int svgf_strips_plan(int width, int height, int rank, int world, int steps, int plan, int moments_radius, int motion_reach, svgf_strip_layout* out) {
+    if (!out || width <= 0 || height <= 0 || world < 1 || rank < 0 || rank >= world || steps < 0 || steps > SVGF_MAX_STEPS || motion_reach < 0) return SVGF_ERR_INVALID;
+    svgf_strip_plan_geo g;
+    int chosen = plan;
+    if (plan == SVGF_PLAN_AUTO) {
+        // the plan with the fewest exchanges whose halo still fits the strips
+        const int order[3] = {SVGF_PLAN_GHOST, SVGF_PLAN_GROUPED, SVGF_PLAN_PER_ITERATION};
+        bool ok = false;
+        for (int cand : order) if (make_geo(width, height, rank, world, steps, cand, moments_radius, motion_reach, g)) { chosen = cand; ok = true; break; }
+        if (!ok) return SVGF_ERR_HALO;
+    } else {
+        if (plan < SVGF_PLAN_GHOST || plan > SVGF_PLAN_PER_ITERATION) return SVGF_ERR_INVALID;
+        if (!make_geo(width, height, rank, world, steps, plan, moments_radius, motion_reach, g)) return SVGF_ERR_HALO;
+    }
+    std::memset(out, 0, sizeof(*out));
+    out->plan = chosen;
+    out->strip = svgf_strip{g.y0, g.y1 - g.y0, g.own0, g.own1};
+    out->ext_moments = g.ext_moments; out->ext_temporal = g.ext_temporal; out->halo_state = g.halo_state; out->halo_max = g.halo_max;
+    out->ngroups = (int)g.groups.size();
+    for (int i = 0; i < steps; i++) out->ext_atrous[i] = g.ext_atrous[i];
+    for (size_t k = 0; k < g.groups.size(); k++) { out->halo_group[k] = g.halo_group[k]; out->group_first[k] = g.groups[k].front(); }
+    return SVGF_OK;
+}
+
+int svgf_strips_create(svgf_strips** out, int width, int height, int world, const svgf_params* params, int plan, int motion_reach,
+                       int nlocal, const int* ranks, const int* devices, void* const* compute_streams, void* const* comms, int loopback) {
+    if (!out) return SVGF_ERR_INVALID;
+    *out = nullptr;
+    if (!params || nlocal < 1 || !ranks || !devices || world < 1 || nlocal > world) return SVGF_ERR_INVALID;
+    if (world > 1 && !comms) return SVGF_ERR_INVALID;
+    std::unique_ptr<svgf_strips> s(new (std::nothrow) svgf_strips());
+    if (!s) return SVGF_ERR_ALLOC;
+    s->W = width; s->H = height; s->world = world; s->steps = params->steps; s->motion_reach = motion_reach;
+    s->moments_radius = params->moments_radius; s->storage = params->storage; s->loopback = loopback != 0;
+    svgf_strip_layout lay;
+    int rc = svgf_strips_plan(width, height, ranks[0], world, params->steps, plan, params->moments_radius, motion_reach, &lay);
+    if (rc != SVGF_OK) return rc;
+    s->plan = lay.plan;
+    s->local.resize(nlocal);
+    auto cleanup = [&]() { svgf_strips* p = s.release(); svgf_strips_destroy(p); };
+    for (int k = 0; k < nlocal; k++) {
+        auto& l = s->local[k];
+        l.rank = ranks[k]; l.device = devices[k];
+        if (l.rank < 0 || l.rank >= world) { cleanup(); return SVGF_ERR_INVALID; }
+        make_geo(width, height, l.rank, world, params->steps, s->plan, params->moments_radius, motion_reach, l.g);
+        l.compute = compute_streams ? (hipStream_t)compute_streams[k] : nullptr;
+        l.comm = comms ? (ncclComm_t)comms[s->loopback ? 0 : k] : nullptr;
+        svgf_strip st{l.g.y0, l.g.y1 - l.g.y0, l.g.own0, l.g.own1};
+        rc = svgf_create_strip(&l.ctx, width, height, &st, params, l.device, l.compute);
+        if (rc != SVGF_OK) { cleanup(); return rc; }
+        l.ctx->strip_drv = reinterpret_cast<svgf_strip_driver*>(s.get());
+        DeviceGuard dg(l.device);
+        hipError_t e = hipSuccess;
+        if (s->loopback && k > 0) l.comm_stream = s->local[0].comm_stream;     // one communicator: one stream for its groups
+        else { e = hipStreamCreateWithFlags(&l.comm_stream, hipStreamNonBlocking); l.own_comm_stream = true; }
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&l.ready, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&l.halo_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&l.state_done, hipEventDisableTiming);
+        if (e != hipSuccess) { cleanup(); return SVGF_ERR_HIP; }
+    }
+    *out = s.release();
+    return SVGF_OK;
+}
+
+void svgf_strips_destroy(svgf_strips* s) {
+    if (!s) return;
+    for (auto& l : s->local) {
+        DeviceGuard dg(l.device);
+        if (l.comm_stream) (void)hipStreamSynchronize(l.comm_stream);
+        if (l.ctx) { (void)hipStreamSynchronize(l.compute); l.ctx->strip_drv = nullptr; svgf_destroy(l.ctx); }
+        for (auto e : l.tev) (void)hipEventDestroy(e);
+        if (l.ready) (void)hipEventDestroy(l.ready);
+        if (l.halo_done) (void)hipEventDestroy(l.halo_done);
+        if (l.state_done) (void)hipEventDestroy(l.state_done);
+        if (l.own_comm_stream && l.comm_stream) (void)hipStreamDestroy(l.comm_stream);
+    }
+    delete s;
+}
+
+const char* svgf_strips_last_error(const svgf_strips* s) { return s ? s->err.c_str() : "null strip driver"; }
+
+svgf_ctx* svgf_strips_context(svgf_strips* s, int local_index) {
+    return s && local_index >= 0 && local_index < (int)s->local.size() ? s->local[local_index].ctx : nullptr;
+}
+
+int svgf_strips_layout(const svgf_strips* s, int local_index, svgf_strip_layout* out) {
+    if (!s || !out || local_index < 0 || local_index >= (int)s->local.size()) return SVGF_ERR_INVALID;
+    return svgf_strips_plan(s->W, s->H, s->local[local_index].rank, s->world, s->steps, s->plan, s->moments_radius, s->motion_reach, out);
+}
+
+// One frame on every local strip = application::Render's filter share (App.cu:552-556) per strip.
+// radiance[k], cur[k], prev[k]: device planes of local rank k holding ITS rows [y0, y0+rows) (prev may be NULL on the first
+// frame); results[k] receives the plane whose owned rows hold the result.
+int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gbuffer* cur, const svgf_gbuffer* prev, const void** results) {
+    if (!s || !radiance || !cur) return SVGF_ERR_INVALID;
+    const int n = (int)s->local.size();
+    // state planes + scratch
+    for (int k = 0; k < n; k++) {
+        auto& l = s->local[k];
+        svgf_ctx* c = l.ctx;
+        DeviceGuard dg(l.device);
+        if (!radiance[k]) return sfail(s, SVGF_ERR_INVALID, "svgf_strips_frame: null radiance");
+        int rc0 = alloc_state(c);                 // svgf_denoise_frame's lazy allocation (exact size, zeroed)
+        if (rc0 == SVGF_OK) rc0 = alloc_flags(c);
+        if (rc0 != SVGF_OK) return sfail(s, rc0, c->err);
+        // previous-frame state halo: posted by the PREVIOUS frame right after its iteration 0
+        if (l.state_pending) { int rc = wait_exchange(s, l, true); if (rc != SVGF_OK) return rc; }
+    }
+    std::vector<int> pp(n, 0);
+    for (int k = 0; k < n; k++) {
+        auto& l = s->local[k];
+        svgf_ctx* c = l.ctx;
+        DeviceGuard dg(l.device);
+        const int P = c->pingpong;
+        const svgf_gbuffer* pv = prev ? &prev[k] : &cur[k];
+        if (!pv->motion) pv = &cur[k];
+        const Rows rt = grown(l.g, s->H, l.g.ext_temporal), rm = grown(l.g, s->H, l.g.ext_moments);
+        c->rb = rt.a; c->re = rt.b;
+        int rc = temporal_moments_impl(c, c->colour[1 - P], radiance[k], c->colour[P], c->filter[0], &cur[k], pv, c->hist[1 - P], c->hist[P],
+                                       c->moments[P], c->moments[1 - P], rm.a, rm.b, s->steps >= 1);
+        if (rc != SVGF_OK) return sfail(s, rc, c->err);
+    }
+    auto post_state = [&]() -> int {
+        if (s->world <= 1) return SVGF_OK;
+        const svgf_strip_plan_geo& g = s->local[0].g;
+        const int P = s->local[0].ctx->pingpong;           // all local contexts advance together
+        const int colour_held = s->steps ? g.ext_atrous[0] : g.ext_temporal;
+        // only rows a rank has NOT computed itself travel: it holds the feedback colour ext_atrous[0] rows beyond its strip and
+        // moments / history ext_temporal rows beyond (bit-identical to the owner's)
+        return post_exchange(s, {{SVGF_PLANE_COLOUR, P}, {SVGF_PLANE_MOMENTS, P}, {SVGF_PLANE_HISTORY, P}}, {colour_held, g.ext_temporal, g.ext_temporal}, g.halo_state, true);
+    };
+    const auto& groups = s->local[0].g.groups;
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+        bool exchanged = false;
+        if (gi > 0 && s->world > 1) {
+            int rc = post_exchange(s, {{SVGF_PLANE_FILTER, pp[0]}}, {0}, s->local[0].g.halo_group[gi], false);
+            if (rc != SVGF_OK) return rc;
+            exchanged = true;
+        }
+        for (size_t q = 0; q < groups[gi].size(); q++) {
+            const int i = groups[gi][q];
+            for (int k = 0; k < n; k++) {
+                auto& l = s->local[k];
+                const int P = l.ctx->pingpong;
+                const Rows rows = grown(l.g, s->H, l.g.ext_atrous[i]);
+                if (exchanged && q == 0) {
+                    // rows that need no neighbour data first (the transfer runs beside them), the edges after it has landed
+                    const int reach = 2 << i;
+                    const int lo = l.rank == 0 ? rows.a : std::max(rows.a, l.g.own0 + reach);
+                    const int hi = l.rank == s->world - 1 ? rows.b : std::min(rows.b, l.g.own1 - reach);
+                    if (hi > lo) {
+                        int rc = launch_atrous_rows(s, l, Rows{lo, hi}, pp[k], 1 - pp[k], P, &cur[k], i);
+                        if (rc == SVGF_OK) rc = wait_exchange(s, l, false);
+                        if (rc == SVGF_OK) rc = launch_atrous_rows(s, l, Rows{rows.a, lo}, pp[k], 1 - pp[k], P, &cur[k], i);
+                        if (rc == SVGF_OK) rc = launch_atrous_rows(s, l, Rows{hi, rows.b}, pp[k], 1 - pp[k], P, &cur[k], i);
+                        if (rc != SVGF_OK) return rc;
+                    } else {
+                        int rc = wait_exchange(s, l, false);
+                        if (rc == SVGF_OK) rc = launch_atrous_rows(s, l, rows, pp[k], 1 - pp[k], P, &cur[k], i);
+                        if (rc != SVGF_OK) return rc;
+                    }
+                } else {
+                    int rc = launch_atrous_rows(s, l, rows, pp[k], 1 - pp[k], P, &cur[k], i);
+                    if (rc != SVGF_OK) return rc;
+                }
+                pp[k] ^= 1;
+            }
+            if (i == 0) { int rc = post_state(); if (rc != SVGF_OK) return rc; }   // this frame's state is final once iteration 0 has written the feedback colour
+        }
+    }
+    if (!s->steps) { int rc = post_state(); if (rc != SVGF_OK) return rc; }
+    for (int k = 0; k < n; k++) {
+        svgf_ctx* c = s->local[k].ctx;
+        c->rb = c->strip.own_begin; c->re = c->strip.own_end;
+        if (results) results[k] = c->filter[pp[k]];
+        c->result_index = pp[k];
+        c->pingpong ^= 1;
+        if (c->frames_since_reset < (1 << 30)) c->frames_since_reset++;
+    }
+    s->frame_no++;
+    return SVGF_OK;
+}
+
+// Wait for the exchange the last frame posted (before tearing the communicator down) and for the filter streams; reports
+// SVGF_ERR_HALO if any local strip's temporal stage reprojected into rows it does not hold.
+int svgf_strips_sync(svgf_strips* s) {
+    if (!s) return SVGF_ERR_INVALID;
+    unsigned long long total = 0;
+    for (auto& l : s->local) {
+        if (l.state_pending) { int rc = wait_exchange(s, l, true); if (rc != SVGF_OK) return rc; }
+        DeviceGuard dg(l.device);
+        unsigned long long n = 0;
+        int rc = read_halo_violations(l.ctx, &n, 1);
+        if (rc != SVGF_OK) return sfail(s, rc, l.ctx->err);
+        SVGF_SHIP(s, hipStreamSynchronize(l.compute));
+        SVGF_SHIP(s, hipStreamSynchronize(l.comm_stream));
+        total += n;
+    }
+    if (total) return sfail(s, SVGF_ERR_HALO, "temporal stage: " + std::to_string(total) + " reprojection(s) reached beyond the state halo (motion_reach = " +
+                                              std::to_string(s->motion_reach) + " rows): the strips differ from the whole frame there");
+    return SVGF_OK;
+}
+
+int svgf_strips_timing_enable(svgf_strips* s, int every) {
+    if (!s) return SVGF_ERR_INVALID;
+    s->timing_every = every > 0 ? every : 0;
+    return SVGF_OK;
+}
+
+// -> launches timed on the first local rank, their summed milliseconds, and the pixels they covered (all iterations / iteration 0 only)
+int svgf_strips_timing_read(svgf_strips* s, int* launches, double* ms, double* px_all, double* px_iter0) {
+    if (!s || !launches || !ms || !px_all || !px_iter0) return SVGF_ERR_INVALID;
+    auto& l = s->local[0];
+    DeviceGuard dg(l.device);
+    for (size_t i = 0; i + 1 < l.tev.size(); i += 2) {
+        SVGF_SHIP(s, hipEventSynchronize(l.tev[i + 1]));
+        float t = 0.f;
+        SVGF_SHIP(s, hipEventElapsedTime(&t, l.tev[i], l.tev[i + 1]));
+        s->t_ms += t; s->t_launches++;
+        s->t_px_iter += l.tbytes_px[i / 2];
+        if (l.titer[i / 2] == 0) s->t_px_fb += l.tbytes_px[i / 2];
+        (void)hipEventDestroy(l.tev[i]); (void)hipEventDestroy(l.tev[i + 1]);
+    }
+    l.tev.clear(); l.tbytes_px.clear(); l.titer.clear();
+    *launches = s->t_launches; *ms = s->t_ms; *px_all = s->t_px_iter; *px_iter0 = s->t_px_fb;
+    s->t_launches = 0; s->t_ms = 0; s->t_px_iter = 0; s->t_px_fb = 0;
+    return SVGF_OK;
+}
+
+}  // extern "C"

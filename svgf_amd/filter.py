@@ -26,7 +26,17 @@ EXPORTS = [
     "svgf_create_strip", "svgf_destroy", "svgf_set_params", "svgf_set_stream", "svgf_set_rows", "svgf_temporal", "svgf_temporal_moments", "svgf_demodulate", "svgf_modulate",
     "svgf_moments", "svgf_atrous", "svgf_taa", "svgf_pack_gbuffer", "svgf_denoise_frame", "svgf_reset_history", "svgf_state_plane",
     "svgf_state_pingpong", "svgf_plane_bytes", "svgf_timing_enable", "svgf_timing_read",
+    "svgf_resize", "svgf_resize_strip", "svgf_get_size", "svgf_sync", "svgf_halo_violations", "svgf_set_debug_mode",
+    "svgf_import_gbuffer_pitched", "svgf_import_gbuffer_array", "svgf_export_to_array",
+    "svgf_strips_plan", "svgf_rccl_unique_id", "svgf_rccl_comm_init", "svgf_rccl_comm_destroy", "svgf_strips_create", "svgf_strips_destroy",
+    "svgf_strips_last_error", "svgf_strips_context", "svgf_strips_layout", "svgf_strips_frame", "svgf_strips_sync",
+    "svgf_strips_timing_enable", "svgf_strips_timing_read",
 ]
+ABI_VERSION = 2
+DEBUG_MODE = {"final": 0, "temporal": 1, "atrous": 2}
+HALO_PLAN = {"auto": 0, "ghost": 1, "grouped": 2, "per-iteration": 3}
+HALO_PLAN_NAME = {v: k for k, v in HALO_PLAN.items()}
+GBUF_MOTION, GBUF_NORMAL, GBUF_UV = 0, 1, 2
 
 
 class SvgfError(RuntimeError):
@@ -49,6 +59,12 @@ class CameraC(C.Structure):
 
 class StripC(C.Structure):
     _fields_ = [("y0", C.c_int), ("rows", C.c_int), ("own_begin", C.c_int), ("own_end", C.c_int)]
+
+
+class StripLayoutC(C.Structure):
+    _fields_ = [("plan", C.c_int), ("strip", StripC), ("ext_atrous", C.c_int * MAX_STEPS), ("ngroups", C.c_int),
+                ("group_first", C.c_int * MAX_STEPS), ("halo_group", C.c_int * MAX_STEPS), ("ext_moments", C.c_int),
+                ("ext_temporal", C.c_int), ("halo_state", C.c_int), ("halo_max", C.c_int)]
 
 
 @dataclass
@@ -89,8 +105,13 @@ def load_library():
         try:
             _build.build_library()
         except Exception as e:  # noqa: BLE001
+            # never fall back to a library older than the sources: tests or the bench would silently run outdated kernels
             if not os.path.exists(path):
                 raise SvgfError(f"libsvgf_mi355x.so is missing and could not be built: {e}") from e
+            if _build.have_hipcc():
+                raise SvgfError(f"libsvgf_mi355x.so is older than its sources and the rebuild failed: {e}") from e
+            import warnings
+            warnings.warn(f"libsvgf_mi355x.so is older than its sources and there is no hipcc here to rebuild it ({e}); using it as shipped", stacklevel=2)
     if not os.path.exists(path):
         raise SvgfError("libsvgf_mi355x.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
     # torch ships a HIP runtime of its own (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's): it has to be the one
@@ -130,6 +151,31 @@ def load_library():
     lib.svgf_plane_bytes.restype = C.c_size_t
     lib.svgf_timing_enable.argtypes = [vp, ip]
     lib.svgf_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(ip), ip]
+    lib.svgf_resize.argtypes = [vp, ip, ip]
+    lib.svgf_resize_strip.argtypes = [vp, ip, ip, C.POINTER(StripC)]
+    lib.svgf_get_size.argtypes = [vp, C.POINTER(ip), C.POINTER(ip), C.POINTER(StripC)]
+    lib.svgf_sync.argtypes = [vp]
+    lib.svgf_halo_violations.argtypes = [vp, C.POINTER(C.c_ulonglong), ip]
+    lib.svgf_set_debug_mode.argtypes = [vp, ip]
+    lib.svgf_import_gbuffer_pitched.argtypes = [vp, ip, vp, C.c_size_t, vp]
+    lib.svgf_import_gbuffer_array.argtypes = [vp, ip, vp, vp]
+    lib.svgf_export_to_array.argtypes = [vp, vp, vp]
+    lib.svgf_strips_plan.argtypes = [ip, ip, ip, ip, ip, ip, ip, ip, C.POINTER(StripLayoutC)]
+    lib.svgf_rccl_unique_id.argtypes = [vp]
+    lib.svgf_rccl_comm_init.argtypes = [C.POINTER(vp), ip, ip, vp, ip]
+    lib.svgf_rccl_comm_destroy.argtypes = [vp]
+    lib.svgf_strips_create.argtypes = [C.POINTER(vp), ip, ip, ip, C.POINTER(ParamsC), ip, ip, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(vp), C.POINTER(vp), ip]
+    lib.svgf_strips_destroy.argtypes = [vp]
+    lib.svgf_strips_destroy.restype = None
+    lib.svgf_strips_last_error.argtypes = [vp]
+    lib.svgf_strips_last_error.restype = C.c_char_p
+    lib.svgf_strips_context.argtypes = [vp, ip]
+    lib.svgf_strips_context.restype = vp
+    lib.svgf_strips_layout.argtypes = [vp, ip, C.POINTER(StripLayoutC)]
+    lib.svgf_strips_frame.argtypes = [vp, C.POINTER(vp), C.POINTER(GBufferC), C.POINTER(GBufferC), C.POINTER(vp)]
+    lib.svgf_strips_sync.argtypes = [vp]
+    lib.svgf_strips_timing_enable.argtypes = [vp, ip]
+    lib.svgf_strips_timing_read.argtypes = [vp, C.POINTER(ip), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     _lib = lib
     return lib
 
@@ -219,6 +265,44 @@ class Denoiser:
 
     def set_rows(self, row_begin=-1, row_end=-1):
         self._check(self.lib.svgf_set_rows(self._h, row_begin, row_end), "svgf_set_rows")
+
+    def sync(self):
+        """Wait for the context's stream; raises (SVGF_ERR_HALO) if a strip's temporal stage reprojected into rows it does not hold."""
+        self._check(self.lib.svgf_sync(self._h), "svgf_sync")
+
+    def halo_violations(self, clear=False) -> int:
+        n = C.c_ulonglong()
+        self._check(self.lib.svgf_halo_violations(self._h, C.byref(n), int(clear)), "svgf_halo_violations")
+        return n.value
+
+    def Resize(self, width, height, strip=None):
+        """application::ResizeRenderTextures (src/App.cu:742-778): new render size, state reallocated and zeroed."""
+        if strip is None:
+            self._check(self.lib.svgf_resize(self._h, width, height), "svgf_resize")
+            self.strip = (0, height, 0, height)
+        else:
+            sc = StripC(*[int(v) for v in strip])
+            self._check(self.lib.svgf_resize_strip(self._h, width, height, C.byref(sc)), "svgf_resize_strip")
+            self.strip = tuple(int(v) for v in strip)
+        self.W, self.H = width, height
+
+    def size(self):
+        w, h, st = C.c_int(), C.c_int(), StripC()
+        self._check(self.lib.svgf_get_size(self._h, C.byref(w), C.byref(h), C.byref(st)), "svgf_get_size")
+        return w.value, h.value, (st.y0, st.rows, st.own_begin, st.own_end)
+
+    def set_debug_mode(self, mode="final"):
+        """SVGFDebugOutput sequences of application::Render (src/App.cu:545-649): 'final', 'temporal', 'atrous'."""
+        self._check(self.lib.svgf_set_debug_mode(self._h, DEBUG_MODE[mode]), "svgf_set_debug_mode")
+
+    def ImportPitched(self, plane, src_ptr, pitch_bytes, dst):
+        self._check(self.lib.svgf_import_gbuffer_pitched(self._h, plane, C.c_void_p(src_ptr), pitch_bytes, _ptr(dst)), "svgf_import_gbuffer_pitched")
+
+    def ImportArray(self, plane, hip_array, dst):
+        self._check(self.lib.svgf_import_gbuffer_array(self._h, plane, C.c_void_p(hip_array), _ptr(dst)), "svgf_import_gbuffer_array")
+
+    def ExportToArray(self, plane_tensor, hip_array):
+        self._check(self.lib.svgf_export_to_array(self._h, _ptr(plane_tensor), C.c_void_p(hip_array)), "svgf_export_to_array")
 
     # -- the three stages (kernel-level API) -------------------------------------------------
     def TemporalFilter(self, prev_colour, radiance, colour_out, gb_cur: GBuffer, gb_prev: GBuffer, hist_prev, hist_cur,

@@ -26,7 +26,7 @@ from dataclasses import dataclass, field
 
 PLANS = {
     "per-iteration": lambda n: [[i] for i in range(n)],
-    "grouped": lambda n: [list(range(0, min(3, n)))] + ([list(range(3, n))] if n > 3 else []),
+    "grouped": lambda n: ([list(range(0, min(3, n)))] if n else []) + ([list(range(3, n))] if n > 3 else []),
     "ghost": lambda n: [list(range(n))] if n else [],
 }
 DEFAULT_PLAN = "grouped"
@@ -384,39 +384,247 @@ def run_virtual(runners, inputs):
     return results
 
 
-def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, make_inputs, prime_frames):
-    """bench.py's N > 1 leg: this rank's strip of a W x H frame, `steps` timed frames."""
+def strips_plan(W, H, rank, world, steps, plan="auto", moments_radius=3, motion_reach=0):
+    """svgf_strips_plan (the C++ restatement of Geometry.make) -> dict; raises ValueError if the strips are too short."""
+    import ctypes as C
+    from . import filter as F
+    lib = F.load_library()
+    lay = F.StripLayoutC()
+    rc = lib.svgf_strips_plan(W, H, rank, world, steps, F.HALO_PLAN[plan], moments_radius, motion_reach, C.byref(lay))
+    if rc != 0:
+        raise ValueError(f"svgf_strips_plan: {lib.svgf_status_string(rc).decode()}")
+    st = lay.strip
+    return dict(plan=F.HALO_PLAN_NAME[lay.plan], y0=st.y0, y1=st.y0 + st.rows, own=(st.own_begin, st.own_end), ext_atrous=list(lay.ext_atrous)[:steps],
+                halo_group=list(lay.halo_group)[:lay.ngroups], group_first=list(lay.group_first)[:lay.ngroups], ext_moments=lay.ext_moments,
+                ext_temporal=lay.ext_temporal, halo_state=lay.halo_state, halo_max=lay.halo_max)
+
+
+def rccl_comm(world, rank, device_index, group=None):
+    """An ncclComm_t for the C++ strip driver: rank 0 draws the unique id (svgf_rccl_unique_id), torch.distributed carries its
+    128 bytes to the other ranks — the only thing Python does for the exchange — and every rank joins (svgf_rccl_comm_init)."""
+    import ctypes as C
+    import torch.distributed as dist
+    from . import filter as F
+    lib = F.load_library()
+    buf = (C.c_char * 128)()
+    if rank == 0:
+        rc = lib.svgf_rccl_unique_id(buf)
+        if rc != 0:
+            raise F.SvgfError("svgf_rccl_unique_id failed (librccl not available?)")
+    box = [bytes(buf.raw)]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    ident = (C.c_char * 128).from_buffer_copy(box[0])
+    comm = C.c_void_p()
+    rc = lib.svgf_rccl_comm_init(C.byref(comm), world, rank, ident, device_index)
+    if rc != 0:
+        raise F.SvgfError("svgf_rccl_comm_init failed")
+    return comm
+
+
+class NativeStrips:
+    """The C++ strip driver of the library (svgf_strips_*, svgf_amd/csrc/svgf_strip.hip): the stage sequence of every local
+    strip, the RCCL groups, the communication stream and the events all live in C++; Python hands over device pointers."""
+
+    def __init__(self, W, H, world, params, ranks, devices, streams=None, comms=None, plan="auto", motion_reach=0, loopback=False):
+        import ctypes as C
+        import torch
+        from . import filter as F
+        self.F, self.C, self.torch = F, C, torch
+        self.lib = F.load_library()
+        self.W, self.H, self.world, self.params, self.n = W, H, world, params, len(ranks)
+        self.ranks, self.devices = list(ranks), list(devices)
+        self.storage = params.storage
+        n = self.n
+        pc = params.to_c()
+        r_arr, d_arr = (C.c_int * n)(*ranks), (C.c_int * n)(*devices)
+        s_arr = (C.c_void_p * n)(*[(s if s is not None else None) for s in (streams or [None] * n)])
+        ncomm = 1 if loopback else n
+        c_arr = (C.c_void_p * ncomm)(*[(c.value if hasattr(c, "value") else c) for c in comms]) if comms else None
+        h = C.c_void_p()
+        rc = self.lib.svgf_strips_create(C.byref(h), W, H, world, C.byref(pc), F.HALO_PLAN[plan], motion_reach, n, r_arr, d_arr, s_arr, c_arr, int(loopback))
+        if rc != 0:
+            raise F.SvgfError(f"svgf_strips_create: {self.lib.svgf_status_string(rc).decode()}")
+        self._h = h
+        self.layouts = []
+        for k in range(n):
+            lay = F.StripLayoutC()
+            self._check(self.lib.svgf_strips_layout(self._h, k, C.byref(lay)))
+            st = lay.strip
+            self.layouts.append(dict(plan=F.HALO_PLAN_NAME[lay.plan], y0=st.y0, y1=st.y0 + st.rows, own=(st.own_begin, st.own_end), halo_state=lay.halo_state,
+                                     halo_max=lay.halo_max, ext_atrous=list(lay.ext_atrous)[:params.steps], ext_temporal=lay.ext_temporal))
+        self.plan = self.layouts[0]["plan"]
+
+    def _check(self, rc, what="svgf_strips"):
+        if rc != 0:
+            raise self.F.SvgfError(f"{what}: {self.lib.svgf_status_string(rc).decode()}: {self.lib.svgf_strips_last_error(self._h).decode()}")
+
+    def frame(self, radiance, cur, prev=None):
+        """radiance: list of tensors, cur / prev: lists of filter.GBuffer (prev None on the first frame) -> list of result tensors
+        (views of library-owned planes holding rows [y0, y1) of each strip)."""
+        C, n = self.C, self.n
+        rad = (C.c_void_p * n)(*[t.data_ptr() for t in radiance])
+        gc = (self.F.GBufferC * n)(*[g._c for g in cur])
+        gp = (self.F.GBufferC * n)(*[g._c for g in prev]) if prev is not None else None
+        res = (C.c_void_p * n)()
+        self._check(self.lib.svgf_strips_frame(self._h, rad, gc, gp, res), "svgf_strips_frame")
+        return [self._wrap(k, res[k]) for k in range(n)]
+
+    def _wrap(self, k, ptr, plane=None):
+        torch, lay = self.torch, self.layouts[k]
+        rows = lay["y1"] - lay["y0"]
+        dt = torch.float32 if self.storage == "f32" else torch.float16
+        if plane == self.F.PLANE_HISTORY:
+            shape, typestr = (rows, self.W), "|u1"
+        else:
+            shape, typestr = (rows, self.W, 2 if plane == self.F.PLANE_MOMENTS else 4), "<f4" if dt == torch.float32 else "<f2"
+
+        class _Holder:
+            pass
+        hld = _Holder()
+        hld.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr), False), "version": 3}
+        hld.owner = self
+        return torch.as_tensor(hld, device=torch.device("cuda", self.devices[k]))
+
+    def state_plane(self, k, plane, index):
+        ctx = self.lib.svgf_strips_context(self._h, k)
+        p = self.lib.svgf_state_plane(ctx, plane, index)
+        return self._wrap(k, p, plane) if p else None
+
+    def pingpong(self, k=0):
+        return self.lib.svgf_state_pingpong(self.lib.svgf_strips_context(self._h, k))
+
+    def owned(self, k, t):
+        lay = self.layouts[k]
+        return t[lay["own"][0] - lay["y0"]:lay["own"][1] - lay["y0"]]
+
+    def sync(self):
+        self._check(self.lib.svgf_strips_sync(self._h), "svgf_strips_sync")
+
+    def timing_enable(self, every):
+        self._check(self.lib.svgf_strips_timing_enable(self._h, int(every)))
+
+    def timing_read(self):
+        C = self.C
+        n, ms, pa, p0 = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+        self._check(self.lib.svgf_strips_timing_read(self._h, C.byref(n), C.byref(ms), C.byref(pa), C.byref(p0)))
+        return n.value, ms.value, pa.value, p0.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.svgf_strips_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, make_inputs, prime_frames, driver="native", motion_reach=None):
+    """bench.py's N > 1 leg: this rank's strip of a W x H frame, `steps` timed frames.  driver = "native": the C++ strip driver
+    of the library (RCCL groups posted from C++); "python": StripRunner + torch.distributed point-to-point ops."""
+    import math
     import time
     import torch
     import torch.distributed as dist
     from . import filter as F
     rank, world = dist.get_rank(), dist.get_world_size()
     # A high-priority side stream for the kernels: HIP maps a priority level to hardware queues of its own, so the RCCL
-    # send/recv kernels (torch's communication stream, normal priority) run BESIDE the filter kernels.  On one shared
+    # send/recv kernels (the communication stream, normal priority) run BESIDE the filter kernels.  On one shared
     # queue they run in line with them (tools/strip_sim.py: 0.66 vs 0.55 ms per 8K/8 strip).
     side = torch.cuda.Stream(device=device, priority=-1)
     torch.cuda.set_stream(side)
     params = F.Params(storage=storage, steps=iters, variant=variant)
-    geo = Geometry.make(W, H, rank, world, iters, plan=plan, moments_radius=params.moments_radius, motion_reach=4)
+    # the strip's inputs: its rows of the frame; the rows needed depend on the plan, which depends on the motion reach, which is
+    # read off the inputs: generate the widest candidate (ghost plan, reach 8), measure, then cut
+    probe = strips_plan(W, H, rank, world, iters, plan="ghost" if plan == "auto" else plan, moments_radius=params.moments_radius, motion_reach=8) \
+        if _plan_fits(W, H, rank, world, iters, "ghost" if plan == "auto" else plan, params.moments_radius, 8) else None
+    y0p, y1p = (probe["y0"], probe["y1"]) if probe else (0, H)
+    gb_all, rads_all = make_inputs(W, H, storage, device, row_begin=y0p, row_end=y1p)
+    if motion_reach is None:
+        mvy = gb_all.motion[..., 1].abs().max().reshape(1).to(torch.float32)
+        if world > 1:
+            dist.all_reduce(mvy, op=dist.ReduceOp.MAX)
+        motion_reach = int(math.ceil(float(mvy.item())))
+    lay = strips_plan(W, H, rank, world, iters, plan=plan, moments_radius=params.moments_radius, motion_reach=motion_reach)
+    y0, y1 = lay["y0"], lay["y1"]
+    cut = slice(y0 - y0p, y1 - y0p)
+    # current and previous G-buffer in DISTINCT planes, ping-ponged (src/App.cu:471-474), also with a static camera
+    gbs = [F.GBuffer(gb_all.motion[cut].clone(), gb_all.normal[cut].clone(), gb_all.uv[cut].clone()) for _ in range(2)]
+    rads = [r[cut].contiguous() for r in rads_all]
+    del gb_all, rads_all
+    host_ms = None
+    if driver == "native":
+        comm = rccl_comm(world, rank, device.index or 0) if world > 1 else None
+        drv = NativeStrips(W, H, world, params, [rank], [device.index or 0], streams=[side.cuda_stream], comms=[comm] if comm else None,
+                           plan=lay["plan"], motion_reach=motion_reach)
+        n = 0
+        for _ in range(prime_frames + warmup):
+            drv.frame([rads[n % len(rads)]], [gbs[n & 1]], [gbs[(n & 1) ^ 1]])
+            n += 1
+        drv.timing_enable(4)
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        host = 0.0
+        for _ in range(steps):
+            h0 = time.perf_counter()
+            drv.frame([rads[n % len(rads)]], [gbs[n & 1]], [gbs[(n & 1) ^ 1]])
+            host += time.perf_counter() - h0
+            n += 1
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        host_ms = host * 1e3 / steps
+        drv.timing_enable(0)
+        out = drv.frame([rads[0]], [gbs[n & 1]], [gbs[(n & 1) ^ 1]])[0]
+        drv.sync()                               # raises if a reprojection left the strip (motion reach too small)
+        assert bool(torch.isfinite(drv.owned(0, out).float()).all())
+
+        def atrous_timing(bytes_iter, bytes_feedback):
+            nl, ms, px_all, px0 = drv.timing_read()
+            return nl, ms, px_all * bytes_iter + px0 * bytes_feedback
+        res = dict(ms_per_step=(t1 - t0) * 1e3 / steps, rows_per_rank=lay["own"][1] - lay["own"][0], plan=lay["plan"], atrous_timing=atrous_timing,
+                   driver="C++ (svgf_strips_frame)", motion_reach=motion_reach, host_ms=round(host_ms, 4), _keep=(drv, comm))
+        return res
+    geo = Geometry.make(W, H, rank, world, iters, plan=lay["plan"], moments_radius=params.moments_radius, motion_reach=motion_reach)
     stages = HipStages(geo, params, device)
     runner = StripRunner(geo, stages, DistComm(device=device), storage=storage, device=device)
-    gb, rads = make_inputs(W, H, storage, device, row_begin=geo.y0, row_end=geo.y1)
-    for k in range(prime_frames + warmup):
-        runner.frame(rads[k % len(rads)], gb, gb)
+    n = 0
+    for _ in range(prime_frames + warmup):
+        runner.frame(rads[n % len(rads)], gbs[n & 1], gbs[(n & 1) ^ 1])
+        n += 1
     torch.cuda.synchronize(device)
     dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
+    host = 0.0
     for k in range(steps):
         stages.timing = (k % 4) == 0             # a-trous launches of every 4th timed frame between HIP events
-        runner.frame(rads[k % len(rads)], gb, gb)
+        h0 = time.perf_counter()
+        runner.frame(rads[n % len(rads)], gbs[n & 1], gbs[(n & 1) ^ 1])
+        host += time.perf_counter() - h0
+        n += 1
     stages.timing = False
     torch.cuda.synchronize(device)
     dist.barrier()
     torch.cuda.synchronize(device)
     t1 = time.perf_counter()
-    out = runner.frame(rads[0], gb, gb)
+    out = runner.frame(rads[0], gbs[n & 1], gbs[(n & 1) ^ 1])
     runner.flush()
+    stages.d.sync()                              # raises if a reprojection left the strip
     assert bool(torch.isfinite(runner.owned(out).float()).all())
-    return dict(ms_per_step=(t1 - t0) * 1e3 / steps, rows_per_rank=geo.own[1] - geo.own[0],
-                plan=geo.plan, stages=stages)
+    return dict(ms_per_step=(t1 - t0) * 1e3 / steps, rows_per_rank=geo.own[1] - geo.own[0], plan=geo.plan, atrous_timing=stages.atrous_timing,
+                driver="python (svgf_amd/strips.py)", motion_reach=motion_reach, host_ms=round(host * 1e3 / steps, 4))
+
+
+def _plan_fits(W, H, rank, world, steps, plan, moments_radius, motion_reach):
+    try:
+        strips_plan(W, H, rank, world, steps, plan=plan, moments_radius=moments_radius, motion_reach=motion_reach)
+        return True
+    except ValueError:
+        return False

@@ -52,11 +52,12 @@ _N_QUAD_A = np.array([0.0, 0.0, -1.0])
 _N_QUAD_B = np.array([0.6, 0.0, -0.8])
 
 
-def _scene_rows(width, height, frame, mv, row_begin, row_end, seed):
-    """Geometry of rows [row_begin,row_end): motion/normal/uv planes, region ids and the noise-free radiance."""
+def _scene_rows(width, height, frame, mv, row_begin, row_end, seed, col_begin=0):
+    """Geometry of rows [row_begin,row_end) x columns [col_begin, col_begin+width): motion/normal/uv planes, region ids and
+    the noise-free radiance.  `height` is the scale of the world coordinates (the frame height), whatever the ranges."""
     rows = row_end - row_begin
     ys = np.arange(row_begin, row_end, dtype=np.int64)
-    xs = np.arange(width, dtype=np.int64)
+    xs = np.arange(col_begin, col_begin + width, dtype=np.int64)
     H = float(height)
     u = np.empty((rows, width), np.float64)
     v = np.empty((rows, width), np.float64)
@@ -163,20 +164,23 @@ _CHUNK = 128
 
 
 def make_scene(width: int, height: int, frame: int = 0, *, mv=(0.0, 0.0), row_begin: int = 0, row_end: int | None = None,
-               seed: int = SEED):
+               seed: int = SEED, col_begin: int = 0, col_end: int | None = None):
     """G-buffer planes + region ids + noise-free radiance ('base') of rows [row_begin,row_end) of frame `frame`.
 
     `mv` is the constant per-frame pan (prev - cur, pixels): the surface point seen at pixel p in frame f was at
-    p + mv in frame f-1, i.e. frame f shows the static world at p + f*mv."""
+    p + mv in frame f-1, i.e. frame f shows the static world at p + f*mv.  Rows and columns may lie outside the frame
+    (a canvas larger than the frame: bench.py cuts the frames of a pan out of two such canvases)."""
     if row_end is None:
         row_end = height
-    rows = row_end - row_begin
-    out = {"motion": np.empty((rows, width, 4), np.float32), "normal": np.empty((rows, width, 4), np.uint16),
-           "uv": np.empty((rows, width, 4), np.uint16), "region": np.empty((rows, width), np.int32),
-           "base": np.empty((rows, width, 3), np.float32)}
+    if col_end is None:
+        col_end = width
+    rows, width_out = row_end - row_begin, col_end - col_begin
+    out = {"motion": np.empty((rows, width_out, 4), np.float32), "normal": np.empty((rows, width_out, 4), np.uint16),
+           "uv": np.empty((rows, width_out, 4), np.uint16), "region": np.empty((rows, width_out), np.int32),
+           "base": np.empty((rows, width_out, 3), np.float32)}
     for a in range(row_begin, row_end, _CHUNK):
         b = min(a + _CHUNK, row_end)
-        mo, no, uv, rg, ba = _scene_rows(width, height, frame, mv, a, b, seed)
+        mo, no, uv, rg, ba = _scene_rows(width_out, height, frame, mv, a, b, seed, col_begin)
         sl = slice(a - row_begin, b - row_begin)
         out["motion"][sl], out["normal"][sl], out["uv"][sl], out["region"][sl], out["base"][sl] = mo, no, uv, rg, ba
     return out

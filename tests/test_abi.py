@@ -23,7 +23,7 @@ def test_header_symbols_all_exported():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/svgf.h but not exported"
     assert sorted(F.EXPORTS) == syms
-    assert lib.svgf_abi_version() == 1
+    assert lib.svgf_abi_version() == F.ABI_VERSION == 2
 
 
 def test_default_params_match_reference_defaults():
@@ -62,3 +62,46 @@ def test_product_never_touches_the_oracle():
                 src = open(os.path.join(dp, f), errors="ignore").read()
                 m = bad.search(src)
                 assert not m, f"{f} references the oracle: {m.group(0)!r}"
+
+
+def test_strip_plan_matches_python_geometry():
+    """svgf_strips_plan (C++, what the strip driver runs on) == svgf_amd.strips.Geometry.make (what the CPU gloo tests run on),
+    over frame sizes, world sizes, iteration counts, plans, radii and motion reaches; and the same refusals."""
+    from svgf_amd import strips
+    n = 0
+    for (W, H) in ((7680, 4320), (3840, 2160), (320, 420), (96, 312), (64, 200)):
+        for world in (1, 2, 3, 8):
+            for steps in (0, 1, 3, 5):
+                for plan in ("ghost", "grouped", "per-iteration", "auto"):
+                    for mr, reach in ((3, 4), (1, 0), (3, 9)):
+                        for rank in sorted({0, world // 2, world - 1}):
+                            try:
+                                g = strips.Geometry.make(W, H, rank, world, steps, plan=plan, moments_radius=mr, motion_reach=reach)
+                            except ValueError:
+                                with pytest.raises(ValueError):
+                                    strips.strips_plan(W, H, rank, world, steps, plan, mr, reach)
+                                continue
+                            lay = strips.strips_plan(W, H, rank, world, steps, plan, mr, reach)
+                            assert (lay["y0"], lay["y1"], lay["own"]) == (g.y0, g.y1, g.own), (W, H, world, steps, plan, rank)
+                            assert lay["ext_atrous"] == g.ext_atrous and lay["halo_group"] == g.halo_group
+                            assert (lay["ext_moments"], lay["ext_temporal"], lay["halo_state"], lay["halo_max"]) == (g.ext_moments, g.ext_temporal, g.halo_state, g.halo_max)
+                            assert lay["plan"] == (g.plan if isinstance(g.plan, str) else plan)
+                            n += 1
+    assert n > 500
+
+
+def test_strip_driver_refuses_without_gpu_or_bad_arguments():
+    import torch
+    from svgf_amd import filter as F
+    lib = F.load_library()
+    lay = F.StripLayoutC()
+    assert lib.svgf_strips_plan(64, 64, 0, 4, 5, F.HALO_PLAN["ghost"], 3, 4, C.byref(lay)) == -4          # SVGF_ERR_HALO: 16-row strips, 69-row halo
+    assert lib.svgf_strips_plan(64, 64, 5, 4, 5, 0, 3, 4, C.byref(lay)) == -1                              # rank outside the world
+    assert lib.svgf_status_string(-6) == b"RCCL error"
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    p = F.Params(storage="f32", steps=5).to_c()
+    ranks, devs = (C.c_int * 1)(0), (C.c_int * 1)(0)
+    rc = lib.svgf_strips_create(C.byref(h), 640, 480, 1, C.byref(p), 0, 0, 1, ranks, devs, None, None, 0)
+    assert rc == -3 and not h.value                                                                        # no device: no driver

@@ -1,0 +1,335 @@
+"""GPU tests of the pieces added after round 1: the C++ strip driver with RCCL groups (loop-back communicator), BASELINE config #4
+(7680x4320 as 8 strips of 540 rows), the 1080p fp32 full-size run, the temporal strip guard turned into a reported error,
+device handling of the ABI, svgf_resize, the debug-view sequences, and a per-stage error report."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from svgf_amd import synth
+from tests.conftest import ROOT
+from tests.helpers import CDT, frames, gbuf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from tests import gpu_helpers
+    return gpu_helpers
+
+
+@pytest.fixture(scope="module")
+def loop_comm():
+    """ONE RCCL communicator of world size 1: every send/recv of the virtual ranks has communicator rank 0 as its peer."""
+    from svgf_amd import filter as F
+    from svgf_amd import strips
+    comm = strips.rccl_comm(1, 0, 0)
+    yield comm
+    F.load_library().svgf_rccl_comm_destroy(comm)
+
+
+def _strip_inputs(G, fr, lay, storage):
+    from svgf_amd import filter as F
+    sl = slice(lay["y0"], lay["y1"])
+    gb = F.GBuffer(*(G.dev(np.ascontiguousarray(fr[k][sl])) for k in ("motion", "normal", "uv")))
+    rad = G.dev(np.ascontiguousarray(fr["radiance"][sl].astype(G.NPDT[storage])))
+    return rad, gb
+
+
+@pytest.mark.parametrize("plan", ["ghost", "grouped", "per-iteration"])
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_native_strip_driver_over_rccl_loopback(G, loop_comm, plan, storage):
+    """svgf_strips_frame (C++: stage sequence, ncclGroupStart/ncclSend/ncclRecv/ncclGroupEnd on its own stream, HIP events, state
+    exchange posted after iteration 0) with 3 virtual ranks on one device: every frame of a panning sequence equals the
+    single-context result bit for bit, history included; no reprojection leaves a strip."""
+    import torch
+    from svgf_amd import filter as F
+    from svgf_amd import strips
+    W, H, world, N = 320, 420, 3, 4
+    fr = frames(W, H, N, mv=(1.0, -2.5))
+    params = F.Params(storage=storage, steps=5)
+    whole = G.HipPipeline(W, H, storage, steps=5)
+    side = torch.cuda.Stream(priority=-1)
+    drv = strips.NativeStrips(W, H, world, params, list(range(world)), [0] * world, streams=[side.cuda_stream] * world, comms=[loop_comm],
+                              plan=plan, motion_reach=3, loopback=True)
+    assert drv.plan == plan
+    gbs = [G.gb_dev(f) for f in fr]
+    torch.cuda.synchronize()
+    prev_in = None
+    for k in range(N):
+        want = whole.frame(fr[k]["radiance"], gbs[k], gbs[max(k - 1, 0)])
+        torch.cuda.synchronize()
+        cur_in = [_strip_inputs(G, fr[k], lay, storage) for lay in drv.layouts]
+        outs = drv.frame([c[0] for c in cur_in], [c[1] for c in cur_in], [p[1] for p in prev_in] if prev_in else None)
+        drv.sync()
+        got = np.concatenate([G.host(drv.owned(r, o)) for r, o in enumerate(outs)], 0)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), f"plan {plan}: frame {k}"
+        prev_in = cur_in
+    hist = np.concatenate([G.host(drv.owned(r, drv.state_plane(r, F.PLANE_HISTORY, 1 - drv.pingpong(r)))) for r in range(world)], 0)
+    assert np.array_equal(hist, whole.taps["hist"])
+    drv.close()
+
+
+def test_config4_8k_as_eight_strips_of_540_rows(G, loop_comm):
+    """BASELINE.json configs[3]: 7680x4320 fp32 cut into 8 strips x 540 rows (plan auto = ghost, 69-row halo), two frames through
+    the C++ strip driver with its RCCL exchanges, bitwise against the whole frame on the same device."""
+    import torch
+    from svgf_amd import filter as F
+    from svgf_amd import strips
+    W, H, world, storage = 7680, 4320, 8, "f32"
+    sc = synth.make_scene(W, H, 0)
+    rads = [synth.make_radiance(sc["base"], W, k) for k in range(2)]
+    params = F.Params(storage=storage, steps=5)
+    drv = strips.NativeStrips(W, H, world, params, list(range(world)), [0] * world, comms=[loop_comm], plan="auto", motion_reach=4, loopback=True)
+    assert drv.plan == "ghost" and [lay["own"][1] - lay["own"][0] for lay in drv.layouts] == [540] * 8
+    assert drv.layouts[3]["y0"] == 1620 - 69 and drv.layouts[3]["y1"] == 2160 + 69
+    whole = G.HipPipeline(W, H, storage, steps=5)
+    gb = G.gb_dev(sc)
+    strip_gb = [F.GBuffer(*(gb_t[lay["y0"]:lay["y1"]].contiguous() for gb_t in (gb.motion, gb.normal, gb.uv))) for lay in drv.layouts]
+    for k in range(2):
+        want = torch.from_numpy(whole.frame(rads[k], gb, gb))
+        rad = G.dev(rads[k])
+        outs = drv.frame([rad[lay["y0"]:lay["y1"]].contiguous() for lay in drv.layouts], strip_gb, strip_gb if k else None)
+        drv.sync()
+        got = torch.cat([drv.owned(r, o) for r, o in enumerate(outs)], 0).cpu()
+        assert torch.equal(got.view(torch.uint8), want.view(torch.uint8)), f"8K / 8 strips: frame {k}"
+    drv.close()
+
+
+def test_1080p_fp32_full_size(G, loop_comm):
+    """BASELINE.json configs[1] at full size: 1920x1080 fp32, temporal + 5 iterations.  Size-independent properties: history
+    counts 1..HistoryLength on surfaces and 1 on sky; the filtered colour stays inside [0,1] (convex weights of clamped
+    inputs); sky texels filter to exactly 0; two strips tile the whole frame bitwise."""
+    import torch
+    from svgf_amd import filter as F
+    from svgf_amd import strips
+    W, H, base = 1920, 1080, 6
+    fr = synth.make_frame(W, H, 0)
+    d = F.Denoiser(W, H, F.Params(storage="f32", steps=5, history_base=base))
+    gb = G.gb_dev(fr)
+    rad = G.dev(fr["radiance"])
+    sky = torch.from_numpy(fr["region"] == synth.SKY).cuda()
+    outs = []
+    for k in range(8):
+        out = d.Render(rad, gb, gb)
+        h = d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong())
+        assert torch.all(h[~sky] == min(k + 1, base)) and torch.all(h[sky] == 1)
+        assert torch.isfinite(out).all() and out[..., :3].min() >= 0 and out[..., :3].max() <= 1
+        outs.append(out.clone())
+    # sky texels never accumulate history (zero normal), stay on the spatial estimate, whose weights are all pow(0, phi_n) = 0:
+    # exactly 0, copied through every iteration ("faithful but ugly")
+    assert torch.all(outs[-1][sky] == 0)
+    # two strips == the whole frame (stage calls), two frames
+    whole = G.HipPipeline(W, H, "f32", steps=5)
+    drv = strips.NativeStrips(W, H, 2, F.Params(storage="f32", steps=5), [0, 1], [0, 0], comms=[loop_comm], plan="auto", motion_reach=0, loopback=True)
+    sgb = [F.GBuffer(*(t[lay["y0"]:lay["y1"]].contiguous() for t in (gb.motion, gb.normal, gb.uv))) for lay in drv.layouts]
+    for k in range(2):
+        r_np = synth.make_radiance(fr["base"], W, k)
+        want = torch.from_numpy(whole.frame(r_np, gb, gb))
+        r_dev = G.dev(r_np)
+        o = drv.frame([r_dev[lay["y0"]:lay["y1"]].contiguous() for lay in drv.layouts], sgb, sgb if k else None)
+        drv.sync()
+        got = torch.cat([drv.owned(r, t) for r, t in enumerate(o)], 0).cpu()
+        assert torch.equal(got.view(torch.uint8), want.view(torch.uint8)), k
+    drv.close()
+
+
+def test_motion_beyond_the_state_halo_is_reported(G, loop_comm):
+    """A strip's temporal stage never reads outside its rows; a reprojection that would (|mv.y| = 6 rows with motion_reach = 4)
+    used to turn silently into a rejection.  Now it is counted on the device and svgf_strips_sync / svgf_sync return
+    SVGF_ERR_HALO; with a sufficient reach the same sequence is bit-identical and raises nothing."""
+    import torch
+    from svgf_amd import filter as F
+    from svgf_amd import strips
+    W, H, world, N, storage = 256, 420, 3, 3, "f32"
+    fr = frames(W, H, N, mv=(0.0, 6.0))
+    params = F.Params(storage=storage, steps=5)
+    whole = G.HipPipeline(W, H, storage, steps=5)
+    gbs = [G.gb_dev(f) for f in fr]
+    wants = [whole.frame(fr[k]["radiance"], gbs[k], gbs[max(k - 1, 0)]) for k in range(N)]
+    for reach, ok in ((4, False), (6, True)):
+        drv = strips.NativeStrips(W, H, world, params, list(range(world)), [0] * world, comms=[loop_comm], plan="grouped", motion_reach=reach, loopback=True)
+        prev_in, raised = None, False
+        for k in range(N):
+            cur_in = [_strip_inputs(G, fr[k], lay, storage) for lay in drv.layouts]
+            outs = drv.frame([c[0] for c in cur_in], [c[1] for c in cur_in], [p[1] for p in prev_in] if prev_in else None)
+            try:
+                drv.sync()
+            except F.SvgfError as e:
+                assert "halo" in str(e) and "reprojection" in str(e)
+                raised = True
+            got = np.concatenate([G.host(drv.owned(r, o)) for r, o in enumerate(outs)], 0)
+            if ok:
+                assert np.array_equal(got.view(np.uint8), wants[k].view(np.uint8)), k
+            prev_in = cur_in
+        assert raised == (not ok), f"motion_reach {reach}"
+        drv.close()
+    # the same guard through the stage calls of a strip context
+    lay = strips.strips_plan(W, H, 1, world, 5, "grouped", 3, 4)
+    d = F.Denoiser(W, H, params, strip=(lay["y0"], lay["y1"] - lay["y0"], lay["own"][0], lay["own"][1]))
+    rad, gb1 = _strip_inputs(G, fr[1], lay, storage)
+    _, gb0 = _strip_inputs(G, fr[0], lay, storage)
+    d.set_rows(lay["y0"], lay["y1"])                     # temporal on every local row: the outermost ones reproject 6 rows out
+    d.TemporalFilter(d.new_colour(), rad, d.new_colour(), gb1, gb0, d.new_history(), d.new_history(), d.new_moments(), d.new_moments())
+    assert d.halo_violations() > 0
+    with pytest.raises(F.SvgfError, match="halo"):
+        d.sync()
+    d.sync()                                             # the counter was cleared by the failing call
+    wd = F.Denoiser(W, H, params)                        # a whole-frame context holds every row: nothing to count
+    wd.Render(G.dev(fr[1]["radiance"]), gbs[1], gbs[0])
+    wd.sync()
+    assert wd.halo_violations() == 0
+
+
+def test_contexts_name_their_device(G):
+    """Every entry point runs on the context's device and leaves the caller's current device alone; a device that does not exist
+    is refused cleanly (on a 1-GPU box: device 1)."""
+    import ctypes as C
+    import torch
+    from svgf_amd import filter as F
+    n = torch.cuda.device_count()
+    lib = F.load_library()
+    h = C.c_void_p()
+    p = F.Params(storage="f32").to_c()
+    assert lib.svgf_create(C.byref(h), 64, 64, C.byref(p), n, None) == -3 and not h.value          # SVGF_ERR_NO_DEVICE
+    assert lib.svgf_create(C.byref(h), 64, 64, C.byref(p), -1, None) == -3
+    with pytest.raises(F.SvgfError, match="no usable gfx950 device"):
+        F.Denoiser(64, 64, F.Params(storage="f32"), device=n)
+    # two contexts side by side (same device on a 1-GPU box, two devices otherwise), interleaved frames, each equal to a lone run
+    W, H = 200, 90
+    fr = frames(W, H, 3, mv=(1.0, 0.0))
+    devs = [0, 1 % n]
+    ds = [F.Denoiser(W, H, F.Params(storage="f32", steps=3), device=dv) for dv in devs]
+    lone = F.Denoiser(W, H, F.Params(storage="f32", steps=3), device=0)
+    before = torch.cuda.current_device()
+    for k in range(3):
+        want = G.host(lone.Render(G.dev(fr[k]["radiance"]), G.gb_dev(fr[k]), G.gb_dev(fr[k - 1]) if k else None))
+        for d, dv in zip(ds, devs):
+            dev = f"cuda:{dv}"
+            got = G.host(d.Render(G.dev(fr[k]["radiance"], dev), G.gb_dev(fr[k], dev), G.gb_dev(fr[k - 1], dev) if k else None))
+            assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (k, dv)
+        assert torch.cuda.current_device() == before
+    # plane sizes the kernels' 32-bit offsets cannot address are refused at creation
+    assert lib.svgf_create(C.byref(h), 16384, 16384, C.byref(p), 0, None) == -1
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_resize_reallocates_and_restarts(G, storage):
+    """svgf_resize = application::ResizeRenderTextures (App.cu:742-778): after it the context behaves like a new one of the new
+    size (state zeroed, ping-pong restarted), tunables kept."""
+    from svgf_amd import filter as F
+    d = F.Denoiser(200, 120, F.Params(storage=storage, steps=4, phi_colour=7.0))
+    fr = frames(200, 120, 3, mv=(1.0, 0.0))
+    for k in range(3):
+        d.Render(G.dev(fr[k]["radiance"].astype(G.NPDT[storage])), G.gb_dev(fr[k]), G.gb_dev(fr[k - 1]) if k else None)
+    for (W, H) in ((331, 203), (64, 40)):
+        d.Resize(W, H)
+        assert d.size() == (W, H, (0, H, 0, H)) and d.pingpong() == 0 and d.state_plane(F.PLANE_COLOUR, 0) is None
+        fresh = F.Denoiser(W, H, F.Params(storage=storage, steps=4, phi_colour=7.0))
+        fr = frames(W, H, 4, mv=(-2.5, 1.5))
+        for k in range(4):
+            args = (G.dev(fr[k]["radiance"].astype(G.NPDT[storage])), G.gb_dev(fr[k]), G.gb_dev(fr[k - 1]) if k else None)
+            a, b = G.host(d.Render(*args)), G.host(fresh.Render(*args))
+            assert a.shape == (H, W, 4) and np.array_equal(a.view(np.uint8), b.view(np.uint8)), (W, H, k)
+    with pytest.raises(F.SvgfError):
+        d.Resize(0, 10)
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_debug_view_sequences(G, oracle, storage):
+    """SVGFDebugOutput::TemporalFilter (App.cu:602-609): temporal only; ::ATrousWaveletFilter (App.cu:611-620): temporal, then the
+    wavelet filter on what FilterBuffer[0] still holds — the previous frame's result — with iteration 0 feeding RenderBuffer
+    back.  Against the oracle's stage functions sequenced the same way."""
+    from svgf_amd import filter as F
+    W, H, N, steps = 160, 96, 4, 3
+    fr = frames(W, H, N, mv=(1.0, 0.0))
+    dt = CDT[storage]
+    P = dict(depth_threshold=0.8, normal_threshold=0.9, history_base=24, mesh_id_test=1)
+    for mode in ("temporal", "atrous"):
+        d = F.Denoiser(W, H, F.Params(storage=storage, steps=steps))
+        d.set_debug_mode(mode)
+        colour = [np.zeros((H, W, 4), dt) for _ in range(2)]
+        mom = [np.zeros((H, W, 2), dt) for _ in range(2)]
+        hist = [np.zeros((H, W), np.uint8) for _ in range(2)]
+        filt = [np.zeros((H, W, 4), dt) for _ in range(2)]
+        pp_res, Pi = 0, 0
+        for k in range(N):
+            kp = max(k - 1, 0)
+            got = G.host(d.Render(G.dev(fr[k]["radiance"].astype(dt)), G.gb_dev(fr[k]), G.gb_dev(fr[kp]) if k else None))
+            oracle.temporal(W, H, storage, colour[1 - Pi], fr[k]["radiance"].astype(dt), colour[Pi], gbuf(fr[k]), gbuf(fr[kp]), hist[1 - Pi], hist[Pi],
+                            mom[Pi], mom[1 - Pi], **P)
+            if mode == "temporal":
+                want = colour[Pi]
+                assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (mode, k)
+            else:
+                pp = pp_res
+                for i in range(steps):
+                    oracle.atrous(W, H, storage, filt[pp], filt[1 - pp], colour[Pi] if i == 0 else None, gbuf(fr[k]), step=1 << i, phi_colour=10.0,
+                                  phi_normal=128.0, iteration=i)
+                    pp ^= 1
+                pp_res = pp
+                if storage == "f32":
+                    G.assert_colour_close(got, filt[pp], storage, f"debug atrous frame {k}")
+                else:
+                    assert np.abs(got.astype(np.float64) - filt[pp].astype(np.float64)).max() <= 2e-3
+            assert np.array_equal(G.host(d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong())), hist[Pi]), (mode, k)
+            Pi ^= 1
+    with pytest.raises(F.SvgfError):
+        d._check(d.lib.svgf_set_debug_mode(d._h, 7), "svgf_set_debug_mode")
+
+
+def test_parity_report(G, oracle):
+    """Max / mean error of every stage against the oracle on identical inputs, and of the free-running sequence, written to
+    gpurun_out/parity_report.json (copied into profiles/ per round) so that drift is visible from round to round.  Bounds
+    as in tests/gpu_helpers.py:TOL; accept/reject masks must match exactly (mismatch counts are reported and must be 0)."""
+    from svgf_amd import filter as F
+    W, H, N = 256, 144, 8
+    report = {"frame": f"{W}x{H}", "frames": N, "mv": [-2.5, 1.5], "stages": {}}
+    for storage in ("f32", "f16"):
+        fr = frames(W, H, N, mv=(-2.5, 1.5))
+        ref = oracle.Pipeline(W, H, storage, steps=5, nthreads=8)
+        free = G.HipPipeline(W, H, storage, steps=5)
+        d = F.Denoiser(W, H, F.Params(storage=storage, steps=5))
+        gbs = [G.gb_dev(f) for f in fr]
+        acc = {}
+
+        def note(name, got, want):
+            e = np.abs(got.astype(np.float64) - want.astype(np.float64))
+            a = acc.setdefault(name, {"max_abs": 0.0, "sum": 0.0, "n": 0})
+            a["max_abs"] = max(a["max_abs"], float(e.max())); a["sum"] += float(e.sum()); a["n"] += e.size
+        mask_mismatch = 0
+        for k in range(N):
+            kp = max(k - 1, 0)
+            want_out = ref.frame(fr[k]["radiance"], gbuf(fr[k]), gbuf(fr[kp]))
+            t = ref.taps
+            col, hist, mom = d.new_colour(), d.new_history(), d.new_moments()
+            d.TemporalFilter(G.dev(t["prev_colour"]), G.dev(t["radiance"]), col, gbs[k], gbs[kp], G.dev(t["prev_hist"]), hist, mom, G.dev(t["prev_mom"]))
+            mask_mismatch += int((G.host(hist) != t["hist"]).sum())
+            note("temporal_colour", G.host(col), t["temporal"]); note("temporal_moments", G.host(mom), t["mom"])
+            out = d.new_colour()
+            d.FilterMoments(G.dev(t["temporal"]), out, G.dev(t["mom"]), gbs[k], G.dev(t["hist"]))
+            note("moments", G.host(out), t["moments"])
+            for i in range(5):
+                d.FilterKernel(G.dev(t["atrous_in"][i]), out, G.dev(t["temporal"]) if i == 0 else None, gbs[k], 1 << i, i)
+                g_, w_ = G.host(out), t["atrous_out"][i]
+                note(f"atrous_step{1 << i}_colour", g_[..., :3], w_[..., :3]); note(f"atrous_step{1 << i}_variance", g_[..., 3], w_[..., 3])
+            got_free = free.frame(fr[k]["radiance"], gbs[k], gbs[kp])
+            mask_mismatch += int((free.taps["hist"] != t["hist"]).sum())
+            note("free_running_colour", got_free[..., :3], want_out[..., :3])
+        rep = {n: {"max_abs": a["max_abs"], "mean_abs": a["sum"] / a["n"]} for n, a in acc.items()}
+        rep["mask_mismatches"] = mask_mismatch
+        report["stages"][storage] = rep
+        assert mask_mismatch == 0
+        assert rep["temporal_colour"]["max_abs"] == 0.0 and rep["temporal_moments"]["max_abs"] == 0.0          # bit-exact stage
+        lim = 2e-5 + 1e-5 if storage == "f32" else 1e-3
+        for i in range(5):
+            assert rep[f"atrous_step{1 << i}_colour"]["max_abs"] <= lim, (storage, i)
+        assert rep["free_running_colour"]["max_abs"] <= (2e-3 if storage == "f32" else 3e-2)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "parity_report.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    print(json.dumps(report))
