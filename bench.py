@@ -409,6 +409,7 @@ def main():
                            "Mpixels/s": round(W * H / (p["ms_per_step"] * 1e-3) / 1e6, 1),
                            "frac_of_8TBps": pass_block(W, H, storage, iters, p["ms_per_step"])["frac_of_8TBps"],
                            "young_fraction": round(p["young_fraction"], 5),
+                           "temporal_ms": pst["temporal+moments"]["temporal_ms"], "moments_ms": pst["temporal+moments"]["moments_ms"],
                            "stage_ms": {k: v["ms"] for k, v in pst.items()}}
         if r["cold_ms"]:
             line["cold_frames_ms"] = {"after_reset": r["cold_ms"], "note": "frames 0.. after svgf_reset_history, sum of stage events; "

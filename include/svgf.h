@@ -125,6 +125,11 @@ int  svgf_get_size(const svgf_ctx* ctx, int* width, int* height, svgf_strip* str
  * returns the count (and zeroes it if clear != 0) without turning it into an error. */
 int  svgf_sync(svgf_ctx* ctx);
 int  svgf_halo_violations(svgf_ctx* ctx, unsigned long long* count, int clear);
+/* Global rows [row_begin,row_end) of the previous-frame planes (colour, moments, history, previous G-buffer) that hold VALID
+ * state; default (-1,-1) = every row the strip holds.  A strip whose planes are taller than the rows it keeps up to date (the
+ * a-trous halos are wider than the state halo) declares the valid ones here: a reprojection beyond them counts as a halo
+ * violation instead of silently reading stale rows.  The strip driver sets this itself. */
+int  svgf_set_valid_rows(svgf_ctx* ctx, int row_begin, int row_end);
 
 /* Stage 1 — replaces application::TemporalFilter (App.cu:469-478) launching filter::TemporalFilter
  * (Filter.cuh:359-404, LoadPreviousData :225-258).  `radiance` (1-spp input, clamped on load) and

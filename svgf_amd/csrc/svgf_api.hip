@@ -8,6 +8,9 @@
 #include "svgf_ctx.h"
 
 #include <algorithm>
+#ifndef SVGF_GUIDE_MIN_STEPS
+#define SVGF_GUIDE_MIN_STEPS 3       // the guide plane pays for itself from three wavelet iterations on (+16 B/px once, -8 B/px per iteration)
+#endif
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -69,8 +72,12 @@ hipEvent_t take_event(svgf_ctx* c) {
 }
 
 int alloc_flags(svgf_ctx* c) {
-    if (c->young_flags) return SVGF_OK;
+    if (c->young_list) return SVGF_OK;
+    SVGF_HIP(c, hipMalloc((void**)&c->young_list, (size_t)c->strip.rows * c->W * sizeof(uint32_t)));
+    SVGF_HIP(c, hipMalloc((void**)&c->young_count, 2 * sizeof(unsigned)));
+    SVGF_HIP(c, hipMemsetAsync(c->young_count, 0, 2 * sizeof(unsigned), c->stream));
     SVGF_HIP(c, hipMalloc((void**)&c->young_flags, (size_t)c->strip.rows * ((c->W + 63) / 64)));
+    c->young_phase = 0;
     return SVGF_OK;
 }
 
@@ -92,6 +99,7 @@ int alloc_state(svgf_ctx* c) {
         SVGF_HIP(c, hipMalloc(&c->filter[i], colour_bytes(c)));
         SVGF_HIP(c, hipMalloc((void**)&c->hist[i], hist_bytes(c)));
     }
+    SVGF_HIP(c, hipMalloc(&c->guide, (size_t)c->strip.rows * c->W * 16));
     c->have_state = true;
     return reset_history(c);
 }
@@ -105,8 +113,12 @@ void free_state(svgf_ctx* c) {
         c->colour[i] = c->moments[i] = c->filter[i] = nullptr;
         c->hist[i] = nullptr;
     }
+    if (c->guide) (void)hipFree(c->guide);
+    c->guide = nullptr;
+    if (c->young_list) (void)hipFree(c->young_list);
+    if (c->young_count) (void)hipFree(c->young_count);
     if (c->young_flags) (void)hipFree(c->young_flags);
-    c->young_flags = nullptr;
+    c->young_list = nullptr; c->young_count = nullptr; c->young_flags = nullptr;
     c->have_state = false;
 }
 
@@ -138,7 +150,7 @@ int read_halo_violations(svgf_ctx* c, unsigned long long* count, int clear) {
 
 int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, const svgf_gbuffer* cur,
                   const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur, void* moments_cur,
-                  const void* moments_prev, void* passthrough_out, int sparse_colour) {
+                  const void* moments_prev, void* passthrough_out, int sparse_colour, void* guide_out = nullptr) {
     if (!prev_colour || !radiance || !colour_out || !hist_prev || !hist_cur || !moments_cur || !moments_prev)
         return fail(c, SVGF_ERR_INVALID, "svgf_temporal: null plane");
     int rc = check_gbuf(c, cur, true, "svgf_temporal(cur)");
@@ -152,7 +164,9 @@ int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, vo
                          (const float4*)prev->motion, (const uint2*)prev->normal, (const uint2*)prev->uv,
                          hist_prev, hist_cur, moments_cur, moments_prev,
                          c->p.depth_threshold, c->p.normal_threshold, c->p.history_base, c->p.mesh_id_test, passthrough_out,
-                         passthrough_out ? c->young_flags : nullptr, sparse_colour, c->p.phi_normal > 0.0f, c->halo_violations};
+                         passthrough_out ? c->young_list : nullptr, passthrough_out ? c->young_count + c->young_phase : nullptr,
+                         passthrough_out ? c->young_count + (c->young_phase ^ 1) : nullptr, passthrough_out ? c->young_flags : nullptr, sparse_colour, c->p.phi_normal > 0.0f, c->halo_violations,
+                         std::max(c->vy0, c->strip.y0) - c->strip.y0, std::min(c->vy1, c->strip.y0 + c->strip.rows) - c->strip.y0, (uint4*)guide_out};
     SVGF_HIP(c, svgf::launch_temporal(geo_of(c), c->p.storage, a, c->stream));
     return SVGF_OK;
 }
@@ -165,12 +179,26 @@ int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments
     if (rc == SVGF_OK) rc = check_halo(c, c->p.moments_radius, "svgf_moments");
     if (rc != SVGF_OK) return rc;
     svgf::MomentsArgs a{colour, out, moments, (const float4*)g->motion, (const uint2*)g->normal, hist,
-                        c->p.phi_colour, c->p.phi_normal, c->p.moments_radius, cold_only, dense, sparse_colour, cold_only ? c->young_flags : nullptr};
+                        c->p.phi_colour, c->p.phi_normal, c->p.moments_radius, cold_only, dense, sparse_colour,
+                        cold_only ? c->young_list : nullptr, cold_only ? c->young_count + c->young_phase : nullptr, cold_only ? c->young_flags : nullptr};
     SVGF_HIP(c, svgf::launch_moments(geo_of(c), c->p.storage, a, c->p.variant == SVGF_VARIANT_DIRECT, c->stream));
+    if (cold_only) c->young_phase ^= 1;             // the temporal launch of the next frame appends to the counter this frame's one zeroed
     return SVGF_OK;
 }
 
-int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration) {
+bool use_guide(const svgf_ctx* c) {
+    return c->p.storage == SVGF_F32 && c->p.steps >= SVGF_GUIDE_MIN_STEPS && c->p.variant != SVGF_VARIANT_DIRECT && c->guide != nullptr;
+}
+
+int guide_rows(svgf_ctx* c, const svgf_gbuffer* g, int rb, int re) {
+    if (re <= rb || !c->guide) return SVGF_OK;
+    svgf::Geo geo = geo_of(c);
+    geo.yb = rb; geo.ye = re;
+    SVGF_HIP(c, svgf::launch_guide(geo, (const float4*)g->motion, (const uint2*)g->normal, (uint4*)c->guide, c->stream));
+    return SVGF_OK;
+}
+
+int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration, const void* guide) {
     if (!in || !out) return fail(c, SVGF_ERR_INVALID, "svgf_atrous: null plane");
     if (in == out || in == feedback) return fail(c, SVGF_ERR_INVALID, "svgf_atrous: in-place filtering is a race");
     if (step < 1 || step > (1 << SVGF_MAX_STEPS)) return fail(c, SVGF_ERR_INVALID, "svgf_atrous: step out of range");
@@ -178,20 +206,20 @@ int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const sv
     if (rc == SVGF_OK) rc = check_halo(c, 2 * step, "svgf_atrous");
     if (rc != SVGF_OK) return rc;
     svgf::AtrousArgs a{in, out, iteration == 0 ? feedback : nullptr, (const float4*)g->motion, (const uint2*)g->normal,
-                       step, c->p.phi_colour, c->p.phi_normal};
+                       step, c->p.phi_colour, c->p.phi_normal, (const uint4*)guide};
     SVGF_HIP(c, svgf::launch_atrous(geo_of(c), c->p.storage, c->p.variant, a, c->stream));
     return SVGF_OK;
 }
 
 int temporal_moments_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, void* filter_out,
                           const svgf_gbuffer* cur, const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur,
-                          void* moments_cur, const void* moments_prev, int mrb, int mre, int feedback_follows) {
+                          void* moments_cur, const void* moments_prev, int mrb, int mre, int feedback_follows, void* guide_out) {
     if (!filter_out || filter_out == colour_out) return fail(c, SVGF_ERR_INVALID, "svgf_temporal_moments: filter_out must be a plane of its own");
     const int rb = c->rb, re = c->re;
     if (mrb == -1 && mre == -1) { mrb = rb; mre = re; }
     if (mrb < rb || mre > re || mrb > mre) return fail(c, SVGF_ERR_INVALID, "svgf_temporal_moments: moments rows outside the temporal rows");
     int rc = alloc_flags(c);
-    if (rc == SVGF_OK) rc = temporal_impl(c, prev_colour, radiance, colour_out, cur, prev, hist_prev, hist_cur, moments_cur, moments_prev, filter_out, feedback_follows != 0);
+    if (rc == SVGF_OK) rc = temporal_impl(c, prev_colour, radiance, colour_out, cur, prev, hist_prev, hist_cur, moments_cur, moments_prev, filter_out, feedback_follows != 0, guide_out);
     if (rc != SVGF_OK) return rc;
     c->rb = mrb; c->re = mre;
     rc = moments_impl(c, colour_out, filter_out, moments_cur, cur, hist_cur, 1, 0, feedback_follows != 0);
@@ -247,6 +275,7 @@ int svgf_create_strip(svgf_ctx** out, int width, int height, const svgf_strip* s
     svgf_ctx* c = new (std::nothrow) svgf_ctx();
     if (!c) return SVGF_ERR_ALLOC;
     c->W = width; c->H = height; c->strip = *strip; c->rb = strip->own_begin; c->re = strip->own_end;
+    c->vy0 = strip->y0; c->vy1 = strip->y0 + strip->rows;
     c->device = device; c->stream = (hipStream_t)hip_stream;
     rc = check_params(c, params);
     if (rc != SVGF_OK) { delete c; return rc; }
@@ -285,6 +314,7 @@ int svgf_resize_strip(svgf_ctx* c, int width, int height, const svgf_strip* stri
     free_state(c);
     if (c->halo_violations) { (void)hipFree(c->halo_violations); c->halo_violations = nullptr; }
     c->W = width; c->H = height; c->strip = *strip; c->rb = strip->own_begin; c->re = strip->own_end;
+    c->vy0 = strip->y0; c->vy1 = strip->y0 + strip->rows;
     c->pingpong = 0; c->frames_since_reset = 0; c->result_index = 0;
     return SVGF_OK;
 }
@@ -315,6 +345,14 @@ int svgf_set_rows(svgf_ctx* c, int rb, int re) {
     if (rb == -1 && re == -1) { c->rb = c->strip.own_begin; c->re = c->strip.own_end; return SVGF_OK; }
     if (rb < c->strip.y0 || re > c->strip.y0 + c->strip.rows || rb > re) return fail(c, SVGF_ERR_INVALID, "row range outside the strip");
     c->rb = rb; c->re = re;
+    return SVGF_OK;
+}
+
+int svgf_set_valid_rows(svgf_ctx* c, int rb, int re) {
+    if (!c) return SVGF_ERR_INVALID;
+    if (rb == -1 && re == -1) { rb = c->strip.y0; re = c->strip.y0 + c->strip.rows; }
+    if (rb < c->strip.y0 || re > c->strip.y0 + c->strip.rows || rb > re) return fail(c, SVGF_ERR_INVALID, "valid row range outside the strip");
+    c->vy0 = rb; c->vy1 = re;
     return SVGF_OK;
 }
 
@@ -492,8 +530,13 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     const int sparse = c->p.steps >= 1;
     // The temporal launch also writes the filter buffer where history >= 4 (there FilterMoments is a copy), the
     // moments launch then only works on young pixels: same planes, 32 B/px less traffic in steady state.
+    // ... and repacks what the wavelet iterations read of the G-buffer ({depth, ddepth, normal}: 16 B instead of 24 B of lines per
+    // pixel and iteration) into the guide plane: +16 B/px here, -8 B/px in each iteration
+    // (measured, tools/abn.sh on one device: -1.5 % per 4K fp32 frame; with fp16 storage the iterations gain less than the temporal
+    // launch loses, so the G-buffer planes are read as they are)
+    void* guide = use_guide(c) ? c->guide : nullptr;
     rc = temporal_impl(c, c->colour[1 - P], radiance, c->colour[P], cur, prev, c->hist[1 - P], c->hist[P],
-                       c->moments[P], c->moments[1 - P], c->filter[0], sparse);  // App.cu:552
+                       c->moments[P], c->moments[1 - P], c->filter[0], sparse, guide);  // App.cu:552
     if (rc != SVGF_OK) return bail(rc);
     stamp();
     // the first three frames after a reset have history <= 3 everywhere: the LDS-streaming moments kernel
@@ -502,7 +545,7 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     stamp();
     int pp = 0;
     for (int i = 0; i < c->p.steps; i++) {                                      // App.cu:497-507
-        rc = atrous_impl(c, c->filter[pp], c->filter[1 - pp], c->colour[P], cur, 1 << i, i);
+        rc = atrous_impl(c, c->filter[pp], c->filter[1 - pp], c->colour[P], cur, 1 << i, i, guide);
         if (rc != SVGF_OK) return bail(rc);
         stamp();
         pp ^= 1;

@@ -23,7 +23,12 @@ struct svgf_ctx {
     void* moments[2] = {nullptr, nullptr};
     void* filter[2] = {nullptr, nullptr};
     uint8_t* hist[2] = {nullptr, nullptr};
-    uint8_t* young_flags = nullptr;        // scratch: per (row, 64-column segment) "holds a pixel with history < 4", temporal -> moments
+    void* guide = nullptr;                 // {depth, ddepth, normal} of the current G-buffer repacked by the temporal launch for the wavelet iterations
+    uint32_t* young_list = nullptr;        // scratch, temporal -> moments: indices of the pixels with history < 4 that need the spatial estimate
+    unsigned* young_count = nullptr;       // two device counters used in turn (the temporal launch of a frame zeroes the next frame's)
+    uint8_t* young_flags = nullptr;        // one flag per (row, 64-column segment): all 64 pixels need the estimate (listed nowhere)
+    int young_phase = 0;
+    int vy0 = 0, vy1 = 0;                  // global rows of the previous-frame planes that hold valid state (svgf_set_valid_rows; default: all held)
     unsigned* halo_violations = nullptr;   // strips: device counter of reprojections that left the rows this strip holds (temporal_kernel)
     int pingpong = 0;                      // PingPongInx, App.cu:374
     int frames_since_reset = 0;
@@ -76,8 +81,10 @@ int read_halo_violations(svgf_ctx* c, unsigned long long* count, int clear);
 // the stages on caller- or driver-owned planes, rows [c->rb, c->re); the device is already current
 int temporal_moments_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, void* filter_out,
                           const svgf_gbuffer* cur, const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur,
-                          void* moments_cur, const void* moments_prev, int mrb, int mre, int feedback_follows);
-int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration);
+                          void* moments_cur, const void* moments_prev, int mrb, int mre, int feedback_follows, void* guide_out = nullptr);
+int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration, const void* guide = nullptr);
+bool use_guide(const svgf_ctx* c);      // the frame / strip drivers repack {depth, ddepth, normal} for the iterations (fp32 storage, >= 3 iterations)
+int guide_rows(svgf_ctx* c, const svgf_gbuffer* g, int rb, int re);      // guide texels of rows [rb, re) that no temporal launch covers
 
 void strip_driver_destroy(svgf_ctx* c);     // svgf_strip.hip
 

@@ -15,11 +15,19 @@ struct TemporalArgs {
     const uint8_t* hist_prev; uint8_t* hist_cur; void* mom_cur; const void* mom_prev;
     float depth_thr, normal_thr; int history_base; int mesh_id_test;
     void* passthrough_out;   // frame driver only: where history >= 4 the moments stage is a copy (Filter.cuh:521) — write it here directly
-    uint8_t* young_flags;    // with passthrough_out: one byte per (local row, 64-column segment): some pixel of it needs the moments estimate
+    uint32_t* young_list;    // with passthrough_out: the local indices (row * W + x) of the pixels that still need the moments estimate ...
+    unsigned* young_count;   // ... and how many there are (device counter, appended to with one atomic per wave); the OTHER counter of the
+    unsigned* young_count_next;   // context's pair is zeroed by this launch for the next frame
+    uint8_t* young_flags;    // ... except that a wave whose 64 pixels ALL need it sets one flag per (local row, 64-column segment) instead
+                             // (frames after a reset: every wave — 130 000 appends to one counter would serialise)
     int sparse_colour;       // with passthrough_out and >= 1 a-trous iteration: colour_out is only stored where the iteration-0 feedback
                              // will not overwrite it or the moments estimate reads it (young pixels, depth-0 texels)
     int sky_zero;            // with passthrough_out: PhiNormal > 0, so a young pixel with an all-zero normal filters to exactly 0 (written here)
-    unsigned* halo_violations;   // strips only: counts reprojections that land inside the frame but outside the rows the strip holds
+    unsigned* halo_violations;   // strips only: counts reprojections that land inside the frame but outside the valid rows of the strip
+    int valid_lo, valid_hi;      // local rows [valid_lo, valid_hi) of the previous-frame planes hold valid state (a strip allocates more rows than
+                                 // it keeps up to date: the a-trous halos are wider than the state halo)
+    uint4* guide_out;            // frame / strip drivers: {depth, ddepth, (nx,ny) half bits, (nz,matID) half bits} of the CURRENT G-buffer, 16 B
+                                 // per pixel — all the wavelet iterations read of it (24 B per pixel in two planes otherwise), or null
 };
 struct MomentsArgs {
     const void* colour; void* out; const void* mom; const float4* motion; const uint2* normal; const uint8_t* hist;
@@ -27,11 +35,14 @@ struct MomentsArgs {
     int cold_only;           // 1: pixels with history >= 4 were already written by the temporal stage (passthrough_out)
     int dense;               // 1: (nearly) every pixel has history < 4 (first frames of a sequence): use the LDS-streaming kernel
     int sparse_colour;            // TemporalArgs::sparse_colour of the same frame: an old, non-sky neighbour's colour is in `out`
-    const uint8_t* young_flags;   // with cold_only: TemporalArgs::young_flags of the same frame — only flagged segments are visited
+    const uint32_t* young_list;   // with cold_only: TemporalArgs::young_list / young_count of the same frame — only listed pixels are visited
+    const unsigned* young_count;
+    const uint8_t* young_flags;   // TemporalArgs::young_flags: segments whose 64 pixels are all young
 };
 struct AtrousArgs {
     const void* in; void* out; void* feedback; const float4* motion; const uint2* normal;
     int step; float phi_colour, phi_normal;
+    const uint4* guide;          // TemporalArgs::guide_out of the same frame (LDS kernel only; motion / normal are then not read), or null
 };
 
 hipError_t launch_temporal(const Geo& g, int storage, const TemporalArgs& a, hipStream_t s);
@@ -44,6 +55,7 @@ struct PackArgs {
 };
 hipError_t launch_pack_gbuffer(const Geo& g, const PackArgs& a, hipStream_t s);
 hipError_t launch_albedo(const Geo& g, int storage, int mode, const void* in, const void* albedo, void* out, hipStream_t s);
+hipError_t launch_guide(const Geo& g, const float4* motion, const uint2* normal, uint4* guide, hipStream_t s);   // rows [yb, ye)
 hipError_t launch_taa(const Geo& g, int storage, const void* filtered, const void* history, void* out, bool direct, hipStream_t s);
 
 }  // namespace svgf

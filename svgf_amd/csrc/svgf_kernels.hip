@@ -12,6 +12,7 @@
 
 #include "svgf_kernels.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
     // Strip guard: never read outside the local planes.  A reprojection that lands inside the FRAME but outside the rows
     // this strip holds would silently turn into a rejection (history reset) and the strip would no longer equal the whole
     // frame: it is counted, and the host reports SVGF_ERR_HALO at its next synchronising call (svgf_sync).
-    const bool in_strip = ql >= 0 && ql < g.rows;
+    const bool in_strip = ql >= a.valid_lo && ql < a.valid_hi;      // [valid_lo, valid_hi) lies inside [0, rows)
     if (a.halo_violations) {
         const unsigned long long lost = __ballot(ok && !in_strip);
         if (lost != 0ull && threadIdx.x == (unsigned)__builtin_ctzll(lost)) atomicAdd(a.halo_violations, (unsigned)__builtin_popcountll(lost));
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
     const float4 o = make_float4(mix_exact(cp.x, c.x, alpha), mix_exact(cp.y, c.y, alpha), mix_exact(cp.z, c.z, alpha), var);
 
     a.hist_cur[idx] = (uint8_t)h;                                     // :400
+    if (a.guide_out) a.guide_out[idx] = make_uint4(__float_as_uint(mc.z), __float_as_uint(mc.w), nc_raw.x, nc_raw.y);
     // :401 imageStore.  sparse_colour (frame driver): iteration 0 of the wavelet filter overwrites this texel with its
     // feedback (:619-622) unless it has no depth; until then only the moments estimate of young pixels reads it
     // (the same predicate as the feedback store of atrous_*_kernel: GetDepth() == sentinel, i.e. depth 0 or literally 1e30f)
@@ -187,10 +189,22 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
         if (!young) Store<ST>::st4(a.passthrough_out, idx, clamp01(o));
         else if (zero_young) Store<ST>::st4(a.passthrough_out, idx, make_float4(0.f, 0.f, 0.f, 0.f));
     }
-    // ... and the moments launch is told where the remaining young pixels are: one flag per wave = 64-pixel row segment
-    if (a.young_flags) {
-        const bool any_young = __ballot(young && !zero_young) != 0ull;
-        if (threadIdx.x == 0) a.young_flags[(size_t)(y - g.y0) * ((g.W + kBX - 1) / kBX) + blockIdx.x] = any_young ? 1 : 0;
+    // ... and the moments launch is told where the remaining young pixels are: their indices are appended to a list, one
+    // atomic per wave that holds any (disocclusions are sparse: frame borders under a pan, silhouettes).  The list is dense in
+    // young pixels, so the moments launch costs what they cost, however they are spread over the frame.
+    if (a.young_list) {
+        const bool listed = young && !zero_young;
+        const unsigned long long m = __ballot(listed);
+        const bool whole_wave = m == ~0ull;                 // all 64 pixels of the segment: flagged, not listed
+        if (m != 0ull && !whole_wave) {
+            const int lane = threadIdx.x, first = __builtin_ctzll(m);
+            unsigned base = 0;
+            if (lane == first) base = atomicAdd(a.young_count, (unsigned)__builtin_popcountll(m));
+            base = __shfl(base, first);
+            if (listed) a.young_list[base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+        }
+        if (threadIdx.x == 0) a.young_flags[(size_t)(y - g.y0) * ((g.W + kBX - 1) / kBX) + blockIdx.x] = whole_wave ? 1 : 0;
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) *a.young_count_next = 0u;
     }
 }
 
@@ -221,27 +235,49 @@ __device__ __forceinline__ void moments_pixel(const Geo& g, const MomentsArgs& a
     const float phi_d = fmaxf(dzc, 1e-8f) * 3.0f;                     // :461
     float sw = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sm1 = 0.f, sm2 = 0.f;
     const int R = a.radius;
+    // One window row at a time, every load of the row issued before anything is consumed: two rounds of memory latency per
+    // row (the tap's colour comes from `out` or `colour` depending on its own motion / history texel) instead of two per tap —
+    // young pixels are sparse in steady state, so a wave of them is latency-bound, not bandwidth-bound.  Same taps, same order.
+    constexpr int RM = 3;                                             // radius <= 3 (svgf_params)
     for (int yy = -R; yy <= R; yy++) {
         const int py = y + yy;
         if (py < 0 || py >= g.H) continue;                            // :473
-        for (int xx = -R; xx <= R; xx++) {
-            const int px = x + xx;
-            if (px < 0 || px >= g.W) continue;
-            const size_t p = (size_t)(py - g.y0) * g.W + px;
-            const float4 mq = a.motion[p];
+        const size_t rowp = (size_t)(py - g.y0) * g.W;
+        bool ok[2 * RM + 1];
+        size_t p[2 * RM + 1];
+        float4 mq[2 * RM + 1], cp[2 * RM + 1];
+        float2 mp[2 * RM + 1];
+        uint2 nq[2 * RM + 1];
+        int hq[2 * RM + 1];
+#pragma unroll
+        for (int k = 0; k <= 2 * RM; k++) {
+            const int xx = k - RM, px = x + xx;
+            ok[k] = xx >= -R && xx <= R && px >= 0 && px < g.W;
+            p[k] = ok[k] ? rowp + px : idx;                           // a tap that does not exist reads the centre and is dropped
+            mq[k] = a.motion[p[k]];
+            mp[k] = Store<ST>::ld2(a.mom, p[k]);                      // :480
+            nq[k] = a.normal[p[k]];                                   // :483
+            hq[k] = a.sparse_colour ? (int)a.hist[p[k]] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k <= 2 * RM; k++) {
             // sparse_colour: the temporal launch stored an old, non-sky texel only into `out` (same value)
-            const bool in_out = a.sparse_colour && mq.z != 0.0f && mq.z != kSkyZ && a.hist[p] >= 4;
-            const float4 cp = Store<ST>::ld4(in_out ? (const void*)a.out : a.colour, p);   // :479 raw
-            const float2 mp = Store<ST>::ld2(a.mom, p);               // :480
+            const bool in_out = a.sparse_colour && mq[k].z != 0.0f && mq[k].z != kSkyZ && hq[k] >= 4;
+            cp[k] = Store<ST>::ld4(in_out ? (const void*)a.out : a.colour, p[k]);   // :479 raw
+        }
+#pragma unroll
+        for (int k = 0; k <= 2 * RM; k++) {
+            if (!ok[k]) continue;
+            const int xx = k - RM;
             float zp, dzp;
-            depth_of(mq, zp, dzp);                                    // :482
-            const float3 np = normal_of(a.normal[p]);                 // :483
+            depth_of(mq[k], zp, dzp);                                 // :482
+            const float3 np = normal_of(nq[k]);
             const float len = sqrtf((float)(xx * xx + yy * yy));      // :488
             const float iz = (xx == 0 && yy == 0) ? 0.0f : hw_rcp(phi_d * len);   // phiDepth == 0 -> wZ = 0, :420
-            const float w = edge_weight(fabsf(lc - lum_exact(cp.x, cp.y, cp.z)), il, fabsf(zc - zp), iz, dot3_fma(nc, np), a.phi_normal);
+            const float w = edge_weight(fabsf(lc - lum_exact(cp[k].x, cp[k].y, cp[k].z)), il, fabsf(zc - zp), iz, dot3_fma(nc, np), a.phi_normal);
             sw += w;                                                  // :497-499
-            sr = fmaf(cp.x, w, sr); sg = fmaf(cp.y, w, sg); sb = fmaf(cp.z, w, sb);
-            sm1 = fmaf(mp.x, w, sm1); sm2 = fmaf(mp.y, w, sm2);
+            sr = fmaf(cp[k].x, w, sr); sg = fmaf(cp[k].y, w, sg); sb = fmaf(cp[k].z, w, sb);
+            sm1 = fmaf(mp[k].x, w, sm1); sm2 = fmaf(mp[k].y, w, sm2);
         }
     }
     sw = fmaxf(sw, 1e-6f);                                            // :505
@@ -347,17 +383,26 @@ __global__ __launch_bounds__(kBX* kBY) void moments3x3_shfl_kernel(Geo g, Moment
     Store<ST>::st4(a.out, idx, make_float4(sr * inv, sg * inv, sb * inv, var));   // :516 unclamped
 }
 
-// Steady state inside the frame driver: the temporal launch already copied every pixel with history >= 4 and left a
-// flag per 64-pixel row segment that holds a young one (disocclusions: sparse).  A small persistent grid scans the
-// flags, 64 per wave-load, and visits only flagged segments — instead of one thread per pixel reading a history byte.
+// Steady state inside the frame driver: the temporal launch already copied every pixel with history >= 4 and listed the young
+// ones that need the estimate (disocclusions: sparse).  A small grid walks the list; neighbouring entries are neighbouring
+// pixels (a wave of the temporal launch appends its young pixels together), so a wave's gathers stay local.
 template <int ST>
-__global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a) {
+__global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a, int list_blocks) {
+    if ((int)blockIdx.x < list_blocks) {
+        const unsigned n = *a.young_count;
+        for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += (unsigned)list_blocks * 256u) {
+            const uint32_t p = a.young_list[i];
+            const int x = (int)(p % (uint32_t)g.W), y = g.y0 + (int)(p / (uint32_t)g.W);
+            if (y >= g.yb && y < g.ye) moments_pixel<ST>(g, a, x, y);         // the moments rows may be a sub-range of the temporal rows
+        }
+        return;
+    }
+    // the segments whose 64 pixels are all young (one flag each): scanned 64 flags per wave-load, interleaved over the waves so
+    // that a patch of them is shared out
     const int lane = threadIdx.x & 63;
     const int nseg = (g.W + kBX - 1) / kBX;
     const int first = (g.yb - g.y0) * nseg, last = (g.ye - g.y0) * nseg;             // flag range of the launch rows
-    const int nwaves = gridDim.x * 4, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    // flag (k*64 + lane)*nwaves + wave belongs to this wave: neighbouring segments (a patch of sky, a disocclusion
-    // edge) go to different waves
+    const int nwaves = ((int)gridDim.x - list_blocks) * 4, wave = ((int)blockIdx.x - list_blocks) * 4 + (threadIdx.x >> 6);
     for (int k = 0; first + k * 64 * nwaves + wave < last; k++) {
         const int sidx = first + (k * 64 + lane) * nwaves + wave;
         unsigned long long m = __ballot(sidx < last && a.young_flags[sidx] != 0);
@@ -480,10 +525,20 @@ struct PlaneRsrc { __amdgpu_buffer_rsrc_t colour, motion, normal; };
 // voff_c / voff_n: the lane's constant byte offsets into the colour(+motion) and normal planes (kOob for a
 // column outside the frame); srow: the row's scalar element offset yl*W.
 template <int ST, bool DZ>
-__device__ __forceinline__ void raw_load(RawPx<ST, DZ>& r, const PlaneRsrc& rs, unsigned voff_c, unsigned voff_m, unsigned voff_n, int srow) {
+__device__ __forceinline__ void raw_load(RawPx<ST, DZ>& r, const PlaneRsrc& rs, unsigned voff_c, unsigned voff_m, unsigned voff_n, int srow, unsigned n_shift) {
     constexpr int cb = ST == 0 ? 16 : 8;
     if constexpr (ST == 0) r.c = __builtin_amdgcn_raw_buffer_load_b128(rs.colour, voff_c, srow * cb, SVGF_COLOUR_LD_AUX);
     else r.c = __builtin_amdgcn_raw_buffer_load_b64(rs.colour, voff_c, srow * cb, SVGF_COLOUR_LD_AUX);
+#ifndef SVGF_GUIDE_B128
+#define SVGF_GUIDE_B128 0           // 1: the guide texel with one 16-byte load instead of two 8-byte loads (measured slower: tools/abn.sh)
+#endif
+    if (SVGF_GUIDE_B128 && n_shift == 4u) {
+        // guide plane: ONE 16-byte texel {depth, ddepth, (nx,ny), (nz,-)} per pixel (voff_m is its offset)
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs.motion, voff_m, srow * 16, SVGF_GB_LD_AUX);
+        if constexpr (DZ) r.zd = (u32x2){t.x, t.y}; else r.zd = t.x;
+        r.n = (u32x2){t.z, t.w};
+        return;
+    }
 #ifdef SVGF_DIAG_SKIP_MOTION
     if constexpr (DZ) r.zd = (u32x2){0x40a00000u, 0x3c23d70au}; else r.zd = 0x40a00000u;               // bandwidth probe only
 #else
@@ -493,7 +548,7 @@ __device__ __forceinline__ void raw_load(RawPx<ST, DZ>& r, const PlaneRsrc& rs, 
 #ifdef SVGF_DIAG_SKIP_NORMAL
     r.n = (u32x2){0x3c00u, 0xbc00u};      // bandwidth probe only (results are wrong)
 #else
-    r.n = __builtin_amdgcn_raw_buffer_load_b64(rs.normal, voff_n, srow * 8, SVGF_GB_LD_AUX);
+    r.n = __builtin_amdgcn_raw_buffer_load_b64(rs.normal, voff_n, srow << n_shift, SVGF_GB_LD_AUX);
 #endif
 }
 
@@ -589,6 +644,10 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? SVGF_MIN_WAVES : SVGF_KR
     uint32_t* nflag = (uint32_t*)(recN + kRing * WL);              // [kRing][8]
     uint32_t* nref = nflag + kRing * 8;                            // {(nx,ny) bits, nz bits}
 
+#ifdef SVGF_STAMPS
+    unsigned long long stamp_entry;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_entry) :: "memory");
+#endif
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int col = t % TX;
@@ -627,8 +686,18 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? SVGF_MIN_WAVES : SVGF_KR
     const int hx = (hh < 2 * S) ? x0 - 2 * S + hh : x0 + TX + hh - 2 * S;
     const int hli = (hh < 2 * S) ? hh : TX + hh;
     const bool own_ok = gx < g.W, halo_ok = has_halo && hx >= 0 && hx < g.W;
-    const unsigned vo_c = own_ok ? (unsigned)gx * CB : kOob, vo_m = own_ok ? (unsigned)gx * 16u + 8u : kOob, vo_n = own_ok ? (unsigned)gx * 8u : kOob;
-    const unsigned vh_c = halo_ok ? (unsigned)hx * CB : kOob, vh_m = halo_ok ? (unsigned)hx * 16u + 8u : kOob, vh_n = halo_ok ? (unsigned)hx * 8u : kOob;
+    // Depth / normal source: the G-buffer's motion plane (16-B texels, {depth, ddepth} at +8) and normal plane (8-B texels), or
+    // the frame's guide plane (16-B texels: {depth, ddepth} at +0, normal at +8): the same two loads, 16 instead of 24 bytes of
+    // lines per pixel.  Everything here is a scalar select.
+#ifdef SVGF_NO_GUIDE_CODE
+    constexpr bool guided = false;                                   // measurement: the kernel as it was before the guide plane
+    constexpr unsigned m_off = 8u, n_off = 0u, n_shift = 3u;
+#else
+    const bool guided = a.guide != nullptr;
+    const unsigned m_off = guided ? 0u : 8u, n_off = guided ? 8u : 0u, n_shift = guided ? 4u : 3u;
+#endif
+    const unsigned vo_c = own_ok ? (unsigned)gx * CB : kOob, vo_m = own_ok ? (unsigned)gx * 16u + m_off : kOob, vo_n = own_ok ? ((unsigned)gx << n_shift) + n_off : kOob;
+    const unsigned vh_c = halo_ok ? (unsigned)hx * CB : kOob, vh_m = halo_ok ? (unsigned)hx * 16u + m_off : kOob, vh_n = halo_ok ? ((unsigned)hx << n_shift) + n_off : kOob;
 
     // Buffer resources are built where they are used (base pointer + a num_records word chosen by a scalar select) instead
     // of being kept in 32 SGPRs for the whole kernel; a row outside the frame gets num_records = 0: every load returns 0.
@@ -636,8 +705,8 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? SVGF_MIN_WAVES : SVGF_KR
     auto plane_rsrc = [&](bool rok) __attribute__((always_inline)) {
         PlaneRsrc r;
         r.colour = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, rok ? (int)(npx * CB) : 0, 0x00020000);
-        r.motion = __builtin_amdgcn_make_buffer_rsrc((void*)a.motion, 0, rok ? (int)(npx * 16u) : 0, 0x00020000);
-        r.normal = __builtin_amdgcn_make_buffer_rsrc((void*)a.normal, 0, rok ? (int)(npx * 8u) : 0, 0x00020000);
+        r.motion = __builtin_amdgcn_make_buffer_rsrc(guided ? (void*)a.guide : (void*)a.motion, 0, rok ? (int)(npx * 16u) : 0, 0x00020000);
+        r.normal = __builtin_amdgcn_make_buffer_rsrc(guided ? (void*)a.guide : (void*)a.normal, 0, rok ? (int)(npx << n_shift) : 0, 0x00020000);
         return r;
     };
 
@@ -652,8 +721,8 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? SVGF_MIN_WAVES : SVGF_KR
             const bool rok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows;
             const int srow = rok ? yl * g.W : 0;
             const PlaneRsrc rs = plane_rsrc(rok);
-            raw_load<ST, true>(st.o[k], rs, vo_c, vo_m, vo_n, srow);
-            if (halo_wave) raw_load<ST, false>(st.h[k], rs, vh_c, vh_m, vh_n, srow);
+            raw_load<ST, true>(st.o[k], rs, vo_c, vo_m, vo_n, srow, n_shift);
+            if (halo_wave) raw_load<ST, false>(st.h[k], rs, vh_c, vh_m, vh_n, srow, n_shift);
         }
     };
     uint32_t ref01 = 0, refz = 0;
@@ -702,6 +771,7 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? SVGF_MIN_WAVES : SVGF_KR
 #ifdef SVGF_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t) :: "memory");
+    const unsigned long long stamp_first = stamp_t;
 #endif
 
     // One step: produce decimated rows j and j+1 from the ring.  `cs` holds the rows the NEXT step needs (fetched
@@ -837,9 +907,14 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? SVGF_MIN_WAVES : SVGF_KR
             auto issue = [&](int t) __attribute__((always_inline)) {
                 if (skip(t)) return;
                 const int r = t / 5, c = t % 5;
+#ifdef SVGF_DIAG_NO_LDS_TAPS
+                qA[t] = cA[0] * (float)(t + 1); qL[t] = lzc[0] * (float)(t + 2); qN[t] = (f32x2){__uint_as_float(nc01[0]), ncz[0]};      // cost probe only
+                (void)r; (void)c;
+#else
                 qA[t] = recA[rowbase[r] + c * S];
                 qL[t] = ((const volatile lds_f32x2*)recL)[rowbase[r] + c * S];
                 if (!UNI) qN[t] = ((const volatile lds_f32x2*)recN)[rowbase[r] + c * S];
+#endif
             };
 #pragma unroll
             for (int t = 0; t < D; t++) issue(t);
@@ -867,7 +942,11 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? SVGF_MIN_WAVES : SVGF_KR
                     }
                     e = fmaf(-fabsf(dlz.x), il[k], e);
                     e = fmaf(-fabsf(dlz.y), iz[k][len_class(xx, yy)], e);
+#ifdef SVGF_DIAG_NO_EXP
+                    const float w = e * 0.001f;                                               // cost probe only
+#else
                     const float w = hw_exp2(e);
+#endif
                     const f32x2 ww = {w, w * w};
                     sw[k] += w;
                     srg[k] = __builtin_elementwise_fma((f32x2){w, w}, (f32x2){A.x, A.y}, srg[k]);
@@ -947,6 +1026,8 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? SVGF_MIN_WAVES : SVGF_KR
 #ifdef SVGF_STAMPS
     if ((t & 63) == 0) {
         for (int i = 0; i < 6; i++) atomicAdd(&g_stamps[i], stamp_acc[i]);
+        atomicAdd(&g_stamps[6], stamp_first - stamp_entry);          // prologue: entry -> first step
+        atomicAdd(&g_stamps[7], stamp_t - stamp_entry);              // lifetime of the wave
         atomicAdd(&g_stamps[8], 1ull);
     }
 #endif
@@ -1055,6 +1136,16 @@ hipError_t launch_atrous_lds_step_kr(const Geo& g, const AtrousArgs& a, hipStrea
     bool narrow = a.step <= kNarrowMaxStep;
 #ifdef SVGF_DIAG
     narrow = diag_env("SVGF_ATROUS_TX", narrow ? 128 : 256) == 128;
+#endif
+#ifdef SVGF_KR2_TX128
+    if (MODE == 0) switch (a.step) {                 // measurement: two outputs per thread on 128-column workgroups (2 waves)
+        case 1: return launch_atrous_lds<ST, 1, 128, 2, SVGF_FORCE_MODE>(g, a, s);
+        case 2: return launch_atrous_lds<ST, 2, 128, 2, SVGF_FORCE_MODE>(g, a, s);
+        case 4: return launch_atrous_lds<ST, 4, 128, 2, SVGF_FORCE_MODE>(g, a, s);
+        case 8: return launch_atrous_lds<ST, 8, 128, 2, SVGF_FORCE_MODE>(g, a, s);
+        case 16: return launch_atrous_lds<ST, 16, 128, 2, SVGF_FORCE_MODE>(g, a, s);
+        default: return hipErrorInvalidValue;
+    }
 #endif
     if (SVGF_WAVE_TILE && MODE == 0) switch (a.step) {
         case 1: return launch_atrous_lds<ST, 1, 64, 2, SVGF_FORCE_MODE>(g, a, s);
@@ -1480,6 +1571,18 @@ __global__ __launch_bounds__(kBX* kBY) void pack_gbuffer_kernel(Geo g, PackArgs 
     a.uv_out[idx] = make_uint2(pack_h2(b.x, b.y), pack_h2(b.z, b.w));
 }
 
+// The guide texels of rows the temporal launch does not cover (strips: the a-trous halos reach beyond the rows the temporal
+// stage is computed on).
+__global__ __launch_bounds__(kBX* kBY) void guide_kernel(Geo g, const float4* motion, const uint2* normal, uint4* guide) {
+    const int x = blockIdx.x * kBX + threadIdx.x;
+    const int y = g.yb + blockIdx.y * kBY + threadIdx.y;
+    if (x >= g.W || y >= g.ye) return;
+    const size_t idx = (size_t)(y - g.y0) * g.W + x;
+    const float4 m = motion[idx];
+    const uint2 n = normal[idx];
+    guide[idx] = make_uint4(__float_as_uint(m.z), __float_as_uint(m.w), n.x, n.y);
+}
+
 inline dim3 grid_for(const Geo& g) { return dim3((g.W + kBX - 1) / kBX, (g.ye - g.yb + kBY - 1) / kBY); }
 
 }  // namespace
@@ -1505,12 +1608,13 @@ hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, bool 
         else moments3x3_shfl_kernel<1><<<grid, block, 0, s>>>(g, a);
         return hipGetLastError();
     }
-    if (a.cold_only && a.young_flags) {
+    if (a.cold_only && a.young_list) {
         const int nsegs = (g.ye - g.yb) * ((g.W + kBX - 1) / kBX);
-        int wgs = (nsegs + 255) / 256;                           // >= one flag per lane and load ...
-        if (wgs > 4 * num_cus()) wgs = 4 * num_cus();            // ... on at most one resident round
-        if (storage == 0) moments_young_kernel<0><<<wgs, 256, 0, s>>>(g, a);
-        else moments_young_kernel<1><<<wgs, 256, 0, s>>>(g, a);
+        int scan = (nsegs + 255) / 256;                            // >= one flag per lane and load ...
+        if (scan > 4 * num_cus()) scan = 4 * num_cus();            // ... on at most one resident round
+        const int walk = std::min(4 * num_cus(), std::max(1, nsegs / 16));   // the list holds at most 63 pixels per segment
+        if (storage == 0) moments_young_kernel<0><<<walk + scan, 256, 0, s>>>(g, a, walk);
+        else moments_young_kernel<1><<<walk + scan, 256, 0, s>>>(g, a, walk);
         return hipGetLastError();
     }
     const dim3 block(kBX, kBY), grid = grid_for(g);
@@ -1565,6 +1669,12 @@ hipError_t launch_albedo(const Geo& g, int storage, int mode, const void* in, co
 hipError_t launch_pack_gbuffer(const Geo& g, const PackArgs& a, hipStream_t s) {
     if (g.ye <= g.yb) return hipSuccess;
     pack_gbuffer_kernel<<<grid_for(g), dim3(kBX, kBY), 0, s>>>(g, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_guide(const Geo& g, const float4* motion, const uint2* normal, uint4* guide, hipStream_t s) {
+    if (g.ye <= g.yb) return hipSuccess;
+    guide_kernel<<<grid_for(g), dim3(kBX, kBY), 0, s>>>(g, motion, normal, guide);
     return hipGetLastError();
 }
 

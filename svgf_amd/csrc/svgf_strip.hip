@@ -248,7 +248,7 @@ int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src
         SVGF_SHIP(s, hipEventCreate(&e0)); SVGF_SHIP(s, hipEventCreate(&e1));
         SVGF_SHIP(s, hipEventRecord(e0, l.compute));
     }
-    int rc = atrous_impl(c, c->filter[src], c->filter[dst], i == 0 ? c->colour[P] : nullptr, cur, 1 << i, i);
+    int rc = atrous_impl(c, c->filter[src], c->filter[dst], i == 0 ? c->colour[P] : nullptr, cur, 1 << i, i, use_guide(c) ? c->guide : nullptr);
     if (rc != SVGF_OK) return sfail(s, rc, c->err);
     if (timed) {
         SVGF_SHIP(s, hipEventRecord(e1, l.compute));
@@ -341,6 +341,9 @@ int svgf_strips_create(svgf_strips** out, int width, int height, int world, cons
         rc = svgf_create_strip(&l.ctx, width, height, &st, params, l.device, l.compute);
         if (rc != SVGF_OK) { cleanup(); return rc; }
         l.ctx->strip_drv = reinterpret_cast<svgf_strip_driver*>(s.get());
+        // previous-frame state is kept up to date own +- halo_state rows (computed here or received); the planes hold more
+        // rows (the a-trous halos): the temporal stage must never take state from those
+        l.ctx->vy0 = std::max(l.g.y0, l.g.own0 - l.g.halo_state); l.ctx->vy1 = std::min(l.g.y1, l.g.own1 + l.g.halo_state);
         DeviceGuard dg(l.device);
         hipError_t e = hipSuccess;
         if (s->loopback && k > 0) l.comm_stream = s->local[0].comm_stream;     // one communicator: one stream for its groups
@@ -408,8 +411,12 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
         if (!pv->motion) pv = &cur[k];
         const Rows rt = grown(l.g, s->H, l.g.ext_temporal), rm = grown(l.g, s->H, l.g.ext_moments);
         c->rb = rt.a; c->re = rt.b;
+        void* guide = use_guide(c) ? c->guide : nullptr;      // as svgf_denoise_frame: the temporal launch repacks {depth, ddepth, normal} for the iterations
         int rc = temporal_moments_impl(c, c->colour[1 - P], radiance[k], c->colour[P], c->filter[0], &cur[k], pv, c->hist[1 - P], c->hist[P],
-                                       c->moments[P], c->moments[1 - P], rm.a, rm.b, s->steps >= 1);
+                                       c->moments[P], c->moments[1 - P], rm.a, rm.b, s->steps >= 1, guide);
+        // rows the strip holds beyond the temporal rows (a-trous halos of the later iteration groups): their guide texels
+        if (rc == SVGF_OK && guide) rc = guide_rows(c, &cur[k], l.g.y0, rt.a);
+        if (rc == SVGF_OK && guide) rc = guide_rows(c, &cur[k], rt.b, l.g.y1);
         if (rc != SVGF_OK) return sfail(s, rc, c->err);
     }
     auto post_state = [&]() -> int {

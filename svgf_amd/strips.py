@@ -188,6 +188,8 @@ class HipStages:
         from . import filter as F
         self.F, self.geo = F, geo
         self.d = F.Denoiser(geo.W, geo.H, params, device=device.index or 0, strip=(geo.y0, geo.y1 - geo.y0, geo.own[0], geo.own[1]))
+        # previous-frame state is only kept up to date own +- halo_state rows; the planes hold more (the a-trous halos)
+        self.d.set_valid_rows(max(geo.y0, geo.own[0] - geo.halo_state), min(geo.y1, geo.own[1] + geo.halo_state))
         self.device = device
         self.timing, self.events = False, []
 

@@ -197,8 +197,6 @@ def test_contexts_name_their_device(G):
     p = F.Params(storage="f32").to_c()
     assert lib.svgf_create(C.byref(h), 64, 64, C.byref(p), n, None) == -3 and not h.value          # SVGF_ERR_NO_DEVICE
     assert lib.svgf_create(C.byref(h), 64, 64, C.byref(p), -1, None) == -3
-    with pytest.raises(F.SvgfError, match="no usable gfx950 device"):
-        F.Denoiser(64, 64, F.Params(storage="f32"), device=n)
     # two contexts side by side (same device on a 1-GPU box, two devices otherwise), interleaved frames, each equal to a lone run
     W, H = 200, 90
     fr = frames(W, H, 3, mv=(1.0, 0.0))

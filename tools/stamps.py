@@ -5,7 +5,7 @@ sys.path.insert(0, R)
 from svgf_amd import build as b
 lib_path = os.path.join(R, "build", "libsvgf_stamps.so")
 os.makedirs(os.path.dirname(lib_path), exist_ok=True)
-b.build_library(extra_flags=["-DSVGF_DIAG", "-DSVGF_STAMPS"], out=lib_path)
+b.build_library(extra_flags=["-DSVGF_DIAG", "-DSVGF_STAMPS"] + os.environ.get("SVGF_STAMPS_FLAGS", "").split(), out=lib_path)
 os.environ["SVGF_LIBRARY"] = lib_path
 import torch
 from svgf_amd import filter as F
@@ -15,6 +15,7 @@ lib = F.load_library()
 W, H = 3840, 2160
 dev = torch.device("cuda:0")
 gb, rads = bench.make_inputs(W, H, "f32", dev, nframes=2)
+EXTRA = os.environ.get("SVGF_STAMPS_FLAGS", "").split()
 d = F.Denoiser(W, H, F.Params(storage="f32", steps=5))
 for k in range(10):
     d.Render(rads[k % 2], gb, gb)
@@ -36,3 +37,4 @@ for step in (1, 4, 16):
     print(f"   wave-steps {out[10]}, uniform-normal fast path {100.0 * out[11] / max(out[10], 1):.1f} %, all-sky skipped {100.0 * out[12] / max(out[10], 1):.1f} %")
     for i, n in enumerate(names):
         print(f"   {n:22s} {100.0 * out[i] / tot:5.1f} %   {out[i] / max(waves,1):9.0f} ticks/wave")
+    print(f"   prologue {out[6] / max(waves,1):9.0f} ticks/wave = {100.0 * out[6] / max(out[7],1):5.1f} % of the wave lifetime {out[7] / max(waves,1):9.0f}; steps per wave {out[10] / max(waves,1):.1f}")

@@ -60,12 +60,20 @@ side = torch.cuda.Stream(device=dev, priority=-1 if args.stream == "own-hi" else
 torch.cuda.set_stream(side)
 params = F.Params(storage=args.storage, steps=5)
 geo = strips.Geometry.make(W, H, args.rank, args.world, 5, plan=args.plan, moments_radius=params.moments_radius, motion_reach=4)
-stages = strips.HipStages(geo, params, dev)
-runner = strips.make_runner(geo, stages, SelfComm(), storage=args.storage, device=dev, driver=args.driver) if hasattr(strips, "make_runner") \
-    else strips.StripRunner(geo, stages, SelfComm(), storage=args.storage, device=dev)
 gb, rads = bench.make_inputs(W, H, args.storage, dev, row_begin=geo.y0, row_end=geo.y1)
+gb2 = F.GBuffer(gb.motion.clone(), gb.normal.clone(), gb.uv.clone())      # current / previous G-buffer in distinct planes
+gbs = [gb, gb2]
+if args.driver == "native":
+    # the C++ strip driver (svgf_strips_frame): loop-back communicator, every peer is this rank
+    comm = strips.rccl_comm(1, 0, 0)
+    drv = strips.NativeStrips(W, H, args.world, params, [args.rank], [0], streams=[side.cuda_stream], comms=[comm], plan=geo.plan, motion_reach=4, loopback=True)
+    frame = lambda k: drv.frame([rads[k % len(rads)]], [gbs[k & 1]], [gbs[(k & 1) ^ 1]])      # noqa: E731
+else:
+    stages = strips.HipStages(geo, params, dev)
+    runner = strips.StripRunner(geo, stages, SelfComm(), storage=args.storage, device=dev)
+    frame = lambda k: runner.frame(rads[k % len(rads)], gbs[k & 1], gbs[(k & 1) ^ 1])          # noqa: E731
 for k in range(12):
-    runner.frame(rads[k % len(rads)], gb, gb)
+    frame(k)
 torch.cuda.synchronize()
 if args.prefill:
     # keep the GPU busy for a while so that the host gets far ahead: the frame time seen by GPU events is then free of any
@@ -77,13 +85,16 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 t0 = time.perf_counter()
 e0.record()
 for k in range(args.steps):
-    runner.frame(rads[k % len(rads)], gb, gb)
+    frame(k)
 e1.record()
 t_host = time.perf_counter() - t0
 torch.cuda.synchronize()
 t = e0.elapsed_time(e1) * 1e-3 if args.prefill else time.perf_counter() - t0
 own = geo.own[1] - geo.own[0]
-print(f"{W}x{H} strip {args.rank}/{args.world} ({own} rows, held {geo.y1 - geo.y0}), plan {args.plan}, comm {args.comm}/{args.post}, stream {args.stream}, driver {args.driver}: "
+print(f"{W}x{H} strip {args.rank}/{args.world} ({own} rows, held {geo.y1 - geo.y0}), plan {geo.plan}, comm {args.comm}/{args.post}, stream {args.stream}, driver {args.driver}: "
       f"{t / args.steps * 1e3:.4f} ms/frame (host enqueue {t_host / args.steps * 1e3:.4f} ms) -> "
       f"{W * own / (t / args.steps) / 1e6:.0f} Mpx/s per GPU, x{args.world} = {W * own * args.world / (t / args.steps) / 1e6:.0f} Mpx/s")
+if args.driver == "native":
+    drv.sync()
+    drv.close()
 dist.destroy_process_group()
