@@ -146,6 +146,20 @@ public:
     // 1-spp radiance before TemporalFilter, and on the filtered plane after WaveletFilter.
     void Demodulate(const void* Albedo) { check(svgf_demodulate(Ctx, Buffers.ColourBuffer->Data, Albedo, Buffers.ColourBuffer->Data), "svgf_demodulate"); }
     void Modulate(void* Filtered, const void* Albedo) { check(svgf_modulate(Ctx, Filtered, Albedo, Filtered), "svgf_modulate"); }
+    // application::ResizeRenderTextures (App.cu:742-778): every buffer reallocated at the new size (zero-filled), accumulation
+    // restarted (ResetRender, App.cu:777); tunables stay.
+    void Resize(uint32_t Width, uint32_t Height) {
+        check(svgf_resize(Ctx, static_cast<int>(Width), static_cast<int>(Height)), "svgf_resize");
+        Buffers.Init(Width, Height);
+        PingPongInx = 0;
+    }
+    // The G-buffer of the reference lives in array-backed GL textures mapped into CUDA (CudaUtil.h:68-99); here an array-backed
+    // (hipArray_t) render target is copied into the linear plane the filter reads, and the filtered plane back into the display
+    // texture's array (cudaMemcpyToArray, App.cu:561).
+    void ImportGBufferPlane(int Plane, hipArray_const_t Array, void* LinearPlane) { check(svgf_import_gbuffer_array(Ctx, Plane, Array, LinearPlane), "svgf_import_gbuffer_array"); }
+    void ImportGBufferPlane(int Plane, const void* Pitched, size_t PitchBytes, void* LinearPlane) { check(svgf_import_gbuffer_pitched(Ctx, Plane, Pitched, PitchBytes, LinearPlane), "svgf_import_gbuffer_pitched"); }
+    void ExportToArray(const void* Plane, hipArray_t Array) { check(svgf_export_to_array(Ctx, Plane, Array), "svgf_export_to_array"); }
+    void Sync() { check(svgf_sync(Ctx), "svgf_sync"); }
     // application::EndFrame's share (App.cu:374): this frame's colour/moments/history become the previous frame's
     void EndFrame() {
         std::swap(Buffers.ColourBuffer, Buffers.HistoryBufferColour);

@@ -29,7 +29,9 @@
 #define SVGF_GB_LD_AUX 0
 #endif
 #ifndef SVGF_REVERSE_MASK
-#define SVGF_REVERSE_MASK 0         // bit i set: iteration with step 2^i walks the frame bottom-up (what the previous launch touched last is read first)
+#define SVGF_REVERSE_MASK 1         // bit i set: the iteration with step 2^i walks the frame bottom-up.  Step 1 does: what the temporal launch wrote last is
+                                    // still in the 256 MB Infinity Cache when it is read first (-4.5 % for that launch; for the later steps, whose
+                                    // row residues sweep the frame several times, the order makes no difference or hurts: tools/abn.sh)
 #endif
 
 namespace svgf {
@@ -611,13 +613,16 @@ __device__ __forceinline__ float dot2_h2(uint32_t a, uint32_t b) {
 #define SVGF_NO_FASTPATH 0          // 1: measure the kernel as it runs on geometry without planar regions (tools/ab.sh)
 #endif
 #ifndef SVGF_TAP_DEPTH
-#define SVGF_TAP_DEPTH 0            // > 0: taps as one rolling pipeline, LDS reads this many taps ahead (see tap_roll)
+#define SVGF_TAP_DEPTH 3            // > 0: taps as one rolling pipeline, LDS reads this many taps ahead (see tap_roll); 0: a ring row at a time
 #endif
 #ifndef SVGF_MIN_WAVES
 #define SVGF_MIN_WAVES 4            // waves per SIMD the register allocation is asked to leave room for (KR = 1)
 #endif
 #ifndef SVGF_KR2_WAVES
 #define SVGF_KR2_WAVES 2            // the same for KR = 2
+#endif
+#ifndef SVGF_PROLOGUE_ALL
+#define SVGF_PROLOGUE_ALL 0         // 1: the six ring rows of a workgroup's prologue requested at once
 #endif
 #ifndef SVGF_FORCE_MODE
 #define SVGF_FORCE_MODE 0           // diagnostic builds: 1 = streaming only, 2 = arithmetic only (see MODE), for the kernels the library launches
@@ -744,7 +749,29 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? SVGF_MIN_WAVES : SVGF_KR
     // prologue: two ring rows at a time (requesting all six at once measured the same: the launch is one resident
     // round, so the first memory latency is paid once per kernel either way).  Rows j0, j0+1 (always inside the
     // frame) go first: thread 0's pixel of row j0 is the workgroup's reference normal.
+#ifdef SVGF_STAGGER
+    // measurement: de-phase the workgroups that start together on a CU (consecutive ids of an XCD), in units of 64*SVGF_STAGGER cycles
+    for (int q = (int)((blockIdx.x >> 3) & 3u) * SVGF_STAGGER; q > 0; q--) __builtin_amdgcn_s_sleep(1);
+#endif
     if (t < kRing * 8) nflag[t] = 0u;
+#if SVGF_PROLOGUE_ALL
+    {
+        // the whole ring requested at once: ONE round of memory latency per workgroup instead of three (a slot runs four
+        // workgroups per launch; the registers of the tap loop are free here)
+        Staged st0, st1, st2;
+        fetch(j0, st0);
+        fetch(j0 - 2, st1);
+        fetch(j0 + 2, st2);
+        if (t == 0) { nref[0] = st0.o[0].n.x; nref[1] = st0.o[0].n.y & 0xffffu; }
+        __syncthreads();
+        ref01 = nref[0]; refz = nref[1];
+        commit(2, st0);
+        commit(0, st1);
+        commit(4, st2);
+#pragma unroll
+        for (int k = 0; k < KR; k++) { dq0[k] = __uint_as_float(st0.o[k].zd.y); dq1[k] = __uint_as_float(st2.o[k].zd.y); }
+    }
+#else
 #pragma unroll 1
     for (int rr = 0; rr < kRing; rr += kRS) {
         const int r = rr == 0 ? 2 : (rr == 2 ? 0 : rr);
@@ -762,6 +789,7 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? SVGF_MIN_WAVES : SVGF_KR
             if (r == 4) dq1[k] = __uint_as_float(st.o[k].zd.y);
         }
     }
+#endif
     __syncthreads();
 
     const float phi_n = a.phi_normal;              // != 0 (launcher)
@@ -957,6 +985,9 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? SVGF_MIN_WAVES : SVGF_KR
             }
         };
         if (MODE != 1 && wave_has_surface) {
+#ifdef SVGF_DIAG_TAPS_TWICE
+            if (uniform_normals && !SVGF_NO_FASTPATH) tap_roll(std::true_type{}); else tap_roll(std::false_type{});      // cost probe only (results are wrong)
+#endif
             if constexpr (SVGF_TAP_DEPTH > 0) {
                 if (uniform_normals && !SVGF_NO_FASTPATH) tap_roll(std::true_type{}); else tap_roll(std::false_type{});
             } else {
@@ -1094,7 +1125,10 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     int nbands = slots / (xtiles * S);
     if (nbands < 1) nbands = 1;
     int band = (njmax + nbands - 1) / nbands;
-    if (band < 8) band = 8;
+#ifndef SVGF_MIN_BAND
+#define SVGF_MIN_BAND 8
+#endif
+    if (band < SVGF_MIN_BAND) band = SVGF_MIN_BAND;
     band = (band + kRS - 1) / kRS * kRS;
     nbands = (njmax + band - 1) / band;
     // m groups per XCD, 8 m groups in all (so that every XCD gets the same number of tiles)

@@ -52,6 +52,66 @@ int main() {
                 }
             }
         }
+        // ---- the G-buffer through array-backed render targets (CudaUtil.h:68-99) and a pitched surface, the result into a
+        //      display array (App.cu:561), then ResizeRenderTextures (App.cu:742-778) and one more frame at the new size
+        {
+            hipChannelFormatDesc f4 = hipCreateChannelDesc(32, 32, 32, 32, hipChannelFormatKindFloat);
+            hipChannelFormatDesc u4 = hipCreateChannelDesc(16, 16, 16, 16, hipChannelFormatKindUnsigned);
+            hipArray_t aMotion = nullptr, aNormal = nullptr, aOut = nullptr;
+            if (hipMallocArray(&aMotion, &f4, W, H, hipArrayDefault) != hipSuccess || hipMallocArray(&aNormal, &u4, W, H, hipArrayDefault) != hipSuccess ||
+                hipMallocArray(&aOut, &f4, W, H, hipArrayDefault) != hipSuccess) { std::printf("hipMallocArray failed\n"); return 4; }
+            for (size_t i = 0; i < px; i++) motion[4 * i] = float(i % 251);                 // something to recognise
+            if (hipMemcpy2DToArray(aMotion, 0, 0, motion.data(), size_t(W) * 16, size_t(W) * 16, H, hipMemcpyHostToDevice) != hipSuccess) return 4;
+            if (hipMemcpy2DToArray(aNormal, 0, 0, normal.data(), size_t(W) * 8, size_t(W) * 8, H, hipMemcpyHostToDevice) != hipSuccess) return 4;
+            gpupt::buffer lMotion(px * 16), lNormal(px * 8), lUV(px * 8);
+            den.ImportGBufferPlane(SVGF_GBUF_MOTION, aMotion, lMotion.Data);
+            den.ImportGBufferPlane(SVGF_GBUF_NORMAL, aNormal, lNormal.Data);
+            const size_t pitch = size_t(W) * 8 + 256;                                           // a pitched surface with padding at the row ends
+            std::vector<uint8_t> pitched(pitch * H, 0xEE);
+            for (int y = 0; y < H; y++) std::memcpy(&pitched[y * pitch], &uv[size_t(y) * W * 4], size_t(W) * 8);
+            gpupt::buffer dPitched(pitched.size(), pitched.data());
+            den.ImportGBufferPlane(SVGF_GBUF_UV, dPitched.Data, pitch, lUV.Data);
+            den.Sync();
+            std::vector<float> m2(px * 4); std::vector<uint16_t> n2(px * 4), u2(px * 4);
+            if (hipMemcpy(m2.data(), lMotion.Data, px * 16, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(n2.data(), lNormal.Data, px * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(u2.data(), lUV.Data, px * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+            if (std::memcmp(m2.data(), motion.data(), px * 16) || std::memcmp(n2.data(), normal.data(), px * 8) || std::memcmp(u2.data(), uv.data(), px * 8)) { std::printf("G-buffer import mismatch\n"); return 1; }
+            // a frame on the imported planes, its result into the display array and back
+            svgf_gbuffer gi{lMotion.Data, lNormal.Data, lUV.Data};
+            den.Buffers.ColourBuffer->updateData(radiance.data(), radiance.size() * 4);
+            den.TemporalFilter(gi, gi); den.FilterMoments(gi);
+            void* res = den.WaveletFilter(gi);
+            den.ExportToArray(res, aOut);
+            den.Sync();
+            std::vector<float> back(px * 4);
+            if (hipMemcpy(out.data(), res, px * 16, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+            if (hipMemcpy2DFromArray(back.data(), size_t(W) * 16, aOut, 0, 0, size_t(W) * 16, H, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+            if (std::memcmp(back.data(), out.data(), px * 16)) { std::printf("array export mismatch\n"); return 1; }
+            den.EndFrame();
+            (void)hipFreeArray(aMotion); (void)hipFreeArray(aNormal); (void)hipFreeArray(aOut);
+        }
+        {
+            const int W2 = 333, H2 = 77;
+            den.Resize(W2, H2);
+            const size_t px2 = size_t(W2) * H2;
+            std::vector<float> mo(px2 * 4, 0.0f), ra(px2 * 4), o2(px2 * 4);
+            std::vector<uint16_t> no(px2 * 4, 0), uu(px2 * 4, 0);
+            for (size_t i = 0; i < px2; i++) { mo[4 * i + 2] = 5.0f; mo[4 * i + 3] = 0.01f; no[4 * i + 2] = half_bits(-1.0f); uu[4 * i + 3] = half_bits(1.0f);
+                                               ra[4 * i] = 0.5f; ra[4 * i + 1] = 0.25f; ra[4 * i + 2] = 0.125f; ra[4 * i + 3] = 1.0f; }
+            gpupt::buffer dM(mo.size() * 4, mo.data()), dN(no.size() * 2, no.data()), dU(uu.size() * 2, uu.data());
+            svgf_gbuffer g2{dM.Data, dN.Data, dU.Data};
+            std::vector<uint8_t> h2(px2);
+            for (int frame = 0; frame < 2; frame++) {
+                den.Buffers.ColourBuffer->updateData(ra.data(), ra.size() * 4);
+                den.TemporalFilter(g2, g2); den.FilterMoments(g2);
+                void* r2 = den.WaveletFilter(g2);
+                if (hipMemcpy(o2.data(), r2, o2.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+                if (hipMemcpy(h2.data(), den.Buffers.HistoryLength[den.PingPongInx]->Data, px2, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+                den.EndFrame();
+                for (size_t i = 0; i < px2; i++)
+                    if (h2[i] != frame + 1 || std::fabs(o2[4 * i] - 0.5f) > 2e-6f || std::fabs(o2[4 * i + 2] - 0.125f) > 2e-6f) { std::printf("after Resize: frame %d pixel %zu\n", frame, i); return 1; }
+            }
+        }
         std::printf("shim ok\n");
         return 0;
     } catch (const std::exception& e) {

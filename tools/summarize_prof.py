@@ -2,7 +2,7 @@
 import csv, glob, os, sys, collections
 
 def short(name):
-    for k in ("temporal_kernel", "moments_kernel", "atrous_lds_kernel", "atrous_direct_kernel"):
+    for k in ("temporal_kernel", "moments_young_kernel", "moments_lds_kernel", "moments_kernel", "atrous_lds_kernel", "atrous_direct_kernel"):
         if k in name:
             import re
             m = re.search(r"ILi(\d+)ELi(\d+)E", name)
