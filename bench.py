@@ -38,11 +38,12 @@ ALG_BYTES = {
 # Bytes the fused frame driver really moves per pixel in steady state, every plane it touches counted once (no cache
 # credit): the temporal launch reads radiance, both G-buffers (3 planes each), previous colour / moments / history and
 # writes history, moments and the filter buffer (the moments stage's copy, Filter.cuh:521, is folded into it and the
-# temporal colour itself is stored only where it is read again); an iteration reads colour, {depth, ddepth} texels and
-# normals and writes colour (+ the feedback colour in iteration 0).
+# temporal colour itself is stored only where it is read again); with fp32 storage it also writes the 16-byte guide texel
+# {depth, ddepth, normal} the iterations read instead of the 16 + 8 byte motion / normal texels.  An iteration reads colour
+# and the guide (fp32) or {depth, ddepth} + normal texels (fp16) and writes colour (+ the feedback colour in iteration 0).
 MOVED_BYTES = {
-    "f32": dict(temporal_moments=16 + 32 + 32 + 16 + 8 + 1 + 1 + 8 + 16, atrous_iter=56, atrous_feedback=16),
-    "f16": dict(temporal_moments=8 + 32 + 32 + 8 + 4 + 1 + 1 + 4 + 8, atrous_iter=40, atrous_feedback=8),
+    "f32": dict(temporal_moments=16 + 32 + 32 + 16 + 8 + 1 + 1 + 8 + 16 + 16, atrous_iter=16 + 16 + 16, atrous_feedback=16),
+    "f16": dict(temporal_moments=8 + 32 + 32 + 8 + 4 + 1 + 1 + 4 + 8, atrous_iter=8 + 16 + 8 + 8, atrous_feedback=8),
 }
 HBM_PEAK_GBPS = 8000.0        # MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 WORKLOADS = {"1080p": (1920, 1080), "4k": (3840, 2160), "8k": (7680, 4320)}
@@ -257,7 +258,9 @@ def roofline_block(W, H, storage, iters, stage_ms, variant="auto"):
                                    "measured_hbm_bytes": measured_traffic(W, H, storage, "temporal_bytes_per_launch")}}
     for i in range(iters):
         px = b["atrous_iter"] + (b["atrous_feedback"] if i == 0 else 0)
-        stages[f"atrous_step{1 << i}"] = {"ms": round(stage_ms[2 + i], 5), "algorithmic_B_per_px": px, "moved_B_per_px": px, "moved_GBps": rate(px, stage_ms[2 + i])}
+        mpx = mv["atrous_iter"] + (mv["atrous_feedback"] if i == 0 else 0)
+        stages[f"atrous_step{1 << i}"] = {"ms": round(stage_ms[2 + i], 5), "algorithmic_B_per_px": px, "moved_B_per_px": mpx,
+                                          "algorithmic_equivalent_GBps": rate(px, stage_ms[2 + i]), "moved_GBps": rate(mpx, stage_ms[2 + i])}
     return roof, stages
 
 
