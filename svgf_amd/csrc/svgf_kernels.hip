@@ -616,10 +616,28 @@ __device__ __forceinline__ float dot2_h2(uint32_t a, uint32_t b) {
 #define SVGF_TAP_DEPTH 3            // > 0: taps as one rolling pipeline, LDS reads this many taps ahead (see tap_roll); 0: a ring row at a time
 #endif
 #ifndef SVGF_MIN_WAVES
-#define SVGF_MIN_WAVES 4            // waves per SIMD the register allocation is asked to leave room for (KR = 1)
+#define SVGF_MIN_WAVES 0            // != 0: waves per SIMD the register allocation is asked to leave room for, every step (KR = 1); 0: per step below
 #endif
+#ifndef SVGF_WAVES_S1
+#define SVGF_WAVES_S1 5             // steps 1 and 2
+#endif
+#ifndef SVGF_WAVES_S4
+#define SVGF_WAVES_S4 5             // steps 4 and 8
+#endif
+#ifndef SVGF_WAVES_S16
+#define SVGF_WAVES_S16 4            // step 16: the ring (37 KB) allows four workgroups per CU anyway
+#endif
+// Resident waves per SIMD the kernel of step S is compiled for: more workgroups per CU keep more loads in flight while others
+// are in their tap phase (5 per CU: -4.5 % per launch at S <= 8, tools/abn.sh W5).  The tap pipeline is one tap shorter per
+// step of occupancy beyond 5 (registers).
+constexpr int cfg_waves(int S) { return SVGF_MIN_WAVES ? SVGF_MIN_WAVES : (S <= 2 ? SVGF_WAVES_S1 : S <= 8 ? SVGF_WAVES_S4 : SVGF_WAVES_S16); }
+constexpr int cfg_tap_depth(int S) { return (SVGF_TAP_DEPTH > 0 && cfg_waves(S) >= 6) ? 1 : SVGF_TAP_DEPTH; }
 #ifndef SVGF_KR2_WAVES
 #define SVGF_KR2_WAVES 2            // the same for KR = 2
+#endif
+#ifndef SVGF_PREFETCH_STEPS
+#define SVGF_PREFETCH_STEPS 1       // ring rows are requested this many steps before the step that needs them (1 = at the start of the step whose
+                                    // end commits them: 15 registers per step of depth, and depth 2 or 3 measured no faster: tools/abn.sh PF1..PF3)
 #endif
 #ifndef SVGF_PROLOGUE_ALL
 #define SVGF_PROLOGUE_ALL 0         // 1: the six ring rows of a workgroup's prologue requested at once
@@ -631,7 +649,7 @@ __device__ __forceinline__ float dot2_h2(uint32_t a, uint32_t b) {
 #define SVGF_WAVE_TILE 0            // 1: single-wave workgroups (64 columns, KR = 2): no barrier, no sibling wave to wait for
 #endif
 template <int ST, int S, int TX, int KR, int MODE = 0>
-__global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? SVGF_MIN_WAVES : SVGF_KR2_WAVES) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup, int xrot, int band_fastest) {
+__global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? cfg_waves(S) : SVGF_KR2_WAVES) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup, int xrot, int band_fastest) {
     constexpr int WL = TX + 4 * S;                 // staged columns per ring row
     constexpr int CB = ST == 0 ? 16 : 8;           // bytes per colour texel
     constexpr int NH = 4 * S;                      // halo pixels per ring row: all staged by wave 0 of the row group (lanes 0..NH-1);
@@ -807,8 +825,8 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? SVGF_MIN_WAVES : SVGF_KR
     // step after that — in flight during this step's arithmetic.
     auto step = [&](int j, Staged& cs, Staged& fs) __attribute__((always_inline)) {
         const bool more = MODE != 2 && (j + kRS) < j1;
-        const bool more2 = MODE != 2 && (j + 2 * kRS) < j1;
-        if (more2) fetch(j + 2 * kRS + 2, fs);
+        const bool more2 = MODE != 2 && (j + SVGF_PREFETCH_STEPS * kRS) < j1;
+        if (more2) fetch(j + SVGF_PREFETCH_STEPS * kRS + 2, fs);
         SVGF_STAMP(0);                             // fetch issue
 
         // this thread's centres are ring rows 2+rg*KR+k, its taps ring rows rg*KR .. rg*KR+KR+3; columns oli-2S .. oli+2S
@@ -918,7 +936,7 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? SVGF_MIN_WAVES : SVGF_KR
         // five LDS round trips per step exposed to the wave), and only D+1 taps' records are live instead of a row's five.
         auto tap_roll = [&](auto uni_tag) __attribute__((always_inline)) {
             constexpr bool UNI = decltype(uni_tag)::value;
-            constexpr int D = SVGF_TAP_DEPTH > 0 ? SVGF_TAP_DEPTH : 1;
+            constexpr int D = cfg_tap_depth(S) > 0 ? cfg_tap_depth(S) : 1;
             constexpr int NT = 5 * NR;                       // records of the thread's NR ring rows, row-major
             float ebase[KR][5];
             if constexpr (UNI) {
@@ -1048,11 +1066,15 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? SVGF_MIN_WAVES : SVGF_KR
     };
 
     // two register sets take turns as "commit next" / "fetch for the step after" (no copies between steps)
-    Staged pa, pb;
-    if (MODE != 2 && j0 + kRS < j1) fetch(j0 + kRS + 2, pa);
-    for (int j = j0; j < j1; j += 2 * kRS) {
-        step(j, pa, pb);
-        if (j + kRS < j1) step(j + kRS, pb, pa);
+    // SVGF_PREFETCH_STEPS register sets take turns as "commit next" / "fetch for the step after ..." (no copies between steps):
+    // rows requested at the start of a step are committed at the end of the step SVGF_PREFETCH_STEPS - 1 steps later
+    constexpr int PD = SVGF_PREFETCH_STEPS;
+    Staged q[PD];
+#pragma unroll
+    for (int d = 1; d < PD; d++) if (MODE != 2 && j0 + d * kRS < j1) fetch(j0 + d * kRS + 2, q[d - 1]);
+    for (int j = j0; j < j1; j += PD * kRS) {
+#pragma unroll
+        for (int u = 0; u < PD; u++) if (j + u * kRS < j1) step(j + u * kRS, q[u], q[(u + PD - 1) % PD]);
     }
 #ifdef SVGF_STAMPS
     if ((t & 63) == 0) {
@@ -1107,7 +1129,7 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     if (hipError_t e = allow_dynamic_lds(atrous_lds_kernel<ST, S, TX, KR, MODE>, lds, attr_done); e != hipSuccess) return e;
     // One round of workgroups: bands are sized so that (x tiles) x (S residues) x (bands) fills the resident
     // slots of the chip once (LDS: 160 KiB per CU; registers: 4 / 2 waves per SIMD) instead of leaving a partial round.
-    constexpr int per_cu_lds = (int)((160 * 1024) / lds), per_cu_waves = (KR == 1 ? 4 * SVGF_MIN_WAVES : 4 * SVGF_KR2_WAVES) / (threads / 64);
+    constexpr int per_cu_lds = (int)((160 * 1024) / lds), per_cu_waves = (KR == 1 ? 4 * cfg_waves(S) : 4 * SVGF_KR2_WAVES) / (threads / 64);
     constexpr int per_cu = per_cu_lds < per_cu_waves ? per_cu_lds : per_cu_waves;
     const int nrows = g.ye - g.yb;
     const int njmax = (nrows + S - 1) / S;
@@ -1118,7 +1140,10 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
 #ifndef SVGF_OVERSUB
 #define SVGF_OVERSUB 4
 #endif
-    int slots = per_cu * num_cus() * (TX <= 128 ? SVGF_OVERSUB : 1);
+#ifndef SVGF_BAND_SLOTS_PER_CU
+#define SVGF_BAND_SLOTS_PER_CU per_cu
+#endif
+    int slots = (SVGF_BAND_SLOTS_PER_CU) * num_cus() * (TX <= 128 ? SVGF_OVERSUB : 1);
 #ifdef SVGF_DIAG
     slots = diag_env("SVGF_ATROUS_SLOTS", slots);
 #endif

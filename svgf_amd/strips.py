@@ -558,11 +558,29 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
     rads = [r[cut].contiguous() for r in rads_all]
     del gb_all, rads_all
     host_ms = None
+    native_note = None
     if driver == "native":
-        comm = rccl_comm(world, rank, device.index or 0) if world > 1 else None
-        drv = NativeStrips(W, H, world, params, [rank], [device.index or 0], streams=[side.cuda_stream], comms=[comm] if comm else None,
-                           plan=lay["plan"], motion_reach=motion_reach)
-        n = 0
+        # every rank tries to bring the C++ driver up (communicator + one frame); if any rank cannot (no librccl to open, an RCCL
+        # error), ALL fall back to the Python twin of the schedule rather than leaving the node without a number
+        drv, comm, err = None, None, ""
+        try:
+            comm = rccl_comm(world, rank, device.index or 0) if world > 1 else None
+            drv = NativeStrips(W, H, world, params, [rank], [device.index or 0], streams=[side.cuda_stream], comms=[comm] if comm else None,
+                               plan=lay["plan"], motion_reach=motion_reach)
+            drv.frame([rads[0]], [gbs[0]], [gbs[1]])
+            torch.cuda.synchronize(device)
+        except Exception as e:  # noqa: BLE001
+            err, drv = f"{type(e).__name__}: {e}", None
+        bad = torch.tensor([0 if drv is not None else 1], device=device, dtype=torch.int32)
+        if world > 1:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):
+            native_note = f"C++ strip driver unavailable on some rank ({err or 'see other ranks'}): Python driver used"
+            if drv is not None:
+                drv.close()
+            driver = "python"
+    if driver == "native":
+        n = 1
         for _ in range(prime_frames + warmup):
             drv.frame([rads[n % len(rads)]], [gbs[n & 1]], [gbs[(n & 1) ^ 1]])
             n += 1
@@ -621,7 +639,8 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
     stages.d.sync()                              # raises if a reprojection left the strip
     assert bool(torch.isfinite(runner.owned(out).float()).all())
     return dict(ms_per_step=(t1 - t0) * 1e3 / steps, rows_per_rank=geo.own[1] - geo.own[0], plan=geo.plan, atrous_timing=stages.atrous_timing,
-                driver="python (svgf_amd/strips.py)", motion_reach=motion_reach, host_ms=round(host * 1e3 / steps, 4))
+                driver="python (svgf_amd/strips.py)" + (f" — {native_note}" if native_note else ""), motion_reach=motion_reach,
+                host_ms=round(host * 1e3 / steps, 4))
 
 
 def _plan_fits(W, H, rank, world, steps, plan, moments_radius, motion_reach):
