@@ -1214,6 +1214,15 @@ hipError_t launch_atrous_lds_step_kr(const Geo& g, const AtrousArgs& a, hipStrea
         case 16: return launch_atrous_lds<ST, 16, 64, 2, SVGF_FORCE_MODE>(g, a, s);
         default: return hipErrorInvalidValue;
     }
+#ifdef SVGF_TX64_MAX_STEP
+    if (KR == 1 && MODE == 0 && a.step <= SVGF_TX64_MAX_STEP) switch (a.step) {      // measurement: 64-column workgroups of two waves
+        case 1: return launch_atrous_lds<ST, 1, 64, 1, SVGF_FORCE_MODE>(g, a, s);
+        case 2: return launch_atrous_lds<ST, 2, 64, 1, SVGF_FORCE_MODE>(g, a, s);
+        case 4: return launch_atrous_lds<ST, 4, 64, 1, SVGF_FORCE_MODE>(g, a, s);
+        case 8: return launch_atrous_lds<ST, 8, 64, 1, SVGF_FORCE_MODE>(g, a, s);
+        default: break;
+    }
+#endif
     if (KR == 1 && MODE == 0 && narrow) switch (a.step) {
         case 1: return launch_atrous_lds<ST, 1, 128, 1, SVGF_FORCE_MODE>(g, a, s);
         case 2: return launch_atrous_lds<ST, 2, 128, 1, SVGF_FORCE_MODE>(g, a, s);
