@@ -1052,6 +1052,9 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? cfg_waves(S) : SVGF_KR2_
                 const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(npx * CB), 0x00020000);
                 const __amdgpu_buffer_rsrc_t rs_fb = __builtin_amdgcn_make_buffer_rsrc(a.feedback ? a.feedback : a.out, 0, a.feedback ? (int)(npx * CB) : 0, 0x00020000);
                 // columns outside the frame carry the out-of-range offset: the store is dropped by the range check
+#ifdef SVGF_DIAG_SKIP_STORE
+                if (o[k].x != 12345.678f) continue;                                                // cost probe only: (almost) never stores
+#endif
                 if constexpr (ST == 0) {
                     const u32x4 raw = {__float_as_uint(o[k].x), __float_as_uint(o[k].y), __float_as_uint(o[k].z), __float_as_uint(o[k].w)};
                     __builtin_amdgcn_raw_buffer_store_b128(raw, rs_out, vo_c, srow * CB, SVGF_COLOUR_ST_AUX);                   // :618
