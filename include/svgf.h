@@ -270,7 +270,8 @@ int svgf_strips_create(svgf_strips** out, int width, int height, int world, cons
                        int nlocal, const int* ranks, const int* devices, void* const* compute_streams, void* const* comms, int loopback);
 void svgf_strips_destroy(svgf_strips* s);
 const char* svgf_strips_last_error(const svgf_strips* s);
-svgf_ctx* svgf_strips_context(svgf_strips* s, int local_index);            /* the strip's context (state planes, svgf_get_size ...) */
+svgf_ctx* svgf_strips_context(svgf_strips* s, int local_index);            /* the strip's context (state planes, svgf_get_size ...);
+                                                                             owned by the driver: svgf_destroy on it does nothing        */
 int svgf_strips_layout(const svgf_strips* s, int local_index, svgf_strip_layout* out);
 /* One frame on every local strip.  radiance[k], cur[k], prev[k] are device planes of local rank k holding ITS rows
  * [strip.y0, strip.y0 + strip.rows) (prev may be NULL, or prev[k].motion NULL, on the first frame); results[k] receives the

@@ -159,6 +159,8 @@ int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, vo
     if (rc != SVGF_OK) return rc;
     if (prev_colour == colour_out || hist_prev == hist_cur || moments_prev == moments_cur)
         return fail(c, SVGF_ERR_INVALID, "svgf_temporal: previous and current state planes must differ (App. B #1)");
+    if (passthrough_out && c->young_pending)        // the list of an earlier launch was never consumed (an error in between): start it again
+        SVGF_HIP(c, hipMemsetAsync(c->young_count + c->young_phase, 0, sizeof(unsigned), c->stream));
     svgf::TemporalArgs a{prev_colour, radiance, colour_out,
                          (const float4*)cur->motion, (const uint2*)cur->normal, (const uint2*)cur->uv,
                          (const float4*)prev->motion, (const uint2*)prev->normal, (const uint2*)prev->uv,
@@ -168,6 +170,7 @@ int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, vo
                          passthrough_out ? c->young_count + (c->young_phase ^ 1) : nullptr, passthrough_out ? c->young_flags : nullptr, sparse_colour, c->p.phi_normal > 0.0f, c->halo_violations,
                          std::max(c->vy0, c->strip.y0) - c->strip.y0, std::min(c->vy1, c->strip.y0 + c->strip.rows) - c->strip.y0, (uint4*)guide_out};
     SVGF_HIP(c, svgf::launch_temporal(geo_of(c), c->p.storage, a, c->stream));
+    if (passthrough_out) c->young_pending = true;
     return SVGF_OK;
 }
 
@@ -182,7 +185,7 @@ int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments
                         c->p.phi_colour, c->p.phi_normal, c->p.moments_radius, cold_only, dense, sparse_colour,
                         cold_only ? c->young_list : nullptr, cold_only ? c->young_count + c->young_phase : nullptr, cold_only ? c->young_flags : nullptr};
     SVGF_HIP(c, svgf::launch_moments(geo_of(c), c->p.storage, a, c->p.variant == SVGF_VARIANT_DIRECT, c->stream));
-    if (cold_only) c->young_phase ^= 1;             // the temporal launch of the next frame appends to the counter this frame's one zeroed
+    if (cold_only) { c->young_phase ^= 1; c->young_pending = false; }   // the next frame's temporal launch appends to the counter this frame's one zeroed
     return SVGF_OK;
 }
 
@@ -291,10 +294,9 @@ int svgf_create(svgf_ctx** out, int width, int height, const svgf_params* params
 }
 
 void svgf_destroy(svgf_ctx* c) {
-    if (!c) return;
+    if (!c || c->strip_drv) return;            // a context handed out by svgf_strips_context belongs to its strip driver (svgf_strips_destroy)
     DeviceGuard dg(c->device);
-    if (c->have_state || !c->pool.empty() || !c->pending.empty() || c->halo_violations || c->strip_drv) (void)hipStreamSynchronize(c->stream);
-    strip_driver_destroy(c);
+    if (c->have_state || !c->pool.empty() || !c->pending.empty() || c->halo_violations) (void)hipStreamSynchronize(c->stream);
     free_state(c);
     if (c->halo_violations) (void)hipFree(c->halo_violations);
     for (auto& f : c->pending) for (auto e : f.ev) (void)hipEventDestroy(e);

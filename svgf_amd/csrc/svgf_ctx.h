@@ -28,6 +28,7 @@ struct svgf_ctx {
     unsigned* young_count = nullptr;       // two device counters used in turn (the temporal launch of a frame zeroes the next frame's)
     uint8_t* young_flags = nullptr;        // one flag per (row, 64-column segment): all 64 pixels need the estimate (listed nowhere)
     int young_phase = 0;
+    bool young_pending = false;            // a temporal launch appended to young_count[young_phase] and no moments launch has consumed it yet
     int vy0 = 0, vy1 = 0;                  // global rows of the previous-frame planes that hold valid state (svgf_set_valid_rows; default: all held)
     unsigned* halo_violations = nullptr;   // strips: device counter of reprojections that left the rows this strip holds (temporal_kernel)
     int pingpong = 0;                      // PingPongInx, App.cu:374
@@ -85,7 +86,5 @@ int temporal_moments_impl(svgf_ctx* c, const void* prev_colour, const void* radi
 int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration, const void* guide = nullptr);
 bool use_guide(const svgf_ctx* c);      // the frame / strip drivers repack {depth, ddepth, normal} for the iterations (fp32 storage, >= 3 iterations)
 int guide_rows(svgf_ctx* c, const svgf_gbuffer* g, int rb, int re);      // guide texels of rows [rb, re) that no temporal launch covers
-
-void strip_driver_destroy(svgf_ctx* c);     // svgf_strip.hip
 
 }  // namespace svgf_host

@@ -161,9 +161,6 @@ struct Msg { int src, dst; size_t src_off, dst_off, bytes; int plane; };
 
 }  // namespace
 
-namespace svgf_host {
-void strip_driver_destroy(svgf_ctx* c) { c->strip_drv = nullptr; }      // the driver owns its contexts, never the other way round
-}
 
 namespace {
 
