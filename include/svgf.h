@@ -213,6 +213,14 @@ int svgf_reset_history(svgf_ctx* ctx);                                 /* zero a
  *                         — and iteration 0 still feeds RenderBuffer back. */
 enum svgf_debug_mode { SVGF_DEBUG_FINAL = 0, SVGF_DEBUG_TEMPORAL = 1, SVGF_DEBUG_ATROUS = 2 };
 int svgf_set_debug_mode(svgf_ctx* ctx, int mode);
+/* The frame and strip drivers keep, of every frame's current G-buffer, the 16 bytes per pixel the filter reads of it ({depth,
+ * ddepth, normal, instance ID}: the "guide" plane).  When the next frame's `prev` is that very G-buffer — the same three
+ * plane addresses, and not the new frame's `cur` — its reprojection test (LoadPreviousData, Filter.cuh:225-258) reads the
+ * kept plane instead of the three planes of `prev` (16 instead of 32 B per pixel; bit-identical results).  This relies on
+ * what "previous G-buffer" means in the reference — Framebuffer[1 - PingPongInx] is not written between the two frames
+ * (App.cu:374,545-556).  A host that rewrites the planes of `prev` in between passes 0 here (default 1); any other `prev`
+ * is read as it is. */
+int svgf_set_prev_guide(svgf_ctx* ctx, int enable);
 
 /* Texture / pitched adapters — what the reference gets from its CUDA <-> OpenGL mappings (CreateMapping, CudaUtil.h:68-99;
  * render targets Framebuffer.cpp:7-49): the G-buffer planes arrive as array-backed textures or pitched surfaces and are

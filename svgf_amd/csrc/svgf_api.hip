@@ -100,6 +100,8 @@ int alloc_state(svgf_ctx* c) {
         SVGF_HIP(c, hipMalloc((void**)&c->hist[i], hist_bytes(c)));
     }
     SVGF_HIP(c, hipMalloc(&c->guide, (size_t)c->strip.rows * c->W * 16));
+    SVGF_HIP(c, hipMalloc(&c->guide_prev, (size_t)c->strip.rows * c->W * 16));
+    c->guide_prev_valid = false;
     c->have_state = true;
     return reset_history(c);
 }
@@ -114,7 +116,9 @@ void free_state(svgf_ctx* c) {
         c->hist[i] = nullptr;
     }
     if (c->guide) (void)hipFree(c->guide);
-    c->guide = nullptr;
+    if (c->guide_prev) (void)hipFree(c->guide_prev);
+    c->guide = c->guide_prev = nullptr;
+    c->guide_prev_valid = false;
     if (c->young_list) (void)hipFree(c->young_list);
     if (c->young_count) (void)hipFree(c->young_count);
     if (c->young_flags) (void)hipFree(c->young_flags);
@@ -133,6 +137,7 @@ int reset_history(svgf_ctx* c) {
     c->pingpong = 0;
     c->frames_since_reset = 0;
     c->result_index = 0;
+    c->guide_prev_valid = false;
     return SVGF_OK;
 }
 
@@ -150,7 +155,7 @@ int read_halo_violations(svgf_ctx* c, unsigned long long* count, int clear) {
 
 int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, const svgf_gbuffer* cur,
                   const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur, void* moments_cur,
-                  const void* moments_prev, void* passthrough_out, int sparse_colour, void* guide_out = nullptr) {
+                  const void* moments_prev, void* passthrough_out, int sparse_colour, void* guide_out = nullptr, const void* guide_prev = nullptr) {
     if (!prev_colour || !radiance || !colour_out || !hist_prev || !hist_cur || !moments_cur || !moments_prev)
         return fail(c, SVGF_ERR_INVALID, "svgf_temporal: null plane");
     int rc = check_gbuf(c, cur, true, "svgf_temporal(cur)");
@@ -168,7 +173,8 @@ int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, vo
                          c->p.depth_threshold, c->p.normal_threshold, c->p.history_base, c->p.mesh_id_test, passthrough_out,
                          passthrough_out ? c->young_list : nullptr, passthrough_out ? c->young_count + c->young_phase : nullptr,
                          passthrough_out ? c->young_count + (c->young_phase ^ 1) : nullptr, passthrough_out ? c->young_flags : nullptr, sparse_colour, c->p.phi_normal > 0.0f, c->halo_violations,
-                         std::max(c->vy0, c->strip.y0) - c->strip.y0, std::min(c->vy1, c->strip.y0 + c->strip.rows) - c->strip.y0, (uint4*)guide_out};
+                         std::max(c->vy0, c->strip.y0) - c->strip.y0, std::min(c->vy1, c->strip.y0 + c->strip.rows) - c->strip.y0, (uint4*)guide_out,
+                         (const uint4*)guide_prev};
     SVGF_HIP(c, svgf::launch_temporal(geo_of(c), c->p.storage, a, c->stream));
     if (passthrough_out) c->young_pending = true;
     return SVGF_OK;
@@ -197,8 +203,26 @@ int guide_rows(svgf_ctx* c, const svgf_gbuffer* g, int rb, int re) {
     if (re <= rb || !c->guide) return SVGF_OK;
     svgf::Geo geo = geo_of(c);
     geo.yb = rb; geo.ye = re;
-    SVGF_HIP(c, svgf::launch_guide(geo, (const float4*)g->motion, (const uint2*)g->normal, (uint4*)c->guide, c->stream));
+    SVGF_HIP(c, svgf::launch_guide(geo, (const float4*)g->motion, (const uint2*)g->normal, (const uint2*)g->uv, (uint4*)c->guide, c->stream));
     return SVGF_OK;
+}
+
+// The reprojection test reads {depth, normal, instance ID} of the previous G-buffer; the guide plane the previous frame wrote
+// holds exactly those bits.  It stands in for `prev` only when `prev` IS the G-buffer that frame was given as current (same
+// three planes, by address) and is not the current one: a host that passes anything else gets the planes read as they are.
+const void* prev_guide_for(const svgf_ctx* c, const svgf_gbuffer* cur, const svgf_gbuffer* prev) {
+    if (!c->prev_guide_enabled || !c->guide_prev_valid || !c->guide_prev || !use_guide(c) || !cur || !prev) return nullptr;
+    const svgf_gbuffer& k = c->guide_prev_of;
+    if (prev->motion != k.motion || prev->normal != k.normal || prev->uv != k.uv) return nullptr;
+    if (prev->motion == cur->motion || prev->normal == cur->normal || prev->uv == cur->uv) return nullptr;
+    return c->guide_prev;
+}
+
+void commit_guide(svgf_ctx* c, const svgf_gbuffer* cur, bool written) {
+    if (!written || !cur) { c->guide_prev_valid = false; return; }
+    std::swap(c->guide, c->guide_prev);
+    c->guide_prev_of = *cur;
+    c->guide_prev_valid = true;
 }
 
 int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration, const void* guide) {
@@ -216,13 +240,13 @@ int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const sv
 
 int temporal_moments_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, void* filter_out,
                           const svgf_gbuffer* cur, const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur,
-                          void* moments_cur, const void* moments_prev, int mrb, int mre, int feedback_follows, void* guide_out) {
+                          void* moments_cur, const void* moments_prev, int mrb, int mre, int feedback_follows, void* guide_out, const void* guide_prev) {
     if (!filter_out || filter_out == colour_out) return fail(c, SVGF_ERR_INVALID, "svgf_temporal_moments: filter_out must be a plane of its own");
     const int rb = c->rb, re = c->re;
     if (mrb == -1 && mre == -1) { mrb = rb; mre = re; }
     if (mrb < rb || mre > re || mrb > mre) return fail(c, SVGF_ERR_INVALID, "svgf_temporal_moments: moments rows outside the temporal rows");
     int rc = alloc_flags(c);
-    if (rc == SVGF_OK) rc = temporal_impl(c, prev_colour, radiance, colour_out, cur, prev, hist_prev, hist_cur, moments_cur, moments_prev, filter_out, feedback_follows != 0, guide_out);
+    if (rc == SVGF_OK) rc = temporal_impl(c, prev_colour, radiance, colour_out, cur, prev, hist_prev, hist_cur, moments_cur, moments_prev, filter_out, feedback_follows != 0, guide_out, guide_prev);
     if (rc != SVGF_OK) return rc;
     c->rb = mrb; c->re = mre;
     rc = moments_impl(c, colour_out, filter_out, moments_cur, cur, hist_cur, 1, 0, feedback_follows != 0);
@@ -365,6 +389,12 @@ int svgf_set_debug_mode(svgf_ctx* c, int mode) {
     return SVGF_OK;
 }
 
+int svgf_set_prev_guide(svgf_ctx* c, int enable) {
+    if (!c) return SVGF_ERR_INVALID;
+    c->prev_guide_enabled = enable != 0;
+    return SVGF_OK;
+}
+
 int svgf_temporal(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, const svgf_gbuffer* cur,
                   const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur, void* moments_cur,
                   const void* moments_prev) {
@@ -495,6 +525,7 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     auto bail = [&](int code) {                     // an error path hands the events already taken back to the pool
         for (auto e : fe.ev) c->pool.push_back(e);
         fe.ev.clear();
+        if (code != SVGF_OK) c->guide_prev_valid = false;      // a frame that failed half-way leaves no guide plane to trust
         return code;
     };
 
@@ -523,6 +554,7 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
             if (fe.nstage >= 2) c->pending.push_back(std::move(fe)); else bail(0);
         }
         if (result) *result = res;
+        commit_guide(c, cur, false);
         c->pingpong ^= 1;
         if (c->frames_since_reset < (1 << 30)) c->frames_since_reset++;
         return SVGF_OK;
@@ -536,9 +568,11 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     // pixel and iteration) into the guide plane: +16 B/px here, -8 B/px in each iteration
     // (measured, tools/abn.sh on one device: -1.5 % per 4K fp32 frame; with fp16 storage the iterations gain less than the temporal
     // launch loses, so the G-buffer planes are read as they are)
+    // ... and the NEXT frame's reprojection test reads this frame's guide plane instead of the three planes of its previous
+    // G-buffer (prev_guide_for): -16 B/px of the temporal launch's 146
     void* guide = use_guide(c) ? c->guide : nullptr;
     rc = temporal_impl(c, c->colour[1 - P], radiance, c->colour[P], cur, prev, c->hist[1 - P], c->hist[P],
-                       c->moments[P], c->moments[1 - P], c->filter[0], sparse, guide);  // App.cu:552
+                       c->moments[P], c->moments[1 - P], c->filter[0], sparse, guide, prev_guide_for(c, cur, prev));  // App.cu:552
     if (rc != SVGF_OK) return bail(rc);
     stamp();
     // the first three frames after a reset have history <= 3 everywhere: the LDS-streaming moments kernel
@@ -559,6 +593,7 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     }
     if (result) *result = c->filter[pp];
     c->result_index = pp;
+    commit_guide(c, cur, guide != nullptr);
     c->pingpong ^= 1;                                                           // App.cu:374
     if (c->frames_since_reset < (1 << 30)) c->frames_since_reset++;
     return SVGF_OK;

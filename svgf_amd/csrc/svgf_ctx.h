@@ -9,6 +9,10 @@
 
 struct svgf_strip_driver;
 
+#ifndef SVGF_PREV_GUIDE_DEFAULT
+#define SVGF_PREV_GUIDE_DEFAULT 1      // measurement twins build with 0 (tools/abn.sh)
+#endif
+
 struct svgf_ctx {
     int W = 0, H = 0;
     svgf_strip strip{};
@@ -23,7 +27,11 @@ struct svgf_ctx {
     void* moments[2] = {nullptr, nullptr};
     void* filter[2] = {nullptr, nullptr};
     uint8_t* hist[2] = {nullptr, nullptr};
-    void* guide = nullptr;                 // {depth, ddepth, normal} of the current G-buffer repacked by the temporal launch for the wavelet iterations
+    void* guide = nullptr;                 // {depth, ddepth, normal, instance ID} of the current G-buffer repacked by the temporal launch for the wavelet iterations
+    void* guide_prev = nullptr;            // ... and the plane the previous frame wrote (the two swap at the end of a frame): the next reprojection test reads it
+    svgf_gbuffer guide_prev_of{};          // the G-buffer guide_prev was made from (the planes' addresses), valid while guide_prev_valid
+    bool guide_prev_valid = false;
+    bool prev_guide_enabled = SVGF_PREV_GUIDE_DEFAULT != 0;   // svgf_set_prev_guide
     uint32_t* young_list = nullptr;        // scratch, temporal -> moments: indices of the pixels with history < 4 that need the spatial estimate
     unsigned* young_count = nullptr;       // two device counters used in turn (the temporal launch of a frame zeroes the next frame's)
     uint8_t* young_flags = nullptr;        // one flag per (row, 64-column segment): all 64 pixels need the estimate (listed nowhere)
@@ -82,8 +90,11 @@ int read_halo_violations(svgf_ctx* c, unsigned long long* count, int clear);
 // the stages on caller- or driver-owned planes, rows [c->rb, c->re); the device is already current
 int temporal_moments_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, void* filter_out,
                           const svgf_gbuffer* cur, const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur,
-                          void* moments_cur, const void* moments_prev, int mrb, int mre, int feedback_follows, void* guide_out = nullptr);
+                          void* moments_cur, const void* moments_prev, int mrb, int mre, int feedback_follows, void* guide_out = nullptr,
+                          const void* guide_prev = nullptr);
 int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration, const void* guide = nullptr);
+const void* prev_guide_for(const svgf_ctx* c, const svgf_gbuffer* cur, const svgf_gbuffer* prev);   // the guide plane that stands in for `prev`, or null
+void commit_guide(svgf_ctx* c, const svgf_gbuffer* cur, bool written);   // end of a frame: the guide just written (all held rows) becomes the previous one
 bool use_guide(const svgf_ctx* c);      // the frame / strip drivers repack {depth, ddepth, normal} for the iterations (fp32 storage, >= 3 iterations)
 int guide_rows(svgf_ctx* c, const svgf_gbuffer* g, int rb, int re);      // guide texels of rows [rb, re) that no temporal launch covers
 

@@ -26,8 +26,10 @@ struct TemporalArgs {
     unsigned* halo_violations;   // strips only: counts reprojections that land inside the frame but outside the valid rows of the strip
     int valid_lo, valid_hi;      // local rows [valid_lo, valid_hi) of the previous-frame planes hold valid state (a strip allocates more rows than
                                  // it keeps up to date: the a-trous halos are wider than the state halo)
-    uint4* guide_out;            // frame / strip drivers: {depth, ddepth, (nx,ny) half bits, (nz,matID) half bits} of the CURRENT G-buffer, 16 B
-                                 // per pixel — all the wavelet iterations read of it (24 B per pixel in two planes otherwise), or null
+    uint4* guide_out;            // frame / strip drivers: {depth, ddepth, (nx,ny) half bits, (nz, instance ID) half bits} of the CURRENT G-buffer,
+                                 // 16 B per pixel — all the wavelet iterations read of it (24 B per pixel in two planes otherwise), or null
+    const uint4* guide_prev;     // the guide_out plane of the frame whose current G-buffer is this frame's previous one: read instead of
+                                 // motion_p / normal_p / uv_p (16 instead of 32 B per pixel), or null
 };
 struct MomentsArgs {
     const void* colour; void* out; const void* mom; const float4* motion; const uint2* normal; const uint8_t* hist;
@@ -55,7 +57,7 @@ struct PackArgs {
 };
 hipError_t launch_pack_gbuffer(const Geo& g, const PackArgs& a, hipStream_t s);
 hipError_t launch_albedo(const Geo& g, int storage, int mode, const void* in, const void* albedo, void* out, hipStream_t s);
-hipError_t launch_guide(const Geo& g, const float4* motion, const uint2* normal, uint4* guide, hipStream_t s);   // rows [yb, ye)
+hipError_t launch_guide(const Geo& g, const float4* motion, const uint2* normal, const uint2* uv, uint4* guide, hipStream_t s);   // rows [yb, ye)
 hipError_t launch_taa(const Geo& g, int storage, const void* filtered, const void* history, void* out, bool direct, hipStream_t s);
 
 }  // namespace svgf

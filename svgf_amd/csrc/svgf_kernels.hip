@@ -86,6 +86,11 @@ __device__ __forceinline__ float3 normal_of(uint2 n) {
     float2 a = unpack_h2(n.x), b = unpack_h2(n.y);
     return make_float3(a.x, a.y, b.x);
 }
+// One guide texel (16 B): what the wavelet iterations and the NEXT frame's reprojection test read of a G-buffer texel:
+// {depth, ddepth} as stored (raw: depth_of() is applied by the reader), (nx, ny) half bits, (nz, instance ID) half bits.
+__device__ __forceinline__ uint4 guide_texel(float4 motion, uint2 normal, uint2 uv) {
+    return make_uint4(__float_as_uint(motion.z), __float_as_uint(motion.w), normal.x, (normal.y & 0xffffu) | (uv.y & 0xffff0000u));
+}
 // glm::dot order; exact (no contraction) — used by threshold tests
 __device__ __forceinline__ float dot3_exact(float3 a, float3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ float dot3_fma(float3 a, float3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
@@ -141,9 +146,20 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
     const float4 c = clamp01(Store<ST>::ld4(a.radiance, idx));        // :370 imageLoad
     const uint2 nc_raw = a.normal_c[idx];
     const uint2 uc_raw = a.uv_c[idx];
-    const float4 mp = a.motion_p[q];
-    const uint2 np_raw = a.normal_p[q];
-    const uint2 up_raw = a.uv_p[q];
+    // What the test needs of the PREVIOUS G-buffer is {depth, normal, instance ID} at q.  The drivers kept exactly that when
+    // that G-buffer was the current one (guide_out of the previous frame, 16 B) and pass it instead of the three planes (32 B).
+    float4 mp;
+    uint2 np_raw, up_raw;
+    if (a.guide_prev) {
+        const uint4 gp = a.guide_prev[q];
+        mp = make_float4(0.f, 0.f, __uint_as_float(gp.x), __uint_as_float(gp.y));
+        np_raw = make_uint2(gp.z, gp.w);             // normal_of() reads the low half of .y only
+        up_raw = make_uint2(0u, gp.w);               // instance ID: high half of .y, where the uv plane has it
+    } else {
+        mp = a.motion_p[q];
+        np_raw = a.normal_p[q];
+        up_raw = a.uv_p[q];
+    }
     const float4 pc = clamp01(Store<ST>::ld4(a.prev_colour, q));      // :254 imageLoad
     const int hp = a.hist_prev[q];                                    // :255
     const float2 pm = Store<ST>::ld2(a.mom_prev, q);                  // :256
@@ -174,7 +190,7 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
     const float4 o = make_float4(mix_exact(cp.x, c.x, alpha), mix_exact(cp.y, c.y, alpha), mix_exact(cp.z, c.z, alpha), var);
 
     a.hist_cur[idx] = (uint8_t)h;                                     // :400
-    if (a.guide_out) a.guide_out[idx] = make_uint4(__float_as_uint(mc.z), __float_as_uint(mc.w), nc_raw.x, nc_raw.y);
+    if (a.guide_out) a.guide_out[idx] = guide_texel(mc, nc_raw, uc_raw);
     // :401 imageStore.  sparse_colour (frame driver): iteration 0 of the wavelet filter overwrites this texel with its
     // feedback (:619-622) unless it has no depth; until then only the moments estimate of young pixels reads it
     // (the same predicate as the feedback store of atrous_*_kernel: GetDepth() == sentinel, i.e. depth 0 or literally 1e30f)
@@ -1156,7 +1172,17 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
 #ifndef SVGF_MIN_BAND
 #define SVGF_MIN_BAND 8
 #endif
-    if (band < SVGF_MIN_BAND) band = SVGF_MIN_BAND;
+    int min_band = SVGF_MIN_BAND;
+#ifdef SVGF_DIAG
+    if (const int only = diag_env("SVGF_ATROUS_ONLY_STEP", 0); only == 0 || only == S) {   // tune one step at a time
+        slots = diag_env("SVGF_ATROUS_SLOTS_S", slots);
+        nbands = slots / (xtiles * S);
+        if (nbands < 1) nbands = 1;
+        band = (njmax + nbands - 1) / nbands;
+        min_band = diag_env("SVGF_ATROUS_MIN_BAND", min_band);
+    }
+#endif
+    if (band < min_band) band = min_band;
     band = (band + kRS - 1) / kRS * kRS;
     nbands = (njmax + band - 1) / band;
     // m groups per XCD, 8 m groups in all (so that every XCD gets the same number of tiles)
@@ -1644,14 +1670,13 @@ __global__ __launch_bounds__(kBX* kBY) void pack_gbuffer_kernel(Geo g, PackArgs 
 
 // The guide texels of rows the temporal launch does not cover (strips: the a-trous halos reach beyond the rows the temporal
 // stage is computed on).
-__global__ __launch_bounds__(kBX* kBY) void guide_kernel(Geo g, const float4* motion, const uint2* normal, uint4* guide) {
+__global__ __launch_bounds__(kBX* kBY) void guide_kernel(Geo g, const float4* motion, const uint2* normal, const uint2* uv, uint4* guide) {
     const int x = blockIdx.x * kBX + threadIdx.x;
     const int y = g.yb + blockIdx.y * kBY + threadIdx.y;
     if (x >= g.W || y >= g.ye) return;
     const size_t idx = (size_t)(y - g.y0) * g.W + x;
     const float4 m = motion[idx];
-    const uint2 n = normal[idx];
-    guide[idx] = make_uint4(__float_as_uint(m.z), __float_as_uint(m.w), n.x, n.y);
+    guide[idx] = guide_texel(m, normal[idx], uv[idx]);
 }
 
 inline dim3 grid_for(const Geo& g) { return dim3((g.W + kBX - 1) / kBX, (g.ye - g.yb + kBY - 1) / kBY); }
@@ -1743,9 +1768,9 @@ hipError_t launch_pack_gbuffer(const Geo& g, const PackArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_guide(const Geo& g, const float4* motion, const uint2* normal, uint4* guide, hipStream_t s) {
+hipError_t launch_guide(const Geo& g, const float4* motion, const uint2* normal, const uint2* uv, uint4* guide, hipStream_t s) {
     if (g.ye <= g.yb) return hipSuccess;
-    guide_kernel<<<grid_for(g), dim3(kBX, kBY), 0, s>>>(g, motion, normal, guide);
+    guide_kernel<<<grid_for(g), dim3(kBX, kBY), 0, s>>>(g, motion, normal, uv, guide);
     return hipGetLastError();
 }
 

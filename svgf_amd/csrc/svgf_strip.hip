@@ -409,8 +409,10 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
         const Rows rt = grown(l.g, s->H, l.g.ext_temporal), rm = grown(l.g, s->H, l.g.ext_moments);
         c->rb = rt.a; c->re = rt.b;
         void* guide = use_guide(c) ? c->guide : nullptr;      // as svgf_denoise_frame: the temporal launch repacks {depth, ddepth, normal} for the iterations
+        const void* guide_prev = prev_guide_for(c, &cur[k], pv);   // the previous frame's guide plane stands in for its G-buffer (all held rows)
+        c->guide_prev_valid = false;                               // until this frame has written its own (commit_guide below)
         int rc = temporal_moments_impl(c, c->colour[1 - P], radiance[k], c->colour[P], c->filter[0], &cur[k], pv, c->hist[1 - P], c->hist[P],
-                                       c->moments[P], c->moments[1 - P], rm.a, rm.b, s->steps >= 1, guide);
+                                       c->moments[P], c->moments[1 - P], rm.a, rm.b, s->steps >= 1, guide, guide_prev);
         // rows the strip holds beyond the temporal rows (a-trous halos of the later iteration groups): their guide texels
         if (rc == SVGF_OK && guide) rc = guide_rows(c, &cur[k], l.g.y0, rt.a);
         if (rc == SVGF_OK && guide) rc = guide_rows(c, &cur[k], rt.b, l.g.y1);
@@ -470,6 +472,7 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
         c->rb = c->strip.own_begin; c->re = c->strip.own_end;
         if (results) results[k] = c->filter[pp[k]];
         c->result_index = pp[k];
+        commit_guide(c, &cur[k], use_guide(c));
         c->pingpong ^= 1;
         if (c->frames_since_reset < (1 << 30)) c->frames_since_reset++;
     }

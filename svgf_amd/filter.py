@@ -26,7 +26,7 @@ EXPORTS = [
     "svgf_create_strip", "svgf_destroy", "svgf_set_params", "svgf_set_stream", "svgf_set_rows", "svgf_temporal", "svgf_temporal_moments", "svgf_demodulate", "svgf_modulate",
     "svgf_moments", "svgf_atrous", "svgf_taa", "svgf_pack_gbuffer", "svgf_denoise_frame", "svgf_reset_history", "svgf_state_plane",
     "svgf_state_pingpong", "svgf_plane_bytes", "svgf_timing_enable", "svgf_timing_read",
-    "svgf_resize", "svgf_resize_strip", "svgf_get_size", "svgf_sync", "svgf_halo_violations", "svgf_set_valid_rows", "svgf_set_debug_mode",
+    "svgf_resize", "svgf_resize_strip", "svgf_get_size", "svgf_sync", "svgf_halo_violations", "svgf_set_valid_rows", "svgf_set_debug_mode", "svgf_set_prev_guide",
     "svgf_import_gbuffer_pitched", "svgf_import_gbuffer_array", "svgf_export_to_array",
     "svgf_strips_plan", "svgf_rccl_unique_id", "svgf_rccl_comm_init", "svgf_rccl_comm_destroy", "svgf_strips_create", "svgf_strips_destroy",
     "svgf_strips_last_error", "svgf_strips_context", "svgf_strips_layout", "svgf_strips_frame", "svgf_strips_sync",
@@ -157,6 +157,7 @@ def load_library():
     lib.svgf_sync.argtypes = [vp]
     lib.svgf_halo_violations.argtypes = [vp, C.POINTER(C.c_ulonglong), ip]
     lib.svgf_set_debug_mode.argtypes = [vp, ip]
+    lib.svgf_set_prev_guide.argtypes = [vp, ip]
     lib.svgf_set_valid_rows.argtypes = [vp, ip, ip]
     lib.svgf_import_gbuffer_pitched.argtypes = [vp, ip, vp, C.c_size_t, vp]
     lib.svgf_import_gbuffer_array.argtypes = [vp, ip, vp, vp]
@@ -299,6 +300,10 @@ class Denoiser:
     def set_debug_mode(self, mode="final"):
         """SVGFDebugOutput sequences of application::Render (src/App.cu:545-649): 'final', 'temporal', 'atrous'."""
         self._check(self.lib.svgf_set_debug_mode(self._h, DEBUG_MODE[mode]), "svgf_set_debug_mode")
+
+    def set_prev_guide(self, enable=True):
+        """Whether the reprojection test may read the guide plane kept from the previous frame instead of `prev` (svgf.h)."""
+        self._check(self.lib.svgf_set_prev_guide(self._h, 1 if enable else 0), "svgf_set_prev_guide")
 
     def ImportPitched(self, plane, src_ptr, pitch_bytes, dst):
         self._check(self.lib.svgf_import_gbuffer_pitched(self._h, plane, C.c_void_p(src_ptr), pitch_bytes, _ptr(dst)), "svgf_import_gbuffer_pitched")

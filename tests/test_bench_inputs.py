@@ -56,4 +56,4 @@ def test_static_pool_ping_pongs_two_sets_of_planes(bench):
     for a, b in ((c0.motion, c1.motion), (c0.normal, c1.normal), (c0.uv, c1.uv)):
         assert a.data_ptr() != b.data_ptr() and torch.equal(a, b)
     assert float(c0.motion[..., :2].abs().max()) == 0.0
-    assert bench.moved_bytes_full("f32", 5) == 146 + 5 * 48 + 16 and bench.alg_bytes_full("f32", 5) == 459 and bench.alg_bytes_full("f16", 5) == 323
+    assert bench.moved_bytes_full("f32", 5) == 130 + 5 * 48 + 16 and bench.alg_bytes_full("f32", 5) == 459 and bench.alg_bytes_full("f16", 5) == 323

@@ -237,6 +237,53 @@ def test_resize_reallocates_and_restarts(G, storage):
         d.Resize(0, 10)
 
 
+@pytest.mark.parametrize("mesh_id_test", [1, 0])
+def test_previous_guide_plane_stands_in_for_the_previous_gbuffer(G, mesh_id_test):
+    """svgf_set_prev_guide (svgf.h): the frame driver keeps {depth, ddepth, normal, instance ID} of every current G-buffer and, when
+    the next frame's `prev` is that G-buffer (same plane addresses), its reprojection test reads the kept plane instead of the three
+    planes.  (a) bit-identical to the driver with the feature off and to a `prev` handed over as copies at other addresses, on a
+    panning sequence with disocclusions and instance-ID rejections, history included; (b) the planes of `prev` are really not read:
+    scrambling them after their frame changes nothing with the feature on, and does with it off."""
+    import torch
+    from svgf_amd import filter as F
+    W, H, N = 333, 210, 6
+    fr = frames(W, H, N, mv=(-2.5, 1.5))
+    p = F.Params(storage="f32", steps=5, mesh_id_test=mesh_id_test)
+    on, off, copies, scr_on, scr_off = (F.Denoiser(W, H, p) for _ in range(5))
+    off.set_prev_guide(False)
+    scr_off.set_prev_guide(False)
+    gbs = [G.gb_dev(f) for f in fr]
+    gbs_scr = [G.gb_dev(f) for f in fr]                     # a second set, scrambled frame by frame
+    differs = False
+    for k in range(N):
+        rad = G.dev(fr[k]["radiance"])
+        prev = gbs[k - 1] if k else None
+        a = G.host(on.Render(rad, gbs[k], prev))
+        b = G.host(off.Render(rad, gbs[k], prev))
+        c = G.host(copies.Render(rad, gbs[k], F.GBuffer(prev.motion.clone(), prev.normal.clone(), prev.uv.clone()) if k else None))
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)) and np.array_equal(a.view(np.uint8), c.view(np.uint8)), k
+        for plane in (F.PLANE_HISTORY, F.PLANE_MOMENTS, F.PLANE_COLOUR):
+            ha, hb = (G.host(d.state_plane(plane, 1 - d.pingpong())) for d in (on, off))
+            assert np.array_equal(ha.view(np.uint8), hb.view(np.uint8)), (k, plane)
+        if k:
+            torch.cuda.synchronize()
+            for t in (gbs_scr[k - 1].motion, gbs_scr[k - 1].normal, gbs_scr[k - 1].uv):
+                t.zero_()                                    # the previous G-buffer is gone: depth 0 everywhere = sky, nothing reprojects
+        s_on = G.host(scr_on.Render(rad, gbs_scr[k], gbs_scr[k - 1] if k else None))
+        s_off = G.host(scr_off.Render(rad, gbs_scr[k], gbs_scr[k - 1] if k else None))
+        assert np.array_equal(s_on.view(np.uint8), a.view(np.uint8)), f"frame {k}: the previous planes were read"
+        differs = differs or not np.array_equal(s_off.view(np.uint8), a.view(np.uint8))
+    assert differs, "scrambling the previous G-buffer must matter when its planes are read"
+    # fp16 storage and fewer than three iterations have no guide plane: the switch is accepted and changes nothing
+    for kw in (dict(storage="f16", steps=5), dict(storage="f32", steps=2)):
+        x, y = F.Denoiser(W, H, F.Params(**kw)), F.Denoiser(W, H, F.Params(**kw))
+        y.set_prev_guide(False)
+        for k in range(3):
+            rad = G.dev(fr[k]["radiance"].astype(G.NPDT[kw["storage"]]))
+            ax, ay = (G.host(d.Render(rad, gbs[k], gbs[k - 1] if k else None)) for d in (x, y))
+            assert np.array_equal(ax.view(np.uint8), ay.view(np.uint8))
+
+
 @pytest.mark.parametrize("storage", ["f32", "f16"])
 def test_debug_view_sequences(G, oracle, storage):
     """SVGFDebugOutput::TemporalFilter (App.cu:602-609): temporal only; ::ATrousWaveletFilter (App.cu:611-620): temporal, then the
