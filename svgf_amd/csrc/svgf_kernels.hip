@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -518,7 +519,35 @@ constexpr unsigned kOob = 0xFFFFFF00u;   // byte offset no plane reaches (planes
 #ifdef SVGF_STAMPS
 // In-kernel phase stamps (a diagnostic twin of the library only, tools/stamps.py; the product build has none of
 // this, and the stamps' own waits slow that twin down: read its shares, not its run time).
-__device__ unsigned long long g_stamps[16];
+// Every wave adds its sums to a slot of its own (blockIdx, wave): no atomics — 100 000 waves adding to the same sixteen words at
+// their exits slowed the instrumented launch twelve-fold and stalled everybody's memory instructions.
+constexpr int kStampSlots = 1 << 18;
+__device__ unsigned long long g_stamp_log[(size_t)kStampSlots * 16];
+__device__ __forceinline__ void stamp_add(int wave, int i, unsigned long long v) {
+    const unsigned slot = (blockIdx.x * 8u + (unsigned)wave) & (unsigned)(kStampSlots - 1);
+    g_stamp_log[(size_t)slot * 16 + i] += v;
+}
+// Where the waves really run: workgroups resident on the CU when a workgroup starts (sum in stamp 9), and a histogram of the
+// SIMD each wave of a workgroup lands on.
+__device__ unsigned g_cu_resident[4096];
+__device__ unsigned g_simd_hist[8 * 4];
+__device__ __forceinline__ unsigned hw_cu_key(unsigned& simd) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    simd = (hw >> 4) & 3u;
+    return ((((xcc & 7u) * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u + ((hw >> 8) & 15u)) & 4095u;
+}
+__device__ __forceinline__ unsigned stamp_enter(int wave, int lane) {        // -> the CU's key (for stamp_leave)
+    unsigned simd;
+    const unsigned key = hw_cu_key(simd);
+    if (lane == 0) {
+        atomicAdd(&g_simd_hist[(wave & 7) * 4 + simd], 1u);
+        if (wave == 0) stamp_add(0, 9, atomicAdd(&g_cu_resident[key], 1u));
+    }
+    return key;
+}
+__device__ __forceinline__ void stamp_leave(int wave, int lane, unsigned key) { if (lane == 0 && wave == 0) atomicSub(&g_cu_resident[key], 1u); }
 #define SVGF_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp_acc[i] += t_ - stamp_t; stamp_t = t_; } while (0)
 #else
 #define SVGF_STAMP(i) do { } while (0)
@@ -529,6 +558,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) f32x2 lds_f32x2;   // explicitly in LDS (a volatile access through a generic pointer would be a flat load)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 // One staged pixel as it comes off the planes: colour (16 B fp32 / 8 B fp16), {depth, ddepth} (ddepth only for
 // pixels of the thread's own column: DZ), normal.
@@ -787,6 +817,9 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? cfg_waves(S) : SVGF_KR2_
     // measurement: de-phase the workgroups that start together on a CU (consecutive ids of an XCD), in units of 64*SVGF_STAGGER cycles
     for (int q = (int)((blockIdx.x >> 3) & 3u) * SVGF_STAGGER; q > 0; q--) __builtin_amdgcn_s_sleep(1);
 #endif
+#ifdef SVGF_STAMPS
+    const unsigned stamp_key = stamp_enter(t >> 6, lane);
+#endif
     if (t < kRing * 8) nflag[t] = 0u;
 #if SVGF_PROLOGUE_ALL
     {
@@ -832,6 +865,7 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? cfg_waves(S) : SVGF_KR2_
     auto wg_barrier = [&]() __attribute__((always_inline)) { if constexpr (TX * (kRS / KR) > 64) lds_barrier(); else asm volatile("" ::: "memory"); };
 #ifdef SVGF_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_t;
+    unsigned long long stamp_cnt[3] = {0, 0, 0};
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t) :: "memory");
     const unsigned long long stamp_first = stamp_t;
 #endif
@@ -1029,7 +1063,7 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? cfg_waves(S) : SVGF_KR2_
             }
         }
 #ifdef SVGF_STAMPS
-        if (lane == 0) { atomicAdd(&g_stamps[10], 1ull); if (uniform_normals) atomicAdd(&g_stamps[11], 1ull); if (!wave_has_surface) atomicAdd(&g_stamps[12], 1ull); }
+        stamp_cnt[0]++; if (uniform_normals) stamp_cnt[1]++; if (!wave_has_surface) stamp_cnt[2]++;
 #endif
         SVGF_STAMP(1);                             // centre setup + tap loop
 
@@ -1097,10 +1131,13 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? cfg_waves(S) : SVGF_KR2_
     }
 #ifdef SVGF_STAMPS
     if ((t & 63) == 0) {
-        for (int i = 0; i < 6; i++) atomicAdd(&g_stamps[i], stamp_acc[i]);
-        atomicAdd(&g_stamps[6], stamp_first - stamp_entry);          // prologue: entry -> first step
-        atomicAdd(&g_stamps[7], stamp_t - stamp_entry);              // lifetime of the wave
-        atomicAdd(&g_stamps[8], 1ull);
+        const int w_ = t >> 6;
+        for (int i = 0; i < 6; i++) stamp_add(w_, i, stamp_acc[i]);
+        stamp_add(w_, 6, stamp_first - stamp_entry);          // prologue: entry -> first step
+        stamp_add(w_, 7, stamp_t - stamp_entry);              // lifetime of the wave
+        stamp_add(w_, 8, 1ull);
+        stamp_add(w_, 10, stamp_cnt[0]); stamp_add(w_, 11, stamp_cnt[1]); stamp_add(w_, 12, stamp_cnt[2]);
+        stamp_leave(w_, 0, stamp_key);
     }
 #endif
 }
@@ -1216,6 +1253,13 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+#ifndef SVGF_WAVE_SPECIALISED
+#define SVGF_WAVE_SPECIALISED 0     // 1: steps 1-16 through atrous_ws_kernel (compute waves + loader waves, no barriers): a measured alternative,
+#endif                              // parity-green and ~10 % slower than atrous_lds_kernel (svgf_atrous_ws.h); not in the product build
+#if SVGF_WAVE_SPECIALISED
+#include "svgf_atrous_ws.h"
+#endif
+
 template <int ST, int KR, int MODE>
 hipError_t launch_atrous_lds_step_kr(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     // 128-column workgroups (4 waves, 4 per CU) for every step: smaller tiles hit the uniform-normal fast path more
@@ -1250,6 +1294,16 @@ hipError_t launch_atrous_lds_step_kr(const Geo& g, const AtrousArgs& a, hipStrea
         case 4: return launch_atrous_lds<ST, 4, 64, 1, SVGF_FORCE_MODE>(g, a, s);
         case 8: return launch_atrous_lds<ST, 8, 64, 1, SVGF_FORCE_MODE>(g, a, s);
         default: break;
+    }
+#endif
+#if SVGF_WAVE_SPECIALISED
+    if (KR == 1 && MODE == 0 && narrow) switch (a.step) {
+        case 1: return launch_atrous_ws<ST, 1>(g, a, s);
+        case 2: return launch_atrous_ws<ST, 2>(g, a, s);
+        case 4: return launch_atrous_ws<ST, 4>(g, a, s);
+        case 8: return launch_atrous_ws<ST, 8>(g, a, s);
+        case 16: return launch_atrous_ws<ST, 16>(g, a, s);
+        default: return hipErrorInvalidValue;
     }
 #endif
     if (KR == 1 && MODE == 0 && narrow) switch (a.step) {
@@ -1721,10 +1775,22 @@ hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, bool 
 
 #ifdef SVGF_STAMPS
 extern "C" int svgf_diag_stamps(unsigned long long* out, int reset) {
-    unsigned long long h[16];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h)) != hipSuccess) return -1;
-    for (int i = 0; i < 16; i++) out[i] = h[i];
-    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
+    std::vector<unsigned long long> h((size_t)kStampSlots * 16);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_stamp_log), h.size() * sizeof(h[0])) != hipSuccess) return -1;
+    for (int i = 0; i < 16; i++) out[i] = 0;
+    for (size_t k = 0; k < h.size(); k++) out[k & 15] += h[k];
+    unsigned hist[32];
+    if (hipMemcpyFromSymbol(hist, HIP_SYMBOL(g_simd_hist), sizeof(hist)) == hipSuccess) {
+        fprintf(stderr, "[svgf stamps] waves per (wave of the workgroup, SIMD):");
+        for (int w = 0; w < 8; w++) fprintf(stderr, "  w%d: %u %u %u %u", w, hist[w * 4], hist[w * 4 + 1], hist[w * 4 + 2], hist[w * 4 + 3]);
+        fprintf(stderr, "\n");
+    }
+    if (reset) {
+        unsigned zh[32] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_simd_hist), zh, sizeof(zh));
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamp_log)) != hipSuccess || hipMemset(p, 0, h.size() * sizeof(h[0])) != hipSuccess) return -1;
+    }
     return 0;
 }
 #endif
