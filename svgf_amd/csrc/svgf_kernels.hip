@@ -539,6 +539,7 @@ __device__ __forceinline__ unsigned hw_cu_key(unsigned& simd) {
     return ((((xcc & 7u) * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u + ((hw >> 8) & 15u)) & 4095u;
 }
 __device__ __forceinline__ unsigned stamp_enter(int wave, int lane) {        // -> the CU's key (for stamp_leave)
+#ifdef SVGF_STAMPS_PLACEMENT        // (its atomics double the instrumented launch: a build of its own, SVGF_STAMPS_FLAGS=-DSVGF_STAMPS_PLACEMENT)
     unsigned simd;
     const unsigned key = hw_cu_key(simd);
     if (lane == 0) {
@@ -546,8 +547,15 @@ __device__ __forceinline__ unsigned stamp_enter(int wave, int lane) {        // 
         if (wave == 0) stamp_add(0, 9, atomicAdd(&g_cu_resident[key], 1u));
     }
     return key;
+#else
+    return 0u;
+#endif
 }
-__device__ __forceinline__ void stamp_leave(int wave, int lane, unsigned key) { if (lane == 0 && wave == 0) atomicSub(&g_cu_resident[key], 1u); }
+__device__ __forceinline__ void stamp_leave(int wave, int lane, unsigned key) {
+#ifdef SVGF_STAMPS_PLACEMENT
+    if (lane == 0 && wave == 0) atomicSub(&g_cu_resident[key], 1u);
+#endif
+}
 #define SVGF_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp_acc[i] += t_ - stamp_t; stamp_t = t_; } while (0)
 #else
 #define SVGF_STAMP(i) do { } while (0)
