@@ -38,15 +38,14 @@ ALG_BYTES = {
 # Bytes the fused frame driver really moves per pixel in steady state, every plane it touches counted once (no cache
 # credit): the temporal launch reads radiance, both G-buffers (3 planes each), previous colour / moments / history and
 # writes history, moments and the filter buffer (the moments stage's copy, Filter.cuh:521, is folded into it and the
-# temporal colour itself is stored only where it is read again); with fp32 storage it also writes the 16-byte guide texel
+# temporal colour itself is stored only where it is read again); it also writes the 16-byte guide texel
 # {depth, ddepth, normal, instance ID} the iterations read instead of the 16 + 8 byte motion / normal texels — and, one frame
 # later, the reprojection test reads instead of the 32 bytes of the previous G-buffer's three planes (the frames the bench hands
 # over ping-pong between two G-buffers, so the previous one is always the one the guide was made from; tests/test_bench_inputs.py).
-# An iteration reads colour and the guide (fp32) or {depth, ddepth} + normal texels (fp16) and writes colour (+ the feedback
-# colour in iteration 0).
+# An iteration reads colour and the guide and writes colour (+ the feedback colour in iteration 0).
 MOVED_BYTES = {
     "f32": dict(temporal_moments=16 + 32 + 16 + 16 + 8 + 1 + 1 + 8 + 16 + 16, atrous_iter=16 + 16 + 16, atrous_feedback=16),
-    "f16": dict(temporal_moments=8 + 32 + 32 + 8 + 4 + 1 + 1 + 4 + 8, atrous_iter=8 + 16 + 8 + 8, atrous_feedback=8),
+    "f16": dict(temporal_moments=8 + 32 + 16 + 8 + 4 + 1 + 1 + 4 + 8 + 16, atrous_iter=8 + 16 + 8, atrous_feedback=8),
 }
 HBM_PEAK_GBPS = 8000.0        # MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 WORKLOADS = {"1080p": (1920, 1080), "4k": (3840, 2160), "8k": (7680, 4320)}

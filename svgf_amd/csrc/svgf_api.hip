@@ -9,6 +9,9 @@
 
 #include <algorithm>
 #ifndef SVGF_GUIDE_MIN_STEPS
+#ifndef SVGF_GUIDE_F16
+#define SVGF_GUIDE_F16 1            // the guide plane with fp16 storage too
+#endif
 #define SVGF_GUIDE_MIN_STEPS 3       // the guide plane pays for itself from three wavelet iterations on (+16 B/px once, -8 B/px per iteration)
 #endif
 #include <cstdio>
@@ -196,7 +199,7 @@ int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments
 }
 
 bool use_guide(const svgf_ctx* c) {
-    return c->p.storage == SVGF_F32 && c->p.steps >= SVGF_GUIDE_MIN_STEPS && c->p.variant != SVGF_VARIANT_DIRECT && c->guide != nullptr;
+    return (c->p.storage == SVGF_F32 || SVGF_GUIDE_F16) && c->p.steps >= SVGF_GUIDE_MIN_STEPS && c->p.variant != SVGF_VARIANT_DIRECT && c->guide != nullptr;
 }
 
 int guide_rows(svgf_ctx* c, const svgf_gbuffer* g, int rb, int re) {
@@ -566,8 +569,8 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     // moments launch then only works on young pixels: same planes, 32 B/px less traffic in steady state.
     // ... and repacks what the wavelet iterations read of the G-buffer ({depth, ddepth, normal}: 16 B instead of 24 B of lines per
     // pixel and iteration) into the guide plane: +16 B/px here, -8 B/px in each iteration
-    // (measured, tools/abn.sh on one device: -1.5 % per 4K fp32 frame; with fp16 storage the iterations gain less than the temporal
-    // launch loses, so the G-buffer planes are read as they are)
+    // (measured, tools/abn.sh on one device: -1.5 % per 4K fp32 frame; with fp16 storage the iterations alone gained less than the
+    // temporal launch lost — since the NEXT frame's reprojection test reads the plane too (below) it pays there as well: -5.7 %)
     // ... and the NEXT frame's reprojection test reads this frame's guide plane instead of the three planes of its previous
     // G-buffer (prev_guide_for): -16 B/px of the temporal launch's 146
     void* guide = use_guide(c) ? c->guide : nullptr;
