@@ -12,7 +12,7 @@
 #ifndef SVGF_GUIDE_F16
 #define SVGF_GUIDE_F16 1            // the guide plane with fp16 storage too
 #endif
-#define SVGF_GUIDE_MIN_STEPS 3       // the guide plane pays for itself from three wavelet iterations on (+16 B/px once, -8 B/px per iteration)
+#define SVGF_GUIDE_MIN_STEPS 1       // the guide plane pays for itself with any wavelet iteration: +16 B/px written, -16 B/px in the next frame's reprojection test, -8 B/px per iteration
 #endif
 #include <cstdio>
 #include <cstring>

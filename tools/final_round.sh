@@ -10,7 +10,7 @@ python3 bench.py --workload 1080p --no-cpu --no-extra 2>/dev/null | grep "^{" > 
 python3 bench.py --workload 8k --no-cpu --no-extra --steps 20 2>/dev/null | grep "^{" > $O/bench_8k_f32.json
 python3 bench.py --strips --workload 8k --steps 20 --warmup 3 2>/dev/null | grep "^{" > $O/bench_8k_f32_stripdriver_1gpu.json
 for pl in ghost grouped; do for drv in native python; do python3 tools/strip_sim.py --plan $pl --driver $drv --stream own-hi 2>&1 | grep -E "ms/frame"; done; done > $O/strip_sim.txt
-python3 tools/stamps.py 2>&1 | grep -v "diag\]" > $O/stamps.txt
+SVGF_STAMPS_PREBUILT=1 python3 tools/stamps.py 2>&1 | grep -v "diag\]\|amdgpu.ids" > $O/stamps.txt      # build/libsvgf_stamps.so: built here from the same sources (tools/README.md)
 tools/prof.sh ${TAG}_4k_f32 > $O/prof_4k_f32.log 2>&1; python3 tools/summarize_prof.py gpurun_out/prof_${TAG}_4k_f32 | grep -v "at::native\|rocclr" > $O/rocprofv3_summary_4k_f32.txt
 tools/prof.sh ${TAG}_4k_f16 --storage f16 > $O/prof_4k_f16.log 2>&1; python3 tools/summarize_prof.py gpurun_out/prof_${TAG}_4k_f16 | grep -v "at::native\|rocclr" > $O/rocprofv3_summary_4k_f16.txt
 tools/prof.sh ${TAG}_1080p --workload 1080p > $O/prof_1080p.log 2>&1; python3 tools/summarize_prof.py gpurun_out/prof_${TAG}_1080p | grep -v "at::native\|rocclr" > $O/rocprofv3_summary_1080p_f32.txt
