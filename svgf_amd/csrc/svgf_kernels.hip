@@ -529,8 +529,10 @@ __device__ __forceinline__ void stamp_add(int wave, int i, unsigned long long v)
 }
 // Where the waves really run: workgroups resident on the CU when a workgroup starts (sum in stamp 9), and a histogram of the
 // SIMD each wave of a workgroup lands on.
+#ifdef SVGF_STAMPS_PLACEMENT
 __device__ unsigned g_cu_resident[4096];
 __device__ unsigned g_simd_hist[8 * 4];
+#endif
 __device__ __forceinline__ unsigned hw_cu_key(unsigned& simd) {
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -1787,15 +1789,16 @@ extern "C" int svgf_diag_stamps(unsigned long long* out, int reset) {
     if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_stamp_log), h.size() * sizeof(h[0])) != hipSuccess) return -1;
     for (int i = 0; i < 16; i++) out[i] = 0;
     for (size_t k = 0; k < h.size(); k++) out[k & 15] += h[k];
+#ifdef SVGF_STAMPS_PLACEMENT
     unsigned hist[32];
     if (hipMemcpyFromSymbol(hist, HIP_SYMBOL(g_simd_hist), sizeof(hist)) == hipSuccess) {
         fprintf(stderr, "[svgf stamps] waves per (wave of the workgroup, SIMD):");
         for (int w = 0; w < 8; w++) fprintf(stderr, "  w%d: %u %u %u %u", w, hist[w * 4], hist[w * 4 + 1], hist[w * 4 + 2], hist[w * 4 + 3]);
         fprintf(stderr, "\n");
     }
+    if (reset) { unsigned zh[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_simd_hist), zh, sizeof(zh)); }
+#endif
     if (reset) {
-        unsigned zh[32] = {0};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_simd_hist), zh, sizeof(zh));
         void* p = nullptr;
         if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamp_log)) != hipSuccess || hipMemset(p, 0, h.size() * sizeof(h[0])) != hipSuccess) return -1;
     }

@@ -39,7 +39,8 @@ for step in (1, 4, 16):
     if "-DSVGF_WAVE_SPECIALISED=1" in EXTRA:
         cw, lw = max(out[8], 1), max(out[15], 1)
         ctot = sum(out[i] for i in range(4))
-        print(f"   workgroups resident on the CU when one starts: {out[9] / max(out[8] / 4, 1):.2f} on average")
+        if out[9]:
+            print(f"   workgroups resident on the CU when one starts: {out[9] / max(out[8] / 4, 1):.2f} on average")
         print(f"step {step} (wave-specialised): compute waves {out[8]}, steps per wave {out[10] / cw:.1f}, loop ticks per wave {ctot / cw:.0f}, prologue {100.0 * out[6] / max(out[7], 1):.1f} % of the lifetime {out[7] / cw:.0f}")
         for i, nm in enumerate(["setup + taps 0-14", "wait for the refill", "taps 15-24 + epilogue", "stores"]):
             print(f"   {nm:24s} {100.0 * out[i] / max(ctot, 1):5.1f} %   {out[i] / cw:9.0f} ticks/wave")
@@ -54,5 +55,6 @@ for step in (1, 4, 16):
     print(f"   wave-steps {out[10]}, uniform-normal fast path {100.0 * out[11] / max(out[10], 1):.1f} %, all-sky skipped {100.0 * out[12] / max(out[10], 1):.1f} %")
     for i, n in enumerate(names):
         print(f"   {n:22s} {100.0 * out[i] / tot:5.1f} %   {out[i] / max(waves,1):9.0f} ticks/wave")
-    print(f"   workgroups resident on the CU when one starts: {out[9] / max(waves / 4, 1):.2f} on average")
+    if out[9]:
+        print(f"   workgroups resident on the CU when one starts: {out[9] / max(waves / 4, 1):.2f} on average")
     print(f"   prologue {out[6] / max(waves,1):9.0f} ticks/wave = {100.0 * out[6] / max(out[7],1):5.1f} % of the wave lifetime {out[7] / max(waves,1):9.0f}; steps per wave {out[10] / max(waves,1):.1f}")
