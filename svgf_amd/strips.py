@@ -409,13 +409,14 @@ def rccl_comm(world, rank, device_index, group=None):
     from . import filter as F
     lib = F.load_library()
     buf = (C.c_char * 128)()
+    ok = True
     if rank == 0:
-        rc = lib.svgf_rccl_unique_id(buf)
-        if rc != 0:
-            raise F.SvgfError("svgf_rccl_unique_id failed (librccl not available?)")
-    box = [bytes(buf.raw)]
+        ok = lib.svgf_rccl_unique_id(buf) == 0
+    box = [bytes(buf.raw) if ok else b""]            # rank 0's failure travels too: nobody is left waiting in the broadcast
     if world > 1:
         dist.broadcast_object_list(box, src=0, group=group)
+    if len(box[0]) != 128:
+        raise F.SvgfError("svgf_rccl_unique_id failed on rank 0 (librccl not available?)")
     ident = (C.c_char * 128).from_buffer_copy(box[0])
     comm = C.c_void_p()
     rc = lib.svgf_rccl_comm_init(C.byref(comm), world, rank, ident, device_index)
