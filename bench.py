@@ -277,14 +277,31 @@ def pass_block(W, H, storage, iters, ms):
                     "so moved_frac_of_8TBps is the share of the HBM peak the frame really uses"}
 
 
+def usable_cpus():
+    """Threads this process may really run on: the affinity mask and the cgroup's CPU quota, not the box's os.cpu_count()."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(storage, iters):
     """The scalar C++ oracle (kind 'port': the reference has no CPU path) timed on the host cores, on a bounded
     sample of the same workload: 1920x1080 synthetic frames (BASELINE configs[1], a quarter of the 4K frame), steady
-    state, all hardware threads — 960x540 where the host has fewer than 32 threads, to stay within ~10 s."""
+    state, on every thread the process may use (usable_cpus: the GPU boxes show 256 CPUs and grant 16) — 960x540 where that is
+    fewer than 32, to stay within ~10 s."""
     from oracle import oracle as orc
     from svgf_amd import synth
-    W, H = (1920, 1080) if (os.cpu_count() or 1) >= 32 else (960, 540)
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
+    W, H = (1920, 1080) if cores >= 32 else (960, 540)
     fr = [synth.make_frame(W, H, k) for k in range(2)]
     gb = {k: fr[0][k] for k in ("motion", "normal", "uv")}
     pipe = orc.Pipeline(W, H, storage, steps=iters, nthreads=cores)
@@ -308,7 +325,7 @@ def cpu_baseline(storage, iters):
     return {"value": round(W * H * n / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
             "single_thread_value": round(one_mpx, 4),
             "sample": f"{n} steady-state frames of {W}x{H} {storage} ({'1/4' if W == 1920 else '1/16'} of the 4K workload), temporal+moments+{iters} a-trous, "
-                      f"oracle/svgf_oracle.cpp -O2 row-parallel on {cores} threads, {dt:.1f} s"}
+                      f"oracle/svgf_oracle.cpp -O2 row-parallel on {cores} threads (os.cpu_count() = {os.cpu_count()}), {dt:.1f} s"}
 
 
 def emit(line):
