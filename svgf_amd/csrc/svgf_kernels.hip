@@ -724,8 +724,8 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? cfg_waves(S) : SVGF_KR2_
     uint32_t* nref = nflag + kRing * 8;                            // {(nx,ny) bits, nz bits}
 
 #ifdef SVGF_STAMPS
-    unsigned long long stamp_entry;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_entry) :: "memory");
+    unsigned long long stamp_entry, stamp_real0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_entry), "=s"(stamp_real0) :: "memory");
 #endif
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -1145,6 +1145,9 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? cfg_waves(S) : SVGF_KR2_
         for (int i = 0; i < 6; i++) stamp_add(w_, i, stamp_acc[i]);
         stamp_add(w_, 6, stamp_first - stamp_entry);          // prologue: entry -> first step
         stamp_add(w_, 7, stamp_t - stamp_entry);              // lifetime of the wave
+        unsigned long long stamp_real1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_real1) :: "memory");
+        stamp_add(w_, 13, stamp_real0); stamp_add(w_, 14, stamp_real1);   // absolute 100 MHz times: the launch's occupancy over time (svgf_diag_stamp_log, ONE launch)
         stamp_add(w_, 8, 1ull);
         stamp_add(w_, 10, stamp_cnt[0]); stamp_add(w_, 11, stamp_cnt[1]); stamp_add(w_, 12, stamp_cnt[2]);
         stamp_leave(w_, 0, stamp_key);
@@ -1784,6 +1787,11 @@ hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, bool 
 }
 
 #ifdef SVGF_STAMPS
+// the raw per-wave log: kStampSlots x 16 words (slot = blockIdx * 8 + wave)
+extern "C" int svgf_diag_stamp_log(unsigned long long* out, unsigned long long words) {
+    const unsigned long long all = (unsigned long long)kStampSlots * 16;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp_log), (words < all ? words : all) * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
 extern "C" int svgf_diag_stamps(unsigned long long* out, int reset) {
     std::vector<unsigned long long> h((size_t)kStampSlots * 16);
     if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_stamp_log), h.size() * sizeof(h[0])) != hipSuccess) return -1;
