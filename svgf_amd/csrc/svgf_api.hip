@@ -576,6 +576,12 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     void* guide = use_guide(c) ? c->guide : nullptr;
     rc = temporal_impl(c, c->colour[1 - P], radiance, c->colour[P], cur, prev, c->hist[1 - P], c->hist[P],
                        c->moments[P], c->moments[1 - P], c->filter[0], sparse, guide, prev_guide_for(c, cur, prev));  // App.cu:552
+    // a strip context computes rows [rb, re) of the rows it holds: the iterations' halos and the next frame's reprojection read the
+    // guide texels of the others too
+    if (rc == SVGF_OK && guide && is_strip(c)) {
+        rc = guide_rows(c, cur, c->strip.y0, c->rb);
+        if (rc == SVGF_OK) rc = guide_rows(c, cur, c->re, c->strip.y0 + c->strip.rows);
+    }
     if (rc != SVGF_OK) return bail(rc);
     stamp();
     // the first three frames after a reset have history <= 3 everywhere: the LDS-streaming moments kernel
