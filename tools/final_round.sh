@@ -4,6 +4,7 @@ TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; O=gpurun_out/$TAG; mkdir -p $O
 python3 -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | grep -E "passed|failed|Error|error|assert" | tail -5 > $O/pytest_gpu.log
+python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 python3 bench.py 2>$O/bench_4k_f32.err | grep "^{" > $O/bench_4k_f32.json
 python3 bench.py --storage f16 --no-cpu --no-extra 2>/dev/null | grep "^{" > $O/bench_4k_f16.json
 python3 bench.py --workload 1080p --no-cpu --no-extra 2>/dev/null | grep "^{" > $O/bench_1080p_f32.json
