@@ -177,7 +177,8 @@ int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, vo
                          passthrough_out ? c->young_list : nullptr, passthrough_out ? c->young_count + c->young_phase : nullptr,
                          passthrough_out ? c->young_count + (c->young_phase ^ 1) : nullptr, passthrough_out ? c->young_flags : nullptr, sparse_colour, c->p.phi_normal > 0.0f, c->halo_violations,
                          std::max(c->vy0, c->strip.y0) - c->strip.y0, std::min(c->vy1, c->strip.y0 + c->strip.rows) - c->strip.y0, (uint4*)guide_out,
-                         (const uint4*)guide_prev};
+                         (const uint4*)guide_prev,
+                         c->strip.y0, c->strip.y0 + c->strip.rows};      // the guide texels of every row held (a strip runs the stage on fewer)
     SVGF_HIP(c, svgf::launch_temporal(geo_of(c), c->p.storage, a, c->stream));
     if (passthrough_out) c->young_pending = true;
     return SVGF_OK;
@@ -202,13 +203,6 @@ bool use_guide(const svgf_ctx* c) {
     return (c->p.storage == SVGF_F32 || SVGF_GUIDE_F16) && c->p.steps >= SVGF_GUIDE_MIN_STEPS && c->p.variant != SVGF_VARIANT_DIRECT && c->guide != nullptr;
 }
 
-int guide_rows(svgf_ctx* c, const svgf_gbuffer* g, int rb, int re) {
-    if (re <= rb || !c->guide) return SVGF_OK;
-    svgf::Geo geo = geo_of(c);
-    geo.yb = rb; geo.ye = re;
-    SVGF_HIP(c, svgf::launch_guide(geo, (const float4*)g->motion, (const uint2*)g->normal, (const uint2*)g->uv, (uint4*)c->guide, c->stream));
-    return SVGF_OK;
-}
 
 // The reprojection test reads {depth, normal, instance ID} of the previous G-buffer; the guide plane the previous frame wrote
 // holds exactly those bits.  It stands in for `prev` only when `prev` IS the G-buffer that frame was given as current (same
@@ -576,12 +570,6 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     void* guide = use_guide(c) ? c->guide : nullptr;
     rc = temporal_impl(c, c->colour[1 - P], radiance, c->colour[P], cur, prev, c->hist[1 - P], c->hist[P],
                        c->moments[P], c->moments[1 - P], c->filter[0], sparse, guide, prev_guide_for(c, cur, prev));  // App.cu:552
-    // a strip context computes rows [rb, re) of the rows it holds: the iterations' halos and the next frame's reprojection read the
-    // guide texels of the others too
-    if (rc == SVGF_OK && guide && is_strip(c)) {
-        rc = guide_rows(c, cur, c->strip.y0, c->rb);
-        if (rc == SVGF_OK) rc = guide_rows(c, cur, c->re, c->strip.y0 + c->strip.rows);
-    }
     if (rc != SVGF_OK) return bail(rc);
     stamp();
     // the first three frames after a reset have history <= 3 everywhere: the LDS-streaming moments kernel

@@ -94,8 +94,7 @@ int temporal_moments_impl(svgf_ctx* c, const void* prev_colour, const void* radi
                           const void* guide_prev = nullptr);
 int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration, const void* guide = nullptr);
 const void* prev_guide_for(const svgf_ctx* c, const svgf_gbuffer* cur, const svgf_gbuffer* prev);   // the guide plane that stands in for `prev`, or null
-void commit_guide(svgf_ctx* c, const svgf_gbuffer* cur, bool written);   // end of a frame: the guide just written (all held rows) becomes the previous one
+void commit_guide(svgf_ctx* c, const svgf_gbuffer* cur, bool written);   // end of a frame: the guide just written (the temporal launch covers all held rows) becomes the previous one
 bool use_guide(const svgf_ctx* c);      // the frame / strip drivers repack {depth, ddepth, normal} for the iterations (fp32 storage, >= 3 iterations)
-int guide_rows(svgf_ctx* c, const svgf_gbuffer* g, int rb, int re);      // guide texels of rows [rb, re) that no temporal launch covers
 
 }  // namespace svgf_host

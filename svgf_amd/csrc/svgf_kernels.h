@@ -30,6 +30,8 @@ struct TemporalArgs {
                                  // 16 B per pixel — all the wavelet iterations read of it (24 B per pixel in two planes otherwise), or null
     const uint4* guide_prev;     // the guide_out plane of the frame whose current G-buffer is this frame's previous one: read instead of
                                  // motion_p / normal_p / uv_p (16 instead of 32 B per pixel), or null
+    int guide_lo, guide_hi;      // global rows [guide_lo, guide_hi) whose guide texel this launch writes (>= the compute rows of Geo: a strip
+                                 // needs the texels of every row it holds)
 };
 struct MomentsArgs {
     const void* colour; void* out; const void* mom; const float4* motion; const uint2* normal; const uint8_t* hist;
@@ -57,7 +59,6 @@ struct PackArgs {
 };
 hipError_t launch_pack_gbuffer(const Geo& g, const PackArgs& a, hipStream_t s);
 hipError_t launch_albedo(const Geo& g, int storage, int mode, const void* in, const void* albedo, void* out, hipStream_t s);
-hipError_t launch_guide(const Geo& g, const float4* motion, const uint2* normal, const uint2* uv, uint4* guide, hipStream_t s);   // rows [yb, ye)
 hipError_t launch_taa(const Geo& g, int storage, const void* filtered, const void* history, void* out, bool direct, hipStream_t s);
 
 }  // namespace svgf

@@ -124,10 +124,19 @@ constexpr int kBX = 64, kBY = 4;                                      // one wav
 // dependent fetches); rejected pixels simply discard them.
 template <int ST>
 __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs a) {
+    if (a.young_list && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) *a.young_count_next = 0u;
+    // The grid covers the compute rows [yb, ye) and, where a guide plane is written, the rows [guide_lo, guide_hi) around them (a strip
+    // holds more rows than it runs the temporal stage on: the later iterations' halos and the next frame's reprojection read their
+    // guide texels too): a row outside the compute rows gets its guide texel and nothing else (a wave is one row: no divergence).
+    const int ylo = a.guide_out ? min(g.yb, a.guide_lo) : g.yb, yhi = a.guide_out ? max(g.ye, a.guide_hi) : g.ye;
     const int x = blockIdx.x * kBX + threadIdx.x;
-    const int y = g.yb + blockIdx.y * kBY + threadIdx.y;
-    if (x >= g.W || y >= g.ye) return;
+    const int y = ylo + blockIdx.y * kBY + threadIdx.y;
+    if (x >= g.W || y >= yhi) return;
     const size_t idx = (size_t)(y - g.y0) * g.W + x;
+    if (y < g.yb || y >= g.ye) {
+        a.guide_out[idx] = guide_texel(a.motion_c[idx], a.normal_c[idx], a.uv_c[idx]);
+        return;
+    }
 
     const float4 mc = a.motion_c[idx];
     const int qx = x + (int)mc.x, qy = y + (int)mc.y;                 // :232, truncation toward zero
@@ -223,7 +232,6 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
             if (listed) a.young_list[base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
         }
         if (threadIdx.x == 0) a.young_flags[(size_t)(y - g.y0) * ((g.W + kBX - 1) / kBX) + blockIdx.x] = whole_wave ? 1 : 0;
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) *a.young_count_next = 0u;
     }
 }
 
@@ -1735,16 +1743,6 @@ __global__ __launch_bounds__(kBX* kBY) void pack_gbuffer_kernel(Geo g, PackArgs 
     a.uv_out[idx] = make_uint2(pack_h2(b.x, b.y), pack_h2(b.z, b.w));
 }
 
-// The guide texels of rows the temporal launch does not cover (strips: the a-trous halos reach beyond the rows the temporal
-// stage is computed on).
-__global__ __launch_bounds__(kBX* kBY) void guide_kernel(Geo g, const float4* motion, const uint2* normal, const uint2* uv, uint4* guide) {
-    const int x = blockIdx.x * kBX + threadIdx.x;
-    const int y = g.yb + blockIdx.y * kBY + threadIdx.y;
-    if (x >= g.W || y >= g.ye) return;
-    const size_t idx = (size_t)(y - g.y0) * g.W + x;
-    const float4 m = motion[idx];
-    guide[idx] = guide_texel(m, normal[idx], uv[idx]);
-}
 
 inline dim3 grid_for(const Geo& g) { return dim3((g.W + kBX - 1) / kBX, (g.ye - g.yb + kBY - 1) / kBY); }
 
@@ -1752,7 +1750,8 @@ inline dim3 grid_for(const Geo& g) { return dim3((g.W + kBX - 1) / kBX, (g.ye - 
 
 hipError_t launch_temporal(const Geo& g, int storage, const TemporalArgs& a, hipStream_t s) {
     if (g.ye <= g.yb) return hipSuccess;
-    const dim3 block(kBX, kBY), grid = grid_for(g);
+    const int ylo = a.guide_out ? std::min(g.yb, a.guide_lo) : g.yb, yhi = a.guide_out ? std::max(g.ye, a.guide_hi) : g.ye;
+    const dim3 block(kBX, kBY), grid((g.W + kBX - 1) / kBX, (yhi - ylo + kBY - 1) / kBY);
     if (storage == 0) temporal_kernel<0><<<grid, block, 0, s>>>(g, a);
     else temporal_kernel<1><<<grid, block, 0, s>>>(g, a);
     return hipGetLastError();
@@ -1853,11 +1852,6 @@ hipError_t launch_pack_gbuffer(const Geo& g, const PackArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_guide(const Geo& g, const float4* motion, const uint2* normal, const uint2* uv, uint4* guide, hipStream_t s) {
-    if (g.ye <= g.yb) return hipSuccess;
-    guide_kernel<<<grid_for(g), dim3(kBX, kBY), 0, s>>>(g, motion, normal, uv, guide);
-    return hipGetLastError();
-}
 
 hipError_t launch_taa(const Geo& g, int storage, const void* filtered, const void* history, void* out, bool direct, hipStream_t s) {
     if (g.ye <= g.yb) return hipSuccess;

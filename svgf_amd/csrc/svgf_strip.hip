@@ -413,9 +413,8 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
         c->guide_prev_valid = false;                               // until this frame has written its own (commit_guide below)
         int rc = temporal_moments_impl(c, c->colour[1 - P], radiance[k], c->colour[P], c->filter[0], &cur[k], pv, c->hist[1 - P], c->hist[P],
                                        c->moments[P], c->moments[1 - P], rm.a, rm.b, s->steps >= 1, guide, guide_prev);
-        // rows the strip holds beyond the temporal rows (a-trous halos of the later iteration groups): their guide texels
-        if (rc == SVGF_OK && guide) rc = guide_rows(c, &cur[k], l.g.y0, rt.a);
-        if (rc == SVGF_OK && guide) rc = guide_rows(c, &cur[k], rt.b, l.g.y1);
+        // (the temporal launch also writes the guide texels of the rows the strip holds beyond the temporal rows: the a-trous halos
+        // of the later iteration groups and the next frame's reprojection read them)
         if (rc != SVGF_OK) return sfail(s, rc, c->err);
     }
     auto post_state = [&]() -> int {
