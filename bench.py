@@ -347,7 +347,8 @@ def launch_ranks(args):
     import socket
     import torch
     have = torch.cuda.device_count()          # does not initialise the GPU
-    if have < args.gpus:
+    share = os.environ.get("SVGF_BENCH_SHARE_DEVICES") == "1"      # testing only: N ranks on fewer devices (process group: gloo, see main)
+    if have < args.gpus and not (share and have >= 1):
         print(f"bench.py: --gpus {args.gpus} but only {have} device(s) are visible", file=sys.stderr)
         return 2
     with socket.socket() as s:
@@ -355,7 +356,7 @@ def launch_ranks(args):
         port = s.getsockname()[1]
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % have if share else r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
@@ -388,7 +389,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=device)
+        # SVGF_BENCH_SHARE_DEVICES=1 (testing the N > 1 flow on a box with fewer GPUs): RCCL refuses two ranks on one device, so the
+        # process group is gloo and the strip schedule runs through the Python driver
+        if os.environ.get("SVGF_BENCH_SHARE_DEVICES") == "1":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
         assert world == N, f"--gpus {N} but WORLD_SIZE={world}"
 
     storage, iters = args.storage, args.iters

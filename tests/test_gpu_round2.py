@@ -378,3 +378,21 @@ def test_parity_report(G, oracle):
     with open(os.path.join(ROOT, "gpurun_out", "parity_report.json"), "w") as f:
         json.dump(report, f, indent=1)
     print(json.dumps(report))
+
+
+def test_bench_flow_of_two_ranks_on_one_device():
+    """`bench.py --gpus 2` end to end on a box with ONE GPU: SVGF_BENCH_SHARE_DEVICES=1 puts both rank processes on device 0 with a gloo
+    process group (RCCL refuses two ranks on one device), so the whole N > 1 flow runs — self-launch, strip geometry, the motion-reach
+    all-reduce, the strip schedule with its halo exchanges (Python driver), max-over-ranks timing, rank 0's JSON line."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SVGF_BENCH_SHARE_DEVICES="1")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--driver", "python", "--workload", "4k"],
+                       env=env, capture_output=True, text=True, timeout=500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["halo_plan"] in ("ghost", "grouped", "per-iteration")
+    assert "1080 rows per GPU" in d["config"]["workload"] and d["roofline"]["launches_timed"] > 0
