@@ -216,7 +216,7 @@ def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, de
 
 def kernel_source_sha():
     h = hashlib.sha256()
-    for f in ("svgf_kernels.hip", "svgf_api.hip", "svgf_kernels.h"):
+    for f in ("svgf_kernels.hip", "svgf_api.hip", "svgf_kernels.h", "svgf_ctx.h"):
         with open(os.path.join(ROOT, "svgf_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
