@@ -1280,6 +1280,12 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
 #if SVGF_WAVE_SPECIALISED
 #include "svgf_atrous_ws.h"
 #endif
+#ifndef SVGF_ROWS4
+#define SVGF_ROWS4 0                // bit mask of steps (1, 2, 4, 8, 16) launched through atrous_r4_kernel (four rows per step, 8-wave workgroups):
+#endif                              // a measured alternative (svgf_atrous_r4.h), not in the product build
+#if SVGF_ROWS4
+#include "svgf_atrous_r4.h"
+#endif
 
 template <int ST, int KR, int MODE>
 hipError_t launch_atrous_lds_step_kr(const Geo& g, const AtrousArgs& a, hipStream_t s) {
@@ -1314,6 +1320,16 @@ hipError_t launch_atrous_lds_step_kr(const Geo& g, const AtrousArgs& a, hipStrea
         case 2: return launch_atrous_lds<ST, 2, 64, 1, SVGF_FORCE_MODE>(g, a, s);
         case 4: return launch_atrous_lds<ST, 4, 64, 1, SVGF_FORCE_MODE>(g, a, s);
         case 8: return launch_atrous_lds<ST, 8, 64, 1, SVGF_FORCE_MODE>(g, a, s);
+        default: break;
+    }
+#endif
+#if SVGF_ROWS4
+    if (KR == 1 && MODE == 0 && narrow && (a.step & SVGF_ROWS4)) switch (a.step) {
+        case 1: return launch_atrous_r4<ST, 1>(g, a, s);
+        case 2: return launch_atrous_r4<ST, 2>(g, a, s);
+        case 4: return launch_atrous_r4<ST, 4>(g, a, s);
+        case 8: return launch_atrous_r4<ST, 8>(g, a, s);
+        case 16: return launch_atrous_r4<ST, 16>(g, a, s);
         default: break;
     }
 #endif
