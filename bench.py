@@ -462,6 +462,15 @@ def main():
                                                  "frac_of_8TBps": pass_block(W, H, "f16", iters, r3["ms_per_step"])["frac_of_8TBps"],
                                                  "atrous_avg_launch_ms": roof3["avg_launch_ms"] if roof3 else None,
                                                  "atrous_roofline_frac": roof3["frac"] if roof3 else None}
+        if not args.no_extra and args.variant == "auto" and wl == "4k":
+            # the synthetic scene is piecewise planar: 68-87 % of the a-trous waves take the uniform-normal fast path (8 instead of 13
+            # vector instructions per tap, same results).  What geometry without planar regions would cost: the fast path switched off.
+            r4 = run_single(FramePool(scene, storage, "static"), W, H, storage, iters, "lds-general", max(args.steps, 20), args.warmup, device)
+            roof4, _ = roofline_block(W, H, storage, iters, r4["stage_ms"], "auto")
+            line["also"]["no_uniform_normal_fast_path"] = {"ms_per_step": round(r4["ms_per_step"], 4), "Mpixels/s": round(W * H / (r4["ms_per_step"] * 1e-3) / 1e6, 1),
+                                                           "frac_of_8TBps": pass_block(W, H, storage, iters, r4["ms_per_step"])["frac_of_8TBps"],
+                                                           "atrous_avg_launch_ms": roof4["avg_launch_ms"] if roof4 else None,
+                                                           "atrous_roofline_frac": roof4["frac"] if roof4 else None}
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(storage, iters)
         if world > 1 or args.strips:

@@ -62,7 +62,9 @@ enum svgf_status {
 enum svgf_storage { SVGF_F32 = 0, SVGF_F16 = 1 };
 
 /* Which à-trous kernel to run (all give the same results; for A/B measurement). */
-enum svgf_variant { SVGF_VARIANT_AUTO = 0, SVGF_VARIANT_DIRECT = 1, SVGF_VARIANT_LDS = 2 };
+enum svgf_variant { SVGF_VARIANT_AUTO = 0, SVGF_VARIANT_DIRECT = 1, SVGF_VARIANT_LDS = 2,
+                    SVGF_VARIANT_LDS_GENERAL = 3 };   /* the LDS kernels with the a-trous uniform-normal fast path switched off (same results): what
+                                                       * geometry without planar regions costs; bench.py reports it next to the headline */
 
 typedef struct svgf_ctx svgf_ctx;
 

@@ -37,7 +37,7 @@ int check_params(svgf_ctx* c, const svgf_params* p) {
     if (p->steps < 0 || p->steps > SVGF_MAX_STEPS) return fail(c, SVGF_ERR_INVALID, "steps must be in [0,10] (GUI.cpp:988)");
     if (p->storage != SVGF_F32 && p->storage != SVGF_F16) return fail(c, SVGF_ERR_INVALID, "storage must be SVGF_F32 or SVGF_F16");
     if (p->moments_radius < 0 || p->moments_radius > 3) return fail(c, SVGF_ERR_INVALID, "moments_radius must be in [0,3]");
-    if (p->variant < SVGF_VARIANT_AUTO || p->variant > SVGF_VARIANT_LDS) return fail(c, SVGF_ERR_INVALID, "unknown variant");
+    if (p->variant < SVGF_VARIANT_AUTO || p->variant > SVGF_VARIANT_LDS_GENERAL) return fail(c, SVGF_ERR_INVALID, "unknown variant");
     return SVGF_OK;
 }
 
@@ -230,7 +230,7 @@ int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const sv
     if (rc == SVGF_OK) rc = check_halo(c, 2 * step, "svgf_atrous");
     if (rc != SVGF_OK) return rc;
     svgf::AtrousArgs a{in, out, iteration == 0 ? feedback : nullptr, (const float4*)g->motion, (const uint2*)g->normal,
-                       step, c->p.phi_colour, c->p.phi_normal, (const uint4*)guide};
+                       step, c->p.phi_colour, c->p.phi_normal, (const uint4*)guide, c->p.variant == SVGF_VARIANT_LDS_GENERAL};
     SVGF_HIP(c, svgf::launch_atrous(geo_of(c), c->p.storage, c->p.variant, a, c->stream));
     return SVGF_OK;
 }

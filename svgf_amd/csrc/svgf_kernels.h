@@ -47,6 +47,7 @@ struct AtrousArgs {
     const void* in; void* out; void* feedback; const float4* motion; const uint2* normal;
     int step; float phi_colour, phi_normal;
     const uint4* guide;          // TemporalArgs::guide_out of the same frame (LDS kernel only; motion / normal are then not read), or null
+    int no_fastpath;             // SVGF_VARIANT_LDS_GENERAL: every wave takes the general tap path (bit-identical, slower)
 };
 
 hipError_t launch_temporal(const Geo& g, int storage, const TemporalArgs& a, hipStream_t s);

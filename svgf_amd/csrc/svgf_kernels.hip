@@ -931,7 +931,7 @@ __global__ __launch_bounds__(TX * (kRS / KR), KR == 1 ? cfg_waves(S) : SVGF_KR2_
         // a wave whose centres are all sky (a band of cleared texels) has nothing to filter (:554-558)
         const bool wave_has_surface = __ballot(any_surface) != 0ull;
         // every surface texel of the ring has the reference normal -> n.n' is each centre's own |n|^2
-        const bool uniform_normals = __ballot(lane < kRing * 8 && nflag[lane < kRing * 8 ? lane : 0] != 0u) == 0ull;
+        const bool uniform_normals = !a.no_fastpath && __ballot(lane < kRing * 8 && nflag[lane < kRing * 8 ? lane : 0] != 0u) == 0ull;
         // One ring row at a time (5 taps = 10 x ds_read_b128 in flight; KR = 2 reads the next row before it
         // consumes the current one).  The empty asm statements pin that order: left alone, instruction selection
         // sinks all arithmetic below all LDS reads of the unrolled loop (256 VGPRs + scratch spills).

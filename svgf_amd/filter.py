@@ -17,7 +17,7 @@ from . import build as _build
 
 SVGF_F32, SVGF_F16 = 0, 1
 STORAGE = {"f32": SVGF_F32, "f16": SVGF_F16}
-VARIANT = {"auto": 0, "direct": 1, "lds": 2}
+VARIANT = {"auto": 0, "direct": 1, "lds": 2, "lds-general": 3}
 PLANE_COLOUR, PLANE_MOMENTS, PLANE_FILTER, PLANE_HISTORY = 0, 1, 2, 3
 MAX_STEPS = 10
 

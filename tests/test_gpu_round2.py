@@ -396,3 +396,18 @@ def test_bench_flow_of_two_ranks_on_one_device():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["halo_plan"] in ("ghost", "grouped", "per-iteration")
     assert "1080 rows per GPU" in d["config"]["workload"] and d["roofline"]["launches_timed"] > 0
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_general_tap_path_equals_the_uniform_normal_fast_path(G, storage):
+    """SVGF_VARIANT_LDS_GENERAL switches the uniform-normal fast path of the a-trous kernel off (every wave evaluates n.n' per tap):
+    the frames of a panning sequence are bit-identical to the default — the fast path is an exact shortcut, whatever the geometry."""
+    from svgf_amd import filter as F
+    W, H, N = 389, 222, 4
+    fr = frames(W, H, N, mv=(1.0, -2.5))
+    a, b = F.Denoiser(W, H, F.Params(storage=storage, steps=5)), F.Denoiser(W, H, F.Params(storage=storage, steps=5, variant="lds-general"))
+    gbs = [G.gb_dev(f) for f in fr]
+    for k in range(N):
+        rad = G.dev(fr[k]["radiance"].astype(G.NPDT[storage]))
+        x, y = (G.host(d.Render(rad, gbs[k], gbs[k - 1] if k else None)) for d in (a, b))
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), (storage, k)
