@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (pan, 1080p, fp16, cold frames)")
     ap.add_argument("--strips", action="store_true", help="run the strip driver even at N=1 (exercises the N>1 code path)")
+    ap.add_argument("--no-fuse", action="store_true", help="one launch per a-trous iteration (default: iterations 0 and 1 as one launch)")
     return ap.parse_args()
 
 
@@ -175,11 +176,12 @@ class FramePool:
 
 
 # ------------------------------------------------------------------ single GPU -----------------
-def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, device, cold_frames=0):
+def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, device, cold_frames=0, fuse=True):
     """-> dict(ms_per_step, stage_ms[list], frames).  Timed region: sync, K frames, sync."""
     import torch
     from svgf_amd import filter as F
     d = F.Denoiser(W, H, F.Params(storage=storage, steps=iters, variant=variant), device=device.index or 0)
+    d.set_iteration_fusion(fuse)
     n = 0
     for _ in range(PRIME_FRAMES + warmup):
         d.Render(*pool.frame(n))

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define SVGF_ABI_VERSION 2
+#define SVGF_ABI_VERSION 3
 
 enum svgf_status {
     SVGF_OK = 0,
@@ -166,6 +166,17 @@ int svgf_temporal_moments(svgf_ctx* ctx, const void* prev_colour, const void* ra
 int svgf_atrous(svgf_ctx* ctx, const void* in, void* out, void* feedback, const svgf_gbuffer* gbuf,
                 int step, int iteration);
 
+/* Stage 3, iterations 0 and 1 in ONE launch — the first two trips of the loop in application::WaveletFilter (App.cu:497-507:
+ * steps 1 and 2, FilterBuffer[0] -> [1] -> [0]) without the plane in between: iteration 0's rows stay on the chip for iteration 1
+ * and reach memory only as `feedback` (RenderOutput, Filter.cuh:619-622; may be NULL).  `out` receives what two svgf_atrous calls
+ * would leave in their second `out`, bit for bit, on the rows set by svgf_set_rows; `feedback` is written on those rows and the
+ * 4 rows beyond them inside the frame (iteration 1 reads iteration 0 there), so the planes must hold 6 rows around the launch
+ * rows (SVGF_ERR_HALO otherwise).  `in`, `out` and `feedback` are three different planes.  Needs variant != SVGF_VARIANT_DIRECT
+ * and PhiNormal != 0.  svgf_denoise_frame and the strip driver use it whenever steps >= 2 (svgf_set_iteration_fusion(ctx, 0)
+ * restores one launch per iteration: same results). */
+int svgf_atrous_pair(svgf_ctx* ctx, const void* in, void* out, void* feedback, const svgf_gbuffer* gbuf);
+int svgf_set_iteration_fusion(svgf_ctx* ctx, int enable);
+
 /* The stage after the path — replaces application::TAA (App.cu:516-522) launching filter::TAAFilterKernel
  * (Filter.cuh:288-357): neighbourhood-clamped temporal anti-aliasing in PAL-YUV + linear->sRGB.  `history` is the
  * previous call's `out` (a separate plane: the reference reads it from the buffer it is writing, a race). */
@@ -241,7 +252,8 @@ int   svgf_state_pingpong(const svgf_ctx* ctx);                        /* PingPo
 size_t svgf_plane_bytes(const svgf_ctx* ctx, int plane);
 
 /* Per-stage device timing with HIP events on the context's stream (the reference only prints whole
- * frame time, App.cu:727-731).  Slots: 0 temporal, 1 moments, 2+i à-trous iteration i. */
+ * frame time, App.cu:727-731).  Slots: 0 temporal, 1 moments, 2+i à-trous iteration i (when iterations 0 and 1 run as one
+ * launch, slot 2 holds the pair and slot 3 the ~1 us between two events). */
 #define SVGF_MAX_STEPS 10                                              /* GUI range 0-10, GUI.cpp:988 */
 int svgf_timing_enable(svgf_ctx* ctx, int on);                                  /* 0 = off, n = time every n-th frame (events cost ~1 us each) */
 int svgf_timing_read(svgf_ctx* ctx, double* ms_sum, int* frames, int slots);   /* synchronises; resets sums */

@@ -62,6 +62,11 @@ int check_halo(svgf_ctx* c, int reach, const char* stage) {
     return SVGF_OK;
 }
 
+bool halo_held(const svgf_ctx* c, int reach) {
+    const int lo = std::max(0, c->rb - reach), hi = std::min(c->H, c->re + reach);
+    return c->re <= c->rb || (lo >= c->strip.y0 && hi <= c->strip.y0 + c->strip.rows);
+}
+
 int check_gbuf(svgf_ctx* c, const svgf_gbuffer* g, bool need_uv, const char* what) {
     if (!g || !g->motion || !g->normal || (need_uv && !g->uv)) return fail(c, SVGF_ERR_INVALID, std::string(what) + ": null G-buffer plane");
     return SVGF_OK;
@@ -233,6 +238,25 @@ int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const sv
                        step, c->p.phi_colour, c->p.phi_normal, (const uint4*)guide, c->p.variant == SVGF_VARIANT_LDS_GENERAL};
     SVGF_HIP(c, svgf::launch_atrous(geo_of(c), c->p.storage, c->p.variant, a, c->stream));
     return SVGF_OK;
+}
+
+// Iterations 0 and 1 of application::WaveletFilter's loop (App.cu:497-507: steps 1 and 2) as ONE launch: iteration 0's rows never
+// leave the chip except as the feedback plane (svgf_atrous_fused.h).  `out` receives iteration 1's result on rows [rb, re).
+int atrous_pair_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, const void* guide) {
+    if (!in || !out) return fail(c, SVGF_ERR_INVALID, "svgf_atrous_pair: null plane");
+    if (in == out || in == feedback || out == feedback) return fail(c, SVGF_ERR_INVALID, "svgf_atrous_pair: in, out and feedback must be three planes");
+    int rc = check_gbuf(c, g, false, "svgf_atrous_pair");
+    if (rc == SVGF_OK) rc = check_halo(c, 2 + 4 + 0, "svgf_atrous_pair");       // iteration 1 reaches 4 rows of iteration 0, which reaches 2
+    if (rc != SVGF_OK) return rc;
+    svgf::AtrousArgs a{in, out, feedback, (const float4*)g->motion, (const uint2*)g->normal,
+                       1, c->p.phi_colour, c->p.phi_normal, (const uint4*)guide, c->p.variant == SVGF_VARIANT_LDS_GENERAL};
+    if (!svgf::atrous_fused_available(c->p.variant, a)) return fail(c, SVGF_ERR_INVALID, "svgf_atrous_pair: needs the LDS kernels (variant != direct) and PhiNormal != 0");
+    SVGF_HIP(c, svgf::launch_atrous_fused(geo_of(c), c->p.storage, a, c->stream));
+    return SVGF_OK;
+}
+
+bool can_fuse01(const svgf_ctx* c) {
+    return c->fuse01 && c->p.steps >= 2 && c->p.variant != SVGF_VARIANT_DIRECT && c->p.phi_normal != 0.0f;
 }
 
 int temporal_moments_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, void* filter_out,
@@ -421,6 +445,18 @@ int svgf_atrous(svgf_ctx* c, const void* in, void* out, void* feedback, const sv
     return atrous_impl(c, in, out, feedback, g, step, iteration);
 }
 
+int svgf_atrous_pair(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g) {
+    if (!c) return SVGF_ERR_INVALID;
+    DeviceGuard dg(c->device);
+    return atrous_pair_impl(c, in, out, feedback, g);
+}
+
+int svgf_set_iteration_fusion(svgf_ctx* c, int enable) {
+    if (!c) return SVGF_ERR_INVALID;
+    c->fuse01 = enable != 0;
+    return SVGF_OK;
+}
+
 int svgf_taa(svgf_ctx* c, const void* filtered, const void* history, void* out) {
     if (!c) return SVGF_ERR_INVALID;
     if (!filtered || !history || !out) return fail(c, SVGF_ERR_INVALID, "svgf_taa: null plane");
@@ -576,8 +612,15 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     rc = moments_impl(c, c->colour[P], c->filter[0], c->moments[P], cur, c->hist[P], 1, c->frames_since_reset < 3 && c->p.variant != SVGF_VARIANT_DIRECT, sparse);   // App.cu:554 (current moments: App. B #4)
     if (rc != SVGF_OK) return bail(rc);
     stamp();
-    int pp = 0;
-    for (int i = 0; i < c->p.steps; i++) {                                      // App.cu:497-507
+    int pp = 0, first = 0;
+    if (can_fuse01(c) && halo_held(c, 6)) {
+        // iterations 0 and 1 as one launch: filter[0] -> filter[1] (iteration 0's own plane is never written), feedback as ever
+        rc = atrous_pair_impl(c, c->filter[0], c->filter[1], c->colour[P], cur, guide);
+        if (rc != SVGF_OK) return bail(rc);
+        stamp(); stamp();                                                       // timing slot 2 holds the pair, slot 3 (next to) nothing
+        pp = 1; first = 2;
+    }
+    for (int i = first; i < c->p.steps; i++) {                                  // App.cu:497-507
         rc = atrous_impl(c, c->filter[pp], c->filter[1 - pp], c->colour[P], cur, 1 << i, i, guide);
         if (rc != SVGF_OK) return bail(rc);
         stamp();

@@ -1,0 +1,400 @@
+// svgf_atrous_fused.h — wavelet iterations 0 and 1 (steps 1 and 2) of application::WaveletFilter (App.cu:497-507, kernel
+// Filter.cuh:527-624) in ONE streaming launch.  Included by svgf_kernels.hip inside namespace svgf::{anonymous}.
+//
+// The reference launches every iteration separately, and so did this library: iteration 0 read 32 B/px and wrote 32 (its
+// result twice: the ping-pong plane and the feedback plane RenderOutput, :618-622), iteration 1 read the ping-pong plane back
+// (+ the guide texel) and wrote 16: 112 B/px through HBM.  Here iteration 0's rows stay in LDS for iteration 1: the pair reads
+// colour + guide once (32 B/px), writes the feedback plane (16) and iteration 1's result (16) — 64 B/px and one launch
+// (one ramp, one tail) less.  The ping-pong plane of iteration 0 is never materialised.
+//
+// A workgroup of 8 waves streams down a band of rows of a 120-column block:
+//   waves 0-3  ("iteration 0"): stage two input rows per step into ring A (6 rows x 132 columns, the layout of
+//              atrous_lds_kernel), filter rows i, i+1 of 128 columns [x0-4, x0+124) with step 1, store the feedback
+//              texels of their own 120 columns, and write the result — rounded to the storage type and clamped exactly as
+//              iteration 1's imageLoad would read it back (:78-83,586) — into ring B (12 rows x 128 columns) together with
+//              the centre's depth / normal / ddepth;
+//   waves 4-7  ("iteration 1"): filter rows j, j+1 of the 120 columns [x0, x0+120) with step 2 from ring B rows written in
+//              EARLIER steps (iteration 1 trails iteration 0 by five steps = ten rows), and store them.
+// Both halves run their 24 taps at the same time on different data; two barriers per step order the ring refills
+// (ring A's two oldest rows are replaced after every wave has read them; ring B's slot of the two rows being written was last
+// read in the previous step).  Iteration 0 is computed on 128 of 120 columns and on band + 8 rows, the input is read on
+// 132 columns and band + 12 rows: bands are long (launcher).
+//
+// Results are bitwise those of the two launches: the per-pixel expressions are the same functions (centre_setup, taps24,
+// finish_px below are the tap code of atrous_lds_kernel with one output per thread), out-of-frame rows and columns enter
+// ring B as what iteration 0 makes of all-zero texels (a sky centre: copied, depth = sentinel, so weight exactly 0 as a tap).
+
+#ifndef SVGF_FUSED_PD
+#define SVGF_FUSED_PD 2              // input rows are requested this many steps before the step whose end commits them
+#endif
+#ifndef SVGF_FUSED_PROLOGUE_ALL
+#define SVGF_FUSED_PROLOGUE_ALL 1    // the six rows of the prologue in one round of memory latency instead of three
+#endif
+#ifndef SVGF_FUSED_SPLIT
+#define SVGF_FUSED_SPLIT 14          // iteration 1 runs its taps [SPLIT, 25) between the two barriers of a step, beside iteration 0's ring refill (25: none)
+#endif
+#ifndef SVGF_FUSED_DIAG
+#define SVGF_FUSED_DIAG 0            // measurement twins only (results are wrong): 1 no iteration-0 taps, 2 no iteration-1 taps, 4 no ring refill after the prologue, 8 no stores
+#endif
+constexpr int kFT0 = 128;                       // iteration-0 columns of a workgroup: two waves per row
+constexpr int kFReach1 = 4;                     // iteration 1 (step 2) reaches 4 rows / columns
+constexpr int kFT1 = kFT0 - 2 * kFReach1;       // 120 iteration-1 columns
+constexpr int kFWA = kFT0 + 4;                  // ring A columns: step-1 halo of 2 each side
+constexpr int kFRA = 6;                         // ring A rows (2 produced per step + 4)
+constexpr int kFRB = 12;                        // ring B rows: 10 read by iteration 1 + the 2 iteration 0 is writing
+constexpr int kFLag = 5;                        // steps by which iteration 1 trails iteration 0
+constexpr size_t kFusedLds = (size_t)16 * (kFRA * kFWA + kFRB * kFT0) + (size_t)8 * 2 * (kFRA * kFWA + kFRB * kFT0) + (size_t)4 * kFRB * kFT0 +
+                             (size_t)4 * 2 * (kFRA + kFRB);
+
+// What a thread keeps of its centre pixel (the set-up of Filter.cuh:543-568 in the fused-exponent form of atrous_lds_kernel).
+struct TapCentre {
+    f32x4 A;             // clamped colour + variance
+    f32x2 lz;            // luminance, depth (sky -> 1e30)
+    uint32_t n01;        // (nx, ny) half bits
+    float nz;
+    float il;            // log2(e) / phi_l
+    float iz[5];         // log2(e) / (phi_z * |offset|) per offset length class
+};
+template <int S>
+__device__ __forceinline__ TapCentre centre_setup(f32x4 A, f32x2 L, f32x2 N, float ddepth, float phi_colour) {
+    TapCentre c;
+    c.A = A; c.lz = L; c.n01 = __float_as_uint(N.x); c.nz = N.y;
+    const float cdz = L.y == kSkyZ ? 0.0f : ddepth;                                      // GetDepth: sky -> ddepth 0
+    const float phi_l = phi_colour * sqrtf(fmaxf(0.0f, 1e-10f + A.w));                   // :562
+    c.il = fminf(hw_rcp(phi_l), 1e30f) * kLog2e;
+    const float izb = hw_rcp(fmaxf(cdz, 1e-6f) * (float)S) * kLog2e;                     // :563
+    c.iz[0] = izb; c.iz[1] = izb * 0.70710678118654752f; c.iz[2] = izb * 0.5f;
+    c.iz[3] = izb * 0.44721359549995794f; c.iz[4] = izb * 0.35355339059327376f;
+    return c;
+}
+
+// The 24 taps of one pixel as a rolling software pipeline (atrous_lds_kernel's tap_roll, one output per thread): the LDS
+// reads of tap t+D are issued before tap t is consumed.  rowbase[r] = LDS index of the thread's leftmost tap in ring row r
+// (r = 0..4: rows -2S..+2S); the taps of a row are CS records apart.
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+template <int CS, int D, bool UNI, int SPLIT = 25, typename Mid = NoMid>
+__device__ __forceinline__ void taps24(const f32x4* recA, const f32x2* recL, const f32x2* recN, const int (&rowbase)[5], const TapCentre& c, float phi_n,
+                                       float& sw, f32x2& srg, f32x2& sbv, Mid mid = Mid()) {
+    float ebase[5];
+    if constexpr (UNI) {
+        const float lg = hw_log2(clamp01(fmaf(c.nz, c.nz, dot2_h2(c.n01, c.n01))));
+        ebase[0] = fmaf(lg, phi_n, klog2(0, 1)); ebase[1] = fmaf(lg, phi_n, klog2(1, 1)); ebase[2] = fmaf(lg, phi_n, klog2(0, 2));
+        ebase[3] = fmaf(lg, phi_n, klog2(1, 2)); ebase[4] = fmaf(lg, phi_n, klog2(2, 2));
+    }
+    constexpr int NT = 25;
+    f32x4 qA[NT];
+    f32x2 qL[NT], qN[NT];
+    auto issue = [&](int t) __attribute__((always_inline)) {
+        if (t == 12) return;                                                             // the centre itself is no tap (:584)
+        const int r = t / 5, cc = t % 5;
+        qA[t] = recA[rowbase[r] + cc * CS];
+        qL[t] = ((const volatile lds_f32x2*)recL)[rowbase[r] + cc * CS];                 // volatile: single ds_read_b64s (see atrous_lds_kernel)
+        if (!UNI) qN[t] = ((const volatile lds_f32x2*)recN)[rowbase[r] + cc * CS];
+    };
+#pragma unroll
+    for (int t = 0; t < D; t++) issue(t);
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        if (t == SPLIT) mid();                                                           // (wave-uniform: a barrier may sit here)
+        if (t + D < NT) issue(t + D);
+        asm volatile("" ::: "memory");
+        if (t == 12) continue;
+        const int yy = t / 5 - 2, xx = t % 5 - 2;
+        const int axx = xx < 0 ? -xx : xx, ayy = yy < 0 ? -yy : yy;
+        const f32x4 A = qA[t];
+        const f32x2 dlz = qL[t] - c.lz;
+        float e;
+        if constexpr (UNI) {
+            e = ebase[kernel_class(axx, ayy)];
+        } else {
+            const f32x2 N = qN[t];
+            const float d = clamp01(fmaf(N.y, c.nz, dot2_h2(__float_as_uint(N.x), c.n01)));
+            e = fmaf(hw_log2(d), phi_n, klog2(axx, ayy));
+        }
+        e = fmaf(-fabsf(dlz.x), c.il, e);
+        e = fmaf(-fabsf(dlz.y), c.iz[len_class(xx, yy)], e);
+        const float w = hw_exp2(e);
+        const f32x2 ww = {w, w * w};                                                     // weights of (b, variance): :604-608
+        sw += w;                                                                         // :607
+        srg = __builtin_elementwise_fma((f32x2){w, w}, (f32x2){A.x, A.y}, srg);
+        sbv = __builtin_elementwise_fma(ww, (f32x2){A.z, A.w}, sbv);
+        asm volatile("" : "+v"(sw), "+v"(srg), "+v"(sbv) :: "memory");
+    }
+}
+
+// One pixel: centre + taps + normalisation (:554-558,615).  `wave_has_surface` / `uniform` are wave-uniform.
+template <int CS, int D, int SPLIT = 25, typename Mid = NoMid>
+__device__ __forceinline__ float4 filter_px(const f32x4* recA, const f32x2* recL, const f32x2* recN, const int (&rowbase)[5], const TapCentre& c, float phi_n,
+                                            bool wave_has_surface, bool uniform, Mid mid = Mid()) {
+    float sw = 1.0f;                                                                     // :567
+    f32x2 srg = {c.A.x, c.A.y}, sbv = {c.A.z, c.A.w};                                    // :568
+    if (wave_has_surface) {
+        if (uniform) taps24<CS, D, true, SPLIT>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv, mid);
+        else taps24<CS, D, false, SPLIT>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv, mid);
+    } else if constexpr (SPLIT < 25) {
+        mid();
+    }
+    if (c.lz.y == kSkyZ) return make_float4(c.A.x, c.A.y, c.A.z, c.A.w);                 // :554-558
+    const float inv = hw_rcp(sw);                                                        // sw >= 1
+    return make_float4(srg.x * inv, srg.y * inv, sbv.x * inv, sbv.y * (inv * inv));      // :615
+}
+
+template <int ST>
+__global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup, int xrot) {
+    constexpr int CB = ST == 0 ? 16 : 8;
+    constexpr int TD = 3;                          // tap pipeline depth (128 registers: four waves per SIMD with two workgroups per CU)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* const aA = (f32x4*)smem;                                  // ring A: iteration 0's input
+    f32x4* const bA = aA + kFRA * kFWA;                              // ring B: iteration 0's output = iteration 1's input
+    f32x2* const aL = (f32x2*)(bA + kFRB * kFT0);
+    f32x2* const aN = aL + kFRA * kFWA;
+    f32x2* const bL = aN + kFRA * kFWA;
+    f32x2* const bN = bL + kFRB * kFT0;
+    float* const bD = (float*)(bN + kFRB * kFT0);                    // ddepth of ring B's pixels (iteration 1's centres)
+    uint32_t* const flagA = (uint32_t*)(bD + kFRB * kFT0);           // [kFRA][2]: a texel of this ring row / half differs from the reference normal
+    uint32_t* const flagB = flagA + 2 * kFRA;                        // [kFRB][2]
+
+    const int t = threadIdx.x, lane = t & 63;
+    const bool second = __builtin_amdgcn_readfirstlane(t >> 8) != 0;             // waves 4-7: iteration 1
+    const int rg = __builtin_amdgcn_readfirstlane((t >> 7) & 1);                 // row of the step's pair
+    const int wig = __builtin_amdgcn_readfirstlane((t >> 6) & 1);                // 64-column half of the row
+
+    // XCD-aware tile order (atrous_lds_kernel): x tile fastest, groups of `xgroup` consecutive tiles per XCD; the frame is walked
+    // bottom-up: what the temporal launch wrote last is still in the Infinity Cache when it is read first
+    const int xtiles = (g.W + kFT1 - 1) / kFT1;
+    const int ntiles = xtiles * nbands;
+    const int wid = blockIdx.x >> 3;
+    const int round = wid / xgroup;
+    int v = (round * kXcds + ((blockIdx.x + xrot * round) & (kXcds - 1))) * xgroup + wid % xgroup;
+    if (v >= ntiles) return;
+    v = ntiles - 1 - v;
+    const int x0 = (v % xtiles) * kFT1;
+    const int band = v / xtiles;
+    const int nrows = g.ye - g.yb;                 // iteration-1 rows
+    const int j0 = band * band_rows;
+    if (j0 >= nrows) return;
+    const int j1 = min(nrows, j0 + band_rows);
+    const int n1 = (j1 - j0 + 1) >> 1;             // iteration-1 steps; iteration 0 runs n1 + 4 steps (rows j0-4 .. j1+3), the loop n1 + 5
+    const int K0 = n1 + 4;
+
+    const bool guided = a.guide != nullptr;
+    const unsigned m_off = guided ? 0u : 8u, n_off = guided ? 8u : 0u, n_shift = guided ? 4u : 3u;
+    const unsigned npx = (unsigned)g.rows * (unsigned)g.W;
+    auto plane_rsrc = [&](bool rok) __attribute__((always_inline)) {
+        PlaneRsrc r;
+        r.colour = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, rok ? (int)(npx * CB) : 0, 0x00020000);
+        r.motion = __builtin_amdgcn_make_buffer_rsrc(guided ? (void*)a.guide : (void*)a.motion, 0, rok ? (int)(npx * 16u) : 0, 0x00020000);
+        r.normal = __builtin_amdgcn_make_buffer_rsrc(guided ? (void*)a.guide : (void*)a.normal, 0, rok ? (int)(npx << n_shift) : 0, 0x00020000);
+        return r;
+    };
+    // the workgroup's reference normal: the texel at (first iteration-1 row, x0) — inside the frame.  Every wave reads it itself.
+    uint32_t ref01, refz;
+    {
+        const PlaneRsrc rs = plane_rsrc(true);
+        const u32x2 n = __builtin_amdgcn_raw_buffer_load_b64(rs.normal, ((unsigned)x0 << n_shift) + n_off, ((g.yb + j0 - g.y0) * g.W) << n_shift, 0);
+        ref01 = __builtin_amdgcn_readfirstlane(n.x); refz = __builtin_amdgcn_readfirstlane(n.y & 0xffffu);
+    }
+    if (t < 2 * (kFRA + kFRB)) flagA[t] = 0u;
+    const float phi_n = a.phi_normal;              // != 0 (launcher)
+
+    if (!second) {
+        // ------------------------------------------------------------------ waves 0-3: staging + iteration 0 (step 1)
+        const int col = t & (kFT0 - 1);
+        const int gx = x0 - kFReach1 + col;                       // own column (may lie left of the frame in the first tile)
+        const int oli = col + 2;
+        const bool halo_wave = wig == 0;
+        const bool has_halo = halo_wave && lane < 4;
+        const int hx = lane < 2 ? gx - 2 : gx + kFT0 - 2;         // lanes 0,1: columns x0-6, x0-5; lanes 2,3: x0+124, x0+125
+        const int hli = lane < 2 ? lane : kFT0 + lane;
+        const bool own_ok = gx >= 0 && gx < g.W, halo_ok = has_halo && hx >= 0 && hx < g.W;
+        const unsigned vo_c = own_ok ? (unsigned)gx * CB : kOob, vo_m = own_ok ? (unsigned)gx * 16u + m_off : kOob, vo_n = own_ok ? ((unsigned)gx << n_shift) + n_off : kOob;
+        const unsigned vh_c = halo_ok ? (unsigned)hx * CB : kOob, vh_m = halo_ok ? (unsigned)hx * 16u + m_off : kOob, vh_n = halo_ok ? ((unsigned)hx << n_shift) + n_off : kOob;
+        // the feedback texel belongs to the tile whose iteration-1 columns hold it
+        const unsigned vo_fb = (own_ok && col >= kFReach1 && col < kFT0 - kFReach1) ? (unsigned)gx * CB : kOob;
+        // ... and to the band whose iteration-1 rows hold it; the first / last band also own the 4 rows beyond the launch rows
+        const int fb_lo = band == 0 ? -kFReach1 : j0, fb_hi = j1 == nrows ? nrows + kFReach1 : j1;
+
+        typedef RawPx<ST, true> OwnPx;
+        typedef RawPx<ST, false> HaloPx;
+        struct Staged { OwnPx o; HaloPx h; };
+        auto fetch = [&](int jn, Staged& st) __attribute__((always_inline)) {          // input rows jn, jn+1 (relative to g.yb): this wave's is jn + rg
+            const int y = g.yb + jn + rg, yl = y - g.y0;
+            const bool rok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows;
+            const int srow = rok ? yl * g.W : 0;
+            const PlaneRsrc rs = plane_rsrc(rok);
+            raw_load<ST, true>(st.o, rs, vo_c, vo_m, vo_n, srow, n_shift);
+            if (halo_wave) raw_load<ST, false>(st.h, rs, vh_c, vh_m, vh_n, srow, n_shift);
+        };
+        auto commit = [&](int sl, const Staged& st) __attribute__((always_inline)) {
+            int so = sl + rg; so = so >= kFRA ? so - kFRA : so;
+            bool differs = commit_px<ST, true>(st.o, aA, aL, aN, so * kFWA + oli, ref01, refz);
+            if (halo_wave) { if (has_halo) differs = commit_px<ST, false>(st.h, aA, aL, aN, so * kFWA + hli, ref01, refz) || differs; }
+            const bool wave_differs = __ballot(differs) != 0ull;
+            if (lane == 0) flagA[so * 2 + wig] = wave_differs ? 1u : 0u;
+        };
+        float dq0 = 0.f, dq1 = 0.f;
+        __syncthreads();                                          // the flags are zero
+        // prologue: input rows j0-6 .. j0-1 (iteration 0 starts at row j0-4)
+#if SVGF_FUSED_PROLOGUE_ALL
+        {
+            Staged s0, s1, s2;                                    // the tap loop's registers are free here
+            fetch(j0 - 6, s0); fetch(j0 - 4, s1); fetch(j0 - 2, s2);
+            commit(0, s0); commit(2, s1); commit(4, s2);
+            dq0 = __uint_as_float(s1.o.zd.y); dq1 = __uint_as_float(s2.o.zd.y);
+        }
+#else
+#pragma unroll 1
+        for (int r = 0; r < kFRA; r += 2) {
+            Staged st;
+            fetch(j0 - 6 + r, st);
+            commit(r, st);
+            if (r == 2) dq0 = __uint_as_float(st.o.zd.y);
+            if (r == 4) dq1 = __uint_as_float(st.o.zd.y);
+        }
+#endif
+        constexpr int PD = SVGF_FUSED_PD;
+        Staged q[PD];
+#pragma unroll
+        for (int d = 0; d + 1 < PD; d++) fetch(j0 + 2 * d, q[d]);   // the rows steps 0 .. PD-2 commit (K0 >= 5 steps: always needed)
+        __syncthreads();
+
+        const uint32_t refz_f = __float_as_uint(unpack_h2(refz).x);
+        int slotA = 0, slotB = rg;                                // ring A slot of input row (step's first row - 2); ring B slot of this wave's row
+        // cs: the rows the NEXT step needs (requested PD steps ago, committed at the end of this step); fs: requested now
+        auto step = [&](int k, Staged& cs, Staged& fs) __attribute__((always_inline)) {
+            const bool active = k < K0, more = k + 1 < K0;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool sky = true;
+            if (active) {
+                if (k + PD < K0 && !(SVGF_FUSED_DIAG & 4)) fetch(j0 + 2 * (k + PD - 1), fs);
+                int rowbase[5];
+#pragma unroll
+                for (int r = 0; r < 5; r++) { int sl = slotA + rg + r; sl = sl >= kFRA ? sl - kFRA : sl; rowbase[r] = sl * kFWA + col; }
+                const int ci = rowbase[2] + 2;
+                const TapCentre c = centre_setup<1>(aA[ci], aL[ci], aN[ci], dq0, a.phi_colour);
+                sky = c.lz.y == kSkyZ;
+                const bool wave_has_surface = !(SVGF_FUSED_DIAG & 1) && __ballot(!sky) != 0ull;
+                const bool uniform = !a.no_fastpath && __ballot(lane < 2 * kFRA && flagA[lane < 2 * kFRA ? lane : 0] != 0u) == 0ull;
+                o = filter_px<1, TD>(aA, aL, aN, rowbase, c, phi_n, wave_has_surface, uniform);
+                // ring B record: the texel iteration 1 would load from the plane iteration 0 stores (:618 unclamped, in the storage type;
+                // :586 imageLoad clamps)
+                float4 q = o;
+                if constexpr (ST == 1) { const float2 lo = unpack_h2(pack_h2(o.x, o.y)), hi = unpack_h2(pack_h2(o.z, o.w)); q = make_float4(lo.x, lo.y, hi.x, hi.y); }
+                q = make_float4(med01(q.x), med01(q.y), med01(q.z), med01(q.w));
+                const int bi = slotB * kFT0 + col;
+                bA[bi] = (f32x4){q.x, q.y, q.z, q.w};
+                bL[bi] = (f32x2){lum_exact(q.x, q.y, q.z), c.lz.y};
+                bN[bi] = (f32x2){__uint_as_float(c.n01), c.nz};
+                bD[bi] = dq0;
+                const bool differs = !sky && (c.n01 != ref01 || __float_as_uint(c.nz) != refz_f);
+                const bool wave_differs = __ballot(differs) != 0ull;
+                if (lane == 0) flagB[slotB * 2 + wig] = wave_differs ? 1u : 0u;
+            }
+            lds_barrier();                                        // every wave is done reading ring A's two oldest rows
+            if (more && !(SVGF_FUSED_DIAG & 4)) {
+                commit(slotA, cs);
+                dq0 = dq1; dq1 = __uint_as_float(cs.o.zd.y);
+                slotA += 2; if (slotA >= kFRA) slotA -= kFRA;
+            }
+            lds_barrier();
+            if (active) {
+                const int i = j0 - kFReach1 + 2 * k + rg, y = g.yb + i;                  // this wave's iteration-0 row
+                if (i >= fb_lo && i < fb_hi && y >= 0 && y < g.H && !((SVGF_FUSED_DIAG & 8) && o.x != 12345.678f)) {          // scalar
+                    const int srow = (y - g.y0) * g.W;
+                    const __amdgpu_buffer_rsrc_t rs_fb = __builtin_amdgcn_make_buffer_rsrc(a.feedback ? a.feedback : a.out, 0, a.feedback ? (int)(npx * CB) : 0, 0x00020000);
+                    if constexpr (ST == 0) {
+                        const u32x4 raw = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+                        __builtin_amdgcn_raw_buffer_store_b128(raw, rs_fb, sky ? kOob : vo_fb, srow * CB, 0);       // :619-622 (not for sky)
+                    } else {
+                        const u32x2 raw = {pack_h2(o.x, o.y), pack_h2(o.z, o.w)};
+                        __builtin_amdgcn_raw_buffer_store_b64(raw, rs_fb, sky ? kOob : vo_fb, srow * CB, 0);
+                    }
+                }
+            }
+            slotB += 2; if (slotB >= kFRB) slotB -= kFRB;
+        };
+        for (int k = 0; k <= K0; k += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; u++) if (k + u <= K0) step(k + u, q[u], q[(u + PD - 1) % PD]);
+        }
+    } else {
+        // ------------------------------------------------------------------ waves 4-7: iteration 1 (step 2) from ring B
+        const int c1 = wig * 64 + lane;                            // 0 .. 127, 120 of them are columns of the tile
+        const bool col_ok = c1 < kFT1 && x0 + c1 < g.W;
+        const int col = c1 < kFT1 ? c1 : kFT1 - 1;                 // lanes beyond the tile repeat its last column (nothing is stored)
+        const unsigned vo_c = col_ok ? (unsigned)(x0 + c1) * CB : kOob;
+        __syncthreads();
+        __syncthreads();
+        int slotB = 0;                                             // ring B slot of iteration-0 row (j - 4), j = the step's first row
+        for (int k = 0; k <= K0; k++) {
+            const bool active = k >= kFLag;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (active) {
+                int rowbase[5];
+#pragma unroll
+                for (int r = 0; r < 5; r++) { int sl = slotB + rg + 2 * r; sl = sl >= kFRB ? sl - kFRB : sl; rowbase[r] = sl * kFT0 + col; }
+                const int ci = rowbase[2] + kFReach1;
+                const TapCentre c = centre_setup<2>(bA[ci], bL[ci], bN[ci], bD[ci], a.phi_colour);
+                const bool wave_has_surface = !(SVGF_FUSED_DIAG & 2) && __ballot(c.lz.y != kSkyZ) != 0ull;
+                const bool uniform = !a.no_fastpath && __ballot(lane < 2 * kFRB && flagB[lane < 2 * kFRB ? lane : 0] != 0u) == 0ull;
+                o = filter_px<2, TD, SVGF_FUSED_SPLIT>(bA, bL, bN, rowbase, c, phi_n, wave_has_surface, uniform, [&]() __attribute__((always_inline)) { lds_barrier(); });
+            }
+            if (!active || SVGF_FUSED_SPLIT >= 25) lds_barrier();
+            if (active) {
+                const int j = j0 + 2 * (k - kFLag) + rg;
+                if (j < j1 && !((SVGF_FUSED_DIAG & 8) && o.x != 12345.678f)) {                                      // scalar
+                    const int srow = (g.yb + j - g.y0) * g.W;
+                    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(npx * CB), 0x00020000);
+                    if constexpr (ST == 0) {
+                        const u32x4 raw = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+                        __builtin_amdgcn_raw_buffer_store_b128(raw, rs_out, vo_c, srow * CB, 0);                    // :618
+                    } else {
+                        const u32x2 raw = {pack_h2(o.x, o.y), pack_h2(o.z, o.w)};
+                        __builtin_amdgcn_raw_buffer_store_b64(raw, rs_out, vo_c, srow * CB, 0);
+                    }
+                }
+                slotB += 2; if (slotB >= kFRB) slotB -= kFRB;
+            }
+            lds_barrier();
+        }
+    }
+}
+
+// The launch rows of Geo are ITERATION 1's rows; iteration 0 runs on them and kFReach1 rows beyond on either side (inside the
+// frame), which is where the feedback plane is written.  The caller has checked that the planes hold kFReach1 + 2 rows around.
+template <int ST>
+hipError_t launch_atrous_fused12(const Geo& g, const AtrousArgs& a, hipStream_t s) {
+    static std::atomic<unsigned long long> attr_done{0};
+    if (hipError_t e = allow_dynamic_lds(atrous_fused12_kernel<ST>, kFusedLds, attr_done); e != hipSuccess) return e;
+    const int nrows = g.ye - g.yb;
+    const int xtiles = (g.W + kFT1 - 1) / kFT1;
+    // Two workgroups per CU (LDS).  A band pays 12 extra input rows and 8 extra iteration-0 rows: bands are as long as one
+    // resident round of workgroups allows, and not shorter than kFusedMinBand.
+#ifndef SVGF_FUSED_OVERSUB
+#define SVGF_FUSED_OVERSUB 2
+#endif
+#ifndef SVGF_FUSED_MIN_BAND
+#define SVGF_FUSED_MIN_BAND 32
+#endif
+    int slots = 2 * num_cus() * SVGF_FUSED_OVERSUB, min_band = SVGF_FUSED_MIN_BAND;
+#ifdef SVGF_DIAG
+    slots = diag_env("SVGF_FUSED_SLOTS", slots);
+    min_band = diag_env("SVGF_FUSED_MIN_BAND", min_band);
+#endif
+    int nbands = slots / xtiles;
+    if (nbands < 1) nbands = 1;
+    int band = (nrows + nbands - 1) / nbands;
+    if (band < min_band) band = min_band;
+    band = (band + 1) / 2 * 2;
+    nbands = (nrows + band - 1) / band;
+    int xm = 16;
+#ifdef SVGF_DIAG
+    xm = diag_env("SVGF_FUSED_XM", xm);
+    if (xm < 1) xm = 1;
+#endif
+    const int xgroup = std::max(1, (xtiles * nbands + kXcds * xm - 1) / (kXcds * xm));
+    const int ngroups = (xtiles * nbands + xgroup - 1) / xgroup;
+    const dim3 grid((unsigned)((ngroups + kXcds - 1) / kXcds) * kXcds * xgroup);
+    atrous_fused12_kernel<ST><<<grid, dim3(512), kFusedLds, s>>>(g, a, band, nbands, xgroup, 3);
+    return hipGetLastError();
+}

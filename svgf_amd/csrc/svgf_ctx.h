@@ -13,6 +13,10 @@ struct svgf_strip_driver;
 #define SVGF_PREV_GUIDE_DEFAULT 1      // measurement twins build with 0 (tools/abn.sh)
 #endif
 
+#ifndef SVGF_FUSE01_DEFAULT
+#define SVGF_FUSE01_DEFAULT 1         // measurement twins build with 0
+#endif
+
 struct svgf_ctx {
     int W = 0, H = 0;
     svgf_strip strip{};
@@ -32,6 +36,7 @@ struct svgf_ctx {
     svgf_gbuffer guide_prev_of{};          // the G-buffer guide_prev was made from (the planes' addresses), valid while guide_prev_valid
     bool guide_prev_valid = false;
     bool prev_guide_enabled = SVGF_PREV_GUIDE_DEFAULT != 0;   // svgf_set_prev_guide
+    bool fuse01 = SVGF_FUSE01_DEFAULT != 0;   // svgf_set_iteration_fusion: iterations 0 and 1 in one launch (frame / strip drivers)
     uint32_t* young_list = nullptr;        // scratch, temporal -> moments: indices of the pixels with history < 4 that need the spatial estimate
     unsigned* young_count = nullptr;       // two device counters used in turn (the temporal launch of a frame zeroes the next frame's)
     uint8_t* young_flags = nullptr;        // one flag per (row, 64-column segment): all 64 pixels need the estimate (listed nowhere)
@@ -93,6 +98,9 @@ int temporal_moments_impl(svgf_ctx* c, const void* prev_colour, const void* radi
                           void* moments_cur, const void* moments_prev, int mrb, int mre, int feedback_follows, void* guide_out = nullptr,
                           const void* guide_prev = nullptr);
 int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration, const void* guide = nullptr);
+// iterations 0 and 1 in one launch on rows [c->rb, c->re) (iteration 1's; iteration 0 and the feedback store cover 4 more rows either side)
+int atrous_pair_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, const void* guide = nullptr);
+bool can_fuse01(const svgf_ctx* c);     // the drivers run iterations 0 and 1 as one launch
 const void* prev_guide_for(const svgf_ctx* c, const svgf_gbuffer* cur, const svgf_gbuffer* prev);   // the guide plane that stands in for `prev`, or null
 void commit_guide(svgf_ctx* c, const svgf_gbuffer* cur, bool written);   // end of a frame: the guide just written (the temporal launch covers all held rows) becomes the previous one
 bool use_guide(const svgf_ctx* c);      // the frame / strip drivers repack {depth, ddepth, normal} for the iterations (fp32 storage, >= 3 iterations)

@@ -53,6 +53,10 @@ struct AtrousArgs {
 hipError_t launch_temporal(const Geo& g, int storage, const TemporalArgs& a, hipStream_t s);
 hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, bool direct, hipStream_t s);
 hipError_t launch_atrous(const Geo& g, int storage, int variant, const AtrousArgs& a, hipStream_t s);
+// iterations 0 and 1 (steps 1 and 2) in ONE launch: `in` -> `out` is iteration 1's result, `feedback` iteration 0's (written on the launch rows
+// and 4 rows beyond inside the frame); the launch rows [yb, ye) are iteration 1's and the planes hold 6 rows around them
+bool atrous_fused_available(int variant, const AtrousArgs& a);
+hipError_t launch_atrous_fused(const Geo& g, int storage, const AtrousArgs& a, hipStream_t s);
 struct PackArgs {
     const float4* position; const float4* normal; const float4* bary;
     float vp[16], pvp[16], cam[3];

@@ -1373,6 +1373,8 @@ hipError_t launch_atrous_lds_step(const Geo& g, const AtrousArgs& a, hipStream_t
     return launch_atrous_lds_step_kr<ST, kDefaultKR, 0>(g, a, s);
 }
 
+#include "svgf_atrous_fused.h"
+
 // ------------------------------------------------------------------ moments (LDS streaming, cold frames) ----
 // Filter.cuh:430-525 for frames in which (nearly) every pixel is young (history < 4: the first three frames of a
 // sequence): the 7x7 window is served from an 8-row LDS ring exactly like the à-trous kernel's 5x5 window
@@ -1839,6 +1841,15 @@ hipError_t launch_atrous(const Geo& g, int storage, int variant, const AtrousArg
     if (storage == 0) atrous_direct_kernel<0><<<grid, block, 0, s>>>(g, a);
     else atrous_direct_kernel<1><<<grid, block, 0, s>>>(g, a);
     return hipGetLastError();
+}
+
+// Iterations 0 and 1 (steps 1 and 2) in one launch (svgf_atrous_fused.h); Geo's launch rows are iteration 1's.
+bool atrous_fused_available(int variant, const AtrousArgs& a) {
+    return variant != 1 /* SVGF_VARIANT_DIRECT */ && a.phi_normal != 0.0f;
+}
+hipError_t launch_atrous_fused(const Geo& g, int storage, const AtrousArgs& a, hipStream_t s) {
+    if (g.ye <= g.yb) return hipSuccess;
+    return storage == 0 ? launch_atrous_fused12<0>(g, a, s) : launch_atrous_fused12<1>(g, a, s);
 }
 
 // Albedo demodulation (MODE 0) / re-modulation (MODE 1), SURVEY.md 8f-4: pointwise, IEEE division (bit-exact vs the oracle).

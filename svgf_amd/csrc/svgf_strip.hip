@@ -69,7 +69,7 @@ Rccl* rccl() {
         for (const char* n : loaded) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // the one already in the process (torch's)
         const char* fresh[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
         for (const char* n : fresh) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (!r.lib) { r.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return; }
+        if (!r.lib) { const char* e = dlerror(); r.why = std::string("librccl not found: ") + (e ? e : ""); return; }
 #define SVGF_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name)); if (!r.field) r.why = std::string("librccl lacks ") + name
         SVGF_SYM(GetUniqueId, "ncclGetUniqueId"); SVGF_SYM(CommInitRank, "ncclCommInitRank"); SVGF_SYM(CommDestroy, "ncclCommDestroy");
         SVGF_SYM(GroupStart, "ncclGroupStart"); SVGF_SYM(GroupEnd, "ncclGroupEnd"); SVGF_SYM(Send, "ncclSend"); SVGF_SYM(Recv, "ncclRecv");
@@ -117,7 +117,8 @@ namespace {
 
 int sfail(svgf_strips* s, int code, const std::string& m) { if (s) s->err = m; return code; }
 #define SVGF_SHIP(s, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return sfail((s), SVGF_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
-#define SVGF_NCCL(s, call) do { int e_ = (call); if (e_ != ncclSuccess) return sfail((s), SVGF_ERR_COMM, std::string(#call) + ": " + rccl()->GetErrorString(e_)); } while (0)
+inline std::string nccl_text(int e) { Rccl* R = rccl(); return R->GetErrorString ? std::string(R->GetErrorString(e)) : "RCCL error " + std::to_string(e); }
+#define SVGF_NCCL(s, call) do { int e_ = (call); if (e_ != ncclSuccess) return sfail((s), SVGF_ERR_COMM, std::string(#call) + ": " + nccl_text(e_)); } while (0)
 
 std::vector<std::vector<int>> plan_groups(int plan, int n) {
     std::vector<std::vector<int>> g;
@@ -234,7 +235,8 @@ int wait_exchange(svgf_strips* s, svgf_strips::Local& l, bool is_state) {
     return SVGF_OK;
 }
 
-int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src, int dst, int P, const svgf_gbuffer* cur, int i) {
+// pair: iterations 0 and 1 in one launch on `rows` (iteration 1's; iteration 0 and the feedback store cover 4 rows more either side)
+int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src, int dst, int P, const svgf_gbuffer* cur, int i, bool pair = false) {
     if (rows.b <= rows.a) return SVGF_OK;
     svgf_ctx* c = l.ctx;
     DeviceGuard dg(l.device);
@@ -242,16 +244,22 @@ int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src
     const bool timed = s->timing_every > 0 && (s->frame_no % s->timing_every) == 0 && l.rank == s->local[0].rank;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) {
-        SVGF_SHIP(s, hipEventCreate(&e0)); SVGF_SHIP(s, hipEventCreate(&e1));
-        SVGF_SHIP(s, hipEventRecord(e0, l.compute));
+        SVGF_SHIP(s, hipEventCreate(&e0));
+        if (hipError_t e = hipEventCreate(&e1); e != hipSuccess) { (void)hipEventDestroy(e0); return sfail(s, SVGF_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
+        if (hipError_t e = hipEventRecord(e0, l.compute); e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return sfail(s, SVGF_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e)); }
     }
-    int rc = atrous_impl(c, c->filter[src], c->filter[dst], i == 0 ? c->colour[P] : nullptr, cur, 1 << i, i, use_guide(c) ? c->guide : nullptr);
-    if (rc != SVGF_OK) return sfail(s, rc, c->err);
+    const void* guide = use_guide(c) ? c->guide : nullptr;
+    int rc = pair ? atrous_pair_impl(c, c->filter[src], c->filter[dst], c->colour[P], cur, guide)
+                  : atrous_impl(c, c->filter[src], c->filter[dst], i == 0 ? c->colour[P] : nullptr, cur, 1 << i, i, guide);
+    if (rc != SVGF_OK) {
+        if (timed) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+        return sfail(s, rc, c->err);
+    }
     if (timed) {
-        SVGF_SHIP(s, hipEventRecord(e1, l.compute));
+        if (hipError_t e = hipEventRecord(e1, l.compute); e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return sfail(s, SVGF_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e)); }
         l.tev.push_back(e0); l.tev.push_back(e1);
         l.tbytes_px.push_back((double)(rows.b - rows.a) * s->W);
-        l.titer.push_back(i);
+        l.titer.push_back(pair ? -1 : i);
     }
     return SVGF_OK;
 }
@@ -436,6 +444,20 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
         }
         for (size_t q = 0; q < groups[gi].size(); q++) {
             const int i = groups[gi][q];
+            // iterations 0 and 1 of one group: ONE launch on iteration 1's rows (svgf_atrous_pair); iteration 0 runs on 4 rows more
+            // either side — grown(ext_atrous[0]) exactly — inside it
+            if (i == 0 && q + 1 < groups[gi].size() && groups[gi][q + 1] == 1 && can_fuse01(s->local[0].ctx)) {
+                for (int k = 0; k < n; k++) {
+                    auto& l = s->local[k];
+                    int rc = launch_atrous_rows(s, l, grown(l.g, s->H, l.g.ext_atrous[1]), pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], 0, true);
+                    if (rc != SVGF_OK) return rc;
+                    pp[k] ^= 1;
+                }
+                int rc = post_state();
+                if (rc != SVGF_OK) return rc;
+                q++;
+                continue;
+            }
             for (int k = 0; k < n; k++) {
                 auto& l = s->local[k];
                 const int P = l.ctx->pingpong;
@@ -515,8 +537,8 @@ int svgf_strips_timing_read(svgf_strips* s, int* launches, double* ms, double* p
         float t = 0.f;
         SVGF_SHIP(s, hipEventElapsedTime(&t, l.tev[i], l.tev[i + 1]));
         s->t_ms += t; s->t_launches++;
-        s->t_px_iter += l.tbytes_px[i / 2];
-        if (l.titer[i / 2] == 0) s->t_px_fb += l.tbytes_px[i / 2];
+        s->t_px_iter += l.tbytes_px[i / 2] * (l.titer[i / 2] < 0 ? 2.0 : 1.0);       // a pair launch covers its rows in two iterations
+        if (l.titer[i / 2] <= 0) s->t_px_fb += l.tbytes_px[i / 2];
         (void)hipEventDestroy(l.tev[i]); (void)hipEventDestroy(l.tev[i + 1]);
     }
     l.tev.clear(); l.tbytes_px.clear(); l.titer.clear();

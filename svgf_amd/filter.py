@@ -24,7 +24,7 @@ MAX_STEPS = 10
 EXPORTS = [
     "svgf_default_params", "svgf_status_string", "svgf_last_error", "svgf_abi_version", "svgf_create",
     "svgf_create_strip", "svgf_destroy", "svgf_set_params", "svgf_set_stream", "svgf_set_rows", "svgf_temporal", "svgf_temporal_moments", "svgf_demodulate", "svgf_modulate",
-    "svgf_moments", "svgf_atrous", "svgf_taa", "svgf_pack_gbuffer", "svgf_denoise_frame", "svgf_reset_history", "svgf_state_plane",
+    "svgf_moments", "svgf_atrous", "svgf_atrous_pair", "svgf_set_iteration_fusion", "svgf_taa", "svgf_pack_gbuffer", "svgf_denoise_frame", "svgf_reset_history", "svgf_state_plane",
     "svgf_state_pingpong", "svgf_plane_bytes", "svgf_timing_enable", "svgf_timing_read",
     "svgf_resize", "svgf_resize_strip", "svgf_get_size", "svgf_sync", "svgf_halo_violations", "svgf_set_valid_rows", "svgf_set_debug_mode", "svgf_set_prev_guide",
     "svgf_import_gbuffer_pitched", "svgf_import_gbuffer_array", "svgf_export_to_array",
@@ -32,7 +32,7 @@ EXPORTS = [
     "svgf_strips_last_error", "svgf_strips_context", "svgf_strips_layout", "svgf_strips_frame", "svgf_strips_sync",
     "svgf_strips_timing_enable", "svgf_strips_timing_read",
 ]
-ABI_VERSION = 2
+ABI_VERSION = 3
 DEBUG_MODE = {"final": 0, "temporal": 1, "atrous": 2}
 HALO_PLAN = {"auto": 0, "ghost": 1, "grouped": 2, "per-iteration": 3}
 HALO_PLAN_NAME = {v: k for k, v in HALO_PLAN.items()}
@@ -140,6 +140,8 @@ def load_library():
     lib.svgf_temporal_moments.argtypes = [vp, vp, vp, vp, vp, C.POINTER(GBufferC), C.POINTER(GBufferC), vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]
     lib.svgf_moments.argtypes = [vp, vp, vp, vp, C.POINTER(GBufferC), vp]
     lib.svgf_atrous.argtypes = [vp, vp, vp, vp, C.POINTER(GBufferC), ip, ip]
+    lib.svgf_atrous_pair.argtypes = [vp, vp, vp, vp, C.POINTER(GBufferC)]
+    lib.svgf_set_iteration_fusion.argtypes = [vp, ip]
     lib.svgf_taa.argtypes = [vp, vp, vp, vp]
     lib.svgf_pack_gbuffer.argtypes = [vp, vp, vp, vp, C.POINTER(CameraC), vp, vp, vp]
     lib.svgf_denoise_frame.argtypes = [vp, vp, C.POINTER(GBufferC), C.POINTER(GBufferC), C.POINTER(vp)]
@@ -336,6 +338,14 @@ class Denoiser:
     def FilterKernel(self, src, dst, feedback, gb: GBuffer, step: int, iteration: int):
         """One filter::FilterKernel launch (src/App.cu:504-505)."""
         self._check(self.lib.svgf_atrous(self._h, _ptr(src), _ptr(dst), _ptr(feedback), gb.c, step, iteration), "svgf_atrous")
+
+    def FilterKernelPair(self, src, dst, feedback, gb: GBuffer):
+        """The first two filter::FilterKernel launches of application::WaveletFilter (steps 1 and 2, src/App.cu:497-507) as one."""
+        self._check(self.lib.svgf_atrous_pair(self._h, _ptr(src), _ptr(dst), _ptr(feedback), gb.c), "svgf_atrous_pair")
+
+    def set_iteration_fusion(self, enable=True):
+        """Whether Render / the strip driver run iterations 0 and 1 as one launch (default) or one launch per iteration."""
+        self._check(self.lib.svgf_set_iteration_fusion(self._h, 1 if enable else 0), "svgf_set_iteration_fusion")
 
     def WaveletFilter(self, filter_buffers, render_buffer, gb: GBuffer, steps=None):
         """application::WaveletFilter, src/App.cu:491-514: ping-pongs filter_buffers[0/1], iteration 0 feeds

@@ -1,0 +1,164 @@
+"""GPU tests of the fused wavelet iterations 0 + 1 (svgf_atrous_pair, svgf_amd/csrc/svgf_atrous_fused.h): ONE launch must leave
+exactly what the two launches of application::WaveletFilter's first two trips (App.cu:497-507, steps 1 and 2) leave — in the
+output plane and in the feedback plane (RenderOutput) — bit for bit, in both storage types, at any size, on row sub-ranges and
+on strips; and the frame driver with the fusion on equals the frame driver with it off, and the plain stage calls."""
+import numpy as np
+import pytest
+
+from svgf_amd import synth
+from tests.helpers import frames
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from tests import gpu_helpers
+    return gpu_helpers
+
+
+def _noisy_colour(G, W, H, storage, seed):
+    """A filter input outside [0,1] in places (imageLoad clamps), with a variance channel that is exactly 0 in places."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-0.1, 1.3, (H, W, 4)).astype(np.float32)
+    c[..., 3] = np.where(rng.uniform(size=(H, W)) < 0.2, 0.0, rng.uniform(0.0, 0.05, (H, W)))
+    return G.dev(c.astype(G.NPDT[storage]))
+
+
+def _two_launches(d, src, gb, rows1=None, H=None):
+    """Iteration 0 (step 1, with feedback) then iteration 1 (step 2) through svgf_atrous; rows1 = iteration 1's rows."""
+    import torch
+    mid, out, fb = torch.full_like(src, 7.0), torch.full_like(src, 7.0), torch.full_like(src, 7.0)
+    if rows1 is not None:
+        d.set_rows(max(0, rows1[0] - 4), min(H, rows1[1] + 4))
+    d.FilterKernel(src, mid, fb, gb, 1, 0)
+    if rows1 is not None:
+        d.set_rows(*rows1)
+    d.FilterKernel(mid, out, None, gb, 2, 1)
+    d.set_rows()
+    return out, fb
+
+
+def _one_launch(d, src, gb, rows1=None):
+    import torch
+    out, fb = torch.full_like(src, 7.0), torch.full_like(src, 7.0)
+    if rows1 is not None:
+        d.set_rows(*rows1)
+    d.FilterKernelPair(src, out, fb, gb)
+    d.set_rows()
+    return out, fb
+
+
+def _same(a, b):
+    import torch
+    return torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+
+
+@pytest.mark.parametrize("variant", ["auto", "lds-general"])
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+@pytest.mark.parametrize("size", [(517, 333), (64, 40), (120, 9), (121, 70), (1921, 1079)])
+def test_pair_equals_two_launches(G, storage, size, variant):
+    """Whole frames of awkward sizes: narrower than a tile, one column more than a tile, fewer rows than the pipeline is deep,
+    odd row counts; panning geometry (spheres, quads, sky), inputs outside [0,1]."""
+    from svgf_amd import filter as F
+    W, H = size
+    fr = synth.make_frame(W, H, 3, mv=(-2.5, 1.5))
+    d = F.Denoiser(W, H, F.Params(storage=storage, steps=5, variant=variant))
+    gb = G.gb_dev(fr)
+    src = _noisy_colour(G, W, H, storage, 11)
+    want, want_fb = _two_launches(d, src, gb)
+    got, got_fb = _one_launch(d, src, gb)
+    assert _same(got, want), "iteration 1's result"
+    assert _same(got_fb, want_fb), "feedback plane"
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_pair_on_row_ranges_and_strips(G, storage):
+    """Iteration 1 restricted to a row range (svgf_set_rows): iteration 0 and the feedback store cover 4 rows more either side,
+    clipped to the frame; nothing else of either plane is touched.  The same on a strip context holding only those rows + 6."""
+    import torch
+    from svgf_amd import filter as F
+    W, H = 333, 260
+    fr = synth.make_frame(W, H, 1, mv=(1.0, 0.0))
+    d = F.Denoiser(W, H, F.Params(storage=storage, steps=5))
+    gb = G.gb_dev(fr)
+    src = _noisy_colour(G, W, H, storage, 5)
+    for rows in [(0, 37), (100, 171), (3, 8), (H - 41, H), (50, 51)]:
+        want, want_fb = _two_launches(d, src, gb, rows, H)
+        got, got_fb = _one_launch(d, src, gb, rows)
+        assert _same(got, want) and _same(got_fb, want_fb), rows
+        y0, y1 = max(0, rows[0] - 6), min(H, rows[1] + 6)
+        ds = F.Denoiser(W, H, F.Params(storage=storage, steps=5), strip=(y0, y1 - y0, rows[0], rows[1]))
+        gl = F.GBuffer(gb.motion[y0:y1].contiguous(), gb.normal[y0:y1].contiguous(), gb.uv[y0:y1].contiguous())
+        o, f = _one_launch(ds, src[y0:y1].contiguous(), gl)
+        assert _same(o, want[y0:y1].contiguous()) and _same(f, want_fb[y0:y1].contiguous()), ("strip", rows)
+    # a strip that lacks the 6 halo rows is refused, as are aliased planes and the direct variant
+    ds = F.Denoiser(W, H, F.Params(storage=storage, steps=5), strip=(100, 60, 104, 150))
+    gl = F.GBuffer(gb.motion[100:160].contiguous(), gb.normal[100:160].contiguous(), gb.uv[100:160].contiguous())
+    s = src[100:160].contiguous()
+    with pytest.raises(F.SvgfError, match="halo"):
+        ds.FilterKernelPair(s, torch.empty_like(s), torch.empty_like(s), gl)
+    with pytest.raises(F.SvgfError, match="three planes"):
+        d.FilterKernelPair(src, src, torch.empty_like(src), gb)
+    dd = F.Denoiser(W, H, F.Params(storage=storage, steps=5, variant="direct"))
+    with pytest.raises(F.SvgfError, match="direct"):
+        dd.FilterKernelPair(src, torch.empty_like(src), torch.empty_like(src), gb)
+
+
+@pytest.mark.parametrize("steps", [2, 3, 5])
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_frame_driver_with_and_without_the_fusion(G, storage, steps):
+    """svgf_denoise_frame with iterations 0 and 1 as one launch == the same driver with one launch per iteration, over the cold ->
+    steady transition of a panning sequence: result, feedback colour, moments, history — every frame, bitwise."""
+    from svgf_amd import filter as F
+    W, H, N = 407, 231, 7
+    fr = frames(W, H, N, mv=(-2.5, 1.5))
+    a = F.Denoiser(W, H, F.Params(storage=storage, steps=steps))
+    b = F.Denoiser(W, H, F.Params(storage=storage, steps=steps))
+    b.set_iteration_fusion(False)
+    gbs = [G.gb_dev(f) for f in fr]
+    for k in range(N):
+        rad = G.dev(fr[k]["radiance"].astype(G.NPDT[storage]))
+        ra = a.Render(rad, gbs[k], gbs[k - 1] if k else None)
+        rb = b.Render(rad, gbs[k], gbs[k - 1] if k else None)
+        assert _same(ra, rb), f"frame {k}: result"
+        for plane in (F.PLANE_COLOUR, F.PLANE_MOMENTS, F.PLANE_HISTORY):
+            assert _same(a.state_plane(plane, 1 - a.pingpong()), b.state_plane(plane, 1 - b.pingpong())), f"frame {k}: state plane {plane}"
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_4k_render_equals_stage_calls(G, storage):
+    """BASELINE.json configs[2] / [4] through the frame driver: 3840x2160, 5 iterations, static camera.  svgf_denoise_frame (fused
+    temporal launch, sparse colour store, young list, guide plane, previous-guide read, iterations 0 + 1 as one launch) against the
+    plain stage calls on caller-owned planes, bitwise, over the cold -> steady transition (variant "lds": both sides then run the
+    LDS moments kernel while every pixel is young)."""
+    import torch
+    from svgf_amd import filter as F
+    W, H, N = 3840, 2160, 5
+    sc = synth.make_scene(W, H, 0)
+    gb = [G.gb_dev(sc), G.gb_dev(sc)]                # two copies: the previous G-buffer is a different set of planes, as in the reference
+    hip = G.HipPipeline(W, H, storage, steps=5, variant="lds")
+    d = F.Denoiser(W, H, F.Params(storage=storage, steps=5, variant="lds"))
+    for k in range(N):
+        rad_np = synth.make_radiance(sc["base"], W, k)
+        want = torch.from_numpy(hip.frame(rad_np, gb[k & 1], gb[(k & 1) ^ 1]))
+        got = d.Render(G.dev(rad_np.astype(G.NPDT[storage])), gb[k & 1], gb[(k & 1) ^ 1] if k else None).cpu()
+        assert torch.equal(got.view(torch.uint8), want.view(torch.uint8)), f"frame {k}"
+    assert np.array_equal(G.host(d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong())), hip.taps["hist"])
+    assert np.array_equal(G.host(d.state_plane(F.PLANE_MOMENTS, 1 - d.pingpong())).view(np.uint8), hip.taps["mom"].view(np.uint8))
+
+
+def test_4k_pair_equals_two_launches(G):
+    """The fused launch at the bench's size, both storage types, on the bench's scene."""
+    from svgf_amd import filter as F
+    W, H = 3840, 2160
+    fr = synth.make_frame(W, H, 0)
+    gb = G.gb_dev(fr)
+    for storage in ("f32", "f16"):
+        d = F.Denoiser(W, H, F.Params(storage=storage, steps=5))
+        src = G.dev(fr["radiance"].astype(G.NPDT[storage]))
+        want, want_fb = _two_launches(d, src, gb)
+        got, got_fb = _one_launch(d, src, gb)
+        assert _same(got, want) and _same(got_fb, want_fb), storage
