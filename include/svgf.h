@@ -172,8 +172,10 @@ int svgf_atrous(svgf_ctx* ctx, const void* in, void* out, void* feedback, const 
  * would leave in their second `out`, bit for bit, on the rows set by svgf_set_rows; `feedback` is written on those rows and the
  * 4 rows beyond them inside the frame (iteration 1 reads iteration 0 there), so the planes must hold 6 rows around the launch
  * rows (SVGF_ERR_HALO otherwise).  `in`, `out` and `feedback` are three different planes.  Needs variant != SVGF_VARIANT_DIRECT
- * and PhiNormal != 0.  svgf_denoise_frame and the strip driver use it whenever steps >= 2 (svgf_set_iteration_fusion(ctx, 0)
- * restores one launch per iteration: same results). */
+ * and PhiNormal != 0.  Measured on MI355X the pair launch is ~10 % SLOWER than the two launches it replaces (the iterations are
+ * bound by their tap arithmetic, not by the 48 B/px the fusion saves: DESIGN.md 3.3c), so svgf_denoise_frame and the strip driver
+ * use it only after svgf_set_iteration_fusion(ctx, 1) (default 0; same results either way; with steps >= 2, and in the strip driver
+ * where the halo plan keeps iterations 0 and 1 in one group). */
 int svgf_atrous_pair(svgf_ctx* ctx, const void* in, void* out, void* feedback, const svgf_gbuffer* gbuf);
 int svgf_set_iteration_fusion(svgf_ctx* ctx, int enable);
 
@@ -227,12 +229,14 @@ int svgf_reset_history(svgf_ctx* ctx);                                 /* zero a
 enum svgf_debug_mode { SVGF_DEBUG_FINAL = 0, SVGF_DEBUG_TEMPORAL = 1, SVGF_DEBUG_ATROUS = 2 };
 int svgf_set_debug_mode(svgf_ctx* ctx, int mode);
 /* The frame and strip drivers keep, of every frame's current G-buffer, the 16 bytes per pixel the filter reads of it ({depth,
- * ddepth, normal, instance ID}: the "guide" plane).  When the next frame's `prev` is that very G-buffer — the same three
- * plane addresses, and not the new frame's `cur` — its reprojection test (LoadPreviousData, Filter.cuh:225-258) reads the
- * kept plane instead of the three planes of `prev` (16 instead of 32 B per pixel; bit-identical results).  This relies on
- * what "previous G-buffer" means in the reference — Framebuffer[1 - PingPongInx] is not written between the two frames
- * (App.cu:374,545-556).  A host that rewrites the planes of `prev` in between passes 0 here (default 1); any other `prev`
- * is read as it is. */
+ * ddepth, normal, instance ID}: the "guide" plane).  After svgf_set_prev_guide(ctx, 1), when the next frame's `prev` is that very
+ * G-buffer — the same three plane addresses, and not the new frame's `cur` — its reprojection test (LoadPreviousData,
+ * Filter.cuh:225-258) reads the kept plane instead of the three planes of `prev` (16 instead of 32 B per pixel: -3 % of a 4K fp32
+ * frame, -6 % with fp16 storage; bit-identical results).
+ * PRECONDITION the host vouches for by enabling it: the planes of `prev` still hold what they held when they were passed as `cur`
+ * — true of the reference, where Framebuffer[1 - PingPongInx] is not written between the two frames (App.cu:374,545-556); NOT
+ * true of a host that re-renders into those addresses without running the denoiser on that frame (it would be tested against a
+ * stale depth / normal / ID, silently).  Default 0: `prev` is read as it is.  Any `prev` at other addresses is read as it is. */
 int svgf_set_prev_guide(svgf_ctx* ctx, int enable);
 
 /* Texture / pitched adapters — what the reference gets from its CUDA <-> OpenGL mappings (CreateMapping, CudaUtil.h:68-99;
@@ -285,6 +289,7 @@ int svgf_strips_plan(int width, int height, int rank, int world, int steps, int 
 int svgf_rccl_unique_id(void* id128);
 int svgf_rccl_comm_init(void** comm, int world, int rank, const void* id128, int device);
 int svgf_rccl_comm_destroy(void* comm);
+int svgf_rccl_comm_count(void* comm, int* count);              /* ncclCommCount: the ranks RCCL itself reports for the communicator */
 /* ranks / devices / compute_streams (hipStream_t, NULL entries = the null stream) / comms (ncclComm_t; loopback: comms[0] only;
  * may be NULL when world == 1) describe the nlocal ranks of this process.  motion_reach = the largest |mv.y| (rows) the
  * temporal reprojection may need beyond what a strip computes itself; exceeding it is reported by svgf_strips_sync. */

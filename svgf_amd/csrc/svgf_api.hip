@@ -80,12 +80,22 @@ hipEvent_t take_event(svgf_ctx* c) {
 }
 
 int alloc_flags(svgf_ctx* c) {
-    if (c->young_list) return SVGF_OK;
-    SVGF_HIP(c, hipMalloc((void**)&c->young_list, (size_t)c->strip.rows * c->W * sizeof(uint32_t)));
-    SVGF_HIP(c, hipMalloc((void**)&c->young_count, 2 * sizeof(unsigned)));
-    SVGF_HIP(c, hipMemsetAsync(c->young_count, 0, 2 * sizeof(unsigned), c->stream));
-    SVGF_HIP(c, hipMalloc((void**)&c->young_flags, (size_t)c->strip.rows * ((c->W + 63) / 64)));
+    if (c->young_list && c->young_count && c->young_flags) return SVGF_OK;
+    // all three or none: a failed allocation leaves nothing behind that a later call would mistake for a complete set
+    auto drop = [&]() {
+        if (c->young_list) (void)hipFree(c->young_list);
+        if (c->young_count) (void)hipFree(c->young_count);
+        if (c->young_flags) (void)hipFree(c->young_flags);
+        c->young_list = nullptr; c->young_count = nullptr; c->young_flags = nullptr;
+    };
+    drop();
+    hipError_t e = hipMalloc((void**)&c->young_list, (size_t)c->strip.rows * c->W * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->young_count, 2 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemsetAsync(c->young_count, 0, 2 * sizeof(unsigned), c->stream);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->young_flags, (size_t)c->strip.rows * ((c->W + 63) / 64));
+    if (e != hipSuccess) { drop(); return hip_fail(c, e, "alloc_flags"); }
     c->young_phase = 0;
+    c->young_pending = false;
     return SVGF_OK;
 }
 
@@ -184,6 +194,7 @@ int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, vo
                          std::max(c->vy0, c->strip.y0) - c->strip.y0, std::min(c->vy1, c->strip.y0 + c->strip.rows) - c->strip.y0, (uint4*)guide_out,
                          (const uint4*)guide_prev,
                          c->strip.y0, c->strip.y0 + c->strip.rows};      // the guide texels of every row held (a strip runs the stage on fewer)
+    if (c->re <= c->rb) return SVGF_OK;             // nothing to launch: the young list and its counters stay as they are
     SVGF_HIP(c, svgf::launch_temporal(geo_of(c), c->p.storage, a, c->stream));
     if (passthrough_out) c->young_pending = true;
     return SVGF_OK;
@@ -199,6 +210,12 @@ int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments
     svgf::MomentsArgs a{colour, out, moments, (const float4*)g->motion, (const uint2*)g->normal, hist,
                         c->p.phi_colour, c->p.phi_normal, c->p.moments_radius, cold_only, dense, sparse_colour,
                         cold_only ? c->young_list : nullptr, cold_only ? c->young_count + c->young_phase : nullptr, cold_only ? c->young_flags : nullptr};
+    if (c->re <= c->rb) {
+        // No moments rows.  If the temporal launch of this frame did run (young_pending), its list is dropped: the counter pair still
+        // has to turn over, because that launch zeroed the OTHER counter for the next frame.
+        if (cold_only && c->young_pending) { c->young_phase ^= 1; c->young_pending = false; }
+        return SVGF_OK;
+    }
     SVGF_HIP(c, svgf::launch_moments(geo_of(c), c->p.storage, a, c->p.variant == SVGF_VARIANT_DIRECT, c->stream));
     if (cold_only) { c->young_phase ^= 1; c->young_pending = false; }   // the next frame's temporal launch appends to the counter this frame's one zeroed
     return SVGF_OK;
@@ -355,7 +372,7 @@ void svgf_destroy(svgf_ctx* c) {
 int svgf_resize_strip(svgf_ctx* c, int width, int height, const svgf_strip* strip) {
     if (!c) return SVGF_ERR_INVALID;
     if (check_geometry(width, height, strip) != SVGF_OK) return fail(c, SVGF_ERR_INVALID, "svgf_resize: bad frame size or strip");
-    if (c->strip_drv) return fail(c, SVGF_ERR_INVALID, "svgf_resize: a strip driver is attached to this context (svgf_strip_detach first)");
+    if (c->strip_drv) return fail(c, SVGF_ERR_INVALID, "svgf_resize: this context belongs to a strip driver: svgf_strips_destroy it and create one for the new size");
     DeviceGuard dg(c->device);
     SVGF_HIP(c, hipStreamSynchronize(c->stream));        // cudaDeviceSynchronize() in the reference (App.cu:758)
     free_state(c);
@@ -375,6 +392,9 @@ int svgf_set_params(svgf_ctx* c, const svgf_params* p) {
     if (!c) return SVGF_ERR_INVALID;
     int rc = check_params(c, p);
     if (rc != SVGF_OK) return rc;
+    // the halo plan of a strip driver was laid out for the iteration count and moments radius it was created with
+    if (c->strip_drv && (p->steps != c->p.steps || p->moments_radius != c->p.moments_radius))
+        return fail(c, SVGF_ERR_INVALID, "svgf_set_params: steps / moments_radius of a strip driver's context are fixed (its halo plan depends on them)");
     if (p->storage != c->p.storage) return fail(c, SVGF_ERR_INVALID, "storage cannot change after creation");
     c->p = *p;
     c->p.history_base = std::min(std::max(c->p.history_base, 1), 255);
@@ -389,6 +409,7 @@ int svgf_set_stream(svgf_ctx* c, void* s) {
 
 int svgf_set_rows(svgf_ctx* c, int rb, int re) {
     if (!c) return SVGF_ERR_INVALID;
+    if (c->strip_drv) return fail(c, SVGF_ERR_INVALID, "svgf_set_rows: the strip driver sets the rows of its contexts");
     if (rb == -1 && re == -1) { c->rb = c->strip.own_begin; c->re = c->strip.own_end; return SVGF_OK; }
     if (rb < c->strip.y0 || re > c->strip.y0 + c->strip.rows || rb > re) return fail(c, SVGF_ERR_INVALID, "row range outside the strip");
     c->rb = rb; c->re = re;

@@ -1,5 +1,10 @@
 // svgf_atrous_fused.h — wavelet iterations 0 and 1 (steps 1 and 2) of application::WaveletFilter (App.cu:497-507, kernel
-// Filter.cuh:527-624) in ONE streaming launch.  Included by svgf_kernels.hip inside namespace svgf::{anonymous}.
+// Filter.cuh:527-624) in ONE streaming launch: svgf_atrous_pair.
+//
+// STATUS: bit-identical to the two launches (tests/test_gpu_fused.py) and ~10 % SLOWER than them on MI355X in every configuration
+// measured (4K / 1080p, fp32 / fp16: profiles/r03_fused_pair_ablations.txt), so the drivers use it only on request
+// (svgf_set_iteration_fusion).  Why: DESIGN.md 3.3c — the tap phase, not HBM, bounds the iterations, and the fusion trades 48 B/px
+// of traffic for 10-19 % more taps.
 //
 // The reference launches every iteration separately, and so did this library: iteration 0 read 32 B/px and wrote 32 (its
 // result twice: the ping-pong plane and the feedback plane RenderOutput, :618-622), iteration 1 read the ping-pong plane back
@@ -20,22 +25,19 @@
 // read in the previous step).  Iteration 0 is computed on 128 of 120 columns and on band + 8 rows, the input is read on
 // 132 columns and band + 12 rows: bands are long (launcher).
 //
-// Results are bitwise those of the two launches: the per-pixel expressions are the same functions (centre_setup, taps24,
-// finish_px below are the tap code of atrous_lds_kernel with one output per thread), out-of-frame rows and columns enter
-// ring B as what iteration 0 makes of all-zero texels (a sky centre: copied, depth = sentinel, so weight exactly 0 as a tap).
+// Results are bitwise those of the two launches: the per-pixel expressions are the same functions (svgf_atrous_taps.h),
+// out-of-frame rows and columns enter ring B as what iteration 0 makes of all-zero texels (a sky centre: copied, depth = sentinel,
+// so weight exactly 0 as a tap).
+#pragma once
+#include "svgf_atrous_taps.h"
 
-#ifndef SVGF_FUSED_PD
-#define SVGF_FUSED_PD 2              // input rows are requested this many steps before the step whose end commits them
-#endif
-#ifndef SVGF_FUSED_PROLOGUE_ALL
-#define SVGF_FUSED_PROLOGUE_ALL 1    // the six rows of the prologue in one round of memory latency instead of three
-#endif
-#ifndef SVGF_FUSED_SPLIT
-#define SVGF_FUSED_SPLIT 14          // iteration 1 runs its taps [SPLIT, 25) between the two barriers of a step, beside iteration 0's ring refill (25: none)
-#endif
+namespace svgf {
+namespace {
+
 #ifndef SVGF_FUSED_DIAG
-#define SVGF_FUSED_DIAG 0            // measurement twins only (results are wrong): 1 no iteration-0 taps, 2 no iteration-1 taps, 4 no ring refill after the prologue, 8 no stores
-#endif
+#define SVGF_FUSED_DIAG 0            // measurement twins only (results are wrong): 1 no iteration-0 taps, 2 no iteration-1 taps, 4 no ring refill after
+#endif                               // the prologue, 8 no stores (profiles/r03_fused_pair_ablations.txt, block 3)
+
 constexpr int kFT0 = 128;                       // iteration-0 columns of a workgroup: two waves per row
 constexpr int kFReach1 = 4;                     // iteration 1 (step 2) reaches 4 rows / columns
 constexpr int kFT1 = kFT0 - 2 * kFReach1;       // 120 iteration-1 columns
@@ -43,106 +45,14 @@ constexpr int kFWA = kFT0 + 4;                  // ring A columns: step-1 halo o
 constexpr int kFRA = 6;                         // ring A rows (2 produced per step + 4)
 constexpr int kFRB = 12;                        // ring B rows: 10 read by iteration 1 + the 2 iteration 0 is writing
 constexpr int kFLag = 5;                        // steps by which iteration 1 trails iteration 0
+constexpr int kFPrefetch = 2;                   // input rows are requested this many steps before the step whose end commits them (1, 2: equal; 3: slower)
 constexpr size_t kFusedLds = (size_t)16 * (kFRA * kFWA + kFRB * kFT0) + (size_t)8 * 2 * (kFRA * kFWA + kFRB * kFT0) + (size_t)4 * kFRB * kFT0 +
                              (size_t)4 * 2 * (kFRA + kFRB);
-
-// What a thread keeps of its centre pixel (the set-up of Filter.cuh:543-568 in the fused-exponent form of atrous_lds_kernel).
-struct TapCentre {
-    f32x4 A;             // clamped colour + variance
-    f32x2 lz;            // luminance, depth (sky -> 1e30)
-    uint32_t n01;        // (nx, ny) half bits
-    float nz;
-    float il;            // log2(e) / phi_l
-    float iz[5];         // log2(e) / (phi_z * |offset|) per offset length class
-};
-template <int S>
-__device__ __forceinline__ TapCentre centre_setup(f32x4 A, f32x2 L, f32x2 N, float ddepth, float phi_colour) {
-    TapCentre c;
-    c.A = A; c.lz = L; c.n01 = __float_as_uint(N.x); c.nz = N.y;
-    const float cdz = L.y == kSkyZ ? 0.0f : ddepth;                                      // GetDepth: sky -> ddepth 0
-    const float phi_l = phi_colour * sqrtf(fmaxf(0.0f, 1e-10f + A.w));                   // :562
-    c.il = fminf(hw_rcp(phi_l), 1e30f) * kLog2e;
-    const float izb = hw_rcp(fmaxf(cdz, 1e-6f) * (float)S) * kLog2e;                     // :563
-    c.iz[0] = izb; c.iz[1] = izb * 0.70710678118654752f; c.iz[2] = izb * 0.5f;
-    c.iz[3] = izb * 0.44721359549995794f; c.iz[4] = izb * 0.35355339059327376f;
-    return c;
-}
-
-// The 24 taps of one pixel as a rolling software pipeline (atrous_lds_kernel's tap_roll, one output per thread): the LDS
-// reads of tap t+D are issued before tap t is consumed.  rowbase[r] = LDS index of the thread's leftmost tap in ring row r
-// (r = 0..4: rows -2S..+2S); the taps of a row are CS records apart.
-struct NoMid { __device__ __forceinline__ void operator()() const {} };
-template <int CS, int D, bool UNI, int SPLIT = 25, typename Mid = NoMid>
-__device__ __forceinline__ void taps24(const f32x4* recA, const f32x2* recL, const f32x2* recN, const int (&rowbase)[5], const TapCentre& c, float phi_n,
-                                       float& sw, f32x2& srg, f32x2& sbv, Mid mid = Mid()) {
-    float ebase[5];
-    if constexpr (UNI) {
-        const float lg = hw_log2(clamp01(fmaf(c.nz, c.nz, dot2_h2(c.n01, c.n01))));
-        ebase[0] = fmaf(lg, phi_n, klog2(0, 1)); ebase[1] = fmaf(lg, phi_n, klog2(1, 1)); ebase[2] = fmaf(lg, phi_n, klog2(0, 2));
-        ebase[3] = fmaf(lg, phi_n, klog2(1, 2)); ebase[4] = fmaf(lg, phi_n, klog2(2, 2));
-    }
-    constexpr int NT = 25;
-    f32x4 qA[NT];
-    f32x2 qL[NT], qN[NT];
-    auto issue = [&](int t) __attribute__((always_inline)) {
-        if (t == 12) return;                                                             // the centre itself is no tap (:584)
-        const int r = t / 5, cc = t % 5;
-        qA[t] = recA[rowbase[r] + cc * CS];
-        qL[t] = ((const volatile lds_f32x2*)recL)[rowbase[r] + cc * CS];                 // volatile: single ds_read_b64s (see atrous_lds_kernel)
-        if (!UNI) qN[t] = ((const volatile lds_f32x2*)recN)[rowbase[r] + cc * CS];
-    };
-#pragma unroll
-    for (int t = 0; t < D; t++) issue(t);
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-        if (t == SPLIT) mid();                                                           // (wave-uniform: a barrier may sit here)
-        if (t + D < NT) issue(t + D);
-        asm volatile("" ::: "memory");
-        if (t == 12) continue;
-        const int yy = t / 5 - 2, xx = t % 5 - 2;
-        const int axx = xx < 0 ? -xx : xx, ayy = yy < 0 ? -yy : yy;
-        const f32x4 A = qA[t];
-        const f32x2 dlz = qL[t] - c.lz;
-        float e;
-        if constexpr (UNI) {
-            e = ebase[kernel_class(axx, ayy)];
-        } else {
-            const f32x2 N = qN[t];
-            const float d = clamp01(fmaf(N.y, c.nz, dot2_h2(__float_as_uint(N.x), c.n01)));
-            e = fmaf(hw_log2(d), phi_n, klog2(axx, ayy));
-        }
-        e = fmaf(-fabsf(dlz.x), c.il, e);
-        e = fmaf(-fabsf(dlz.y), c.iz[len_class(xx, yy)], e);
-        const float w = hw_exp2(e);
-        const f32x2 ww = {w, w * w};                                                     // weights of (b, variance): :604-608
-        sw += w;                                                                         // :607
-        srg = __builtin_elementwise_fma((f32x2){w, w}, (f32x2){A.x, A.y}, srg);
-        sbv = __builtin_elementwise_fma(ww, (f32x2){A.z, A.w}, sbv);
-        asm volatile("" : "+v"(sw), "+v"(srg), "+v"(sbv) :: "memory");
-    }
-}
-
-// One pixel: centre + taps + normalisation (:554-558,615).  `wave_has_surface` / `uniform` are wave-uniform.
-template <int CS, int D, int SPLIT = 25, typename Mid = NoMid>
-__device__ __forceinline__ float4 filter_px(const f32x4* recA, const f32x2* recL, const f32x2* recN, const int (&rowbase)[5], const TapCentre& c, float phi_n,
-                                            bool wave_has_surface, bool uniform, Mid mid = Mid()) {
-    float sw = 1.0f;                                                                     // :567
-    f32x2 srg = {c.A.x, c.A.y}, sbv = {c.A.z, c.A.w};                                    // :568
-    if (wave_has_surface) {
-        if (uniform) taps24<CS, D, true, SPLIT>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv, mid);
-        else taps24<CS, D, false, SPLIT>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv, mid);
-    } else if constexpr (SPLIT < 25) {
-        mid();
-    }
-    if (c.lz.y == kSkyZ) return make_float4(c.A.x, c.A.y, c.A.z, c.A.w);                 // :554-558
-    const float inv = hw_rcp(sw);                                                        // sw >= 1
-    return make_float4(srg.x * inv, srg.y * inv, sbv.x * inv, sbv.y * (inv * inv));      // :615
-}
 
 template <int ST>
 __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup, int xrot) {
     constexpr int CB = ST == 0 ? 16 : 8;
-    constexpr int TD = 3;                          // tap pipeline depth (128 registers: four waves per SIMD with two workgroups per CU)
+    constexpr int TD = 3;                          // tap pipeline depth (99 registers; LDS allows two workgroups per CU = four waves per SIMD)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* const aA = (f32x4*)smem;                                  // ring A: iteration 0's input
     f32x4* const bA = aA + kFRA * kFWA;                              // ring B: iteration 0's output = iteration 1's input
@@ -159,13 +69,11 @@ __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArg
     const int rg = __builtin_amdgcn_readfirstlane((t >> 7) & 1);                 // row of the step's pair
     const int wig = __builtin_amdgcn_readfirstlane((t >> 6) & 1);                // 64-column half of the row
 
-    // XCD-aware tile order (atrous_lds_kernel): x tile fastest, groups of `xgroup` consecutive tiles per XCD; the frame is walked
-    // bottom-up: what the temporal launch wrote last is still in the Infinity Cache when it is read first
+    // tile order: x tile fastest, XCD-aware groups (svgf_device.h); the frame is walked bottom-up: what the temporal launch wrote
+    // last is still in the Infinity Cache when it is read first
     const int xtiles = (g.W + kFT1 - 1) / kFT1;
     const int ntiles = xtiles * nbands;
-    const int wid = blockIdx.x >> 3;
-    const int round = wid / xgroup;
-    int v = (round * kXcds + ((blockIdx.x + xrot * round) & (kXcds - 1))) * xgroup + wid % xgroup;
+    int v = xcd_tile(xgroup, xrot);
     if (v >= ntiles) return;
     v = ntiles - 1 - v;
     const int x0 = (v % xtiles) * kFT1;
@@ -177,20 +85,13 @@ __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArg
     const int n1 = (j1 - j0 + 1) >> 1;             // iteration-1 steps; iteration 0 runs n1 + 4 steps (rows j0-4 .. j1+3), the loop n1 + 5
     const int K0 = n1 + 4;
 
-    const bool guided = a.guide != nullptr;
-    const unsigned m_off = guided ? 0u : 8u, n_off = guided ? 8u : 0u, n_shift = guided ? 4u : 3u;
+    const GuideSel gs(a.guide != nullptr);
+    const unsigned m_off = gs.m_off, n_off = gs.n_off, n_shift = gs.n_shift;
     const unsigned npx = (unsigned)g.rows * (unsigned)g.W;
-    auto plane_rsrc = [&](bool rok) __attribute__((always_inline)) {
-        PlaneRsrc r;
-        r.colour = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, rok ? (int)(npx * CB) : 0, 0x00020000);
-        r.motion = __builtin_amdgcn_make_buffer_rsrc(guided ? (void*)a.guide : (void*)a.motion, 0, rok ? (int)(npx * 16u) : 0, 0x00020000);
-        r.normal = __builtin_amdgcn_make_buffer_rsrc(guided ? (void*)a.guide : (void*)a.normal, 0, rok ? (int)(npx << n_shift) : 0, 0x00020000);
-        return r;
-    };
     // the workgroup's reference normal: the texel at (first iteration-1 row, x0) — inside the frame.  Every wave reads it itself.
     uint32_t ref01, refz;
     {
-        const PlaneRsrc rs = plane_rsrc(true);
+        const PlaneRsrc rs = plane_rsrc(a, npx, CB, n_shift, true);
         const u32x2 n = __builtin_amdgcn_raw_buffer_load_b64(rs.normal, ((unsigned)x0 << n_shift) + n_off, ((g.yb + j0 - g.y0) * g.W) << n_shift, 0);
         ref01 = __builtin_amdgcn_readfirstlane(n.x); refz = __builtin_amdgcn_readfirstlane(n.y & 0xffffu);
     }
@@ -221,7 +122,7 @@ __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArg
             const int y = g.yb + jn + rg, yl = y - g.y0;
             const bool rok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows;
             const int srow = rok ? yl * g.W : 0;
-            const PlaneRsrc rs = plane_rsrc(rok);
+            const PlaneRsrc rs = plane_rsrc(a, npx, CB, n_shift, rok);
             raw_load<ST, true>(st.o, rs, vo_c, vo_m, vo_n, srow, n_shift);
             if (halo_wave) raw_load<ST, false>(st.h, rs, vh_c, vh_m, vh_n, srow, n_shift);
         };
@@ -235,24 +136,13 @@ __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArg
         float dq0 = 0.f, dq1 = 0.f;
         __syncthreads();                                          // the flags are zero
         // prologue: input rows j0-6 .. j0-1 (iteration 0 starts at row j0-4)
-#if SVGF_FUSED_PROLOGUE_ALL
         {
-            Staged s0, s1, s2;                                    // the tap loop's registers are free here
+            Staged s0, s1, s2;                                    // one round of memory latency (the tap loop's registers are free here)
             fetch(j0 - 6, s0); fetch(j0 - 4, s1); fetch(j0 - 2, s2);
             commit(0, s0); commit(2, s1); commit(4, s2);
             dq0 = __uint_as_float(s1.o.zd.y); dq1 = __uint_as_float(s2.o.zd.y);
         }
-#else
-#pragma unroll 1
-        for (int r = 0; r < kFRA; r += 2) {
-            Staged st;
-            fetch(j0 - 6 + r, st);
-            commit(r, st);
-            if (r == 2) dq0 = __uint_as_float(st.o.zd.y);
-            if (r == 4) dq1 = __uint_as_float(st.o.zd.y);
-        }
-#endif
-        constexpr int PD = SVGF_FUSED_PD;
+        constexpr int PD = kFPrefetch;
         Staged q[PD];
 #pragma unroll
         for (int d = 0; d + 1 < PD; d++) fetch(j0 + 2 * d, q[d]);   // the rows steps 0 .. PD-2 commit (K0 >= 5 steps: always needed)
@@ -337,9 +227,9 @@ __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArg
                 const TapCentre c = centre_setup<2>(bA[ci], bL[ci], bN[ci], bD[ci], a.phi_colour);
                 const bool wave_has_surface = !(SVGF_FUSED_DIAG & 2) && __ballot(c.lz.y != kSkyZ) != 0ull;
                 const bool uniform = !a.no_fastpath && __ballot(lane < 2 * kFRB && flagB[lane < 2 * kFRB ? lane : 0] != 0u) == 0ull;
-                o = filter_px<2, TD, SVGF_FUSED_SPLIT>(bA, bL, bN, rowbase, c, phi_n, wave_has_surface, uniform, [&]() __attribute__((always_inline)) { lds_barrier(); });
+                o = filter_px<2, TD>(bA, bL, bN, rowbase, c, phi_n, wave_has_surface, uniform);
             }
-            if (!active || SVGF_FUSED_SPLIT >= 25) lds_barrier();
+            lds_barrier();
             if (active) {
                 const int j = j0 + 2 * (k - kFLag) + rg;
                 if (j < j1 && !((SVGF_FUSED_DIAG & 8) && o.x != 12345.678f)) {                                      // scalar
@@ -368,33 +258,19 @@ hipError_t launch_atrous_fused12(const Geo& g, const AtrousArgs& a, hipStream_t 
     if (hipError_t e = allow_dynamic_lds(atrous_fused12_kernel<ST>, kFusedLds, attr_done); e != hipSuccess) return e;
     const int nrows = g.ye - g.yb;
     const int xtiles = (g.W + kFT1 - 1) / kFT1;
-    // Two workgroups per CU (LDS).  A band pays 12 extra input rows and 8 extra iteration-0 rows: bands are as long as one
-    // resident round of workgroups allows, and not shorter than kFusedMinBand.
-#ifndef SVGF_FUSED_OVERSUB
-#define SVGF_FUSED_OVERSUB 2
-#endif
-#ifndef SVGF_FUSED_MIN_BAND
-#define SVGF_FUSED_MIN_BAND 32
-#endif
-    int slots = 2 * num_cus() * SVGF_FUSED_OVERSUB, min_band = SVGF_FUSED_MIN_BAND;
-#ifdef SVGF_DIAG
-    slots = diag_env("SVGF_FUSED_SLOTS", slots);
-    min_band = diag_env("SVGF_FUSED_MIN_BAND", min_band);
-#endif
-    int nbands = slots / xtiles;
+    // Two workgroups per CU (LDS).  A band pays 12 extra input rows and 8 extra iteration-0 rows: bands are as long as two rounds
+    // of resident workgroups allow (one round, 136 rows at 4K: +6 %; four, 34 rows: +3 %), and not shorter than 32 rows.
+    int nbands = 2 * num_cus() * 2 / xtiles;
     if (nbands < 1) nbands = 1;
     int band = (nrows + nbands - 1) / nbands;
-    if (band < min_band) band = min_band;
+    if (band < 32) band = 32;
     band = (band + 1) / 2 * 2;
     nbands = (nrows + band - 1) / band;
-    int xm = 16;
-#ifdef SVGF_DIAG
-    xm = diag_env("SVGF_FUSED_XM", xm);
-    if (xm < 1) xm = 1;
-#endif
-    const int xgroup = std::max(1, (xtiles * nbands + kXcds * xm - 1) / (kXcds * xm));
-    const int ngroups = (xtiles * nbands + xgroup - 1) / xgroup;
-    const dim3 grid((unsigned)((ngroups + kXcds - 1) / kXcds) * kXcds * xgroup);
+    int xgroup;
+    const dim3 grid = xcd_grid(xtiles * nbands, 16, xgroup);
     atrous_fused12_kernel<ST><<<grid, dim3(512), kFusedLds, s>>>(g, a, band, nbands, xgroup, 3);
     return hipGetLastError();
 }
+
+}  // namespace
+}  // namespace svgf

@@ -1,0 +1,208 @@
+// svgf_atrous_lds.h — one iteration of the wavelet filter (filter::FilterKernel, Filter.cuh:527-624) as an LDS-streaming kernel
+// for CDNA4, steps 1..16.  (tools/variants/atrous_lds_instrumented.h is this kernel with its measurement switches and stamps;
+// -DSVGF_DIAG builds compile that one instead.)
+//
+// The reference gathers 25 taps x 3 textures per pixel.  For step S a pixel only ever reads pixels of its own row residue
+// (y mod S), so a workgroup (4 waves) owns ONE residue of a band of rows and a 128-column block and STREAMS DOWN the band: a ring
+// of 6 decimated rows x (128 + 4S) columns lives in LDS as fp32 records (svgf_device.h); every step waves 0-1 produce decimated
+// row j and waves 2-3 row j+1 from the ring (one output per thread, svgf_atrous_taps.h), then the two oldest ring rows are
+// replaced by the two rows requested from HBM at the start of the step.  Global loads are always full-width row segments
+// (16 B per lane, coalesced) whatever the step; the y over-fetch is (band+4)/band and the x over-fetch (128+4S)/128 instead of the
+// 25x gather of a per-pixel kernel.
+//
+// The centre's ddepth is the only per-pixel input that is not in the records: the thread that stages a pixel of its own column
+// is the thread that filters it two steps later, so ddepth rides in a two-register queue.  Everything that is the same for all
+// lanes of a wave — row offsets, ring slots, validity of a row — lives in scalar registers; staging a row costs no vector ALU.
+//
+// Uniform-normal fast path (bit-identical): nflag[slot][wave] = "a surface texel of this ring row staged by this wave differs
+// from the workgroup's reference normal"; while no flag is set, n.n' is each centre's own |n|^2 (taps24<.., UNI>).
+#pragma once
+#include "svgf_atrous_taps.h"
+
+namespace svgf {
+namespace {
+
+constexpr int kTX = 128;                 // columns of a workgroup: two waves per row, two rows per step
+constexpr int kTapDepth = 3;             // LDS reads run this many taps ahead of the arithmetic
+// Resident waves per SIMD the kernel of step S is compiled for (registers: 95 -> five).  At step 16 the ring (37 KB) allows four
+// workgroups per CU anyway.
+constexpr int atrous_waves(int S) { return S <= 8 ? 5 : 4; }
+
+template <int ST, int S>
+__global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup, int xrot) {
+    constexpr int TX = kTX;
+    constexpr int WL = TX + 4 * S;                 // staged columns per ring row
+    constexpr int CB = ST == 0 ? 16 : 8;           // bytes per colour texel
+    constexpr int NH = 4 * S;                      // halo pixels per ring row: all staged by wave 0 of the row group (lanes 0..NH-1);
+                                                   // spread over the waves, every wave paid the halo's ~20 VALU + 3 loads for a few lanes
+    static_assert(NH >= 1 && NH <= 64, "halo does not fit one wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* recA = (f32x4*)smem;
+    f32x2* recL = (f32x2*)(recA + kRing * WL);     // 8-byte records, contiguous: conflict-free ds_read_b64 (64 banks)
+    f32x2* recN = recL + kRing * WL;
+    uint32_t* nflag = (uint32_t*)(recN + kRing * WL);              // [kRing][8]
+    uint32_t* nref = nflag + kRing * 8;                            // {(nx,ny) bits, nz bits}
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int col = t % TX;
+    const int rg = __builtin_amdgcn_readfirstlane(t / TX);          // row group: wave-uniform -> scalar
+    const int wig = __builtin_amdgcn_readfirstlane((t % TX) >> 6);  // wave index inside its row group
+    // tile order v = (residue, band, x tile), x fastest.  Step 1 walks the frame bottom-up: what the temporal launch wrote last is
+    // still in the 256 MB Infinity Cache when it is read first (-4.5 % for that launch; later steps sweep the frame once per row
+    // residue and gain nothing from an order)
+    const int xtiles = (g.W + TX - 1) / TX;
+    const int ntiles = xtiles * nbands * S;
+    int v = xcd_tile(xgroup, xrot);
+    if (v >= ntiles) return;                       // padding of the last groups
+    if (S == 1) v = ntiles - 1 - v;
+    const int x0 = (v % xtiles) * TX;
+    const int band = (v / xtiles) % nbands;
+    const int rv = v / (xtiles * nbands);          // row residue (relative to g.yb) this workgroup owns
+    const int nrows = g.ye - g.yb;
+    const int nj = (nrows - rv + S - 1) / S;       // decimated rows of this residue
+    const int j0 = band * band_rows;
+    if (j0 >= nj) return;
+    const int j1 = min(nj, j0 + band_rows);
+    const int ybase = g.yb + rv;                   // global row of decimated index j: ybase + S*j
+
+    // per-lane constants
+    const int gx = x0 + col;                       // own column
+    const int oli = col + 2 * S;                   // its LDS column
+    const bool halo_wave = wig == 0;               // scalar
+    const bool has_halo = halo_wave && lane < NH;  // this lane also stages one halo pixel per row of its row group
+    const int hx = (lane < 2 * S) ? x0 - 2 * S + lane : x0 + TX + lane - 2 * S;
+    const int hli = (lane < 2 * S) ? lane : TX + lane;
+    const bool own_ok = gx < g.W, halo_ok = has_halo && hx >= 0 && hx < g.W;
+    const GuideSel gs(a.guide != nullptr);
+    const unsigned vo_c = own_ok ? (unsigned)gx * CB : kOob, vo_m = own_ok ? (unsigned)gx * 16u + gs.m_off : kOob, vo_n = own_ok ? ((unsigned)gx << gs.n_shift) + gs.n_off : kOob;
+    const unsigned vh_c = halo_ok ? (unsigned)hx * CB : kOob, vh_m = halo_ok ? (unsigned)hx * 16u + gs.m_off : kOob, vh_n = halo_ok ? ((unsigned)hx << gs.n_shift) + gs.n_off : kOob;
+    const unsigned npx = (unsigned)g.rows * (unsigned)g.W;
+
+    // A thread's share of one staged step: its own pixel of row (jn + rg), and a halo pixel on lanes < NH.  Buffer resources are
+    // built where they are used (a scalar select of num_records) instead of being kept in SGPRs for the whole kernel.
+    struct Staged { RawPx<ST, true> o; RawPx<ST, false> h; };
+    auto fetch = [&](int jn, Staged& st) __attribute__((always_inline)) {
+        const int y = ybase + S * (jn + rg), yl = y - g.y0;                             // scalar
+        const bool rok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows;
+        const int srow = rok ? yl * g.W : 0;
+        const PlaneRsrc rs = plane_rsrc(a, npx, CB, gs.n_shift, rok);
+        raw_load<ST, true>(st.o, rs, vo_c, vo_m, vo_n, srow, gs.n_shift);
+        if (halo_wave) raw_load<ST, false>(st.h, rs, vh_c, vh_m, vh_n, srow, gs.n_shift);
+    };
+    uint32_t ref01 = 0, refz = 0;
+    auto commit = [&](int sl, const Staged& st) __attribute__((always_inline)) {
+        int so = sl + rg; so = so >= kRing ? so - kRing : so;                           // scalar
+        bool differs = commit_px<ST, true>(st.o, recA, recL, recN, so * WL + oli, ref01, refz);
+        if (halo_wave) { if (has_halo) differs = commit_px<ST, false>(st.h, recA, recL, recN, so * WL + hli, ref01, refz) || differs; }
+        const bool wave_differs = __ballot(differs) != 0ull;
+        if (lane == 0) nflag[so * 8 + wig] = wave_differs ? 1u : 0u;                    // a ring slot is always staged by the same waves
+    };
+
+    // ddepth of this thread's next two centres (rows j+rg and two rows further).  A staged row becomes a centre two steps after it
+    // is committed; its ddepth is taken over at commit time (never at fetch time: that would wait for the prefetch).
+    float dq0 = 0.f, dq1 = 0.f;
+    // prologue: two ring rows at a time (requesting all six at once measured the same).  Rows j0, j0+1 (always inside the frame) go
+    // first: thread 0's pixel of row j0 is the workgroup's reference normal.
+    if (t < kRing * 8) nflag[t] = 0u;
+#pragma unroll 1
+    for (int rr = 0; rr < kRing; rr += kRS) {
+        const int r = rr == 0 ? 2 : (rr == 2 ? 0 : rr);
+        Staged st;
+        fetch(j0 - 2 + r, st);
+        if (rr == 0) {
+            if (t == 0) { nref[0] = st.o.n.x; nref[1] = st.o.n.y & 0xffffu; }
+            __syncthreads();
+            ref01 = nref[0]; refz = nref[1];
+        }
+        commit(r, st);
+        if (r == 2) dq0 = __uint_as_float(st.o.zd.y);
+        if (r == 4) dq1 = __uint_as_float(st.o.zd.y);
+    }
+    __syncthreads();
+
+    const float phi_n = a.phi_normal;              // != 0 (launcher)
+    int slot0 = 0;
+    Staged cs;                                     // the rows the NEXT step needs: requested at the start of a step, committed at its end
+    for (int j = j0; j < j1; j += kRS) {
+        const bool more = (j + kRS) < j1;
+        if (more) fetch(j + kRS + 2, cs);
+
+        // this thread's centre is ring row 2+rg, its taps ring rows rg .. rg+4, columns oli-2S .. oli+2S
+        int rowbase[5];
+#pragma unroll
+        for (int r = 0; r < 5; r++) { int sl = slot0 + rg + r; sl = sl >= kRing ? sl - kRing : sl; rowbase[r] = sl * WL + col; }   // scalar + lane constant
+        const int ci = rowbase[2] + 2 * S;
+        const TapCentre c = centre_setup<S>(recA[ci], recL[ci], recN[ci], dq0, a.phi_colour);
+        const bool sky = c.lz.y == kSkyZ;
+        const bool wave_has_surface = __ballot(!sky) != 0ull;
+        const bool uniform = !a.no_fastpath && __ballot(lane < kRing * 8 && nflag[lane < kRing * 8 ? lane : 0] != 0u) == 0ull;
+        const float4 o = filter_px<S, kTapDepth>(recA, recL, recN, rowbase, c, phi_n, wave_has_surface, uniform);
+
+        // Output values now, their stores AFTER the ring refill: hipcc's vmcnt bookkeeping cannot tell that the rows committed
+        // below were fetched long before this step's stores, so stores issued first would be waited for.
+        if (more) {
+            lds_barrier();                         // every wave is done reading the two oldest ring rows
+            commit(slot0, cs);
+            dq0 = dq1; dq1 = __uint_as_float(cs.o.zd.y);                                 // row j+4+rg: the centre two steps on
+            slot0 += kRS; if (slot0 >= kRing) slot0 -= kRing;
+            lds_barrier();
+        }
+        if (j + rg < j1) {                                                               // scalar
+            const int srow = (ybase + S * (j + rg) - g.y0) * g.W;
+            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(npx * CB), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_fb = __builtin_amdgcn_make_buffer_rsrc(a.feedback ? a.feedback : a.out, 0, a.feedback ? (int)(npx * CB) : 0, 0x00020000);
+            // columns outside the frame carry the out-of-range offset: the store is dropped by the range check
+            if constexpr (ST == 0) {
+                const u32x4 raw = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(raw, rs_out, vo_c, srow * CB, 0);                   // :618
+                __builtin_amdgcn_raw_buffer_store_b128(raw, rs_fb, sky ? kOob : vo_c, srow * CB, 0);       // :619-622 (not for sky)
+            } else {
+                const u32x2 raw = {pack_h2(o.x, o.y), pack_h2(o.z, o.w)};
+                __builtin_amdgcn_raw_buffer_store_b64(raw, rs_out, vo_c, srow * CB, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(raw, rs_fb, sky ? kOob : vo_c, srow * CB, 0);
+            }
+        }
+    }
+}
+
+template <int ST, int S>
+hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
+    constexpr int WL = kTX + 4 * S;
+    constexpr size_t lds = (size_t)kRing * WL * kRecBytes + (kRing * 8 + 2) * sizeof(uint32_t);
+    static std::atomic<unsigned long long> attr_done{0};
+    if (hipError_t e = allow_dynamic_lds(atrous_lds_kernel<ST, S>, lds, attr_done); e != hipSuccess) return e;
+    // Bands are sized so that (x tiles) x (S residues) x (bands) is FOUR times the resident slots of the chip (LDS: 160 KiB per CU;
+    // registers: atrous_waves(S) waves per SIMD): workgroups that take a fast path (all sky, uniform normals) make room for others
+    // instead of idling until the slowest one of a single round finishes (A/B on one device: 2x -3..5 %, 4x another -1.5 %, 6x worse).
+    constexpr int per_cu_lds = (int)((160 * 1024) / lds), per_cu_waves = atrous_waves(S);      // 4-wave workgroups
+    constexpr int per_cu = per_cu_lds < per_cu_waves ? per_cu_lds : per_cu_waves;
+    const int nrows = g.ye - g.yb;
+    const int njmax = (nrows + S - 1) / S;
+    const int xtiles = (g.W + kTX - 1) / kTX;
+    int nbands = per_cu * num_cus() * 4 / (xtiles * S);
+    if (nbands < 1) nbands = 1;
+    int band = (njmax + nbands - 1) / nbands;
+    if (band < 8) band = 8;
+    band = (band + kRS - 1) / kRS * kRS;
+    nbands = (njmax + band - 1) / band;
+    int xgroup;
+    const dim3 grid = xcd_grid(xtiles * nbands * S, S <= 2 ? 16 : (S == 16 ? 2 : 1), xgroup);     // groups per XCD: A/B per step on one device (4K)
+    atrous_lds_kernel<ST, S><<<grid, dim3(kTX * kRS), lds, s>>>(g, a, band, nbands, xgroup, 3);
+    return hipGetLastError();
+}
+
+template <int ST>
+hipError_t launch_atrous_lds_step(const Geo& g, const AtrousArgs& a, hipStream_t s) {
+    switch (a.step) {
+        case 1: return launch_atrous_lds<ST, 1>(g, a, s);
+        case 2: return launch_atrous_lds<ST, 2>(g, a, s);
+        case 4: return launch_atrous_lds<ST, 4>(g, a, s);
+        case 8: return launch_atrous_lds<ST, 8>(g, a, s);
+        case 16: return launch_atrous_lds<ST, 16>(g, a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+}  // namespace svgf

@@ -1,0 +1,111 @@
+// svgf_atrous_taps.h — one pixel of the edge-avoiding à-trous wavelet (filter::FilterKernel, Filter.cuh:527-624) served from LDS
+// records: the code both streaming kernels (svgf_atrous_lds.h, svgf_atrous_fused.h) run per output pixel, so that one launch per
+// iteration and iterations 0 + 1 in one launch give the same bits.
+//
+// The edge-stopping weight (computeWeight, :407-427) times the kernel weight (:540,582) is ONE v_exp_f32 of a fused exponent:
+//   w = exp2( log2 K  +  phi_n * log2 sat(n.n')  -  |dl| * log2(e)/phi_l  -  |dz| * log2(e)/(phi_z |offset|) )
+// 8 vector instructions per tap on the uniform-normal path (v_pk_add of {dl, dz}, two FMAs with -|x| modifiers, v_exp, w^2, sum w,
+// two v_pk_fma for the four channels), 13 on the general path (v_dot2_f32_f16, clamp-FMA, v_log, FMA more).
+#pragma once
+#include "svgf_device.h"
+
+namespace svgf {
+namespace {
+
+// What a thread keeps of its centre pixel (the set-up of :543-568).
+struct TapCentre {
+    f32x4 A;             // clamped colour + variance
+    f32x2 lz;            // luminance, depth (sky -> 1e30)
+    uint32_t n01;        // (nx, ny) half bits
+    float nz;
+    float il;            // log2(e) / phi_l
+    float iz[5];         // log2(e) / (phi_z * |offset|) per offset length class
+};
+// A, L, N: the centre's LDS records; ddepth: its depth derivative as stored; S: the iteration's step.
+template <int S>
+__device__ __forceinline__ TapCentre centre_setup(f32x4 A, f32x2 L, f32x2 N, float ddepth, float phi_colour) {
+    TapCentre c;
+    c.A = A; c.lz = L; c.n01 = __float_as_uint(N.x); c.nz = N.y;
+    const float cdz = L.y == kSkyZ ? 0.0f : ddepth;                                      // GetDepth: sky -> ddepth 0
+    const float phi_l = phi_colour * sqrtf(fmaxf(0.0f, 1e-10f + A.w));                   // :562
+    c.il = fminf(hw_rcp(phi_l), 1e30f) * kLog2e;
+    const float izb = hw_rcp(fmaxf(cdz, 1e-6f) * (float)S) * kLog2e;                     // :563
+    c.iz[0] = izb; c.iz[1] = izb * 0.70710678118654752f; c.iz[2] = izb * 0.5f;
+    c.iz[3] = izb * 0.44721359549995794f; c.iz[4] = izb * 0.35355339059327376f;
+    return c;
+}
+
+// The 24 taps as ONE rolling software pipeline: the LDS reads of tap t+D are issued before tap t is consumed, across row
+// boundaries; only D+1 taps' records are live.  rowbase[r] = LDS index of the thread's leftmost tap in ring row r (r = 0..4: rows
+// -2S..+2S); the taps of a row are CS records apart.  UNI: every surface texel the taps can touch carries the centre's normal
+// bits, so n.n' is the centre's own |n|^2 — the same expression the general path evaluates per tap, bit for bit — and the
+// normal records are not read at all.  The empty asm statements pin the order: left alone, instruction selection sinks all
+// arithmetic below all LDS reads of the unrolled loop (256 VGPRs + scratch spills).
+template <int CS, int D, bool UNI>
+__device__ __forceinline__ void taps24(const f32x4* recA, const f32x2* recL, const f32x2* recN, const int (&rowbase)[5], const TapCentre& c, float phi_n,
+                                       float& sw, f32x2& srg, f32x2& sbv) {
+    float ebase[5];                                    // UNI: exponent of the normal term + kernel weight, per kernel-weight class
+    if constexpr (UNI) {
+        const float lg = hw_log2(clamp01(fmaf(c.nz, c.nz, dot2_h2(c.n01, c.n01))));
+        ebase[0] = fmaf(lg, phi_n, klog2(0, 1)); ebase[1] = fmaf(lg, phi_n, klog2(1, 1)); ebase[2] = fmaf(lg, phi_n, klog2(0, 2));
+        ebase[3] = fmaf(lg, phi_n, klog2(1, 2)); ebase[4] = fmaf(lg, phi_n, klog2(2, 2));
+    }
+    constexpr int NT = 25;
+    f32x4 qA[NT];
+    f32x2 qL[NT], qN[NT];
+    auto issue = [&](int t) __attribute__((always_inline)) {
+        if (t == 12) return;                                                             // the centre itself is no tap (:584)
+        const int r = t / 5, cc = t % 5;
+        qA[t] = recA[rowbase[r] + cc * CS];
+        // volatile: keeps these as single ds_read_b64 (2 LDS cycles each); merged into ds_read2_b64 they take 8
+        qL[t] = ((const volatile lds_f32x2*)recL)[rowbase[r] + cc * CS];
+        if (!UNI) qN[t] = ((const volatile lds_f32x2*)recN)[rowbase[r] + cc * CS];
+    };
+#pragma unroll
+    for (int t = 0; t < D; t++) issue(t);
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        if (t + D < NT) issue(t + D);
+        asm volatile("" ::: "memory");
+        if (t == 12) continue;
+        const int yy = t / 5 - 2, xx = t % 5 - 2;
+        const int axx = xx < 0 ? -xx : xx, ayy = yy < 0 ? -yy : yy;
+        const f32x4 A = qA[t];
+        const f32x2 dlz = qL[t] - c.lz;
+        float e;
+        if constexpr (UNI) {
+            e = ebase[kernel_class(axx, ayy)];
+        } else {
+            const f32x2 N = qN[t];
+            const float d = clamp01(fmaf(N.y, c.nz, dot2_h2(__float_as_uint(N.x), c.n01)));
+            e = fmaf(hw_log2(d), phi_n, klog2(axx, ayy));
+        }
+        e = fmaf(-fabsf(dlz.x), c.il, e);
+        e = fmaf(-fabsf(dlz.y), c.iz[len_class(xx, yy)], e);
+        const float w = hw_exp2(e);
+        const f32x2 ww = {w, w * w};                                                     // weights of (b, variance): :604-608
+        sw += w;                                                                         // :607
+        srg = __builtin_elementwise_fma((f32x2){w, w}, (f32x2){A.x, A.y}, srg);           // accumulators packed by channel pairs:
+        sbv = __builtin_elementwise_fma(ww, (f32x2){A.z, A.w}, sbv);                     // (r,g) and (b,variance), one v_pk_fma_f32 each
+        asm volatile("" : "+v"(sw), "+v"(srg), "+v"(sbv) :: "memory");
+    }
+}
+
+// One pixel: taps + normalisation (:554-558,567-568,615).  `wave_has_surface` (a wave whose centres are all sky has nothing to
+// filter) and `uniform` are wave-uniform.
+template <int CS, int D>
+__device__ __forceinline__ float4 filter_px(const f32x4* recA, const f32x2* recL, const f32x2* recN, const int (&rowbase)[5], const TapCentre& c, float phi_n,
+                                            bool wave_has_surface, bool uniform) {
+    float sw = 1.0f;                                                                     // :567
+    f32x2 srg = {c.A.x, c.A.y}, sbv = {c.A.z, c.A.w};                                    // :568
+    if (wave_has_surface) {
+        if (uniform) taps24<CS, D, true>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv);
+        else taps24<CS, D, false>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv);
+    }
+    if (c.lz.y == kSkyZ) return make_float4(c.A.x, c.A.y, c.A.z, c.A.w);                 // :554-558
+    const float inv = hw_rcp(sw);                                                        // sw >= 1
+    return make_float4(srg.x * inv, srg.y * inv, sbv.x * inv, sbv.y * (inv * inv));      // :615
+}
+
+}  // namespace
+}  // namespace svgf

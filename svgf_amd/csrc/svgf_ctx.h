@@ -10,11 +10,11 @@
 struct svgf_strip_driver;
 
 #ifndef SVGF_PREV_GUIDE_DEFAULT
-#define SVGF_PREV_GUIDE_DEFAULT 1      // measurement twins build with 0 (tools/abn.sh)
+#define SVGF_PREV_GUIDE_DEFAULT 0      // opt-in (svgf_set_prev_guide): it relies on the host not rewriting the previous G-buffer's planes
 #endif
 
 #ifndef SVGF_FUSE01_DEFAULT
-#define SVGF_FUSE01_DEFAULT 1         // measurement twins build with 0
+#define SVGF_FUSE01_DEFAULT 0         // off: the pair launch is bit-identical and ~10 % slower than two launches
 #endif
 
 struct svgf_ctx {
@@ -103,6 +103,6 @@ int atrous_pair_impl(svgf_ctx* c, const void* in, void* out, void* feedback, con
 bool can_fuse01(const svgf_ctx* c);     // the drivers run iterations 0 and 1 as one launch
 const void* prev_guide_for(const svgf_ctx* c, const svgf_gbuffer* cur, const svgf_gbuffer* prev);   // the guide plane that stands in for `prev`, or null
 void commit_guide(svgf_ctx* c, const svgf_gbuffer* cur, bool written);   // end of a frame: the guide just written (the temporal launch covers all held rows) becomes the previous one
-bool use_guide(const svgf_ctx* c);      // the frame / strip drivers repack {depth, ddepth, normal} for the iterations (fp32 storage, >= 3 iterations)
+bool use_guide(const svgf_ctx* c);      // the frame / strip drivers repack {depth, ddepth, normal, instance ID} for the iterations (any storage, >= 1 iteration, LDS kernels)
 
 }  // namespace svgf_host

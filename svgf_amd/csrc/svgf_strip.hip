@@ -51,6 +51,7 @@ struct Rccl {
     int (*GetUniqueId)(ncclUniqueId*) = nullptr;
     int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommCount)(const ncclComm_t, int*) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -73,7 +74,7 @@ Rccl* rccl() {
 #define SVGF_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name)); if (!r.field) r.why = std::string("librccl lacks ") + name
         SVGF_SYM(GetUniqueId, "ncclGetUniqueId"); SVGF_SYM(CommInitRank, "ncclCommInitRank"); SVGF_SYM(CommDestroy, "ncclCommDestroy");
         SVGF_SYM(GroupStart, "ncclGroupStart"); SVGF_SYM(GroupEnd, "ncclGroupEnd"); SVGF_SYM(Send, "ncclSend"); SVGF_SYM(Recv, "ncclRecv");
-        SVGF_SYM(GetErrorString, "ncclGetErrorString");
+        SVGF_SYM(GetErrorString, "ncclGetErrorString"); SVGF_SYM(CommCount, "ncclCommCount");
 #undef SVGF_SYM
     });
     return &r;
@@ -92,6 +93,7 @@ struct svgf_strip_plan_geo {
 struct svgf_strips {
     int W = 0, H = 0, world = 1, steps = 0, plan = SVGF_PLAN_AUTO, motion_reach = 0, moments_radius = 3, storage = SVGF_F32;
     bool loopback = false;
+    bool broken = false;                   // an RCCL call failed inside a group: every later frame is refused
     struct Local {
         int rank = 0, device = 0;
         svgf_ctx* ctx = nullptr;
@@ -174,6 +176,14 @@ size_t row_bytes(const svgf_strips* s, int plane) {
     }
 }
 
+// A send / receive failed between ncclGroupStart and ncclGroupEnd: close the group (whatever it returns) so that the thread's RCCL state
+// is not left half open, and mark the driver unusable — the events and transfers of this frame are in an unknown state.
+int group_failed(svgf_strips* s, const char* what, int e) {
+    (void)rccl()->GroupEnd();
+    s->broken = true;
+    return sfail(s, SVGF_ERR_COMM, std::string(what) + ": " + nccl_text(e) + " (the strip driver is unusable from here: destroy it)");
+}
+
 // Post ONE exchange for all local ranks: rows at distance [lo, h) from each strip boundary of the given planes.
 // planes[k] = {plane kind, index}; done_is_state selects which event the filter stream will wait for.
 int post_exchange(svgf_strips* s, const std::vector<std::pair<int, int>>& planes, const std::vector<int>& held, int h, bool is_state) {
@@ -210,11 +220,11 @@ int post_exchange(svgf_strips* s, const std::vector<std::pair<int, int>>& planes
                 const int g0 = dir == 0 ? o1 - h : o0 + lo, g1 = dir == 0 ? o1 - lo : o0 + h;
                 if (src) {
                     char* base = (char*)svgf_state_plane(src->ctx, planes[k].first, planes[k].second);
-                    SVGF_NCCL(s, R->Send(base + (size_t)(g0 - src->g.y0) * rb, (size_t)(g1 - g0) * rb, ncclInt8, s->loopback ? 0 : dst_rank, src->comm, src->comm_stream));
+                    if (int e = R->Send(base + (size_t)(g0 - src->g.y0) * rb, (size_t)(g1 - g0) * rb, ncclInt8, s->loopback ? 0 : dst_rank, src->comm, src->comm_stream); e != ncclSuccess) return group_failed(s, "ncclSend", e);
                 }
                 if (dst) {
                     char* base = (char*)svgf_state_plane(dst->ctx, planes[k].first, planes[k].second);
-                    SVGF_NCCL(s, R->Recv(base + (size_t)(g0 - dst->g.y0) * rb, (size_t)(g1 - g0) * rb, ncclInt8, s->loopback ? 0 : src_rank, dst->comm, dst->comm_stream));
+                    if (int e = R->Recv(base + (size_t)(g0 - dst->g.y0) * rb, (size_t)(g1 - g0) * rb, ncclInt8, s->loopback ? 0 : src_rank, dst->comm, dst->comm_stream); e != ncclSuccess) return group_failed(s, "ncclRecv", e);
                 }
             }
         }
@@ -293,6 +303,12 @@ int svgf_rccl_comm_destroy(void* comm) {
     Rccl* R = rccl();
     if (!comm || !R->CommDestroy) return SVGF_ERR_COMM;
     return R->CommDestroy((ncclComm_t)comm) == ncclSuccess ? SVGF_OK : SVGF_ERR_COMM;
+}
+
+int svgf_rccl_comm_count(void* comm, int* count) {
+    Rccl* R = rccl();
+    if (!comm || !count || !R->CommCount) return SVGF_ERR_COMM;
+    return R->CommCount((ncclComm_t)comm, count) == ncclSuccess ? SVGF_OK : SVGF_ERR_COMM;
 }
 
 int svgf_strips_plan(int width, int height, int rank, int world, int steps, int plan, int moments_radius, int motion_reach, svgf_strip_layout* out) {
@@ -393,6 +409,7 @@ int svgf_strips_layout(const svgf_strips* s, int local_index, svgf_strip_layout*
 // frame); results[k] receives the plane whose owned rows hold the result.
 int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gbuffer* cur, const svgf_gbuffer* prev, const void** results) {
     if (!s || !radiance || !cur) return SVGF_ERR_INVALID;
+    if (s->broken) return sfail(s, SVGF_ERR_COMM, "svgf_strips_frame: an earlier exchange failed; destroy this driver");
     const int n = (int)s->local.size();
     // state planes + scratch
     for (int k = 0; k < n; k++) {

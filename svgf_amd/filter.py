@@ -28,7 +28,7 @@ EXPORTS = [
     "svgf_state_pingpong", "svgf_plane_bytes", "svgf_timing_enable", "svgf_timing_read",
     "svgf_resize", "svgf_resize_strip", "svgf_get_size", "svgf_sync", "svgf_halo_violations", "svgf_set_valid_rows", "svgf_set_debug_mode", "svgf_set_prev_guide",
     "svgf_import_gbuffer_pitched", "svgf_import_gbuffer_array", "svgf_export_to_array",
-    "svgf_strips_plan", "svgf_rccl_unique_id", "svgf_rccl_comm_init", "svgf_rccl_comm_destroy", "svgf_strips_create", "svgf_strips_destroy",
+    "svgf_strips_plan", "svgf_rccl_unique_id", "svgf_rccl_comm_init", "svgf_rccl_comm_destroy", "svgf_rccl_comm_count", "svgf_strips_create", "svgf_strips_destroy",
     "svgf_strips_last_error", "svgf_strips_context", "svgf_strips_layout", "svgf_strips_frame", "svgf_strips_sync",
     "svgf_strips_timing_enable", "svgf_strips_timing_read",
 ]
@@ -168,6 +168,7 @@ def load_library():
     lib.svgf_rccl_unique_id.argtypes = [vp]
     lib.svgf_rccl_comm_init.argtypes = [C.POINTER(vp), ip, ip, vp, ip]
     lib.svgf_rccl_comm_destroy.argtypes = [vp]
+    lib.svgf_rccl_comm_count.argtypes = [vp, C.POINTER(ip)]
     lib.svgf_strips_create.argtypes = [C.POINTER(vp), ip, ip, ip, C.POINTER(ParamsC), ip, ip, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(vp), C.POINTER(vp), ip]
     lib.svgf_strips_destroy.argtypes = [vp]
     lib.svgf_strips_destroy.restype = None

@@ -497,6 +497,16 @@ class NativeStrips:
     def pingpong(self, k=0):
         return self.lib.svgf_state_pingpong(self.lib.svgf_strips_context(self._h, k))
 
+    def set_prev_guide(self, enable=True):
+        """svgf_set_prev_guide on every local strip: the caller vouches that the previous G-buffer's planes are not rewritten between frames."""
+        for k in range(self.n):
+            self._check(self.lib.svgf_set_prev_guide(self.lib.svgf_strips_context(self._h, k), 1 if enable else 0))
+
+    def set_iteration_fusion(self, enable=True):
+        """Iterations 0 and 1 as one launch on every local strip (where the halo plan keeps them in one group)."""
+        for k in range(self.n):
+            self._check(self.lib.svgf_set_iteration_fusion(self.lib.svgf_strips_context(self._h, k), 1 if enable else 0))
+
     def owned(self, k, t):
         lay = self.layouts[k]
         return t[lay["own"][0] - lay["y0"]:lay["own"][1] - lay["y0"]]
@@ -525,9 +535,104 @@ class NativeStrips:
             pass
 
 
-def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, make_inputs, prime_frames, driver="native", motion_reach=None):
-    """bench.py's N > 1 leg: this rank's strip of a W x H frame, `steps` timed frames.  driver = "native": the C++ strip driver
-    of the library (RCCL groups posted from C++); "python": StripRunner + torch.distributed point-to-point ops."""
+class _NativeRunner:
+    """One rank's strip through the C++ strip driver (svgf_strips_frame)."""
+    name = "C++ (svgf_strips_frame)"
+
+    def __init__(self, W, H, world, rank, params, device, stream, comm, plan, motion_reach):
+        self.drv = NativeStrips(W, H, world, params, [rank], [device.index or 0], streams=[stream], comms=[comm] if comm else None, plan=plan, motion_reach=motion_reach)
+        self.drv.set_prev_guide(True)             # bench inputs: the previous G-buffer IS last frame's current one, untouched (tests/test_bench_inputs.py)
+        self.lay = self.drv.layouts[0]
+
+    def frame(self, rad, cur, prev):
+        return self.drv.frame([rad], [cur], [prev])[0]
+
+    def owned(self, t):
+        return self.drv.owned(0, t)
+
+    def timing(self, on):
+        self.drv.timing_enable(4 if on else 0)
+
+    def frame_timing(self, k):
+        pass
+
+    def sync(self):
+        self.drv.sync()
+
+    def atrous_timing(self, bytes_iter, bytes_feedback):
+        nl, ms, px_all, px0 = self.drv.timing_read()
+        return nl, ms, px_all * bytes_iter + px0 * bytes_feedback
+
+    def close(self):
+        self.drv.close()
+
+
+class _PythonRunner:
+    """The same schedule through svgf_amd/strips.py (StripRunner + torch.distributed point-to-point ops)."""
+    name = "python (svgf_amd/strips.py)"
+
+    def __init__(self, W, H, world, rank, params, device, stream, comm, plan, motion_reach):
+        geo = Geometry.make(W, H, rank, world, params.steps, plan=plan, moments_radius=params.moments_radius, motion_reach=motion_reach)
+        self.stages = HipStages(geo, params, device)
+        self.runner = StripRunner(geo, self.stages, DistComm(device=device), storage=params.storage, device=device)
+        self.lay = dict(plan=geo.plan, y0=geo.y0, y1=geo.y1, own=geo.own)
+        self._on = False
+
+    def frame(self, rad, cur, prev):
+        return self.runner.frame(rad, cur, prev)
+
+    def owned(self, t):
+        return self.runner.owned(t)
+
+    def timing(self, on):
+        self._on = bool(on)
+        if not on:
+            self.stages.timing = False
+
+    def frame_timing(self, k):
+        self.stages.timing = self._on and (k % 4) == 0     # a-trous launches of every 4th timed frame between HIP events
+
+    def sync(self):
+        self.runner.flush()
+        self.stages.d.sync()
+
+    def atrous_timing(self, bytes_iter, bytes_feedback):
+        return self.stages.atrous_timing(bytes_iter, bytes_feedback)
+
+    def close(self):
+        self.runner.flush()
+        self.stages.d.close()
+
+
+def _strip_pan_frames(W, H, storage, device, mv, y0, y1):
+    """Two consecutive frames of a camera pan (rows [y0, y1)), walked forth and back: frame n shows canvas n & 1; walking back, a
+    frame's predecessor is the other one with the motion vector negated (bench.py's FramePool, pool of 2).
+    -> (radiances[2], G-buffer of frame n as current: gbs[n & 1][direction])."""
+    import numpy as np
+    import torch
+    from . import filter as F
+    from . import synth
+    npdt = np.float32 if storage == "f32" else np.float16
+    rads, gbs = [], []
+    for f in (0, 1):
+        sc = synth.make_scene(W, H, f, mv=mv, row_begin=y0, row_end=y1)
+        mo = torch.from_numpy(sc["motion"]).to(device)
+        back = mo.clone()
+        back[..., :2] *= -1.0
+        no, uv = torch.from_numpy(sc["normal"]).to(device), torch.from_numpy(sc["uv"]).to(device)
+        gbs.append((F.GBuffer(mo, no, uv), F.GBuffer(back, no, uv)))
+        rads.append(torch.from_numpy(synth.make_radiance(sc["base"], W, f, row_begin=y0).astype(npdt)).to(device))
+    return rads, gbs
+
+
+def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, make_inputs, prime_frames, driver="native", motion_reach=None,
+                 plans=("per-iteration", "grouped"), pan_mv=(1.5, -3.5), one_gpu_reference=True):
+    """bench.py's N > 1 leg: this rank's strip of a W x H frame; every measurement is `steps` frames between barriers, MAX over ranks.
+    Measured: the headline plan (`plan`, static camera), the other halo plans (BASELINE config #4 names "per-iteration"), a camera
+    pan whose state exchange really carries moments and history (motion reach >= 3), and — on rank 0 alone, before the strips —
+    the whole frame on one GPU, which is what the strip-parallel speed-up is relative to.
+    driver = "native": the C++ strip driver of the library (RCCL groups posted from C++); a rank that cannot bring it up makes every
+    rank raise (bench.py exits non-zero): the Python twin of the schedule runs only when asked for (driver = "python")."""
     import math
     import time
     import torch
@@ -540,10 +645,43 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
     side = torch.cuda.Stream(device=device, priority=-1)
     torch.cuda.set_stream(side)
     params = F.Params(storage=storage, steps=iters, variant=variant)
-    # the strip's inputs: its rows of the frame; the rows needed depend on the plan, which depends on the motion reach, which is
-    # read off the inputs: generate the widest candidate (ghost plan, reach 8), measure, then cut
-    probe = strips_plan(W, H, rank, world, iters, plan="ghost" if plan == "auto" else plan, moments_radius=params.moments_radius, motion_reach=8) \
-        if _plan_fits(W, H, rank, world, iters, "ghost" if plan == "auto" else plan, params.moments_radius, 8) else None
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- the whole frame on ONE GPU (rank 0), through svgf_denoise_frame: the time the N-GPU speed-up is relative to
+    one_gpu_ms = None
+    if one_gpu_reference:
+        if rank == 0:
+            gb_w, rads_w = make_inputs(W, H, storage, device, nframes=2)
+            gb2 = F.GBuffer(gb_w.motion.clone(), gb_w.normal.clone(), gb_w.uv.clone())
+            d = F.Denoiser(W, H, params, device=device.index or 0, stream=side.cuda_stream)
+            d.set_prev_guide(True)
+            gbp = [gb_w, gb2]
+            n = 0
+            for _ in range(min(prime_frames, 12) + warmup):
+                d.Render(rads_w[n & 1], gbp[n & 1], gbp[(n & 1) ^ 1])
+                n += 1
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                d.Render(rads_w[n & 1], gbp[n & 1], gbp[(n & 1) ^ 1])
+                n += 1
+            torch.cuda.synchronize(device)
+            one_gpu_ms = (time.perf_counter() - t0) * 1e3 / steps
+            d.close()
+            del d, gb_w, gb2, rads_w, gbp
+            torch.cuda.empty_cache()
+        one_gpu_ms = max_over_ranks(one_gpu_ms or 0.0)          # every rank learns rank 0's figure (and waits for it)
+
+    # ---- the strip's static inputs: its rows of the frame; the rows needed depend on the plan, which depends on the motion reach,
+    # which is read off the inputs: generate the widest candidate (ghost plan, reach 8), measure, then cut
+    wide = "ghost" if plan == "auto" else plan
+    probe = strips_plan(W, H, rank, world, iters, plan=wide, moments_radius=params.moments_radius, motion_reach=8) \
+        if _plan_fits(W, H, rank, world, iters, wide, params.moments_radius, 8) else None
     y0p, y1p = (probe["y0"], probe["y1"]) if probe else (0, H)
     gb_all, rads_all = make_inputs(W, H, storage, device, row_begin=y0p, row_end=y1p)
     if motion_reach is None:
@@ -551,97 +689,108 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
         if world > 1:
             dist.all_reduce(mvy, op=dist.ReduceOp.MAX)
         motion_reach = int(math.ceil(float(mvy.item())))
-    lay = strips_plan(W, H, rank, world, iters, plan=plan, moments_radius=params.moments_radius, motion_reach=motion_reach)
-    y0, y1 = lay["y0"], lay["y1"]
-    cut = slice(y0 - y0p, y1 - y0p)
-    # current and previous G-buffer in DISTINCT planes, ping-ponged (src/App.cu:471-474), also with a static camera
-    gbs = [F.GBuffer(gb_all.motion[cut].clone(), gb_all.normal[cut].clone(), gb_all.uv[cut].clone()) for _ in range(2)]
-    rads = [r[cut].contiguous() for r in rads_all]
-    del gb_all, rads_all
-    host_ms = None
-    native_note = None
-    if driver == "native":
-        # every rank tries to bring the C++ driver up (communicator + one frame); if any rank cannot (no librccl to open, an RCCL
-        # error), ALL fall back to the Python twin of the schedule rather than leaving the node without a number
-        drv, comm, err = None, None, ""
+
+    comm, rccl_ranks = None, None
+    if driver == "native" and world > 1:
+        # every rank brings the communicator up; if any rank cannot, ALL stop (no silent change of what is measured)
+        err = ""
         try:
-            comm = rccl_comm(world, rank, device.index or 0) if world > 1 else None
-            drv = NativeStrips(W, H, world, params, [rank], [device.index or 0], streams=[side.cuda_stream], comms=[comm] if comm else None,
-                               plan=lay["plan"], motion_reach=motion_reach)
-            drv.frame([rads[0]], [gbs[0]], [gbs[1]])
-            torch.cuda.synchronize(device)
+            comm = rccl_comm(world, rank, device.index or 0)
+            rccl_ranks = rccl_comm_count(comm)
         except Exception as e:  # noqa: BLE001
-            err, drv = f"{type(e).__name__}: {e}", None
-        bad = torch.tensor([0 if drv is not None else 1], device=device, dtype=torch.int32)
-        if world > 1:
-            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            err, comm = f"{type(e).__name__}: {e}", None
+        bad = torch.tensor([0 if comm is not None else 1], device=device, dtype=torch.int32)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         if int(bad.item()):
-            native_note = f"C++ strip driver unavailable on some rank ({err or 'see other ranks'}): Python driver used"
-            if drv is not None:
-                drv.close()
-            driver = "python"
-    if driver == "native":
-        n = 1
+            raise F.SvgfError(f"rank {rank}: the C++ strip driver's RCCL communicator is unavailable on some rank ({err or 'see the other ranks'}); "
+                              "rerun with --driver python to measure the Python twin of the schedule instead")
+    Runner = _NativeRunner if driver == "native" else _PythonRunner
+
+    def measure(plan_name, reach, frame_of, keep_timing=False):
+        """One driver under one plan: prime, then `steps` frames between barriers.  frame_of(n) -> (radiance, cur, prev) of THIS layout."""
+        lay = strips_plan(W, H, rank, world, iters, plan=plan_name, moments_radius=params.moments_radius, motion_reach=reach)
+        run = Runner(W, H, world, rank, params, device, side.cuda_stream, comm, lay["plan"], reach)
+        get = frame_of(lay)
+        n = 0
         for _ in range(prime_frames + warmup):
-            drv.frame([rads[n % len(rads)]], [gbs[n & 1]], [gbs[(n & 1) ^ 1]])
+            run.frame(*get(n))
             n += 1
-        drv.timing_enable(4)
+        run.timing(True)
         torch.cuda.synchronize(device)
         dist.barrier()
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         host = 0.0
-        for _ in range(steps):
+        for k in range(steps):
+            run.frame_timing(k)
             h0 = time.perf_counter()
-            drv.frame([rads[n % len(rads)]], [gbs[n & 1]], [gbs[(n & 1) ^ 1]])
+            run.frame(*get(n))
             host += time.perf_counter() - h0
             n += 1
         torch.cuda.synchronize(device)
         dist.barrier()
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
-        host_ms = host * 1e3 / steps
-        drv.timing_enable(0)
-        out = drv.frame([rads[0]], [gbs[n & 1]], [gbs[(n & 1) ^ 1]])[0]
-        drv.sync()                               # raises if a reprojection left the strip (motion reach too small)
-        assert bool(torch.isfinite(drv.owned(0, out).float()).all())
-
-        def atrous_timing(bytes_iter, bytes_feedback):
-            nl, ms, px_all, px0 = drv.timing_read()
-            return nl, ms, px_all * bytes_iter + px0 * bytes_feedback
-        res = dict(ms_per_step=(t1 - t0) * 1e3 / steps, rows_per_rank=lay["own"][1] - lay["own"][0], plan=lay["plan"], atrous_timing=atrous_timing,
-                   driver="C++ (svgf_strips_frame)", motion_reach=motion_reach, host_ms=round(host_ms, 4), _keep=(drv, comm))
+        run.timing(False)
+        out = run.frame(*get(n))
+        run.sync()                               # raises if a reprojection left the strip (motion reach too small)
+        assert bool(torch.isfinite(run.owned(out).float()).all())
+        res = dict(ms_per_step=max_over_ranks((t1 - t0) * 1e3 / steps), plan=lay["plan"], rows_per_rank=lay["own"][1] - lay["own"][0],
+                   rows_held=lay["y1"] - lay["y0"], host_ms=round(host * 1e3 / steps, 4), motion_reach=reach)
+        if keep_timing:
+            res["atrous_timing"] = run.atrous_timing
+            res["_keep"] = run
+        else:
+            run.close()
         return res
-    geo = Geometry.make(W, H, rank, world, iters, plan=lay["plan"], moments_radius=params.moments_radius, motion_reach=motion_reach)
-    stages = HipStages(geo, params, device)
-    runner = StripRunner(geo, stages, DistComm(device=device), storage=storage, device=device)
-    n = 0
-    for _ in range(prime_frames + warmup):
-        runner.frame(rads[n % len(rads)], gbs[n & 1], gbs[(n & 1) ^ 1])
-        n += 1
-    torch.cuda.synchronize(device)
-    dist.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    host = 0.0
-    for k in range(steps):
-        stages.timing = (k % 4) == 0             # a-trous launches of every 4th timed frame between HIP events
-        h0 = time.perf_counter()
-        runner.frame(rads[n % len(rads)], gbs[n & 1], gbs[(n & 1) ^ 1])
-        host += time.perf_counter() - h0
-        n += 1
-    stages.timing = False
-    torch.cuda.synchronize(device)
-    dist.barrier()
-    torch.cuda.synchronize(device)
-    t1 = time.perf_counter()
-    out = runner.frame(rads[0], gbs[n & 1], gbs[(n & 1) ^ 1])
-    runner.flush()
-    stages.d.sync()                              # raises if a reprojection left the strip
-    assert bool(torch.isfinite(runner.owned(out).float()).all())
-    return dict(ms_per_step=(t1 - t0) * 1e3 / steps, rows_per_rank=geo.own[1] - geo.own[0], plan=geo.plan, atrous_timing=stages.atrous_timing,
-                driver="python (svgf_amd/strips.py)" + (f" — {native_note}" if native_note else ""), motion_reach=motion_reach,
-                host_ms=round(host * 1e3 / steps, 4))
+
+    def static_frames(lay):
+        assert lay["y0"] >= y0p and lay["y1"] <= y1p, "the probe rows do not cover this layout"
+        cut = slice(lay["y0"] - y0p, lay["y1"] - y0p)
+        # current and previous G-buffer in DISTINCT planes, ping-ponged (src/App.cu:471-474), also with a static camera
+        gbs = [F.GBuffer(gb_all.motion[cut].clone(), gb_all.normal[cut].clone(), gb_all.uv[cut].clone()) for _ in range(2)]
+        rads = [r[cut].contiguous() for r in rads_all]
+        return lambda n: (rads[n % len(rads)], gbs[n & 1], gbs[(n & 1) ^ 1])
+
+    head = measure(plan, motion_reach, static_frames, keep_timing=True)
+    others = {}
+    for pl in plans:
+        if pl == head["plan"] or not _plan_fits(W, H, rank, world, iters, pl, params.moments_radius, motion_reach):
+            continue
+        r = measure(pl, motion_reach, static_frames)
+        others[pl] = {k: r[k] for k in ("ms_per_step", "rows_held", "host_ms")}
+
+    pan = None
+    if pan_mv is not None:
+        reach = int(math.ceil(abs(pan_mv[1])))
+        if _plan_fits(W, H, rank, world, iters, "auto", params.moments_radius, reach):
+            def pan_frames(lay):
+                rads, gbs = _strip_pan_frames(W, H, storage, device, pan_mv, lay["y0"], lay["y1"])
+                state = {"prev": None}
+
+                def get(n):
+                    cur = gbs[n & 1][0 if (n & 1) else (1 if n else 0)]        # odd frames walk forth (0 -> 1), even ones back (1 -> 0)
+                    prev = state["prev"] if state["prev"] is not None else cur
+                    state["prev"] = cur
+                    return rads[n & 1], cur, prev
+                return get
+            r = measure("auto", reach, pan_frames)
+            pan = {"mv": list(pan_mv), "motion_reach": reach, "plan": r["plan"], "ms_per_step": r["ms_per_step"], "rows_held": r["rows_held"]}
+
+    res = dict(head)
+    res.update(driver=Runner.name, other_plans=others, pan=pan, one_gpu_ms=one_gpu_ms, rccl_ranks=rccl_ranks, _comm=comm)
+    return res
+
+
+def rccl_comm_count(comm):
+    """The number of ranks RCCL itself reports for the communicator (ncclCommCount)."""
+    import ctypes as C
+    from . import filter as F
+    n = C.c_int(-1)
+    rc = F.load_library().svgf_rccl_comm_count(comm, C.byref(n))
+    if rc != 0:
+        raise F.SvgfError("svgf_rccl_comm_count failed")
+    return n.value
 
 
 def _plan_fits(W, H, rank, world, steps, plan, moments_radius, motion_reach):

@@ -117,7 +117,7 @@ def test_frame_driver_with_and_without_the_fusion(G, storage, steps):
     fr = frames(W, H, N, mv=(-2.5, 1.5))
     a = F.Denoiser(W, H, F.Params(storage=storage, steps=steps))
     b = F.Denoiser(W, H, F.Params(storage=storage, steps=steps))
-    b.set_iteration_fusion(False)
+    a.set_iteration_fusion(True)                    # (off by default: the pair launch is the slower one)
     gbs = [G.gb_dev(f) for f in fr]
     for k in range(N):
         rad = G.dev(fr[k]["radiance"].astype(G.NPDT[storage]))
@@ -128,11 +128,12 @@ def test_frame_driver_with_and_without_the_fusion(G, storage, steps):
             assert _same(a.state_plane(plane, 1 - a.pingpong()), b.state_plane(plane, 1 - b.pingpong())), f"frame {k}: state plane {plane}"
 
 
+@pytest.mark.parametrize("fusion", [False, True])
 @pytest.mark.parametrize("storage", ["f32", "f16"])
-def test_4k_render_equals_stage_calls(G, storage):
+def test_4k_render_equals_stage_calls(G, storage, fusion):
     """BASELINE.json configs[2] / [4] through the frame driver: 3840x2160, 5 iterations, static camera.  svgf_denoise_frame (fused
-    temporal launch, sparse colour store, young list, guide plane, previous-guide read, iterations 0 + 1 as one launch) against the
-    plain stage calls on caller-owned planes, bitwise, over the cold -> steady transition (variant "lds": both sides then run the
+    temporal launch, sparse colour store, young list, guide plane, previous-guide read; with and without iterations 0 + 1 as one
+    launch) against the plain stage calls on caller-owned planes, bitwise, over the cold -> steady transition (variant "lds": both sides then run the
     LDS moments kernel while every pixel is young)."""
     import torch
     from svgf_amd import filter as F
@@ -141,6 +142,7 @@ def test_4k_render_equals_stage_calls(G, storage):
     gb = [G.gb_dev(sc), G.gb_dev(sc)]                # two copies: the previous G-buffer is a different set of planes, as in the reference
     hip = G.HipPipeline(W, H, storage, steps=5, variant="lds")
     d = F.Denoiser(W, H, F.Params(storage=storage, steps=5, variant="lds"))
+    d.set_iteration_fusion(fusion)
     for k in range(N):
         rad_np = synth.make_radiance(sc["base"], W, k)
         want = torch.from_numpy(hip.frame(rad_np, gb[k & 1], gb[(k & 1) ^ 1]))
@@ -162,3 +164,41 @@ def test_4k_pair_equals_two_launches(G):
         want, want_fb = _two_launches(d, src, gb)
         got, got_fb = _one_launch(d, src, gb)
         assert _same(got, want) and _same(got_fb, want_fb), storage
+
+
+@pytest.mark.parametrize("plan", ["ghost", "grouped", "per-iteration"])
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_strip_driver_with_the_fusion(G, plan, storage):
+    """The C++ strip driver with the pair launch switched on (ghost / grouped keep iterations 0 and 1 in one group: ONE launch on
+    iteration 1's rows, the feedback colour written 4 rows beyond them; per-iteration has an exchange between them and stays with two
+    launches): 3 virtual ranks over the loop-back communicator == the whole frame through the stage calls, bitwise, history included."""
+    import torch
+    from svgf_amd import filter as F
+    from svgf_amd import strips
+    comm = strips.rccl_comm(1, 0, 0)
+    try:
+        W, H, world, N = 320, 420, 3, 4
+        fr = frames(W, H, N, mv=(1.0, -2.5))
+        whole = G.HipPipeline(W, H, storage, steps=5)
+        drv = strips.NativeStrips(W, H, world, F.Params(storage=storage, steps=5), list(range(world)), [0] * world, comms=[comm], plan=plan, motion_reach=3, loopback=True)
+        drv.set_iteration_fusion(True)
+        gbs = [G.gb_dev(f) for f in fr]
+        prev_in = None
+        for k in range(N):
+            want = whole.frame(fr[k]["radiance"], gbs[k], gbs[max(k - 1, 0)])
+            torch.cuda.synchronize()
+            cur_in = []
+            for lay in drv.layouts:
+                sl = slice(lay["y0"], lay["y1"])
+                cur_in.append((G.dev(np.ascontiguousarray(fr[k]["radiance"][sl].astype(G.NPDT[storage]))),
+                               F.GBuffer(*(G.dev(np.ascontiguousarray(fr[k][n][sl])) for n in ("motion", "normal", "uv")))))
+            outs = drv.frame([c[0] for c in cur_in], [c[1] for c in cur_in], [p[1] for p in prev_in] if prev_in else None)
+            drv.sync()
+            got = np.concatenate([G.host(drv.owned(r, o)) for r, o in enumerate(outs)], 0)
+            assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), f"plan {plan}: frame {k}"
+            prev_in = cur_in
+        hist = np.concatenate([G.host(drv.owned(r, drv.state_plane(r, F.PLANE_HISTORY, 1 - drv.pingpong(r)))) for r in range(world)], 0)
+        assert np.array_equal(hist, whole.taps["hist"])
+        drv.close()
+    finally:
+        F.load_library().svgf_rccl_comm_destroy(comm)

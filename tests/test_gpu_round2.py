@@ -250,8 +250,9 @@ def test_previous_guide_plane_stands_in_for_the_previous_gbuffer(G, mesh_id_test
     fr = frames(W, H, N, mv=(-2.5, 1.5))
     p = F.Params(storage="f32", steps=5, mesh_id_test=mesh_id_test)
     on, off, copies, scr_on, scr_off = (F.Denoiser(W, H, p) for _ in range(5))
-    off.set_prev_guide(False)
-    scr_off.set_prev_guide(False)
+    on.set_prev_guide(True)                                 # opt-in: the host vouches that it leaves the previous planes alone
+    scr_on.set_prev_guide(True)
+    copies.set_prev_guide(True)                             # ... and a `prev` at other addresses is read as it is anyway
     gbs = [G.gb_dev(f) for f in fr]
     gbs_scr = [G.gb_dev(f) for f in fr]                     # a second set, scrambled frame by frame
     differs = False
@@ -274,10 +275,11 @@ def test_previous_guide_plane_stands_in_for_the_previous_gbuffer(G, mesh_id_test
         assert np.array_equal(s_on.view(np.uint8), a.view(np.uint8)), f"frame {k}: the previous planes were read"
         differs = differs or not np.array_equal(s_off.view(np.uint8), a.view(np.uint8))
     assert differs, "scrambling the previous G-buffer must matter when its planes are read"
-    # fp16 storage and fewer than three iterations have no guide plane: the switch is accepted and changes nothing
-    for kw in (dict(storage="f16", steps=5), dict(storage="f32", steps=2)):
+    # fp16 storage keeps a guide plane too (same bits with the switch on and off); without any iteration, and with the direct
+    # variant, there is none: the switch is accepted and changes nothing
+    for kw in (dict(storage="f16", steps=5), dict(storage="f32", steps=0), dict(storage="f32", steps=3, variant="direct")):
         x, y = F.Denoiser(W, H, F.Params(**kw)), F.Denoiser(W, H, F.Params(**kw))
-        y.set_prev_guide(False)
+        x.set_prev_guide(True)
         for k in range(3):
             rad = G.dev(fr[k]["radiance"].astype(G.NPDT[kw["storage"]]))
             ax, ay = (G.host(d.Render(rad, gbs[k], gbs[k - 1] if k else None)) for d in (x, y))
@@ -396,6 +398,40 @@ def test_bench_flow_of_two_ranks_on_one_device():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["halo_plan"] in ("ghost", "grouped", "per-iteration")
     assert "1080 rows per GPU" in d["config"]["workload"] and d["roofline"]["launches_timed"] > 0
+    # the N > 1 line is self-contained: the one-GPU time of the same frame, the factor, every halo plan (BASELINE config #4 names
+    # per-iteration), a pan whose state exchange carries moments / history, and the communicator's own rank count (null under gloo)
+    assert d["one_gpu_ms"] > 0 and d["speedup_vs_one_gpu"] == pytest.approx(d["one_gpu_ms"] / d["ms_per_step"], rel=1e-2)
+    assert set(d["halo_plans"]) == {"ghost", "grouped", "per-iteration"} and all(v["ms_per_step"] > 0 for v in d["halo_plans"].values())
+    assert d["halo_plans"][d["config"]["halo_plan"]]["ms_per_step"] == d["ms_per_step"]
+    assert d["pan"]["motion_reach"] >= 3 and d["pan"]["ms_per_step"] > 0
+    assert "rccl_ranks" in d and d["rccl_ranks"] is None and d["config"]["driver"].startswith("python")
+
+
+def test_bench_refuses_a_silent_change_of_driver():
+    """Two rank processes on one device cannot bring an RCCL communicator up (RCCL refuses two ranks per device): with the default
+    --driver native the bench must FAIL (non-zero exit, no JSON line) instead of quietly measuring the Python twin of the schedule."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SVGF_BENCH_SHARE_DEVICES="1")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "1080p", "--no-extra", "--no-one-gpu"],
+                       env=env, capture_output=True, text=True, timeout=500)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert "--driver python" in p.stderr
+
+
+def test_bench_strips_line_on_one_gpu(G):
+    """`bench.py --gpus 1 --strips`: the N > 1 code path (C++ strip driver, world size 1) prints every field of the N > 1 line."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--strips", "--steps", "3", "--warmup", "1", "--workload", "4k"],
+                       env=env, capture_output=True, text=True, timeout=500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["driver"].startswith("C++") and d["one_gpu_ms"] > 0 and d["speedup_vs_one_gpu"] > 0
+    assert set(d["halo_plans"]) == {"ghost", "grouped", "per-iteration"} and d["pan"]["ms_per_step"] > 0 and d["roofline"]["frac"] > 0
 
 
 @pytest.mark.parametrize("storage", ["f32", "f16"])
