@@ -228,6 +228,101 @@ __device__ __forceinline__ void moments_pixel(const Geo& g, const MomentsArgs& a
     Store<ST>::st4(a.out, idx, make_float4(sr * inv, sg * inv, sb * inv, var));   // :516 unclamped
 }
 
+// The same estimate for the pixels of the young list (disocclusions under a moving camera: a few tens of thousands of pixels along
+// the frame borders and the silhouettes).  One thread per listed pixel made that launch the slowest per pixel of the frame: a wave of
+// 64 scattered pixels touches ~60 different cache lines with EVERY one of its ~350 loads, and the launch is bound by the L1s' lookup
+// rate (rocprofv3: 9.9 M line accesses for 164 K load instructions, 48 us; fewer rounds of latency or more CUs did not move it).
+// Here EIGHT LANES serve one pixel: lane j < 7 owns window column j-3 and loads its seven taps (one per row) — the eight lanes of a
+// group read adjacent texels of one row, one or two cache lines per load — and evaluates their weights; then every lane walks the 49
+// taps in the reference's order (rows outer, columns inner, :467-500), fetching each tap's weight, colour and moments from the lane
+// that holds them (__shfl = ds_bpermute: no memory), so the sums are accumulated in exactly the order — and to exactly the bits —
+// of moments_pixel.  The colour of a tap is fetched from BOTH planes it can live in (the choice depends on the tap's own depth /
+// history texel), which keeps every load of the window independent: one round of memory latency for the taps.
+template <int ST>
+__device__ __forceinline__ void moments_group8(const Geo& g, const MomentsArgs& a, bool valid, uint32_t pix) {
+    constexpr int RM = 3, NW = 2 * RM + 1;
+    const int lane = threadIdx.x & 63, j = lane & 7, base = lane & ~7;
+    const int x = (int)(pix % (uint32_t)g.W), y = g.y0 + (int)(pix / (uint32_t)g.W);
+    valid = valid && y >= g.yb && y < g.ye;                           // the moments rows may be a sub-range of the temporal rows
+    const size_t idx = valid ? (size_t)(y - g.y0) * g.W + x : 0;
+    const int R = a.radius, xx = j - RM;
+    const float h = (float)a.hist[idx];                               // :442
+    const float4 cc = Store<ST>::ld4(a.colour, idx);                  // :450 raw load
+    const float4 mc = a.motion[idx];
+    const uint2 nraw = a.normal[idx];
+    // the window column of this lane
+    bool ok[NW];
+    float tz[NW];
+    float2 tm[NW];
+    uint2 tn[NW];
+    int th[NW];
+    float4 ca[NW], cb[NW];
+#pragma unroll
+    for (int r = 0; r < NW; r++) {
+        const int yy = r - RM, py = y + yy, px = x + xx;
+        ok[r] = valid && j < NW && yy >= -R && yy <= R && py >= 0 && py < g.H && xx >= -R && xx <= R && px >= 0 && px < g.W;   // :473
+        const size_t p = ok[r] ? (size_t)(py - g.y0) * g.W + px : idx;                 // a tap that does not exist reads the centre and is dropped
+        tz[r] = ((const float*)a.motion)[p * 4 + 2];
+        tm[r] = Store<ST>::ld2(a.mom, p);                                              // :480
+        tn[r] = a.normal[p];                                                           // :483
+        th[r] = a.sparse_colour ? (int)a.hist[p] : 0;
+        ca[r] = Store<ST>::ld4(a.colour, p);                                           // :479 raw ...
+        cb[r] = Store<ST>::ld4(a.sparse_colour ? (const void*)a.out : a.colour, p);    // ... or, for an old non-sky texel, where the temporal launch put it
+    }
+    const float lc = lum_exact(cc.x, cc.y, cc.z);
+    float zc, dzc;
+    depth_of(mc, zc, dzc);
+    const float3 nc = normal_of(nraw);
+    const float il = hw_rcp(a.phi_colour);                            // :460
+    const float phi_d = fmaxf(dzc, 1e-8f) * 3.0f;                     // :461
+    // this lane's seven taps: weight and the values the sums take from them
+    float tw[NW], t0[NW], t1[NW], t2[NW];
+    unsigned okbits = 0u;
+#pragma unroll
+    for (int r = 0; r < NW; r++) {
+        const int yy = r - RM;
+        const bool in_out = a.sparse_colour && tz[r] != 0.0f && tz[r] != kSkyZ && th[r] >= 4;
+        const float4 va = ca[r], vb = cb[r];
+        t0[r] = in_out ? vb.x : va.x; t1[r] = in_out ? vb.y : va.y; t2[r] = in_out ? vb.z : va.z;
+        const float zp = tz[r] == 0.0f ? kSkyZ : tz[r];               // depth_of, :482
+        const float3 np = normal_of(tn[r]);
+        const float len = sqrtf((float)(xx * xx + yy * yy));          // :488 (IEEE sqrt of a small integer: the value a constant would have)
+        const float iz = (xx == 0 && yy == 0) ? 0.0f : hw_rcp(phi_d * len);   // phiDepth == 0 -> wZ = 0, :420
+        tw[r] = edge_weight(fabsf(lc - lum_exact(t0[r], t1[r], t2[r])), il, fabsf(zc - zp), iz, dot3_fma(nc, np), a.phi_normal);
+        okbits |= ok[r] ? 1u << r : 0u;
+    }
+    // the 49 taps in the reference's order; every lane of the group accumulates the same sums
+    unsigned okc[NW];
+#pragma unroll
+    for (int c = 0; c < NW; c++) okc[c] = (unsigned)__shfl((int)okbits, base + c);
+    float sw = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sm1 = 0.f, sm2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < NW; r++) {
+#pragma unroll
+        for (int c = 0; c < NW; c++) {
+            const float w = __shfl(tw[r], base + c), c0 = __shfl(t0[r], base + c), c1 = __shfl(t1[r], base + c), c2 = __shfl(t2[r], base + c);
+            const float m1 = __shfl(tm[r].x, base + c), m2 = __shfl(tm[r].y, base + c);
+            if ((okc[c] >> r) & 1u) {
+                sw += w;                                              // :497-499
+                sr = fmaf(c0, w, sr); sg = fmaf(c1, w, sg); sb = fmaf(c2, w, sb);
+                sm1 = fmaf(m1, w, sm1); sm2 = fmaf(m2, w, sm2);
+            }
+        }
+    }
+    if (!valid || j != 0) return;                                     // one lane of the group writes
+    if (a.cold_only && !(h < 4.0f)) return;                           // already written by temporal_kernel (passthrough_out)
+    if (!(h < 4.0f)) { Store<ST>::st4(a.out, idx, cc); return; }      // :521
+    if (((nraw.x & 0x7fff7fffu) | (nraw.y & 0x7fffu)) == 0u && a.phi_normal > 0.0f) {      // see moments_pixel
+        Store<ST>::st4(a.out, idx, make_float4(0.f, 0.f, 0.f, 0.f * (4.0f / h)));
+        return;
+    }
+    sw = fmaxf(sw, 1e-6f);                                            // :505
+    const float inv = 1.0f / sw;
+    sm1 *= inv; sm2 *= inv;
+    const float var = (sm2 - sm1 * sm1) * (4.0f / h);                 // :511-514
+    Store<ST>::st4(a.out, idx, make_float4(sr * inv, sg * inv, sb * inv, var));   // :516 unclamped
+}
+
 template <int ST>
 __global__ __launch_bounds__(kBX* kBY) void moments_kernel(Geo g, MomentsArgs a) {
     const int x = blockIdx.x * kBX + threadIdx.x;
@@ -324,35 +419,49 @@ __global__ __launch_bounds__(kBX* kBY) void moments3x3_shfl_kernel(Geo g, Moment
     Store<ST>::st4(a.out, idx, make_float4(sr * inv, sg * inv, sb * inv, var));   // :516 unclamped
 }
 
-// Steady state inside the frame driver: the temporal launch already copied every pixel with history >= 4 and listed the young
-// ones that need the estimate (disocclusions: sparse).  A small grid walks the list; neighbouring entries are neighbouring
-// pixels (a wave of the temporal launch appends its young pixels together), so a wave's gathers stay local.
+// Steady state inside the frame driver: the temporal launch already copied every pixel with history >= 4 and told this launch where
+// the young ones are: the LIST (indices appended wave by wave) and, for a 64-pixel segment whose pixels are ALL young, one FLAG.
+// Both are served by moments_group8, eight pixels per wave-pass.  List waves take eight consecutive entries per pass.  A scan
+// workgroup reads 256 flags (segment s belongs to workgroup s mod scan_blocks: a row of flagged segments spreads over as many
+// workgroups), shares the four ballots through LDS, and its four waves split every flagged segment between them: two passes
+// each instead of one wave's fourteen dependent rounds.  Scan workgroups come first in the grid: theirs are the longer chains.
+// (Bench pan, ~28 000 listed pixels + ~180 flagged segments per 4K frame: 0.051 -> 0.03x ms; nothing young: 0.0065 ms as before.)
 template <int ST>
-__global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a, int list_blocks) {
-    if ((int)blockIdx.x < list_blocks) {
-        const unsigned n = *a.young_count;
-        for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += (unsigned)list_blocks * 256u) {
-            const uint32_t p = a.young_list[i];
-            const int x = (int)(p % (uint32_t)g.W), y = g.y0 + (int)(p / (uint32_t)g.W);
-            if (y >= g.yb && y < g.ye) moments_pixel<ST>(g, a, x, y);         // the moments rows may be a sub-range of the temporal rows
+__global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a, int scan_blocks) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= scan_blocks) {
+        const unsigned list_blocks = gridDim.x - (unsigned)scan_blocks, b = blockIdx.x - (unsigned)scan_blocks;
+        const unsigned n = *a.young_count, ngroups = (n + 7u) / 8u;
+        for (unsigned grp = b + list_blocks * (unsigned)w; grp < ngroups; grp += list_blocks * 4u) {
+            const unsigned i = grp * 8u + ((unsigned)lane >> 3);
+            const bool valid = i < n;
+            moments_group8<ST>(g, a, valid, valid ? a.young_list[i] : 0u);
         }
         return;
     }
-    // the segments whose 64 pixels are all young (one flag each): scanned 64 flags per wave-load, interleaved over the waves so
-    // that a patch of them is shared out
-    const int lane = threadIdx.x & 63;
+    __shared__ unsigned long long masks[4];
     const int nseg = (g.W + kBX - 1) / kBX;
     const int first = (g.yb - g.y0) * nseg, last = (g.ye - g.y0) * nseg;             // flag range of the launch rows
-    const int nwaves = ((int)gridDim.x - list_blocks) * 4, wave = ((int)blockIdx.x - list_blocks) * 4 + (threadIdx.x >> 6);
-    for (int k = 0; first + k * 64 * nwaves + wave < last; k++) {
-        const int sidx = first + (k * 64 + lane) * nwaves + wave;
-        unsigned long long m = __ballot(sidx < last && a.young_flags[sidx] != 0);
-        while (m) {
-            const int b = __builtin_ctzll(m);
-            m &= m - 1;
-            const int seg = first + (k * 64 + b) * nwaves + wave, x = (seg % nseg) * kBX + lane, y = g.y0 + seg / nseg;
-            if (x < g.W) moments_pixel<ST>(g, a, x, y);
+    for (int base = first; base + (int)blockIdx.x < last; base += scan_blocks * 256) {   // (uniform over the workgroup)
+        const int sidx = base + (w * 64 + lane) * scan_blocks + (int)blockIdx.x;
+        const unsigned long long m = __ballot(sidx < last && a.young_flags[sidx] != 0);
+        if (lane == 0) masks[w] = m;
+        __syncthreads();
+#pragma unroll 1
+        for (int ww = 0; ww < 4; ww++) {
+            unsigned long long mm = masks[ww];
+            while (mm) {
+                const int bit = __builtin_ctzll(mm);
+                mm &= mm - 1;
+                const int seg = base + (ww * 64 + bit) * scan_blocks + (int)blockIdx.x, yl = seg / nseg;
+#pragma unroll 1
+                for (int o = w; o < 8; o += 4) {                                      // this wave's two eighths of the segment
+                    const int x = (seg % nseg) * kBX + o * 8 + (lane >> 3);
+                    moments_group8<ST>(g, a, x < g.W, (uint32_t)(yl * g.W + (x < g.W ? x : 0)));
+                }
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -824,8 +933,8 @@ hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, bool 
         int scan = (nsegs + 255) / 256;                            // >= one flag per lane and load ...
         if (scan > 4 * num_cus()) scan = 4 * num_cus();            // ... on at most one resident round
         const int walk = std::min(4 * num_cus(), std::max(1, nsegs / 16));   // the list holds at most 63 pixels per segment
-        if (storage == 0) moments_young_kernel<0><<<walk + scan, 256, 0, s>>>(g, a, walk);
-        else moments_young_kernel<1><<<walk + scan, 256, 0, s>>>(g, a, walk);
+        if (storage == 0) moments_young_kernel<0><<<scan + walk, 256, 0, s>>>(g, a, scan);
+        else moments_young_kernel<1><<<scan + walk, 256, 0, s>>>(g, a, scan);
         return hipGetLastError();
     }
     const dim3 block(kBX, kBY), grid = grid_for(g);

@@ -109,7 +109,7 @@ struct svgf_strips {
         std::vector<int> titer;
     };
     std::vector<Local> local;
-    int timing_every = 0, frame_no = 0;
+    int timing_every = 0, timing_base = 0, frame_no = 0;       // timed: frames timing_base, timing_base + every, ...
     double t_ms = 0, t_px_iter = 0, t_px_fb = 0;
     int t_launches = 0;
     std::string err;
@@ -251,7 +251,7 @@ int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src
     svgf_ctx* c = l.ctx;
     DeviceGuard dg(l.device);
     c->rb = rows.a; c->re = rows.b;
-    const bool timed = s->timing_every > 0 && (s->frame_no % s->timing_every) == 0 && l.rank == s->local[0].rank;
+    const bool timed = s->timing_every > 0 && ((s->frame_no - s->timing_base) % s->timing_every) == 0 && l.rank == s->local[0].rank;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) {
         SVGF_SHIP(s, hipEventCreate(&e0));
@@ -541,6 +541,7 @@ int svgf_strips_sync(svgf_strips* s) {
 int svgf_strips_timing_enable(svgf_strips* s, int every) {
     if (!s) return SVGF_ERR_INVALID;
     s->timing_every = every > 0 ? every : 0;
+    s->timing_base = s->frame_no;                  // the first frame after this call is a timed one
     return SVGF_OK;
 }
 

@@ -109,7 +109,7 @@ def test_hip_matches_atrous_golden(variant):
 @pytest.mark.gpu
 def test_hip_matches_pipeline_golden():
     """The free-running HIP pipeline against the committed 8-frame golden: accept/reject masks exact (mismatch count printed,
-    must be 0), colour in two tiers as in test_pipeline_free_running — a tight bound that all but 0.5 % of the values must
+    must be 0), colour in two tiers as in test_pipeline_free_running — a tight bound that all but 0.1 % (fp32) / 0.2 % (fp16) of the values must
     meet (a 1e-3 regression fails it) and the loose bound of the ill-conditioned zero-variance pixels (Tolerance)."""
     from tests import gpu_helpers as G
     z = np.load(os.path.join(GOLD, "pipeline_64x48.npz"))
@@ -118,7 +118,7 @@ def test_hip_matches_pipeline_golden():
         hip = G.HipPipeline(W, H, st, steps=5)
         frs = [synth.make_frame(W, H, k, mv=mv) for k in range(N)]
         gbs = [G.gb_dev(f) for f in frs]
-        tight, loose = (2e-5, 2e-3) if st == "f32" else (1e-3, 3e-2)
+        tight, loose, frac = (2e-5, 5e-4, 1e-3) if st == "f32" else (1e-3, 2e-2, 2e-3)      # 2x the maxima measured on MI355X (profiles/r0N_parity_report.json)
         for k in range(N):
             o = hip.frame(frs[k]["radiance"], gbs[k], gbs[max(k - 1, 0)])
             if k in (3, N - 1):
@@ -129,4 +129,4 @@ def test_hip_matches_pipeline_golden():
                 print(f"golden pipeline {st} frame {k}: mask mismatches {mism}, max err {err.max():.3e}, mean err {err.mean():.3e}, beyond tight {beyond:.2e}")
                 assert mism == 0
                 assert err.max() <= loose
-                assert beyond <= 5e-3, f"{st} frame {k}: {beyond:.2e} of the values beyond the tight tolerance {tight}"
+                assert beyond <= frac, f"{st} frame {k}: {beyond:.2e} of the values beyond the tight tolerance {tight}"

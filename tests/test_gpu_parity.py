@@ -224,10 +224,12 @@ def test_pipeline_free_running(G, oracle, storage, mv, variant):
     ref = oracle.Pipeline(W, H, storage, steps=5, nthreads=8)
     hip = G.HipPipeline(W, H, storage, steps=5, variant=variant)
     gbs = [G.gb_dev(f) for f in fr]
-    # measured on MI355X (tools/diag_free.py): f32 max 2e-4 with <1e-3 of values beyond 2e-5; f16 max 1e-2 with
-    # <1e-4 of values beyond 1e-3, all in frame 3-4 where the first pixels leave the spatial variance estimate
+    # measured on MI355X (profiles/r0N_parity_report.json, tools/diag_free.py): f32 max 2.5e-4 with < 1e-3 of the values beyond 2e-5;
+    # f16 max 1.0e-2 (static camera, frame 3: ten half-ulps at 0.5-1.0 on a handful of pixels) with < 1e-4 of the values beyond 1e-3 —
+    # all in frames 3-4, where the first pixels leave the spatial variance estimate.  The bounds are 2x the measured maxima.
     tight = 2e-5 if storage == "f32" else 1e-3
-    loose = 2e-3 if storage == "f32" else 3e-2
+    loose = 5e-4 if storage == "f32" else 2e-2
+    frac = 1e-3 if storage == "f32" else 2e-3
     for k in range(N):
         kp = max(k - 1, 0)
         want = ref.frame(fr[k]["radiance"], gbuf(fr[k]), gbuf(fr[kp])).astype(np.float64)
@@ -235,7 +237,7 @@ def test_pipeline_free_running(G, oracle, storage, mv, variant):
         assert np.array_equal(hip.taps["hist"], ref.taps["hist"]), f"frame {k}: history mask mismatch"
         err = np.abs(got - want)[..., :3]
         assert err.max() <= loose, f"frame {k}: max colour error {err.max():.3e}"
-        assert (err > tight + 1e-5 * np.abs(want[..., :3])).mean() <= 5e-3, f"frame {k}: {(err > tight).mean():.2e} of values beyond the tight tolerance"
+        assert (err > tight + 1e-5 * np.abs(want[..., :3])).mean() <= frac, f"frame {k}: {(err > tight).mean():.2e} of values beyond the tight tolerance"
 
 
 @pytest.mark.parametrize("storage", ["f32", "f16"])
@@ -322,7 +324,8 @@ def test_frame_driver_default_path(G, oracle, storage):
     d = F.Denoiser(W, H, F.Params(storage=storage, steps=5))
     gbs = [G.gb_dev(f) for f in fr]
     tight = 2e-5 if storage == "f32" else 1e-3
-    loose = 2e-3 if storage == "f32" else 3e-2
+    loose = 5e-4 if storage == "f32" else 2e-2             # 2x the maxima measured on MI355X (see test_pipeline_free_running)
+    frac = 1e-3 if storage == "f32" else 2e-3
     for k in range(N):
         kp = max(k - 1, 0)
         want = ref.frame(fr[k]["radiance"], gbuf(fr[k]), gbuf(fr[kp])).astype(np.float64)
@@ -330,7 +333,7 @@ def test_frame_driver_default_path(G, oracle, storage):
         assert np.array_equal(G.host(d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong())), ref.taps["hist"]), f"frame {k}: history"
         err = np.abs(got - want)[..., :3]
         assert err.max() <= loose, f"frame {k}: max colour error {err.max():.3e}"
-        assert (err > tight + 1e-5 * np.abs(want[..., :3])).mean() <= 5e-3, f"frame {k}"
+        assert (err > tight + 1e-5 * np.abs(want[..., :3])).mean() <= frac, f"frame {k}"
     d.reset_history()
     want0 = oracle.Pipeline(W, H, storage, steps=5, nthreads=8).frame(fr[0]["radiance"], gbuf(fr[0]), gbuf(fr[0]))
     got0 = G.host(d.Render(G.dev(fr[0]["radiance"].astype(G.NPDT[storage])), gbs[0], None))

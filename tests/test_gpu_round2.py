@@ -375,7 +375,18 @@ def test_parity_report(G, oracle):
         lim = 2e-5 + 1e-5 if storage == "f32" else 1e-3
         for i in range(5):
             assert rep[f"atrous_step{1 << i}_colour"]["max_abs"] <= lim, (storage, i)
-        assert rep["free_running_colour"]["max_abs"] <= (2e-3 if storage == "f32" else 3e-2)
+        assert rep["free_running_colour"]["max_abs"] <= (5e-4 if storage == "f32" else 2e-2)
+    # drift guard: no stage's max error may grow beyond 4x what the last committed report recorded (identical inputs, deterministic
+    # kernels: the numbers only move when a kernel changes)
+    import glob
+    committed = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_parity_report.json")))
+    assert committed, "profiles/r0N_parity_report.json is missing"
+    base = json.load(open(committed[-1]))["stages"]
+    for storage, rep in report["stages"].items():
+        for name, v in rep.items():
+            if isinstance(v, dict) and name in base.get(storage, {}):
+                old = base[storage][name]["max_abs"]
+                assert v["max_abs"] <= 4.0 * old + 1e-12, f"{storage} {name}: max error {v['max_abs']:.3e} vs {old:.3e} in {os.path.basename(committed[-1])}"
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "parity_report.json"), "w") as f:
         json.dump(report, f, indent=1)

@@ -1,11 +1,11 @@
 #!/bin/bash
 # The uniform-normal fast path must be bit-identical to the general path: run the same frames through a build with the fast
-# path compiled out (-DSVGF_NO_FASTPATH=1) and through the normal build, compare checksums of every output plane.
+# path compiled out (-DSVGF_DIAG -DSVGF_NO_FASTPATH=1: the instrumented kernel of tools/variants) and through the normal build, compare checksums of every output plane.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p build
 python3 -c "
 from svgf_amd import build as b
-b.build_library(extra_flags=['-DSVGF_NO_FASTPATH=1'], out='$R/build/libsvgf_nofast.so')
+b.build_library(extra_flags=['-DSVGF_DIAG', '-DSVGF_NO_FASTPATH=1'], out='$R/build/libsvgf_nofast.so')
 b.build_library(out='$R/build/libsvgf_fast.so', force=True)" 2>/dev/null
 cat > /tmp/fp_run.py <<'PY'
 import hashlib, os, sys
