@@ -102,8 +102,9 @@ __global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(
     // ddepth of this thread's next two centres (rows j+rg and two rows further).  A staged row becomes a centre two steps after it
     // is committed; its ddepth is taken over at commit time (never at fetch time: that would wait for the prefetch).
     float dq0 = 0.f, dq1 = 0.f;
-    // prologue: two ring rows at a time (requesting all six at once measured the same).  Rows j0, j0+1 (always inside the frame) go
-    // first: thread 0's pixel of row j0 is the workgroup's reference normal.
+    // prologue: two ring rows at a time, three dependent rounds of memory latency.  (All six rows requested at once measure the
+    // same at 4K and 1 % slower at 1080p: profiles/r03_small_experiments.txt.)  Rows j0, j0+1 (always inside the frame) go first:
+    // thread 0's pixel of row j0 is the workgroup's reference normal.
     if (t < kRing * 8) nflag[t] = 0u;
 #pragma unroll 1
     for (int rr = 0; rr < kRing; rr += kRS) {
@@ -122,6 +123,10 @@ __global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(
     __syncthreads();
 
     const float phi_n = a.phi_normal;              // != 0 (launcher)
+    // the uniform-normal path's exponent bases, once per workgroup: wave-uniform values (scalar registers)
+    UniBase ref_base = uni_base(ref01, unpack_h2(refz).x, phi_n);
+#pragma unroll
+    for (int k = 0; k < 5; k++) ref_base.e[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ref_base.e[k])));
     int slot0 = 0;
     Staged cs;                                     // the rows the NEXT step needs: requested at the start of a step, committed at its end
     for (int j = j0; j < j1; j += kRS) {
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(
         const bool sky = c.lz.y == kSkyZ;
         const bool wave_has_surface = __ballot(!sky) != 0ull;
         const bool uniform = !a.no_fastpath && __ballot(lane < kRing * 8 && nflag[lane < kRing * 8 ? lane : 0] != 0u) == 0ull;
-        const float4 o = filter_px<S, kTapDepth>(recA, recL, recN, rowbase, c, phi_n, wave_has_surface, uniform);
+        const float4 o = filter_px<S, kTapDepth>(recA, recL, recN, rowbase, c, phi_n, wave_has_surface, uniform, &ref_base);
 
         // Output values now, their stores AFTER the ring refill: hipcc's vmcnt bookkeeping cannot tell that the rows committed
         // below were fetched long before this step's stores, so stores issued first would be waited for.

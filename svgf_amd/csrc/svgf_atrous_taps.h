@@ -41,15 +41,24 @@ __device__ __forceinline__ TapCentre centre_setup(f32x4 A, f32x2 L, f32x2 N, flo
 // bits, so n.n' is the centre's own |n|^2 — the same expression the general path evaluates per tap, bit for bit — and the
 // normal records are not read at all.  The empty asm statements pin the order: left alone, instruction selection sinks all
 // arithmetic below all LDS reads of the unrolled loop (256 VGPRs + scratch spills).
+// UNI: the exponent of the normal term + kernel weight per kernel-weight class, from a normal's own |n|^2
+struct UniBase { float e[5]; };
+__device__ __forceinline__ UniBase uni_base(uint32_t n01, float nz, float phi_n) {
+    UniBase u;
+    const float lg = hw_log2(clamp01(fmaf(nz, nz, dot2_h2(n01, n01))));
+    u.e[0] = fmaf(lg, phi_n, klog2(0, 1)); u.e[1] = fmaf(lg, phi_n, klog2(1, 1)); u.e[2] = fmaf(lg, phi_n, klog2(0, 2));
+    u.e[3] = fmaf(lg, phi_n, klog2(1, 2)); u.e[4] = fmaf(lg, phi_n, klog2(2, 2));
+    return u;
+}
+
 template <int CS, int D, bool UNI>
 __device__ __forceinline__ void taps24(const f32x4* recA, const f32x2* recL, const f32x2* recN, const int (&rowbase)[5], const TapCentre& c, float phi_n,
-                                       float& sw, f32x2& srg, f32x2& sbv) {
-    float ebase[5];                                    // UNI: exponent of the normal term + kernel weight, per kernel-weight class
-    if constexpr (UNI) {
-        const float lg = hw_log2(clamp01(fmaf(c.nz, c.nz, dot2_h2(c.n01, c.n01))));
-        ebase[0] = fmaf(lg, phi_n, klog2(0, 1)); ebase[1] = fmaf(lg, phi_n, klog2(1, 1)); ebase[2] = fmaf(lg, phi_n, klog2(0, 2));
-        ebase[3] = fmaf(lg, phi_n, klog2(1, 2)); ebase[4] = fmaf(lg, phi_n, klog2(2, 2));
-    }
+                                       float& sw, f32x2& srg, f32x2& sbv, const UniBase* shared_base) {
+    // shared_base: the workgroup's reference normal's values, computed once (every surface centre of a uniform wave carries exactly
+    // those normal bits, so they are what uni_base(c.n01, c.nz) would give); null: per pixel
+    UniBase ub;
+    if constexpr (UNI) ub = shared_base ? *shared_base : uni_base(c.n01, c.nz, phi_n);
+    const float (&ebase)[5] = ub.e;
     constexpr int NT = 25;
     f32x4 qA[NT];
     f32x2 qL[NT], qN[NT];
@@ -95,12 +104,12 @@ __device__ __forceinline__ void taps24(const f32x4* recA, const f32x2* recL, con
 // filter) and `uniform` are wave-uniform.
 template <int CS, int D>
 __device__ __forceinline__ float4 filter_px(const f32x4* recA, const f32x2* recL, const f32x2* recN, const int (&rowbase)[5], const TapCentre& c, float phi_n,
-                                            bool wave_has_surface, bool uniform) {
+                                            bool wave_has_surface, bool uniform, const UniBase* shared_base = nullptr) {
     float sw = 1.0f;                                                                     // :567
     f32x2 srg = {c.A.x, c.A.y}, sbv = {c.A.z, c.A.w};                                    // :568
     if (wave_has_surface) {
-        if (uniform) taps24<CS, D, true>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv);
-        else taps24<CS, D, false>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv);
+        if (uniform) taps24<CS, D, true>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv, shared_base);
+        else taps24<CS, D, false>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv, nullptr);
     }
     if (c.lz.y == kSkyZ) return make_float4(c.A.x, c.A.y, c.A.z, c.A.w);                 // :554-558
     const float inv = hw_rcp(sw);                                                        // sw >= 1
