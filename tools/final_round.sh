@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything the round's profiles/ files come from, in one gpurun call: tools/final_round.sh <tag>
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; O=gpurun_out/$TAG; mkdir -p $O
 python3 -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | grep -E "passed|failed|Error|error|assert" | tail -5 > $O/pytest_gpu.log
@@ -9,9 +9,9 @@ python3 bench.py 2>$O/bench_4k_f32.err | grep "^{" > $O/bench_4k_f32.json
 python3 bench.py --storage f16 --no-cpu --no-extra 2>/dev/null | grep "^{" > $O/bench_4k_f16.json
 python3 bench.py --workload 1080p --no-cpu --no-extra 2>/dev/null | grep "^{" > $O/bench_1080p_f32.json
 python3 bench.py --workload 8k --no-cpu --no-extra --steps 20 2>/dev/null | grep "^{" > $O/bench_8k_f32.json
+python3 bench.py --fuse --no-cpu --no-extra 2>/dev/null | grep "^{" > $O/bench_4k_f32_pair_launch.json
 python3 bench.py --strips --workload 8k --steps 20 --warmup 3 2>/dev/null | grep "^{" > $O/bench_8k_f32_stripdriver_1gpu.json
-for pl in ghost grouped; do for drv in native python; do python3 tools/strip_sim.py --plan $pl --driver $drv --stream own-hi 2>&1 | grep -E "ms/frame"; done; done > $O/strip_sim.txt
-SVGF_STAMPS_PREBUILT=1 python3 tools/stamps.py 2>&1 | grep -v "diag\]\|amdgpu.ids" > $O/stamps.txt      # build/libsvgf_stamps.so: built here from the same sources (tools/README.md)
+for pl in ghost grouped per-iteration; do python3 tools/strip_sim.py --plan $pl --driver native --stream own-hi 2>&1 | grep -E "ms/frame"; done > $O/strip_sim.txt
 tools/prof.sh ${TAG}_4k_f32 > $O/prof_4k_f32.log 2>&1; python3 tools/summarize_prof.py gpurun_out/prof_${TAG}_4k_f32 | grep -v "at::native\|rocclr" > $O/rocprofv3_summary_4k_f32.txt
 tools/prof.sh ${TAG}_4k_f16 --storage f16 > $O/prof_4k_f16.log 2>&1; python3 tools/summarize_prof.py gpurun_out/prof_${TAG}_4k_f16 | grep -v "at::native\|rocclr" > $O/rocprofv3_summary_4k_f16.txt
 tools/prof.sh ${TAG}_1080p --workload 1080p > $O/prof_1080p.log 2>&1; python3 tools/summarize_prof.py gpurun_out/prof_${TAG}_1080p | grep -v "at::native\|rocclr" > $O/rocprofv3_summary_1080p_f32.txt

@@ -67,6 +67,7 @@ if args.driver == "native":
     # the C++ strip driver (svgf_strips_frame): loop-back communicator, every peer is this rank
     comm = strips.rccl_comm(1, 0, 0)
     drv = strips.NativeStrips(W, H, args.world, params, [args.rank], [0], streams=[side.cuda_stream], comms=[comm], plan=geo.plan, motion_reach=4, loopback=True)
+    drv.set_prev_guide(True)          # the previous G-buffer below IS last frame's current one, untouched
     frame = lambda k: drv.frame([rads[k % len(rads)]], [gbs[k & 1]], [gbs[(k & 1) ^ 1]])      # noqa: E731
 else:
     stages = strips.HipStages(geo, params, dev)
