@@ -454,7 +454,11 @@ def main():
     if world > 1 or args.strips:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:           # single process (--strips): any free port
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         # SVGF_BENCH_SHARE_DEVICES=1 (testing the N > 1 flow on a box with fewer GPUs): RCCL refuses two ranks on one device, so the

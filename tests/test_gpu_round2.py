@@ -424,7 +424,8 @@ def test_bench_refuses_a_silent_change_of_driver():
     import subprocess
     import sys
     env = dict(os.environ, SVGF_BENCH_SHARE_DEVICES="1")
-    env.pop("WORLD_SIZE", None)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "1080p", "--no-extra", "--no-one-gpu"],
                        env=env, capture_output=True, text=True, timeout=500)
     assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -436,7 +437,8 @@ def test_bench_strips_line_on_one_gpu(G):
     import subprocess
     import sys
     env = dict(os.environ)
-    env.pop("WORLD_SIZE", None)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):      # an in-process group of this pytest run may own that port
+        env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--strips", "--steps", "3", "--warmup", "1", "--workload", "4k"],
                        env=env, capture_output=True, text=True, timeout=500)
     assert p.returncode == 0, p.stderr[-2000:]

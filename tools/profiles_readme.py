@@ -77,7 +77,8 @@ def main(tag):
     traced = load(f"{tag}_bench_under_rocprofv3_4k_f32.json")
     if lds:
         avg = sum(v[1] for v in lds.values()) / len(lds)
-        per = ", ".join(f"S={re.search(r'S=(\\d+)', k).group(1)}: {v[1] / 1e3:.1f}" for k, v in sorted(lds.items(), key=lambda kv: int(re.search(r"S=(\d+)", kv[0]).group(1))))
+        step_of = lambda name: int(re.search(r"S=(\d+)", name).group(1))      # noqa: E731
+        per = ", ".join("S=%d: %.1f" % (step_of(k), v[1] / 1e3) for k, v in sorted(lds.items(), key=lambda kv: step_of(kv[0])))
         alg = 491028480
         notes.append(f"* `{tag}_rocprofv3_summary_4k_f32.txt` / `{tag}_kernel_stats_4k_f32.csv` (one trace run): `atrous_lds_kernel` averages {per} us, "
                      f"mean **{avg / 1e3:.1f} us** over the five launches of a frame; on the contract's {alg / 1e6:.1f} MB of algorithmic bytes per launch that is "

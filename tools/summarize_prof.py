@@ -2,14 +2,14 @@
 import csv, glob, os, sys, collections
 
 def short(name):
-    for k in ("temporal_kernel", "moments_young_kernel", "moments_lds_kernel", "moments_kernel", "atrous_lds_kernel", "atrous_direct_kernel"):
+    """'void svgf::(anonymous namespace)::atrous_lds_kernel<0, 4>(svgf::Geo, ...)' or its mangled form -> 'atrous_lds_kernel<ST=0,S=4>'."""
+    import re
+    for k in ("temporal_kernel", "moments_young_kernel", "moments_lds_kernel", "moments_kernel", "atrous_lds_kernel", "atrous_fused12_kernel", "atrous_direct_kernel"):
         if k in name:
-            import re
-            m = re.search(r"ILi(\d+)ELi(\d+)E", name)
-            m1 = re.search(r"ILi(\d+)E", name)
-            if k == "atrous_lds_kernel" and m:
+            m = re.search(k + r"<(\d+)(?:, (\d+))?", name) or re.search(k + r"ILi(\d+)E(?:Li(\d+)E)?", name)
+            if m and k == "atrous_lds_kernel" and m.group(2) is not None:
                 return f"{k}<ST={m.group(1)},S={m.group(2)}>"
-            return f"{k}<ST={m1.group(1)}>" if m1 else k
+            return f"{k}<ST={m.group(1)}>" if m else k
     return name[:60]
 
 def main(d):
