@@ -97,6 +97,7 @@ __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArg
     }
     if (t < 2 * (kFRA + kFRB)) flagA[t] = 0u;
     const float phi_n = a.phi_normal;              // != 0 (launcher)
+    const float inv_phi_c = hw_rcp(a.phi_colour) * kLog2e;     // log2(e) / PhiColour
 
     if (!second) {
         // ------------------------------------------------------------------ waves 0-3: staging + iteration 0 (step 1)
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArg
 #pragma unroll
                 for (int r = 0; r < 5; r++) { int sl = slotA + rg + r; sl = sl >= kFRA ? sl - kFRA : sl; rowbase[r] = sl * kFWA + col; }
                 const int ci = rowbase[2] + 2;
-                const TapCentre c = centre_setup<1>(aA[ci], aL[ci], aN[ci], dq0, a.phi_colour);
+                const TapCentre c = centre_setup<1>(aA[ci], aL[ci], aN[ci], dq0, inv_phi_c);
                 sky = c.lz.y == kSkyZ;
                 const bool wave_has_surface = !(SVGF_FUSED_DIAG & 1) && __ballot(!sky) != 0ull;
                 const bool uniform = !a.no_fastpath && __ballot(lane < 2 * kFRA && flagA[lane < 2 * kFRA ? lane : 0] != 0u) == 0ull;
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArg
 #pragma unroll
                 for (int r = 0; r < 5; r++) { int sl = slotB + rg + 2 * r; sl = sl >= kFRB ? sl - kFRB : sl; rowbase[r] = sl * kFT0 + col; }
                 const int ci = rowbase[2] + kFReach1;
-                const TapCentre c = centre_setup<2>(bA[ci], bL[ci], bN[ci], bD[ci], a.phi_colour);
+                const TapCentre c = centre_setup<2>(bA[ci], bL[ci], bN[ci], bD[ci], inv_phi_c);
                 const bool wave_has_surface = !(SVGF_FUSED_DIAG & 2) && __ballot(c.lz.y != kSkyZ) != 0ull;
                 const bool uniform = !a.no_fastpath && __ballot(lane < 2 * kFRB && flagB[lane < 2 * kFRB ? lane : 0] != 0u) == 0ull;
                 o = filter_px<2, TD>(bA, bL, bN, rowbase, c, phi_n, wave_has_surface, uniform);

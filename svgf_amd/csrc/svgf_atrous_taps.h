@@ -21,15 +21,14 @@ struct TapCentre {
     float il;            // log2(e) / phi_l
     float iz[5];         // log2(e) / (phi_z * |offset|) per offset length class
 };
-// A, L, N: the centre's LDS records; ddepth: its depth derivative as stored; S: the iteration's step.
+// A, L, N: the centre's LDS records; ddepth: its depth derivative as stored; S: the iteration's step; k_colour = log2(e) / PhiColour.
 template <int S>
-__device__ __forceinline__ TapCentre centre_setup(f32x4 A, f32x2 L, f32x2 N, float ddepth, float phi_colour) {
+__device__ __forceinline__ TapCentre centre_setup(f32x4 A, f32x2 L, f32x2 N, float ddepth, float k_colour) {
     TapCentre c;
     c.A = A; c.lz = L; c.n01 = __float_as_uint(N.x); c.nz = N.y;
     const float cdz = L.y == kSkyZ ? 0.0f : ddepth;                                      // GetDepth: sky -> ddepth 0
-    const float phi_l = phi_colour * sqrtf(fmaxf(0.0f, 1e-10f + A.w));                   // :562
-    c.il = fminf(hw_rcp(phi_l), 1e30f) * kLog2e;
-    const float izb = hw_rcp(fmaxf(cdz, 1e-6f) * (float)S) * kLog2e;                     // :563
+    c.il = inv_phi_l_log2e(A.w, k_colour);                                               // :562
+    const float izb = hw_rcp(fmaxf(cdz, 1e-6f) * ((float)S * 0.6931471805599453f));      // :563: log2(e) / (max(ddepth, 1e-6) * S)
     c.iz[0] = izb; c.iz[1] = izb * 0.70710678118654752f; c.iz[2] = izb * 0.5f;
     c.iz[3] = izb * 0.44721359549995794f; c.iz[4] = izb * 0.35355339059327376f;
     return c;

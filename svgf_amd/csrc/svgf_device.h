@@ -74,6 +74,12 @@ __device__ __forceinline__ float mix_exact(float x, float y, float a) { return x
 __device__ __forceinline__ float hw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float hw_log2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float hw_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+// log2(e) / phi_l of the a-trous filter, phi_l = PhiColour * sqrt(max(0, 1e-10 + variance)) (Filter.cuh:562), as ONE v_rsq_f32 times the launch's
+// log2(e) / PhiColour (`k`); capped like the reciprocal of a zero phi_l (PhiColour = 0: the luminance term is -inf, or NaN -> fmax(.., 0) in :424).
+// The variance is a clamped texel (imageLoad: in [0,1]), so the max(0, .) of :562 is the identity.  (sqrtf() compiles to a 17-instruction
+// correctly rounded sequence whose result only ever fed an approximate reciprocal: -2.5 % per launch, profiles/r03_small_experiments.txt.)
+__device__ __forceinline__ float inv_phi_l_log2e(float variance01, float k) { return fminf(hw_rsq(1e-10f + variance01) * k, 1.4426950e30f); }
 
 // Edge-stopping weight, computeWeight Filter.cuh:407-427:
 //   w = exp(-max(|dl|/phi_l,0) - max(|dz|/phi_z,0)) * pow(saturate(n.n'), phi_n)
@@ -148,6 +154,13 @@ __device__ __forceinline__ void raw_load(RawPx<ST, DZ>& r, const PlaneRsrc& rs, 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ float med01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }   // = min(max(v,0),1) for non-NaN v
+// the same for two values with ONE instruction: x * 1.0 with the result clamp of a packed multiply (hipcc emits one v_max .. clamp per value)
+__device__ __forceinline__ f32x2 clamp01_pk(f32x2 v) {
+    f32x2 r;
+    const f32x2 one = {1.0f, 1.0f};
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(v), "s"(one));
+    return r;
+}
 
 // Convert a staged pixel into its LDS records; -> "a surface texel whose normal differs from the reference normal (ref01, refz)".
 template <int ST, bool DZ>
@@ -155,7 +168,8 @@ __device__ __forceinline__ bool commit_px(const RawPx<ST, DZ>& r, f32x4* recA, f
     float4 c;
     if constexpr (ST == 0) c = make_float4(__uint_as_float(r.c.x), __uint_as_float(r.c.y), __uint_as_float(r.c.z), __uint_as_float(r.c.w));
     else { float2 lo = unpack_h2(r.c.x), hi = unpack_h2(r.c.y); c = make_float4(lo.x, lo.y, hi.x, hi.y); }
-    c = make_float4(med01(c.x), med01(c.y), med01(c.z), med01(c.w));    // imageLoad, :586
+    const f32x2 c01 = clamp01_pk((f32x2){c.x, c.y}), c23 = clamp01_pk((f32x2){c.z, c.w});    // imageLoad, :586
+    c = make_float4(c01.x, c01.y, c23.x, c23.y);
     float z;
     if constexpr (DZ) z = __uint_as_float(r.zd.x); else z = __uint_as_float(r.zd);
     if (z == 0.0f) z = kSkyZ;                                           // GetDepth, :199-207

@@ -480,7 +480,7 @@ __global__ __launch_bounds__(kBX* kBY) void atrous_direct_kernel(Geo g, AtrousAr
     if (zc == kSkyZ) { Store<ST>::st4(a.out, idx, c); return; }       // :554-558
     const float3 nc = normal_of(a.normal[idx]);
     const float lc = lum_exact(c.x, c.y, c.z);
-    const float il = hw_rcp(a.phi_colour * sqrtf(fmaxf(0.0f, 1e-10f + c.w)));   // :562
+    const float il = inv_phi_l_log2e(c.w, hw_rcp(a.phi_colour) * kLog2e) * 0.6931471805599453f;   // :562 (the LDS kernels' expression, back in natural units)
     const float phi_d = fmaxf(dzc, 1e-6f) * (float)a.step;            // :563
     float sw = 1.0f, sr = c.x, sg = c.y, sb = c.z, sv = c.w;          // :567-568
     const float K[3] = {1.0f, (float)(2.0 / 3.0), (float)(1.0 / 6.0)};           // :540
