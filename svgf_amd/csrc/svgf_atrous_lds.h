@@ -123,6 +123,7 @@ __global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(
     __syncthreads();
 
     const float phi_n = a.phi_normal;              // != 0 (launcher)
+    const float inv_phi_c = hw_rcp(a.phi_colour) * kLog2e;  // log2(e) / PhiColour (wave-uniform)
     // the uniform-normal path's exponent bases, once per workgroup: wave-uniform values (scalar registers)
     UniBase ref_base = uni_base(ref01, unpack_h2(refz).x, phi_n);
 #pragma unroll
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(
 #pragma unroll
         for (int r = 0; r < 5; r++) { int sl = slot0 + rg + r; sl = sl >= kRing ? sl - kRing : sl; rowbase[r] = sl * WL + col; }   // scalar + lane constant
         const int ci = rowbase[2] + 2 * S;
-        const TapCentre c = centre_setup<S>(recA[ci], recL[ci], recN[ci], dq0, a.phi_colour);
+        const TapCentre c = centre_setup<S>(recA[ci], recL[ci], recN[ci], dq0, inv_phi_c);
         const bool sky = c.lz.y == kSkyZ;
         const bool wave_has_surface = __ballot(!sky) != 0ull;
         const bool uniform = !a.no_fastpath && __ballot(lane < kRing * 8 && nflag[lane < kRing * 8 ? lane : 0] != 0u) == 0ull;
