@@ -5,9 +5,7 @@ TAG=${1:-r03}
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/$TAG
 RN=$(echo $TAG | sed 's/^r0*//')
-python3 tools/make_traffic.py gpurun_out/prof_${TAG}_4k_f32 3840x2160_f32 $RN > /dev/null
-python3 tools/make_traffic.py gpurun_out/prof_${TAG}_4k_f16 3840x2160_f16 $RN > /dev/null
-python3 tools/make_traffic.py gpurun_out/prof_${TAG}_1080p 1920x1080_f32 $RN > /dev/null
+cp $O/hbm_traffic.json profiles/hbm_traffic.json          # made on the box from that call's PMC passes (tools/final_round.sh), before its bench lines
 for t in 4k_f32 4k_f16 1080p_f32; do cp $O/rocprofv3_summary_$t.txt profiles/${TAG}_rocprofv3_summary_$t.txt; done
 # the raw per-kernel stats of THE SAME trace run the 4K fp32 summary was condensed from
 cp "$(ls gpurun_out/prof_${TAG}_4k_f32/trace/*/*kernel_stats.csv | head -1)" profiles/${TAG}_kernel_stats_4k_f32.csv
