@@ -163,8 +163,8 @@ __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArg
                 for (int r = 0; r < 5; r++) { int sl = slotA + rg + r; sl = sl >= kFRA ? sl - kFRA : sl; rowbase[r] = sl * kFWA + col; }
                 const int ci = rowbase[2] + 2;
                 const TapCentre c = centre_setup<1>(aA[ci], aL[ci], aN[ci], dq0, inv_phi_c);
-                sky = c.lz.y == kSkyZ;
-                const bool wave_has_surface = !(SVGF_FUSED_DIAG & 1) && __ballot(!sky) != 0ull;
+                sky = c.sky;
+                const bool wave_has_surface = !(SVGF_FUSED_DIAG & 1) && wave_any(!sky);
                 const bool uniform = !a.no_fastpath && __ballot(lane < 2 * kFRA && flagA[lane < 2 * kFRA ? lane : 0] != 0u) == 0ull;
                 o = filter_px<1, TD>(aA, aL, aN, rowbase, c, phi_n, wave_has_surface, uniform);
                 // ring B record: the texel iteration 1 would load from the plane iteration 0 stores (:618 unclamped, in the storage type;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArg
                 q = make_float4(med01(q.x), med01(q.y), med01(q.z), med01(q.w));
                 const int bi = slotB * kFT0 + col;
                 bA[bi] = (f32x4){q.x, q.y, q.z, q.w};
-                bL[bi] = (f32x2){lum_exact(q.x, q.y, q.z), c.lz.y};
+                bL[bi] = (f32x2){lum_exact(q.x, q.y, q.z), sky ? kSkyZ : c.lz.y};
                 bN[bi] = (f32x2){__uint_as_float(c.n01), c.nz};
                 bD[bi] = dq0;
                 const bool differs = !sky && (c.n01 != ref01 || __float_as_uint(c.nz) != refz_f);
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArg
                 for (int r = 0; r < 5; r++) { int sl = slotB + rg + 2 * r; sl = sl >= kFRB ? sl - kFRB : sl; rowbase[r] = sl * kFT0 + col; }
                 const int ci = rowbase[2] + kFReach1;
                 const TapCentre c = centre_setup<2>(bA[ci], bL[ci], bN[ci], bD[ci], inv_phi_c);
-                const bool wave_has_surface = !(SVGF_FUSED_DIAG & 2) && __ballot(c.lz.y != kSkyZ) != 0ull;
+                const bool wave_has_surface = !(SVGF_FUSED_DIAG & 2) && wave_any(!c.sky);
                 const bool uniform = !a.no_fastpath && __ballot(lane < 2 * kFRB && flagB[lane < 2 * kFRB ? lane : 0] != 0u) == 0ull;
                 o = filter_px<2, TD>(bA, bL, bN, rowbase, c, phi_n, wave_has_surface, uniform);
             }

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(
         int so = sl + rg; so = so >= kRing ? so - kRing : so;                           // scalar
         bool differs = commit_px<ST, true>(st.o, recA, recL, recN, so * WL + oli, ref01, refz);
         if (halo_wave) { if (has_halo) differs = commit_px<ST, false>(st.h, recA, recL, recN, so * WL + hli, ref01, refz) || differs; }
-        const bool wave_differs = __ballot(differs) != 0ull;
+        const bool wave_differs = wave_any(differs);
         if (lane == 0) nflag[so * 8 + wig] = wave_differs ? 1u : 0u;                    // a ring slot is always staged by the same waves
     };
 
@@ -140,9 +140,9 @@ __global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(
         for (int r = 0; r < 5; r++) { int sl = slot0 + rg + r; sl = sl >= kRing ? sl - kRing : sl; rowbase[r] = sl * WL + col; }   // scalar + lane constant
         const int ci = rowbase[2] + 2 * S;
         const TapCentre c = centre_setup<S>(recA[ci], recL[ci], recN[ci], dq0, inv_phi_c);
-        const bool sky = c.lz.y == kSkyZ;
-        const bool wave_has_surface = __ballot(!sky) != 0ull;
-        const bool uniform = !a.no_fastpath && __ballot(lane < kRing * 8 && nflag[lane < kRing * 8 ? lane : 0] != 0u) == 0ull;
+        const bool sky = c.sky;
+        const bool wave_has_surface = wave_any(!sky);
+        const bool uniform = !a.no_fastpath && !wave_any(lane < kRing * 8 && nflag[lane < kRing * 8 ? lane : 0] != 0u);
         const float4 o = filter_px<S, kTapDepth>(recA, recL, recN, rowbase, c, phi_n, wave_has_surface, uniform, &ref_base);
 
         // Output values now, their stores AFTER the ring refill: hipcc's vmcnt bookkeeping cannot tell that the rows committed

@@ -15,31 +15,30 @@ namespace {
 // What a thread keeps of its centre pixel (the set-up of :543-568).
 struct TapCentre {
     f32x4 A;             // clamped colour + variance
-    f32x2 lz;            // luminance, depth (sky -> 1e30)
+    f32x2 lz;            // luminance, depth; the depth of a SKY centre (sentinel 1e30) is replaced by -1e30, see centre_setup
     uint32_t n01;        // (nx, ny) half bits
     float nz;
     float il;            // log2(e) / phi_l
     float iz[5];         // log2(e) / (phi_z * |offset|) per offset length class
+    bool sky;            // GetDepth() == sentinel: the pixel is copied (:554-558)
 };
 // A, L, N: the centre's LDS records; ddepth: its depth derivative as stored; S: the iteration's step; k_colour = log2(e) / PhiColour.
+// A sky centre is copied, not filtered (:554-558).  Instead of selecting between the filtered value and the copy afterwards (four
+// v_cndmask), its depth enters the taps as -1e30: every tap — surface or sky (+1e30) — is then at least 1e30 away in depth, its
+// weight exp2(-1e30 * iz) is exactly 0, the sums stay {1, colour} and the normalisation multiplies by rcp(1) = 1: the copy, bit for bit.
 template <int S>
 __device__ __forceinline__ TapCentre centre_setup(f32x4 A, f32x2 L, f32x2 N, float ddepth, float k_colour) {
     TapCentre c;
-    c.A = A; c.lz = L; c.n01 = __float_as_uint(N.x); c.nz = N.y;
-    const float cdz = L.y == kSkyZ ? 0.0f : ddepth;                                      // GetDepth: sky -> ddepth 0
+    c.sky = L.y == kSkyZ;
+    c.A = A; c.lz = (f32x2){L.x, c.sky ? -kSkyZ : L.y}; c.n01 = __float_as_uint(N.x); c.nz = N.y;
     c.il = inv_phi_l_log2e(A.w, k_colour);                                               // :562
-    const float izb = hw_rcp(fmaxf(cdz, 1e-6f) * ((float)S * 0.6931471805599453f));      // :563: log2(e) / (max(ddepth, 1e-6) * S)
-    c.iz[0] = izb; c.iz[1] = izb * 0.70710678118654752f; c.iz[2] = izb * 0.5f;
-    c.iz[3] = izb * 0.44721359549995794f; c.iz[4] = izb * 0.35355339059327376f;
+    // :563: log2(e) / (max(ddepth, 1e-6) * S); (GetDepth gives a sky texel ddepth 0: irrelevant now, any positive value kills its taps)
+    const float izb = hw_rcp(fmaxf(ddepth, 1e-6f) * ((float)S * 0.6931471805599453f));
+    const f32x2 i12 = (f32x2){izb, izb} * (f32x2){0.70710678118654752f, 0.5f}, i34 = (f32x2){izb, izb} * (f32x2){0.44721359549995794f, 0.35355339059327376f};
+    c.iz[0] = izb; c.iz[1] = i12.x; c.iz[2] = i12.y; c.iz[3] = i34.x; c.iz[4] = i34.y;
     return c;
 }
 
-// The 24 taps as ONE rolling software pipeline: the LDS reads of tap t+D are issued before tap t is consumed, across row
-// boundaries; only D+1 taps' records are live.  rowbase[r] = LDS index of the thread's leftmost tap in ring row r (r = 0..4: rows
-// -2S..+2S); the taps of a row are CS records apart.  UNI: every surface texel the taps can touch carries the centre's normal
-// bits, so n.n' is the centre's own |n|^2 — the same expression the general path evaluates per tap, bit for bit — and the
-// normal records are not read at all.  The empty asm statements pin the order: left alone, instruction selection sinks all
-// arithmetic below all LDS reads of the unrolled loop (256 VGPRs + scratch spills).
 // UNI: the exponent of the normal term + kernel weight per kernel-weight class, from a normal's own |n|^2
 struct UniBase { float e[5]; };
 __device__ __forceinline__ UniBase uni_base(uint32_t n01, float nz, float phi_n) {
@@ -110,8 +109,7 @@ __device__ __forceinline__ float4 filter_px(const f32x4* recA, const f32x2* recL
         if (uniform) taps24<CS, D, true>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv, shared_base);
         else taps24<CS, D, false>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv, nullptr);
     }
-    if (c.lz.y == kSkyZ) return make_float4(c.A.x, c.A.y, c.A.z, c.A.w);                 // :554-558
-    const float inv = hw_rcp(sw);                                                        // sw >= 1
+    const float inv = hw_rcp(sw);                                                        // sw >= 1 (a sky centre: exactly 1, and the sums are its colour)
     return make_float4(srg.x * inv, srg.y * inv, sbv.x * inv, sbv.y * (inv * inv));      // :615
 }
 

@@ -150,6 +150,10 @@ __device__ __forceinline__ void raw_load(RawPx<ST, DZ>& r, const PlaneRsrc& rs, 
     r.n = __builtin_amdgcn_raw_buffer_load_b64(rs.normal, voff_n, srow << n_shift, 0);
 }
 
+// "does any lane of the wave hold `pred`": HIP's __ballot() compares a materialised 0/1 (v_cndmask + v_cmp per call); the builtin folds
+// into the compare that produced the predicate.
+__device__ __forceinline__ bool wave_any(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0ull; }
+
 // Raw barrier: __syncthreads() would also wait for vmcnt(0), i.e. for the rows a step has just requested.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
