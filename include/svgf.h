@@ -31,7 +31,9 @@
  *  - Sky.  A texel whose GetDepth() is the sentinel (depth 0, Filter.cuh:199-207 — a depth of literally 1e30f reads the
  *    same) is "sky": the wavelet filter copies it and skips its feedback store.  The kernels rely on a sky TAP having
  *    weight exactly 0, which holds while ddepth * step < ~1e22 (|1e30 - z| / phi_z overflows the exponent of exp to -inf
- *    or beyond -150): any real depth derivative.
+ *    or beyond -150): any real depth derivative.  The LDS kernels also copy a sky CENTRE through the taps (its depth enters
+ *    them as -1e30, so that every one of its weights is exactly 0 and the normalisation multiplies its own colour by rcp(1)):
+ *    the same bound, on the sky texel's own ddepth.
  *  - Strips: a context may hold only rows [y0, y0+rows) of a WxH frame (multi-GPU row strips);
  *    "inside the frame" tests always use the global frame, so strip results are bit-identical
  *    to the whole-frame result as long as the halo rows hold valid data.
