@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--strips", action="store_true", help="run the strip driver even at N=1 (exercises the N>1 code path)")
     ap.add_argument("--no-one-gpu", action="store_true", help="N > 1: skip the whole frame on rank 0's GPU alone (one_gpu_ms / speedup_vs_one_gpu)")
     ap.add_argument("--fuse", action="store_true", help="iterations 0 and 1 as one launch (svgf_atrous_pair): bit-identical, measured slower (DESIGN.md 3.3c)")
+    ap.add_argument("--frames-in-flight", type=int, choices=[1, 2], default=1,
+                    help="2: svgf_set_frames_in_flight(2) - iterations 1.. of a frame on a side stream beside the next frame's temporal launch (bit-identical results; "
+                         "a frame's result is ordered on the stream one call later)")
     ap.add_argument("--windows", type=int, default=5, help="the --steps-frame timed window is repeated this many times; ms_per_step is the median window")
     return ap.parse_args()
 
@@ -181,13 +184,14 @@ class FramePool:
 
 
 # ------------------------------------------------------------------ single GPU -----------------
-def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, device, cold_frames=0, fuse=False, windows=5):
+def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, device, cold_frames=0, fuse=False, windows=5, in_flight=1):
     """-> dict(ms_per_step = median over `windows` timed windows of `steps` frames each (sync, K frames, sync), windows_ms, stage_ms[list],
     ms_no_events: one more window without the per-stage HIP events, ...)."""
     import torch
     from svgf_amd import filter as F
     d = F.Denoiser(W, H, F.Params(storage=storage, steps=iters, variant=variant), device=device.index or 0)
     d.set_iteration_fusion(fuse)
+    d.set_frames_in_flight(in_flight)
     d.set_prev_guide(True)     # the pools hand over last frame's current G-buffer, untouched, as `prev` (tests/test_bench_inputs.py): the precondition of svgf_set_prev_guide
     n = 0
     for _ in range(PRIME_FRAMES + warmup):
@@ -209,7 +213,9 @@ def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, de
     d.timing_enable(False)
     no_events = window()       # the same window without any stage event: what the events cost the timed frames
     out = d.Render(*pool.frame(n))
+    d.flush()                  # (two frames in flight: the result is ordered on the stream by the next call, or by this)
     assert bool(torch.isfinite(out.float()).all()), "non-finite output"
+    d.set_frames_in_flight(1)
     hist = d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong())
     young = float((hist < 4).float().mean().item())
     cold = []
@@ -226,7 +232,8 @@ def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, de
     d.close()
     srt = sorted(win)
     return dict(ms_per_step=srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2]), windows_ms=win, ms_no_events=no_events,
-                stage_ms=[m / max(frames, 1) for m in stage_ms], frames=frames, cold_ms=cold, young_fraction=young, fused=bool(fuse and iters >= 2 and variant != "direct"))
+                stage_ms=[m / max(frames, 1) for m in stage_ms], frames=frames, cold_ms=cold, young_fraction=young, fused=bool(fuse and iters >= 2 and variant != "direct"),
+                in_flight=in_flight)
 
 
 def timing_fields(r):
@@ -479,7 +486,7 @@ def main():
         fuse = bool(args.fuse)
         for m in motions:
             res[m] = run_single(FramePool(scene, storage, m), W, H, storage, iters, args.variant, args.steps, args.warmup, device,
-                                cold_frames=5 if (m == "static" and not args.no_extra) else 0, fuse=fuse, windows=args.windows)
+                                cold_frames=5 if (m == "static" and not args.no_extra) else 0, fuse=fuse, windows=args.windows, in_flight=args.frames_in_flight)
         head = motions[0]
         r = res[head]
         ms = r["ms_per_step"]
@@ -494,7 +501,7 @@ def main():
                                    f"steady state (history >= 4), {'static camera' if head == 'static' else 'camera pan ' + str(PAN_MV)}, current and previous "
                                    f"G-buffer in distinct planes (ping-ponged), 1-spp noise, seed 0x5356474600000001",
                        "width": W, "height": H, "storage": storage, "atrous_iterations": iters, "variant": args.variant, "motion": head,
-                       "iterations_0_and_1_in_one_launch": r["fused"],
+                       "iterations_0_and_1_in_one_launch": r["fused"], "frames_in_flight": r["in_flight"],
                        "prev_guide": "on (svgf_set_prev_guide: the previous G-buffer's planes are last frame's current ones, not rewritten in between - as in the reference, App.cu:374)"},
             **timing_fields(r),
             "roofline": roof,
@@ -551,6 +558,18 @@ def main():
                                                            "frac_of_8TBps": pass_block(W, H, storage, iters, r4["ms_per_step"])["frac_of_8TBps"],
                                                            "atrous_avg_launch_ms": roof4["avg_launch_ms"] if roof4 else None,
                                                            "atrous_roofline_frac": roof4["frac"] if roof4 else None}
+        if not args.no_extra and args.frames_in_flight == 1 and wl == "4k":
+            # throughput mode: iterations 1.. of frame f on a side stream beside the temporal launch of frame f + 1 (same results)
+            r5 = run_single(FramePool(scene, storage, "static"), W, H, storage, iters, args.variant, args.steps, args.warmup, device, fuse=fuse, windows=args.windows, in_flight=2)
+            roof5, st5 = roofline_block(W, H, storage, iters, r5["stage_ms"], args.variant, r5["fused"])
+            line.setdefault("also", {})["two_frames_in_flight"] = {
+                "ms_per_step": round(r5["ms_per_step"], 4), "ms_per_step_min": round(min(r5["windows_ms"]), 4), "ms_per_step_max": round(max(r5["windows_ms"]), 4),
+                "Mpixels/s": round(W * H / (r5["ms_per_step"] * 1e-3) / 1e6, 1), **{k: v for k, v in pass_block(W, H, storage, iters, r5["ms_per_step"], r5["fused"]).items()
+                                                                                  if k in ("frac_of_8TBps", "moved_frac_of_8TBps")},
+                "atrous_avg_launch_ms": roof5["avg_launch_ms"] if roof5 else None, "atrous_roofline_frac": roof5["frac"] if roof5 else None,
+                "temporal_ms": st5["temporal+moments"]["temporal_ms"] if st5 else None,
+                "note": "svgf_set_frames_in_flight(2): launch durations here overlap (a-trous launches of frame f beside the temporal launch of frame f + 1), "
+                        "so they are longer than in the headline run while the frame is shorter"}
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(storage, iters)
         if world > 1 or args.strips:

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define SVGF_ABI_VERSION 3
+#define SVGF_ABI_VERSION 4
 
 enum svgf_status {
     SVGF_OK = 0,
@@ -222,6 +222,22 @@ int svgf_modulate(svgf_ctx* ctx, const void* filtered, const void* albedo, void*
 int svgf_denoise_frame(svgf_ctx* ctx, const void* radiance, const svgf_gbuffer* cur,
                        const svgf_gbuffer* prev, const void** result);
 int svgf_reset_history(svgf_ctx* ctx);                                 /* zero all state planes (ResetRender) */
+/* Two frames in flight — a throughput mode the reference has no counterpart of (application::Render runs one frame at a time on
+ * the default stream, App.cu:545-556).  A frame's temporal launch is HBM-bound and its wavelet iterations are bound by their tap
+ * arithmetic; from iteration 0 on nothing a frame still does is read by the next frame's temporal launch (iteration 0 feeds the
+ * history back, App.cu:504-505).  With svgf_set_frames_in_flight(ctx, 2), svgf_denoise_frame enqueues the temporal, moments and
+ * iteration-0 launches on the context's stream and iterations 1.. on a stream of its own, where they run beside the NEXT frame's
+ * temporal launch (-8 % per 4K fp32 frame; results bit-identical).  What changes for the caller:
+ *   - *result of call f is returned at once but is ORDERED on the context's stream only by the next svgf_denoise_frame, svgf_flush
+ *     or svgf_sync (enqueue the consumer of frame f after one of those); it stays valid until the call after the next one (frames
+ *     alternate between two pairs of filter planes: +2 colour planes of memory);
+ *   - the planes of `cur` given to call f must stay as they are until call f + 1 has been made when the iterations read them
+ *     (variant DIRECT, or steps == 0: without the guide plane) — with the reference's two framebuffers they do;
+ *   - the debug views (svgf_set_debug_mode) and strip-driver contexts do not combine with it (refused).
+ * frames = 1 (default) restores stream order at once.  svgf_flush orders the frame in flight on the context's stream without
+ * waiting for it. */
+int svgf_set_frames_in_flight(svgf_ctx* ctx, int frames);
+int svgf_flush(svgf_ctx* ctx);
 /* The sequences application::Render runs in its debug views (SVGFDebugOutput, App.cu:545-649) on the same state:
  *   SVGF_DEBUG_FINAL     TemporalFilter, FilterMoments, WaveletFilter (App.cu:552-556)                  — the default
  *   SVGF_DEBUG_TEMPORAL  TemporalFilter only; *result = the temporally accumulated colour (App.cu:602-609)

@@ -124,13 +124,31 @@ int alloc_state(svgf_ctx* c) {
     return reset_history(c);
 }
 
+// frames_in_flight == 2: the second pair of filter planes (zeroed like the first, so that both pairs read the same after a reset)
+int alloc_alt(svgf_ctx* c) {
+    if (c->frames_in_flight < 2 || (c->filter_alt[0] && c->filter_alt[1])) return SVGF_OK;
+    for (int i = 0; i < 2; i++) {
+        if (!c->filter_alt[i]) SVGF_HIP(c, hipMalloc(&c->filter_alt[i], colour_bytes(c)));
+        SVGF_HIP(c, hipMemsetAsync(c->filter_alt[i], 0, colour_bytes(c), c->stream));
+    }
+    return SVGF_OK;
+}
+
+int join_side(svgf_ctx* c, hipStream_t onto) {
+    if (!c->in_flight) return SVGF_OK;
+    SVGF_HIP(c, hipStreamWaitEvent(onto, c->ev_done, 0));
+    c->in_flight = false;
+    return SVGF_OK;
+}
+
 void free_state(svgf_ctx* c) {
     for (int i = 0; i < 2; i++) {
         if (c->colour[i]) (void)hipFree(c->colour[i]);
         if (c->moments[i]) (void)hipFree(c->moments[i]);
         if (c->filter[i]) (void)hipFree(c->filter[i]);
         if (c->hist[i]) (void)hipFree(c->hist[i]);
-        c->colour[i] = c->moments[i] = c->filter[i] = nullptr;
+        if (c->filter_alt[i]) (void)hipFree(c->filter_alt[i]);
+        c->colour[i] = c->moments[i] = c->filter[i] = c->filter_alt[i] = nullptr;
         c->hist[i] = nullptr;
     }
     if (c->guide) (void)hipFree(c->guide);
@@ -146,10 +164,13 @@ void free_state(svgf_ctx* c) {
 
 int reset_history(svgf_ctx* c) {
     if (!c->have_state) return SVGF_OK;
+    int rc = join_side(c, c->stream);             // the frame in flight still writes filter planes
+    if (rc != SVGF_OK) return rc;
     for (int i = 0; i < 2; i++) {
         SVGF_HIP(c, hipMemsetAsync(c->colour[i], 0, colour_bytes(c), c->stream));
         SVGF_HIP(c, hipMemsetAsync(c->moments[i], 0, moments_bytes(c), c->stream));
         SVGF_HIP(c, hipMemsetAsync(c->filter[i], 0, colour_bytes(c), c->stream));
+        if (c->filter_alt[i]) SVGF_HIP(c, hipMemsetAsync(c->filter_alt[i], 0, colour_bytes(c), c->stream));
         SVGF_HIP(c, hipMemsetAsync(c->hist[i], 0, hist_bytes(c), c->stream));
     }
     c->pingpong = 0;
@@ -355,10 +376,20 @@ int svgf_create(svgf_ctx** out, int width, int height, const svgf_params* params
     return svgf_create_strip(out, width, height, &s, params, device, hip_stream);
 }
 
+// the side stream and its events (frames_in_flight back to 1, destruction); waits for what is on it
+static void drop_side(svgf_ctx* c) {
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); c->side = nullptr; }
+    if (c->ev_first) { (void)hipEventDestroy(c->ev_first); c->ev_first = nullptr; }
+    if (c->ev_done) { (void)hipEventDestroy(c->ev_done); c->ev_done = nullptr; }
+
+    c->in_flight = false;
+}
+
 void svgf_destroy(svgf_ctx* c) {
     if (!c || c->strip_drv) return;            // a context handed out by svgf_strips_context belongs to its strip driver (svgf_strips_destroy)
     DeviceGuard dg(c->device);
     if (c->have_state || !c->pool.empty() || !c->pending.empty() || c->halo_violations) (void)hipStreamSynchronize(c->stream);
+    drop_side(c);
     free_state(c);
     if (c->halo_violations) (void)hipFree(c->halo_violations);
     for (auto& f : c->pending) for (auto e : f.ev) (void)hipEventDestroy(e);
@@ -375,11 +406,13 @@ int svgf_resize_strip(svgf_ctx* c, int width, int height, const svgf_strip* stri
     if (c->strip_drv) return fail(c, SVGF_ERR_INVALID, "svgf_resize: this context belongs to a strip driver: svgf_strips_destroy it and create one for the new size");
     DeviceGuard dg(c->device);
     SVGF_HIP(c, hipStreamSynchronize(c->stream));        // cudaDeviceSynchronize() in the reference (App.cu:758)
+    if (c->side) SVGF_HIP(c, hipStreamSynchronize(c->side));
+    c->in_flight = false;
     free_state(c);
     if (c->halo_violations) { (void)hipFree(c->halo_violations); c->halo_violations = nullptr; }
     c->W = width; c->H = height; c->strip = *strip; c->rb = strip->own_begin; c->re = strip->own_end;
     c->vy0 = strip->y0; c->vy1 = strip->y0 + strip->rows;
-    c->pingpong = 0; c->frames_since_reset = 0; c->result_index = 0;
+    c->pingpong = 0; c->frames_since_reset = 0; c->result_index = 0; c->filter_set = 0;
     return SVGF_OK;
 }
 
@@ -403,6 +436,11 @@ int svgf_set_params(svgf_ctx* c, const svgf_params* p) {
 
 int svgf_set_stream(svgf_ctx* c, void* s) {
     if (!c) return SVGF_ERR_INVALID;
+    if (c->in_flight) {                                   // the frame in flight is ordered on the stream the caller works on from now on
+        DeviceGuard dg(c->device);
+        int rc = join_side(c, (hipStream_t)s);
+        if (rc != SVGF_OK) return rc;
+    }
     c->stream = (hipStream_t)s;
     return SVGF_OK;
 }
@@ -427,6 +465,8 @@ int svgf_set_valid_rows(svgf_ctx* c, int rb, int re) {
 int svgf_set_debug_mode(svgf_ctx* c, int mode) {
     if (!c) return SVGF_ERR_INVALID;
     if (mode < SVGF_DEBUG_FINAL || mode > SVGF_DEBUG_ATROUS) return fail(c, SVGF_ERR_INVALID, "unknown debug mode");
+    if (mode != SVGF_DEBUG_FINAL && c->frames_in_flight > 1)
+        return fail(c, SVGF_ERR_INVALID, "svgf_set_debug_mode: the debug views filter what the previous frame left in FilterBuffer[0]; set frames in flight back to 1 first");
     c->debug_mode = mode;
     return SVGF_OK;
 }
@@ -476,6 +516,32 @@ int svgf_set_iteration_fusion(svgf_ctx* c, int enable) {
     if (!c) return SVGF_ERR_INVALID;
     c->fuse01 = enable != 0;
     return SVGF_OK;
+}
+
+int svgf_set_frames_in_flight(svgf_ctx* c, int frames) {
+    if (!c) return SVGF_ERR_INVALID;
+    if (frames != 1 && frames != 2) return fail(c, SVGF_ERR_INVALID, "svgf_set_frames_in_flight: 1 or 2");
+    if (frames == c->frames_in_flight) return SVGF_OK;
+    if (frames == 2 && c->strip_drv) return fail(c, SVGF_ERR_INVALID, "svgf_set_frames_in_flight: the strip driver schedules its contexts itself");
+    if (frames == 2 && c->debug_mode != SVGF_DEBUG_FINAL) return fail(c, SVGF_ERR_INVALID, "svgf_set_frames_in_flight: not with a debug view selected");
+    DeviceGuard dg(c->device);
+    if (frames == 2) {
+        if (!c->side) SVGF_HIP(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        if (!c->ev_first) SVGF_HIP(c, hipEventCreateWithFlags(&c->ev_first, hipEventDisableTiming));
+        if (!c->ev_done) SVGF_HIP(c, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    } else {
+        int rc = join_side(c, c->stream);
+        if (rc != SVGF_OK) return rc;
+        // the last result may sit in the second pair: it stays allocated (and valid) until the context is resized or destroyed
+    }
+    c->frames_in_flight = frames;
+    return SVGF_OK;
+}
+
+int svgf_flush(svgf_ctx* c) {
+    if (!c) return SVGF_ERR_INVALID;
+    DeviceGuard dg(c->device);
+    return join_side(c, c->stream);
 }
 
 int svgf_taa(svgf_ctx* c, const void* filtered, const void* history, void* out) {
@@ -565,12 +631,16 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     if (!prev) prev = cur;
     rc = alloc_state(c);
     if (rc == SVGF_OK) rc = alloc_flags(c);
+    if (rc == SVGF_OK) rc = alloc_alt(c);
     if (rc != SVGF_OK) return rc;
     const int P = c->pingpong;
+    // frames in flight: this frame's pair of filter planes (the previous frame's result sits in the other one until the call after this)
+    void** const F = c->frames_in_flight > 1 && c->filter_set ? c->filter_alt : c->filter;
+    if (c->frames_in_flight > 1) c->filter_set ^= 1;
 
     svgf_ctx::FrameEvents fe;
     const bool timed = c->timing > 0 && (c->timing_phase++ % c->timing) == 0;
-    auto stamp = [&]() {
+    auto stamp = [&]() {                            // on c->stream AS IT IS when called (the side stream for the tail of a frame in flight)
         if (!timed) return;
         hipEvent_t e = take_event(c);
         if (e && hipEventRecord(e, c->stream) == hipSuccess) fe.ev.push_back(e);
@@ -626,33 +696,64 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     // G-buffer (prev_guide_for): -16 B/px of the temporal launch's 146
     void* guide = use_guide(c) ? c->guide : nullptr;
     rc = temporal_impl(c, c->colour[1 - P], radiance, c->colour[P], cur, prev, c->hist[1 - P], c->hist[P],
-                       c->moments[P], c->moments[1 - P], c->filter[0], sparse, guide, prev_guide_for(c, cur, prev));  // App.cu:552
+                       c->moments[P], c->moments[1 - P], F[0], sparse, guide, prev_guide_for(c, cur, prev));  // App.cu:552
     if (rc != SVGF_OK) return bail(rc);
     stamp();
     // the first three frames after a reset have history <= 3 everywhere: the LDS-streaming moments kernel
-    rc = moments_impl(c, c->colour[P], c->filter[0], c->moments[P], cur, c->hist[P], 1, c->frames_since_reset < 3 && c->p.variant != SVGF_VARIANT_DIRECT, sparse);   // App.cu:554 (current moments: App. B #4)
+    rc = moments_impl(c, c->colour[P], F[0], c->moments[P], cur, c->hist[P], 1, c->frames_since_reset < 3 && c->p.variant != SVGF_VARIANT_DIRECT, sparse);   // App.cu:554 (current moments: App. B #4)
     if (rc != SVGF_OK) return bail(rc);
     stamp();
     int pp = 0, first = 0;
-    if (can_fuse01(c) && halo_held(c, 6)) {
-        // iterations 0 and 1 as one launch: filter[0] -> filter[1] (iteration 0's own plane is never written), feedback as ever
-        rc = atrous_pair_impl(c, c->filter[0], c->filter[1], c->colour[P], cur, guide);
-        if (rc != SVGF_OK) return bail(rc);
-        stamp(); stamp();                                                       // timing slot 2 holds the pair, slot 3 (next to) nothing
-        pp = 1; first = 2;
+    hipStream_t const caller_stream = c->stream;
+    const bool pair = can_fuse01(c) && halo_held(c, 6);
+    bool aside = false;
+    auto go_aside = [&]() -> int {
+        // the rest of this frame goes onto the side stream; the frame that was there is ordered on the caller's stream first (its
+        // result may be consumed, its planes reused)
+        hipError_t e = hipEventRecord(c->ev_first, caller_stream);
+        if (e != hipSuccess) return hip_fail(c, e, "hipEventRecord");
+        int r = join_side(c, caller_stream);
+        if (r != SVGF_OK) return r;
+        e = hipStreamWaitEvent(c->side, c->ev_first, 0);
+        if (e != hipSuccess) return hip_fail(c, e, "hipStreamWaitEvent");
+        c->stream = c->side;
+        aside = true;
+        stamp();                                                                // the tail's own start: it may have waited for the frame before it
+        return SVGF_OK;
+    };
+    if (pair) {
+        // iterations 0 and 1 as one launch: F[0] -> F[1] (iteration 0's own plane is never written), feedback as ever
+        rc = atrous_pair_impl(c, F[0], F[1], c->colour[P], cur, guide);
+        if (rc == SVGF_OK) { stamp(); stamp(); pp = 1; first = 2; }             // timing slot 2 holds the pair, slot 3 (next to) nothing
+    } else if (c->p.steps >= 1) {
+        rc = atrous_impl(c, F[0], F[1], c->colour[P], cur, 1, 0, guide);        // App.cu:497-507, iteration 0: feeds the history back
+        if (rc == SVGF_OK) { stamp(); pp = 1; first = 1; }
     }
-    for (int i = first; i < c->p.steps; i++) {                                  // App.cu:497-507
-        rc = atrous_impl(c, c->filter[pp], c->filter[1 - pp], c->colour[P], cur, 1 << i, i, guide);
-        if (rc != SVGF_OK) return bail(rc);
-        stamp();
-        pp ^= 1;
+    // Everything the NEXT frame's temporal launch reads is written now: with two frames in flight the remaining iterations leave the
+    // caller's stream.  (Iteration 0 on the side stream as well - the next temporal launch waiting for an event behind it - measured
+    // 1-2 % slower: beside a queue of nothing but wavelet launches the temporal launch gets too few workgroup slots, profiles/r03_small_experiments.txt.)
+    if (rc == SVGF_OK && c->frames_in_flight > 1) {
+        if (c->side && first < c->p.steps) { fe.split = 2 + first; rc = go_aside(); }
+        else rc = join_side(c, caller_stream);
     }
+    for (int i = first; i < c->p.steps && rc == SVGF_OK; i++) {
+        rc = atrous_impl(c, F[pp], F[1 - pp], c->colour[P], cur, 1 << i, i, guide);
+        if (rc == SVGF_OK) { stamp(); pp ^= 1; }
+    }
+    if (aside) {
+        if (rc == SVGF_OK) {
+            hipError_t e = hipEventRecord(c->ev_done, c->side);
+            if (e == hipSuccess) c->in_flight = true; else rc = hip_fail(c, e, "hipEventRecord");
+        }
+        c->stream = caller_stream;
+    }
+    if (rc != SVGF_OK) return bail(rc);
     if (timed) {
         fe.nstage = 2 + c->p.steps;
-        if ((int)fe.ev.size() == fe.nstage + 1) c->pending.push_back(std::move(fe));
+        if ((int)fe.ev.size() == fe.nstage + 1 + (aside ? 1 : 0)) c->pending.push_back(std::move(fe));
         else bail(0);
     }
-    if (result) *result = c->filter[pp];
+    if (result) *result = F[pp];
     c->result_index = pp;
     commit_guide(c, cur, guide != nullptr);
     c->pingpong ^= 1;                                                           // App.cu:374
@@ -703,7 +804,8 @@ int svgf_sync(svgf_ctx* c) {
     if (!c) return SVGF_ERR_INVALID;
     DeviceGuard dg(c->device);
     unsigned long long n = 0;
-    int rc = read_halo_violations(c, &n, 1);
+    int rc = join_side(c, c->stream);
+    if (rc == SVGF_OK) rc = read_halo_violations(c, &n, 1);
     if (rc != SVGF_OK) return rc;
     if (!c->halo_violations) SVGF_HIP(c, hipStreamSynchronize(c->stream));
     if (n) return fail(c, SVGF_ERR_HALO, "temporal stage: " + std::to_string(n) + " reprojection(s) landed inside the frame but outside the rows this strip holds "
@@ -725,7 +827,8 @@ int svgf_timing_read(svgf_ctx* c, double* ms_sum, int* frames, int slots) {
         SVGF_HIP(c, hipEventSynchronize(f.ev.back()));
         for (int i = 0; i < f.nstage; i++) {
             float ms = 0.f;
-            SVGF_HIP(c, hipEventElapsedTime(&ms, f.ev[i], f.ev[i + 1]));
+            const int b = i >= f.split ? i + 1 : i;
+            SVGF_HIP(c, hipEventElapsedTime(&ms, f.ev[b], f.ev[b + 1]));
             c->ms_sum[i] += ms;
         }
         for (auto e : f.ev) c->pool.push_back(e);

@@ -37,6 +37,16 @@ struct svgf_ctx {
     bool guide_prev_valid = false;
     bool prev_guide_enabled = SVGF_PREV_GUIDE_DEFAULT != 0;   // svgf_set_prev_guide
     bool fuse01 = SVGF_FUSE01_DEFAULT != 0;   // svgf_set_iteration_fusion: iterations 0 and 1 in one launch (frame / strip drivers)
+    // svgf_set_frames_in_flight(2): the frame driver runs iterations 1.. of a frame on `side` while the NEXT frame's temporal, moments
+    // and first-iteration launches run on `stream` (the HBM-bound launch beside the arithmetic-bound ones).  Frames then alternate
+    // between two pairs of filter planes (the guide planes alternate anyway), and a frame's result is ordered on `stream` by the next
+    // svgf_denoise_frame / svgf_flush / svgf_sync.
+    int frames_in_flight = 1;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_first = nullptr, ev_done = nullptr;   // iteration 0 of the frame being enqueued is on `stream`; the last iteration of the frame in flight is on `side`
+    void* filter_alt[2] = {nullptr, nullptr};
+    int filter_set = 0;                    // which pair the NEXT frame uses (toggles per frame while frames_in_flight == 2)
+    bool in_flight = false;                // a frame's tail is on `side` and `stream` has not been made to wait for it yet
     uint32_t* young_list = nullptr;        // scratch, temporal -> moments: indices of the pixels with history < 4 that need the spatial estimate
     unsigned* young_count = nullptr;       // two device counters used in turn (the temporal launch of a frame zeroes the next frame's)
     uint8_t* young_flags = nullptr;        // one flag per (row, 64-column segment): all 64 pixels need the estimate (listed nowhere)
@@ -53,7 +63,8 @@ struct svgf_ctx {
     // per-stage timing
     int timing = 0;               // 0 = off, n = stage events on every n-th frame
     int timing_phase = 0;
-    struct FrameEvents { std::vector<hipEvent_t> ev; int nstage = 0; };
+    // stage i ran between ev[i] and ev[i + 1]; from stage `split` on (the launches on the side stream) between ev[i + 1] and ev[i + 2]
+    struct FrameEvents { std::vector<hipEvent_t> ev; int nstage = 0; int split = 1 << 30; };
     std::vector<FrameEvents> pending;
     std::vector<hipEvent_t> pool;
     double ms_sum[2 + SVGF_MAX_STEPS] = {0};
@@ -91,6 +102,7 @@ int reset_history(svgf_ctx* c);
 int alloc_state(svgf_ctx* c);
 int alloc_flags(svgf_ctx* c);
 int read_halo_violations(svgf_ctx* c, unsigned long long* count, int clear);
+int join_side(svgf_ctx* c, hipStream_t onto);   // `onto` waits for the frame in flight on the side stream (frames_in_flight == 2); no-op otherwise
 
 // the stages on caller- or driver-owned planes, rows [c->rb, c->re); the device is already current
 int temporal_moments_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, void* filter_out,

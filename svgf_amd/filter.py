@@ -24,7 +24,7 @@ MAX_STEPS = 10
 EXPORTS = [
     "svgf_default_params", "svgf_status_string", "svgf_last_error", "svgf_abi_version", "svgf_create",
     "svgf_create_strip", "svgf_destroy", "svgf_set_params", "svgf_set_stream", "svgf_set_rows", "svgf_temporal", "svgf_temporal_moments", "svgf_demodulate", "svgf_modulate",
-    "svgf_moments", "svgf_atrous", "svgf_atrous_pair", "svgf_set_iteration_fusion", "svgf_taa", "svgf_pack_gbuffer", "svgf_denoise_frame", "svgf_reset_history", "svgf_state_plane",
+    "svgf_moments", "svgf_atrous", "svgf_atrous_pair", "svgf_set_iteration_fusion", "svgf_taa", "svgf_pack_gbuffer", "svgf_denoise_frame", "svgf_reset_history", "svgf_set_frames_in_flight", "svgf_flush", "svgf_state_plane",
     "svgf_state_pingpong", "svgf_plane_bytes", "svgf_timing_enable", "svgf_timing_read",
     "svgf_resize", "svgf_resize_strip", "svgf_get_size", "svgf_sync", "svgf_halo_violations", "svgf_set_valid_rows", "svgf_set_debug_mode", "svgf_set_prev_guide",
     "svgf_import_gbuffer_pitched", "svgf_import_gbuffer_array", "svgf_export_to_array",
@@ -32,7 +32,7 @@ EXPORTS = [
     "svgf_strips_last_error", "svgf_strips_context", "svgf_strips_layout", "svgf_strips_frame", "svgf_strips_sync",
     "svgf_strips_timing_enable", "svgf_strips_timing_read",
 ]
-ABI_VERSION = 3
+ABI_VERSION = 4
 DEBUG_MODE = {"final": 0, "temporal": 1, "atrous": 2}
 HALO_PLAN = {"auto": 0, "ghost": 1, "grouped": 2, "per-iteration": 3}
 HALO_PLAN_NAME = {v: k for k, v in HALO_PLAN.items()}
@@ -146,6 +146,8 @@ def load_library():
     lib.svgf_pack_gbuffer.argtypes = [vp, vp, vp, vp, C.POINTER(CameraC), vp, vp, vp]
     lib.svgf_denoise_frame.argtypes = [vp, vp, C.POINTER(GBufferC), C.POINTER(GBufferC), C.POINTER(vp)]
     lib.svgf_reset_history.argtypes = [vp]
+    lib.svgf_set_frames_in_flight.argtypes = [vp, ip]
+    lib.svgf_flush.argtypes = [vp]
     lib.svgf_state_plane.argtypes = [vp, ip, ip]
     lib.svgf_state_plane.restype = vp
     lib.svgf_state_pingpong.argtypes = [vp]
@@ -391,6 +393,15 @@ class Denoiser:
         self._check(self.lib.svgf_denoise_frame(self._h, _ptr(radiance), gb_cur.c, gb_prev.c if gb_prev else None,
                                                 C.byref(out)), "svgf_denoise_frame")
         return self._wrap(out.value, (self.rows, self.W, 4), self.colour_dtype())
+
+    def set_frames_in_flight(self, frames=2):
+        """2: iterations 1.. of a frame run on a stream of the context's own beside the next frame's temporal launch; the view Render
+        returned is ordered on the context's stream only by the next Render / flush / sync (include/svgf.h)."""
+        self._check(self.lib.svgf_set_frames_in_flight(self._h, int(frames)), "svgf_set_frames_in_flight")
+
+    def flush(self):
+        """Order the frame in flight on the context's stream (no host wait)."""
+        self._check(self.lib.svgf_flush(self._h), "svgf_flush")
 
     def reset_history(self):
         self._check(self.lib.svgf_reset_history(self._h), "svgf_reset_history")
