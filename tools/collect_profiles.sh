@@ -10,7 +10,7 @@ for t in 4k_f32 4k_f16 1080p_f32; do cp $O/rocprofv3_summary_$t.txt profiles/${T
 # the raw per-kernel stats of THE SAME trace run the 4K fp32 summary was condensed from
 cp "$(ls gpurun_out/prof_${TAG}_4k_f32/trace/*/*kernel_stats.csv | head -1)" profiles/${TAG}_kernel_stats_4k_f32.csv
 grep -h "^{" gpurun_out/prof_${TAG}_4k_f32/bench_trace.log > profiles/${TAG}_bench_under_rocprofv3_4k_f32.json
-for f in bench_4k_f32 bench_4k_f16 bench_1080p_f32 bench_8k_f32 bench_4k_f32_pair_launch bench_8k_f32_stripdriver_1gpu; do cp $O/$f.json profiles/${TAG}_$f.json; done
+for f in bench_4k_f32 bench_4k_f16 bench_1080p_f32 bench_8k_f32 bench_4k_f32_pair_launch bench_4k_f32_two_in_flight bench_8k_f32_stripdriver_1gpu; do cp $O/$f.json profiles/${TAG}_$f.json; done
 cp $O/strip_sim.txt profiles/${TAG}_strip_sim_8k_over_8.txt
 cp $O/pytest_gpu.log profiles/${TAG}_pytest_gpu.txt
 cp gpurun_out/parity_report.json profiles/${TAG}_parity_report.json

@@ -20,6 +20,7 @@ python3 bench.py --storage f16 --no-cpu --no-extra 2>/dev/null | grep "^{" > $O/
 python3 bench.py --workload 1080p --no-cpu --no-extra 2>/dev/null | grep "^{" > $O/bench_1080p_f32.json
 python3 bench.py --workload 8k --no-cpu --no-extra --steps 20 2>/dev/null | grep "^{" > $O/bench_8k_f32.json
 python3 bench.py --fuse --no-cpu --no-extra 2>/dev/null | grep "^{" > $O/bench_4k_f32_pair_launch.json
+python3 bench.py --frames-in-flight 2 --no-cpu --no-extra 2>/dev/null | grep "^{" > $O/bench_4k_f32_two_in_flight.json
 python3 bench.py --strips --workload 8k --steps 20 --warmup 3 2>/dev/null | grep "^{" > $O/bench_8k_f32_stripdriver_1gpu.json
 for pl in ghost grouped per-iteration; do python3 tools/strip_sim.py --plan $pl --driver native --stream own-hi 2>&1 | grep -E "ms/frame"; done > $O/strip_sim.txt
 cat $O/pytest_gpu.log; cut -c1-160 $O/bench_4k_f32.json; cat $O/strip_sim.txt

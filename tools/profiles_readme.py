@@ -55,6 +55,7 @@ def main(tag):
         (f"{tag}_bench_4k_f32.json", "`bench.py` (defaults: 3840x2160 fp32, 5 windows of 50 frames, pan / 1080p / fp16 / general-path extras, cpu_baseline) at the round's final sources"),
         (f"{tag}_bench_4k_f16.json, {tag}_bench_1080p_f32.json, {tag}_bench_8k_f32.json", "`bench.py --storage f16 | --workload 1080p | --workload 8k` (`--no-cpu --no-extra`)"),
         (f"{tag}_bench_4k_f32_pair_launch.json", "`bench.py --fuse`: iterations 0 + 1 as one launch (`svgf_atrous_pair`), same call"),
+        (f"{tag}_bench_4k_f32_two_in_flight.json", "`bench.py --frames-in-flight 2`: `svgf_set_frames_in_flight(2)` — iterations 1-4 of a frame beside the next frame's temporal launch (stage times are brackets of overlapping launches)"),
         (f"{tag}_bench_8k_f32_stripdriver_1gpu.json", "`bench.py --gpus 1 --strips --workload 8k`: the N > 1 code path (C++ strip driver, every halo plan, the pan, the one-GPU reference) on ONE GPU"),
         (f"{tag}_rocprofv3_summary_4k_f32.txt, _4k_f16.txt, _1080p_f32.txt", "`tools/prof.sh`: kernel stats (`rocprofv3 --kernel-trace --stats`) + SQ / LDS / FETCH_SIZE / WRITE_SIZE counters (separate `--pmc` passes) of `bench.py --steps 20 --warmup 3 --no-cpu --no-extra [...]`"),
         (f"{tag}_kernel_stats_4k_f32.csv", f"the raw `*_kernel_stats.csv` of the SAME trace run `{tag}_rocprofv3_summary_4k_f32.txt` was condensed from"),
@@ -112,7 +113,8 @@ def main(tag):
                          f"{e['atrous_write_size_kib']:.0f} KiB written = **{e['atrous_bytes_per_launch'] / 1e6:.1f} MB** per launch; temporal launch "
                          f"{e.get('temporal_bytes_per_launch', 0) / 1e6:.1f} MB.")
     for f, label in ((f"{tag}_bench_4k_f16.json", "4K fp16"), (f"{tag}_bench_1080p_f32.json", "1080p fp32"), (f"{tag}_bench_8k_f32.json", "8K fp32, one GPU"),
-                     (f"{tag}_bench_4k_f32_pair_launch.json", "4K fp32 with the pair launch")):
+                     (f"{tag}_bench_4k_f32_pair_launch.json", "4K fp32 with the pair launch"),
+                     (f"{tag}_bench_4k_f32_two_in_flight.json", "4K fp32 with two frames in flight")):
         d = load(f)
         if d:
             r = d.get("roofline") or {}
