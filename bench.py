@@ -198,6 +198,20 @@ def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, de
         d.Render(*pool.frame(n))
         n += 1
 
+    def rewarm(ms=60.0, frames=0):
+        """untimed frames right before a timed window whenever the host has just kept the device idle (timing_read, a garbage collection):
+        after >= 2 ms of idleness the part needs tens of milliseconds to be back at its clocks (tools/idle_gap.py: the next 10-40 frames run
+        5-20 % slower).  The first call also runs `frames` frames: a process sees ONE stall of 20-65 ms when it has enqueued its first
+        ~4 000 stream operations (tools/strip_sim.py --per-frame) - it belongs in front of the timed windows, not in one of them."""
+        nonlocal n
+        t0, k = time.perf_counter(), 0
+        while (time.perf_counter() - t0) * 1e3 < ms or k < frames:
+            for _ in range(10):
+                d.Render(*pool.frame(n))
+                n += 1
+            k += 10
+            torch.cuda.synchronize(device)
+
     def window():
         nonlocal n
         torch.cuda.synchronize(device)
@@ -207,11 +221,17 @@ def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, de
             n += 1
         torch.cuda.synchronize(device)
         return (time.perf_counter() - t0) * 1e3 / steps
+    import gc
+    gc.collect()
+    gc.disable()               # no generation-2 collection of the interpreter (20-30 ms with torch loaded) inside a window: it would starve the launch queue
+    rewarm(300.0, 600)
     d.timing_enable(4)         # HIP events between the stages of every 4th timed frame, on the stream the kernels are launched on
     win = [window() for _ in range(max(1, windows))]
     stage_ms, frames = d.timing_read()
     d.timing_enable(False)
+    rewarm()
     no_events = window()       # the same window without any stage event: what the events cost the timed frames
+    gc.enable()
     out = d.Render(*pool.frame(n))
     d.flush()                  # (two frames in flight: the result is ordered on the stream by the next call, or by this)
     assert bool(torch.isfinite(out.float()).all()), "non-finite output"

@@ -234,8 +234,9 @@ int svgf_reset_history(svgf_ctx* ctx);                                 /* zero a
  *   - the planes of `cur` given to call f must stay as they are until call f + 1 has been made when the iterations read them
  *     (variant DIRECT, or steps == 0: without the guide plane) — with the reference's two framebuffers they do;
  *   - the debug views (svgf_set_debug_mode) and strip-driver contexts do not combine with it (refused).
- * frames = 1 (default) restores stream order at once.  svgf_flush orders the frame in flight on the context's stream without
- * waiting for it. */
+ * frames = 1 (default) restores stream order at once: the frame in flight is ordered on the context's stream by that call and its
+ * result is then valid until the next svgf_denoise_frame, as ever.  svgf_flush orders the frame in flight on the context's stream
+ * without waiting for it; svgf_reset_history / svgf_resize / svgf_destroy wait for or order it themselves. */
 int svgf_set_frames_in_flight(svgf_ctx* ctx, int frames);
 int svgf_flush(svgf_ctx* ctx);
 /* The sequences application::Render runs in its debug views (SVGFDebugOutput, App.cu:545-649) on the same state:

@@ -83,6 +83,8 @@ Rccl* rccl() {
 }  // namespace
 
 // ------------------------------------------------------------------ the driver -----------------------------
+constexpr int kMaxAhead = 32;
+
 struct svgf_strip_plan_geo {
     int own0 = 0, own1 = 0;
     std::vector<std::vector<int>> groups;
@@ -102,6 +104,9 @@ struct svgf_strips {
         bool own_comm_stream = false;
         hipEvent_t ready = nullptr, halo_done = nullptr, state_done = nullptr;
         bool state_pending = false;
+        // the host never runs more than kMaxAhead frames ahead of the device: frame f waits for the end of frame f - kMaxAhead.  With ~100
+        // frames of launches, events and RCCL groups queued the device starts to starve (0.43 -> 0.6 ms per 8K/8 strip, tools/strip_sim.py)
+        std::vector<hipEvent_t> frame_done;
         svgf_strip_plan_geo g;
         // timing of the a-trous launches (bench.py's roofline block at N > 1)
         std::vector<hipEvent_t> tev;           // pairs
@@ -385,6 +390,7 @@ void svgf_strips_destroy(svgf_strips* s) {
         if (l.comm_stream) (void)hipStreamSynchronize(l.comm_stream);
         if (l.ctx) { (void)hipStreamSynchronize(l.compute); l.ctx->strip_drv = nullptr; svgf_destroy(l.ctx); }
         for (auto e : l.tev) (void)hipEventDestroy(e);
+        for (auto e : l.frame_done) if (e) (void)hipEventDestroy(e);
         if (l.ready) (void)hipEventDestroy(l.ready);
         if (l.halo_done) (void)hipEventDestroy(l.halo_done);
         if (l.state_done) (void)hipEventDestroy(l.state_done);
@@ -417,6 +423,8 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
         svgf_ctx* c = l.ctx;
         DeviceGuard dg(l.device);
         if (!radiance[k]) return sfail(s, SVGF_ERR_INVALID, "svgf_strips_frame: null radiance");
+        if (l.frame_done.empty()) l.frame_done.assign(kMaxAhead, nullptr);
+        if (hipEvent_t old = l.frame_done[s->frame_no % kMaxAhead]) SVGF_SHIP(s, hipEventSynchronize(old));   // the end of frame f - kMaxAhead
         int rc0 = alloc_state(c);                 // svgf_denoise_frame's lazy allocation (exact size, zeroed)
         if (rc0 == SVGF_OK) rc0 = alloc_flags(c);
         if (rc0 != SVGF_OK) return sfail(s, rc0, c->err);
@@ -506,7 +514,14 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
     }
     if (!s->steps) { int rc = post_state(); if (rc != SVGF_OK) return rc; }
     for (int k = 0; k < n; k++) {
-        svgf_ctx* c = s->local[k].ctx;
+        auto& l = s->local[k];
+        svgf_ctx* c = l.ctx;
+        {
+            DeviceGuard dg(l.device);
+            hipEvent_t& done = l.frame_done[s->frame_no % kMaxAhead];
+            if (!done) SVGF_SHIP(s, hipEventCreateWithFlags(&done, hipEventDisableTiming));
+            SVGF_SHIP(s, hipEventRecord(done, l.compute));
+        }
         c->rb = c->strip.own_begin; c->re = c->strip.own_end;
         if (results) results[k] = c->filter[pp[k]];
         c->result_index = pp[k];

@@ -712,7 +712,21 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
         run = Runner(W, H, world, rank, params, device, side.cuda_stream, comm, lay["plan"], reach)
         get = frame_of(lay)
         n = 0
+        dist.barrier()                           # the ranks enter the untimed frames together ...
+        torch.cuda.synchronize(device)
+        w0 = time.perf_counter()
         for _ in range(prime_frames + warmup):
+            run.frame(*get(n))
+            n += 1
+        torch.cuda.synchronize(device)
+        # ... and keep the device busy for >= 400 ms and >= 600 frames before anything is timed: after the idle gaps of the set-up
+        # (allocations, rank 0's whole-frame reference) the part needs tens of milliseconds at load to be back at its clocks
+        # (tools/idle_gap.py), and a process sees one stall of 20-65 ms when it has enqueued its first ~4 000 stream operations (~300
+        # frames; tools/strip_sim.py --per-frame) that would otherwise land in the timed frames.  The number of extra frames comes from
+        # the all-reduced per-frame time, so every rank runs the same count (frames exchange halos).
+        done = prime_frames + warmup
+        per = max(max_over_ranks((time.perf_counter() - w0) * 1e3 / done), 1e-3)
+        for _ in range(int(min(3000, max(600 - done, math.ceil((400.0 - per * done) / per), 0)))):
             run.frame(*get(n))
             n += 1
         run.timing(True)

@@ -28,10 +28,13 @@ ap.add_argument("--rank", type=int, default=3)
 ap.add_argument("--plan", default="grouped")
 ap.add_argument("--comm", default="self")
 ap.add_argument("--storage", default="f32")
-ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--stream", default="own", help="own = a non-blocking side stream; own-hi = the same at high priority (its own hardware queue); null = the legacy default stream")
 ap.add_argument("--post", default="side", help="side = post RCCL batches from a stream of their own; inline = from the compute stream")
 ap.add_argument("--prefill", type=int, default=0, help="N 8192^3 bf16 GEMMs queued before the timed frames (GPU-event timing)")
+ap.add_argument("--warm-ms", type=float, default=400.0, help="untimed frames for at least this long before the timed ones")
+ap.add_argument("--warm-frames", type=int, default=600, help="... and at least this many")
+ap.add_argument("--per-frame", action="store_true", help="print the device and host time of every frame")
 ap.add_argument("--driver", default="python", help="python = StripRunner; native = svgf_strip_* C driver if present")
 args = ap.parse_args(argv[1:])
 
@@ -73,9 +76,17 @@ else:
     stages = strips.HipStages(geo, params, dev)
     runner = strips.StripRunner(geo, stages, SelfComm(), storage=args.storage, device=dev)
     frame = lambda k: runner.frame(rads[k % len(rads)], gbs[k & 1], gbs[(k & 1) ^ 1])          # noqa: E731
-for k in range(12):
-    frame(k)
-torch.cuda.synchronize()
+# --warm-ms (and >= --warm-frames) of untimed frames.  Two things must be behind us before anything is timed (--per-frame shows both):
+# after the idle gaps of the set-up the part needs tens of milliseconds at load to be back at its clocks (tools/idle_gap.py: the next
+# 10-40 frames run 5-20 % slower), and a process sees ONE stall of 20-65 ms when it has enqueued its first ~4 000 stream operations
+# (launches, event records / waits, RCCL groups: ~300 frames of the ghost plan) - never again in the 1 500 frames after it.  With
+# 12 untimed and 30 timed frames, as this tool used to run, the whole timed region sat in the ramp.
+w0, k = time.perf_counter(), 0
+while (time.perf_counter() - w0) < args.warm_ms * 1e-3 or k < args.warm_frames:
+    for _ in range(10):
+        frame(k)
+        k += 1
+    torch.cuda.synchronize()
 if args.prefill:
     # keep the GPU busy for a while so that the host gets far ahead: the frame time seen by GPU events is then free of any
     # host-side launch latency (is a gap in the kernel trace the host's or the GPU's?)
@@ -85,12 +96,24 @@ if args.prefill:
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 t0 = time.perf_counter()
 e0.record()
+marks = []
 for k in range(args.steps):
     frame(k)
+    if args.per_frame:
+        ev = torch.cuda.Event(enable_timing=True); ev.record(); marks.append((ev, time.perf_counter()))
 e1.record()
 t_host = time.perf_counter() - t0
 torch.cuda.synchronize()
 t = e0.elapsed_time(e1) * 1e-3 if args.prefill else time.perf_counter() - t0
+if args.per_frame:       # device time between the ends of consecutive frames, and when the host got there
+    hp = t0
+    last = e0
+    dev_ms, host_ms = [], []
+    for ev, th in marks:
+        dev_ms.append(last.elapsed_time(ev)); host_ms.append((th - hp) * 1e3); last, hp = ev, th
+    print("stalls (frame: device ms / host ms): " + ", ".join(f"{i}: {d:.1f}/{h:.1f}" for i, (d, h) in enumerate(zip(dev_ms, host_ms)) if d > 2.0 or h > 2.0))
+    for i in range(0, len(dev_ms) if args.steps <= 200 else 0, 10):
+        print(f"frames {i:4d}..: device " + " ".join(f"{v:.2f}" for v in dev_ms[i:i + 10]) + "   host " + " ".join(f"{v:.2f}" for v in host_ms[i:i + 10]))
 own = geo.own[1] - geo.own[0]
 print(f"{W}x{H} strip {args.rank}/{args.world} ({own} rows, held {geo.y1 - geo.y0}), plan {geo.plan}, comm {args.comm}/{args.post}, stream {args.stream}, driver {args.driver}: "
       f"{t / args.steps * 1e3:.4f} ms/frame (host enqueue {t_host / args.steps * 1e3:.4f} ms) -> "
