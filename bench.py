@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--frames-in-flight", type=int, choices=[1, 2], default=1,
                     help="2: svgf_set_frames_in_flight(2) - iterations 1.. of a frame on a side stream beside the next frame's temporal launch (bit-identical results; "
                          "a frame's result is ordered on the stream one call later)")
+    ap.add_argument("--prime-ms", type=float, default=400.0, help="untimed load before the first timed frame: at least this long ...")
+    ap.add_argument("--prime-frames", type=int, default=600, help="... and at least this many frames, --warmup included (DESIGN.md 6: the post-idle clock ramp and the "
+                                                                   "one-off stall of a process's first ~4 000 stream operations belong in front of the timed region; 0 / 0 for smoke runs)")
     ap.add_argument("--windows", type=int, default=5, help="the --steps-frame timed window is repeated this many times; ms_per_step is the median window")
     return ap.parse_args()
 
@@ -184,7 +187,7 @@ class FramePool:
 
 
 # ------------------------------------------------------------------ single GPU -----------------
-def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, device, cold_frames=0, fuse=False, windows=5, in_flight=1):
+def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, device, cold_frames=0, fuse=False, windows=5, in_flight=1, prime=(400.0, 600)):
     """-> dict(ms_per_step = median over `windows` timed windows of `steps` frames each (sync, K frames, sync), windows_ms, stage_ms[list],
     ms_no_events: one more window without the per-stage HIP events, ...)."""
     import torch
@@ -224,7 +227,7 @@ def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, de
     import gc
     gc.collect()
     gc.disable()               # no generation-2 collection of the interpreter (20-30 ms with torch loaded) inside a window: it would starve the launch queue
-    rewarm(300.0, 600)
+    rewarm(prime[0], max(0, prime[1] - PRIME_FRAMES - warmup))
     d.timing_enable(4)         # HIP events between the stages of every 4th timed frame, on the stream the kernels are launched on
     win = [window() for _ in range(max(1, windows))]
     stage_ms, frames = d.timing_read()
@@ -506,7 +509,7 @@ def main():
         fuse = bool(args.fuse)
         for m in motions:
             res[m] = run_single(FramePool(scene, storage, m), W, H, storage, iters, args.variant, args.steps, args.warmup, device,
-                                cold_frames=5 if (m == "static" and not args.no_extra) else 0, fuse=fuse, windows=args.windows, in_flight=args.frames_in_flight)
+                                cold_frames=5 if (m == "static" and not args.no_extra) else 0, fuse=fuse, windows=args.windows, in_flight=args.frames_in_flight, prime=(args.prime_ms, args.prime_frames))
         head = motions[0]
         r = res[head]
         ms = r["ms_per_step"]
@@ -554,7 +557,7 @@ def main():
         if not args.no_extra and wl != "1080p":
             W2, H2 = WORKLOADS["1080p"]
             sc2 = Scene(W2, H2, device, pool=2)
-            r2 = run_single(FramePool(sc2, storage, "static"), W2, H2, storage, iters, args.variant, max(args.steps, 20), args.warmup, device, fuse=fuse, windows=args.windows)
+            r2 = run_single(FramePool(sc2, storage, "static"), W2, H2, storage, iters, args.variant, max(args.steps, 20), args.warmup, device, fuse=fuse, windows=args.windows, prime=(args.prime_ms, args.prime_frames))
             roof2, _ = roofline_block(W2, H2, storage, iters, r2["stage_ms"], args.variant, r2["fused"])
             line["also"] = {"1920x1080": {"ms_per_step": round(r2["ms_per_step"], 4), "ms_per_step_min": round(min(r2["windows_ms"]), 4),
                                           "Mpixels/s": round(W2 * H2 / (r2["ms_per_step"] * 1e-3) / 1e6, 1),
@@ -562,7 +565,7 @@ def main():
                                           "atrous_avg_launch_ms": roof2["avg_launch_ms"] if roof2 else None, "atrous_roofline_frac": roof2["frac"] if roof2 else None}}
             del sc2
             if storage == "f32" and wl == "4k":      # BASELINE configs[4]: the reference-native fp16 storage on the same frame
-                r3 = run_single(FramePool(scene, "f16", "static"), W, H, "f16", iters, args.variant, max(args.steps, 20), args.warmup, device, fuse=fuse, windows=args.windows)
+                r3 = run_single(FramePool(scene, "f16", "static"), W, H, "f16", iters, args.variant, max(args.steps, 20), args.warmup, device, fuse=fuse, windows=args.windows, prime=(args.prime_ms, args.prime_frames))
                 roof3, _ = roofline_block(W, H, "f16", iters, r3["stage_ms"], args.variant, r3["fused"])
                 line["also"]["3840x2160_f16"] = {"ms_per_step": round(r3["ms_per_step"], 4),
                                                  "Mpixels/s": round(W * H / (r3["ms_per_step"] * 1e-3) / 1e6, 1),
@@ -572,7 +575,7 @@ def main():
         if not args.no_extra and args.variant == "auto" and wl == "4k":
             # the synthetic scene is piecewise planar: 68-87 % of the a-trous waves take the uniform-normal fast path (8 instead of 13
             # vector instructions per tap, same results).  What geometry without planar regions would cost: the fast path switched off.
-            r4 = run_single(FramePool(scene, storage, "static"), W, H, storage, iters, "lds-general", max(args.steps, 20), args.warmup, device, fuse=fuse, windows=args.windows)
+            r4 = run_single(FramePool(scene, storage, "static"), W, H, storage, iters, "lds-general", max(args.steps, 20), args.warmup, device, fuse=fuse, windows=args.windows, prime=(args.prime_ms, args.prime_frames))
             roof4, _ = roofline_block(W, H, storage, iters, r4["stage_ms"], "auto", r4["fused"])
             line["also"]["no_uniform_normal_fast_path"] = {"ms_per_step": round(r4["ms_per_step"], 4), "Mpixels/s": round(W * H / (r4["ms_per_step"] * 1e-3) / 1e6, 1),
                                                            "frac_of_8TBps": pass_block(W, H, storage, iters, r4["ms_per_step"])["frac_of_8TBps"],
@@ -580,7 +583,7 @@ def main():
                                                            "atrous_roofline_frac": roof4["frac"] if roof4 else None}
         if not args.no_extra and args.frames_in_flight == 1 and wl == "4k":
             # throughput mode: iterations 1.. of frame f on a side stream beside the temporal launch of frame f + 1 (same results)
-            r5 = run_single(FramePool(scene, storage, "static"), W, H, storage, iters, args.variant, args.steps, args.warmup, device, fuse=fuse, windows=args.windows, in_flight=2)
+            r5 = run_single(FramePool(scene, storage, "static"), W, H, storage, iters, args.variant, args.steps, args.warmup, device, fuse=fuse, windows=args.windows, in_flight=2, prime=(args.prime_ms, args.prime_frames))
             roof5, st5 = roofline_block(W, H, storage, iters, r5["stage_ms"], args.variant, r5["fused"])
             line.setdefault("also", {})["two_frames_in_flight"] = {
                 "ms_per_step": round(r5["ms_per_step"], 4), "ms_per_step_min": round(min(r5["windows_ms"]), 4), "ms_per_step_max": round(max(r5["windows_ms"]), 4),
@@ -607,7 +610,7 @@ def main():
         res = strips.bench_strips(W, H, storage, iters, args.variant, args.steps, args.warmup, device, plan=args.halo_plan,
                                   make_inputs=make_inputs, prime_frames=PRIME_FRAMES, driver=args.driver,
                                   plans=() if args.no_extra else ("per-iteration", "grouped"), pan_mv=None if args.no_extra else STRIP_PAN_MV,
-                                  one_gpu_reference=not args.no_one_gpu)
+                                  one_gpu_reference=not args.no_one_gpu, busy=(args.prime_ms, args.prime_frames))
     except Exception as e:  # noqa: BLE001
         print(f"bench.py: rank {rank}: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
         os._exit(3)            # a rank that cannot run the measurement asked for ends the job (the launcher reports the exit codes)

@@ -626,7 +626,7 @@ def _strip_pan_frames(W, H, storage, device, mv, y0, y1):
 
 
 def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, make_inputs, prime_frames, driver="native", motion_reach=None,
-                 plans=("per-iteration", "grouped"), pan_mv=(1.5, -3.5), one_gpu_reference=True):
+                 plans=("per-iteration", "grouped"), pan_mv=(1.5, -3.5), one_gpu_reference=True, busy=(400.0, 600)):
     """bench.py's N > 1 leg: this rank's strip of a W x H frame; every measurement is `steps` frames between barriers, MAX over ranks.
     Measured: the headline plan (`plan`, static camera), the other halo plans (BASELINE config #4 names "per-iteration"), a camera
     pan whose state exchange really carries moments and history (motion reach >= 3), and — on rank 0 alone, before the strips —
@@ -719,14 +719,14 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
             run.frame(*get(n))
             n += 1
         torch.cuda.synchronize(device)
-        # ... and keep the device busy for >= 400 ms and >= 600 frames before anything is timed: after the idle gaps of the set-up
+        # ... and keep the device busy for >= busy[0] = 400 ms and >= busy[1] = 600 frames before anything is timed: after the idle gaps of the set-up
         # (allocations, rank 0's whole-frame reference) the part needs tens of milliseconds at load to be back at its clocks
         # (tools/idle_gap.py), and a process sees one stall of 20-65 ms when it has enqueued its first ~4 000 stream operations (~300
         # frames; tools/strip_sim.py --per-frame) that would otherwise land in the timed frames.  The number of extra frames comes from
         # the all-reduced per-frame time, so every rank runs the same count (frames exchange halos).
         done = prime_frames + warmup
         per = max(max_over_ranks((time.perf_counter() - w0) * 1e3 / done), 1e-3)
-        for _ in range(int(min(3000, max(600 - done, math.ceil((400.0 - per * done) / per), 0)))):
+        for _ in range(int(min(3000, max(busy[1] - done, math.ceil((busy[0] - per * done) / per), 0)))):
             run.frame(*get(n))
             n += 1
         run.timing(True)

@@ -401,7 +401,7 @@ def test_bench_flow_of_two_ranks_on_one_device():
     import sys
     env = dict(os.environ, SVGF_BENCH_SHARE_DEVICES="1")
     env.pop("WORLD_SIZE", None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--driver", "python", "--workload", "4k"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--driver", "python", "--workload", "4k", "--prime-ms", "0", "--prime-frames", "0"],
                        env=env, capture_output=True, text=True, timeout=500)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -426,7 +426,7 @@ def test_bench_refuses_a_silent_change_of_driver():
     env = dict(os.environ, SVGF_BENCH_SHARE_DEVICES="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "1080p", "--no-extra", "--no-one-gpu"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "1080p", "--no-extra", "--no-one-gpu", "--prime-ms", "0", "--prime-frames", "0"],
                        env=env, capture_output=True, text=True, timeout=500)
     assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert "--driver python" in p.stderr
@@ -439,7 +439,7 @@ def test_bench_strips_line_on_one_gpu(G):
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):      # an in-process group of this pytest run may own that port
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--strips", "--steps", "3", "--warmup", "1", "--workload", "4k"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--strips", "--steps", "3", "--warmup", "1", "--workload", "4k", "--prime-ms", "0", "--prime-frames", "0"],
                        env=env, capture_output=True, text=True, timeout=500)
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
