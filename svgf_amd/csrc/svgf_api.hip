@@ -741,10 +741,9 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
         if (rc == SVGF_OK) { stamp(); pp ^= 1; }
     }
     if (aside) {
-        if (rc == SVGF_OK) {
-            hipError_t e = hipEventRecord(c->ev_done, c->side);
-            if (e == hipSuccess) c->in_flight = true; else rc = hip_fail(c, e, "hipEventRecord");
-        }
+        // (also after a failed launch: whatever did get onto the side stream must be waited for before its planes are touched again)
+        hipError_t e = hipEventRecord(c->ev_done, c->side);
+        if (e == hipSuccess) c->in_flight = true; else if (rc == SVGF_OK) rc = hip_fail(c, e, "hipEventRecord");
         c->stream = caller_stream;
     }
     if (rc != SVGF_OK) return bail(rc);
