@@ -227,7 +227,7 @@ int svgf_reset_history(svgf_ctx* ctx);                                 /* zero a
  * arithmetic; from iteration 0 on nothing a frame still does is read by the next frame's temporal launch (iteration 0 feeds the
  * history back, App.cu:504-505).  With svgf_set_frames_in_flight(ctx, 2), svgf_denoise_frame enqueues the temporal, moments and
  * iteration-0 launches on the context's stream and iterations 1.. on a stream of its own, where they run beside the NEXT frame's
- * temporal launch (measured: -3 to -5 % per 4K fp32 frame, -7 % at 1080p; results bit-identical).  What changes for the caller:
+ * temporal launch (measured: -1 to -5 % per 4K fp32 frame depending on the board, -7 % at 1080p; results bit-identical).  What changes for the caller:
  *   - *result of call f is returned at once but is ORDERED on the context's stream only by the next svgf_denoise_frame, svgf_flush
  *     or svgf_sync (enqueue the consumer of frame f after one of those); it stays valid until the call after the next one (frames
  *     alternate between two pairs of filter planes: +2 colour planes of memory);
