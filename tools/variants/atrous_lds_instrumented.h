@@ -6,6 +6,9 @@
 // tools/sweep_launch.py build such twins under build/).  profiles/r02_atrous_ablations.txt was measured with it.
 // The text lives in a namespace of its own (svgf::{anonymous}::r02): it brings its own copies of the staging helpers.
 #pragma once
+#ifdef SVGF_P2
+#include "atrous_p2.h"        // two output pixels per thread: another kernel altogether
+#else
 #include "../../svgf_amd/csrc/svgf_device.h"
 
 #include <algorithm>
@@ -950,3 +953,4 @@ extern "C" int svgf_diag_stamps(unsigned long long* out, int reset) {
 #endif
 
 }  // namespace svgf
+#endif  // SVGF_P2
