@@ -49,13 +49,14 @@ __global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(
     const int rg = __builtin_amdgcn_readfirstlane(t / TX);          // row group: wave-uniform -> scalar
     const int wig = __builtin_amdgcn_readfirstlane((t % TX) >> 6);  // wave index inside its row group
     // tile order v = (residue, band, x tile), x fastest.  Step 1 walks the frame bottom-up: what the temporal launch wrote last is
-    // still in the 256 MB Infinity Cache when it is read first (-4.5 % for that launch; later steps sweep the frame once per row
-    // residue and gain nothing from an order)
+    // still in the 256 MB Infinity Cache when it is read first (-4.5 % for that launch).  Later steps sweep the frame once per row
+    // residue; of the 16 direction patterns tried for them, only "step 8 backwards too" measured better than all forwards (-1.5 to
+    // -3 % for that launch, -0.7 % for step 16 after it; steps 2 and 4 backwards are 1-4 % slower: profiles/r03_small_experiments.txt)
     const int xtiles = (g.W + TX - 1) / TX;
     const int ntiles = xtiles * nbands * S;
     int v = xcd_tile(xgroup, xrot);
     if (v >= ntiles) return;                       // padding of the last groups
-    if (S == 1) v = ntiles - 1 - v;
+    if (S == 1 || S == 8) v = ntiles - 1 - v;
     const int x0 = (v % xtiles) * TX;
     const int band = (v / xtiles) % nbands;
     const int rv = v / (xtiles * nbands);          // row residue (relative to g.yb) this workgroup owns
