@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(
     const int wig = __builtin_amdgcn_readfirstlane((t % TX) >> 6);  // wave index inside its row group
     // tile order v = (residue, band, x tile), x fastest.  Step 1 walks the frame bottom-up: what the temporal launch wrote last is
     // still in the 256 MB Infinity Cache when it is read first (-4.5 % for that launch).  Later steps sweep the frame once per row
-    // residue; of the 16 direction patterns tried for them, only "step 8 backwards too" measured better than all forwards (-1.5 to
+    // residue; of the six direction patterns tried for them, only "step 8 backwards too" measured better than all forwards (-1.5 to
     // -3 % for that launch, -0.7 % for step 16 after it; steps 2 and 4 backwards are 1-4 % slower: profiles/r03_small_experiments.txt)
     const int xtiles = (g.W + TX - 1) / TX;
     const int ntiles = xtiles * nbands * S;
