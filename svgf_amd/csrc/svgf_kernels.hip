@@ -422,10 +422,13 @@ __global__ __launch_bounds__(kBX* kBY) void moments3x3_shfl_kernel(Geo g, Moment
 // Steady state inside the frame driver: the temporal launch already copied every pixel with history >= 4 and told this launch where
 // the young ones are: the LIST (indices appended wave by wave) and, for a 64-pixel segment whose pixels are ALL young, one FLAG.
 // Both are served by moments_group8, eight pixels per wave-pass.  List waves take eight consecutive entries per pass.  A scan
-// workgroup reads 256 flags (segment s belongs to workgroup s mod scan_blocks: a row of flagged segments spreads over as many
-// workgroups), shares the four ballots through LDS, and its four waves split every flagged segment between them: two passes
-// each instead of one wave's fourteen dependent rounds.  Scan workgroups come first in the grid: theirs are the longer chains.
-// (Bench pan, ~28 000 listed pixels + ~180 flagged segments per 4K frame: 0.051 -> 0.03x ms; nothing young: 0.0065 ms as before.)
+// workgroup reads 256 flags (segment s belongs to scan slot s mod (scan_blocks / 2): a row of flagged segments spreads over as many
+// slots), shares the four ballots through LDS, and the eight waves of the slot's TWO workgroups take one eighth of every flagged
+// segment each: one pass instead of one wave's fourteen dependent rounds (one workgroup per slot, two passes per wave: +0.004 ms
+// under the bench pan).  Scan workgroups come first in the grid: theirs are the longer chains.
+// (Bench pan, ~28 000 listed pixels + ~360 flagged segments per 4K frame: 0.051 -> 0.034 ms; nothing young: 0.0069 ms.  By parts,
+// tools/pan_moments_ab.sh: an empty launch 0.0069, the list alone 0.025, the flagged segments alone 0.029, a pass ~0.004 ms.)
+constexpr int kScanSplit = 2;
 template <int ST>
 __global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a, int scan_blocks) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -439,11 +442,14 @@ __global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a
         }
         return;
     }
+    constexpr int F = kScanSplit;                   // workgroups that share the flags of one scan slot: each takes 8 / F octants of a flagged segment
+    const int part = (int)blockIdx.x % F, bid = (int)blockIdx.x / F;
+    scan_blocks /= F;
     __shared__ unsigned long long masks[4];
     const int nseg = (g.W + kBX - 1) / kBX;
     const int first = (g.yb - g.y0) * nseg, last = (g.ye - g.y0) * nseg;             // flag range of the launch rows
-    for (int base = first; base + (int)blockIdx.x < last; base += scan_blocks * 256) {   // (uniform over the workgroup)
-        const int sidx = base + (w * 64 + lane) * scan_blocks + (int)blockIdx.x;
+    for (int base = first; base + bid < last; base += scan_blocks * 256) {   // (uniform over the workgroup)
+        const int sidx = base + (w * 64 + lane) * scan_blocks + bid;
         const unsigned long long m = __ballot(sidx < last && a.young_flags[sidx] != 0);
         if (lane == 0) masks[w] = m;
         __syncthreads();
@@ -453,9 +459,9 @@ __global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a
             while (mm) {
                 const int bit = __builtin_ctzll(mm);
                 mm &= mm - 1;
-                const int seg = base + (ww * 64 + bit) * scan_blocks + (int)blockIdx.x, yl = seg / nseg;
+                const int seg = base + (ww * 64 + bit) * scan_blocks + bid, yl = seg / nseg;
 #pragma unroll 1
-                for (int o = w; o < 8; o += 4) {                                      // this wave's two eighths of the segment
+                for (int o = part * (8 / F) + w; o < (part + 1) * (8 / F); o += 4) {     // this wave's eighth(s) of the segment
                     const int x = (seg % nseg) * kBX + o * 8 + (lane >> 3);
                     moments_group8<ST>(g, a, x < g.W, (uint32_t)(yl * g.W + (x < g.W ? x : 0)));
                 }
@@ -933,6 +939,7 @@ hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, bool 
         int scan = (nsegs + 255) / 256;                            // >= one flag per lane and load ...
         if (scan > 4 * num_cus()) scan = 4 * num_cus();            // ... on at most one resident round
         const int walk = std::min(4 * num_cus(), std::max(1, nsegs / 16));   // the list holds at most 63 pixels per segment
+        scan *= kScanSplit;
         if (storage == 0) moments_young_kernel<0><<<scan + walk, 256, 0, s>>>(g, a, scan);
         else moments_young_kernel<1><<<scan + walk, 256, 0, s>>>(g, a, scan);
         return hipGetLastError();
