@@ -66,6 +66,7 @@ def main(tag):
         (f"{tag}_small_experiments.txt", "the other `tools/abn.sh` blocks of the round (restructured kernel vs round 2's, exponent bases per workgroup, one-round prologue, the young-pixel moments launch and its counters)"),
         (f"{tag}_repeat_suite_prefix.txt", "`tools/repeat_suite_prefix.py 200`: the tests around the spot where two round-2 suite runs hung, 200 times in one process"),
         (f"{tag}_pytest_gpu.txt", "summary line of `pytest tests -q -m gpu` in the same call as the bench lines"),
+        (f"{tag}_pytest_gpu_soak.txt", "five more full `pytest tests -q -m gpu` runs in one call at the final sources (the round-2 suite abort: not seen)"),
         (f"{tag}_parity_report.json", "`tests/test_gpu_round2.py::test_parity_report`: max / mean error per stage against the oracle, mask mismatch counts"),
     ]
     for name, what in files:
