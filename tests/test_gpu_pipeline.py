@@ -183,3 +183,41 @@ def test_stage_timing_with_two_frames_in_flight(G):
     _, _, t = _run(G, seq, "f32", 2, timing=True)
     ms, n = t
     assert n == 6 and all(0.0 < v < 50.0 for v in ms[:7]), (ms, n)
+
+
+def test_stream_change_and_destruction_with_a_frame_in_flight(G):
+    """svgf_set_stream while a frame's tail is on the side stream (the frame is ordered on the NEW stream), and svgf_destroy with one
+    in flight (waits for both streams)."""
+    import torch
+    from svgf_amd import filter as F
+    seq = frames(384, 216, 6, mv=(1.0, 0.5))
+    want, _, _ = _run(G, seq, "f32", 1)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    d = F.Denoiser(384, 216, F.Params(storage="f32", steps=5), stream=s1.cuda_stream)
+    d.set_frames_in_flight(2)
+    gbs = [G.gb_dev(f) for f in seq]
+    rads = [G.dev(f["radiance"]) for f in seq]
+    torch.cuda.synchronize()
+    got, waiting, cur = [], None, s1
+    for k in range(len(seq)):
+        if k == 3:
+            s2.wait_stream(s1)                           # what the caller itself enqueued on the old stream ...
+            d.set_stream(s2.cuda_stream)                 # ... and the frame in flight is ordered on the new one by the library
+            cur = s2
+            with torch.cuda.stream(cur):
+                got.append(waiting.clone())
+            waiting = None
+        v = d.Render(rads[k], gbs[k], gbs[k - 1] if k else None)
+        with torch.cuda.stream(cur):
+            if waiting is not None:
+                got.append(waiting.clone())
+        waiting = v
+    d.flush()
+    with torch.cuda.stream(cur):
+        got.append(waiting.clone())
+    torch.cuda.synchronize()
+    for k, (x, y) in enumerate(zip(got, want)):
+        assert np.array_equal(G.host(x).view(np.uint8), y.view(np.uint8)), f"frame {k}"
+    d.Render(rads[0], gbs[0], gbs[1])                    # a frame in flight ...
+    d.close()                                            # ... at destruction
+    torch.cuda.synchronize()
