@@ -270,7 +270,7 @@ def timing_fields(r):
                            "HIP events (the stage times); stage_sum_ms is the mean of those frames' stage times; one more window without events gives the overhead"}
 
 
-KERNEL_SOURCES = ("svgf_kernels.hip", "svgf_api.hip", "svgf_kernels.h", "svgf_ctx.h", "svgf_device.h", "svgf_atrous_taps.h", "svgf_atrous_lds.h", "svgf_atrous_fused.h")
+KERNEL_SOURCES = ("svgf_kernels.hip", "svgf_api.hip", "svgf_kernels.h", "svgf_ctx.h", "svgf_device.h", "svgf_atrous_taps.h", "svgf_atrous_lds.h", "svgf_atrous_fused.h", "svgf_moments_lds.h")
 
 
 def kernel_source_sha():

@@ -80,19 +80,21 @@ hipEvent_t take_event(svgf_ctx* c) {
 }
 
 int alloc_flags(svgf_ctx* c) {
-    if (c->young_list && c->young_count && c->young_flags) return SVGF_OK;
-    // all three or none: a failed allocation leaves nothing behind that a later call would mistake for a complete set
+    if (c->young_list && c->young_count && c->young_flags && c->nan_list) return SVGF_OK;
+    // all four or none: a failed allocation leaves nothing behind that a later call would mistake for a complete set
     auto drop = [&]() {
         if (c->young_list) (void)hipFree(c->young_list);
         if (c->young_count) (void)hipFree(c->young_count);
         if (c->young_flags) (void)hipFree(c->young_flags);
-        c->young_list = nullptr; c->young_count = nullptr; c->young_flags = nullptr;
+        if (c->nan_list) (void)hipFree(c->nan_list);
+        c->young_list = nullptr; c->young_count = nullptr; c->young_flags = nullptr; c->nan_list = nullptr;
     };
     drop();
     hipError_t e = hipMalloc((void**)&c->young_list, (size_t)c->strip.rows * c->W * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&c->young_count, 2 * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMemsetAsync(c->young_count, 0, 2 * sizeof(unsigned), c->stream);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->young_count, 4 * sizeof(unsigned));          // {young[2], non-finite[2]} (svgf_kernels.h: kNanCounter)
+    if (e == hipSuccess) e = hipMemsetAsync(c->young_count, 0, 4 * sizeof(unsigned), c->stream);
     if (e == hipSuccess) e = hipMalloc((void**)&c->young_flags, (size_t)c->strip.rows * ((c->W + 63) / 64));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->nan_list, (size_t)svgf::kNanListCap * sizeof(uint32_t));
     if (e != hipSuccess) { drop(); return hip_fail(c, e, "alloc_flags"); }
     c->young_phase = 0;
     c->young_pending = false;
@@ -158,7 +160,8 @@ void free_state(svgf_ctx* c) {
     if (c->young_list) (void)hipFree(c->young_list);
     if (c->young_count) (void)hipFree(c->young_count);
     if (c->young_flags) (void)hipFree(c->young_flags);
-    c->young_list = nullptr; c->young_count = nullptr; c->young_flags = nullptr;
+    if (c->nan_list) (void)hipFree(c->nan_list);
+    c->young_list = nullptr; c->young_count = nullptr; c->young_flags = nullptr; c->nan_list = nullptr;
     c->have_state = false;
 }
 
@@ -203,8 +206,10 @@ int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, vo
     if (rc != SVGF_OK) return rc;
     if (prev_colour == colour_out || hist_prev == hist_cur || moments_prev == moments_cur)
         return fail(c, SVGF_ERR_INVALID, "svgf_temporal: previous and current state planes must differ (App. B #1)");
-    if (passthrough_out && c->young_pending)        // the list of an earlier launch was never consumed (an error in between): start it again
+    if (passthrough_out && c->young_pending) {      // the lists of an earlier launch were never consumed (an error in between): start them again
         SVGF_HIP(c, hipMemsetAsync(c->young_count + c->young_phase, 0, sizeof(unsigned), c->stream));
+        SVGF_HIP(c, hipMemsetAsync(c->young_count + svgf::kNanCounter + c->young_phase, 0, sizeof(unsigned), c->stream));
+    }
     svgf::TemporalArgs a{prev_colour, radiance, colour_out,
                          (const float4*)cur->motion, (const uint2*)cur->normal, (const uint2*)cur->uv,
                          (const float4*)prev->motion, (const uint2*)prev->normal, (const uint2*)prev->uv,
@@ -214,7 +219,8 @@ int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, vo
                          passthrough_out ? c->young_count + (c->young_phase ^ 1) : nullptr, passthrough_out ? c->young_flags : nullptr, sparse_colour, c->p.phi_normal > 0.0f, c->halo_violations,
                          std::max(c->vy0, c->strip.y0) - c->strip.y0, std::min(c->vy1, c->strip.y0 + c->strip.rows) - c->strip.y0, (uint4*)guide_out,
                          (const uint4*)guide_prev,
-                         c->strip.y0, c->strip.y0 + c->strip.rows};      // the guide texels of every row held (a strip runs the stage on fewer)
+                         c->strip.y0, c->strip.y0 + c->strip.rows,       // the guide texels of every row held (a strip runs the stage on fewer)
+                         passthrough_out ? c->nan_list : nullptr};
     if (c->re <= c->rb) return SVGF_OK;             // nothing to launch: the young list and its counters stay as they are
     SVGF_HIP(c, svgf::launch_temporal(geo_of(c), c->p.storage, a, c->stream));
     if (passthrough_out) c->young_pending = true;
@@ -230,7 +236,8 @@ int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments
     if (rc != SVGF_OK) return rc;
     svgf::MomentsArgs a{colour, out, moments, (const float4*)g->motion, (const uint2*)g->normal, hist,
                         c->p.phi_colour, c->p.phi_normal, c->p.moments_radius, cold_only, dense, sparse_colour,
-                        cold_only ? c->young_list : nullptr, cold_only ? c->young_count + c->young_phase : nullptr, cold_only ? c->young_flags : nullptr};
+                        cold_only ? c->young_list : nullptr, cold_only ? c->young_count + c->young_phase : nullptr, cold_only ? c->young_flags : nullptr,
+                        cold_only ? c->nan_list : nullptr, c->p.variant == SVGF_VARIANT_LDS_GENERAL};
     if (c->re <= c->rb) {
         // No moments rows.  If the temporal launch of this frame did run (young_pending), its list is dropped: the counter pair still
         // has to turn over, because that launch zeroed the OTHER counter for the next frame.
@@ -489,7 +496,7 @@ int svgf_moments(svgf_ctx* c, const void* colour, void* out, const void* moments
     if (!c) return SVGF_ERR_INVALID;
     DeviceGuard dg(c->device);
     // stage call: history is unknown to the host, so the per-pixel kernel — unless the caller asks for the LDS variant
-    return moments_impl(c, colour, out, moments, g, hist, 0, c->p.variant == SVGF_VARIANT_LDS, 0);
+    return moments_impl(c, colour, out, moments, g, hist, 0, c->p.variant == SVGF_VARIANT_LDS || c->p.variant == SVGF_VARIANT_LDS_GENERAL, 0);
 }
 
 int svgf_temporal_moments(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, void* filter_out,

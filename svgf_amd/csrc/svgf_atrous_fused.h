@@ -47,13 +47,14 @@ constexpr int kFRB = 12;                        // ring B rows: 10 read by itera
 constexpr int kFLag = 5;                        // steps by which iteration 1 trails iteration 0
 constexpr int kFPrefetch = 2;                   // input rows are requested this many steps before the step whose end commits them (1, 2: equal; 3: slower)
 constexpr size_t kFusedLds = (size_t)16 * (kFRA * kFWA + kFRB * kFT0) + (size_t)8 * 2 * (kFRA * kFWA + kFRB * kFT0) + (size_t)4 * kFRB * kFT0 +
-                             (size_t)4 * 2 * (kFRA + kFRB);
+                             (size_t)4 * (2 * (kFRA + kFRB) + 1);
 
-template <int ST>
-__global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup, int xrot) {
+// One workgroup streaming down its band (both iterations).  EXACT = false is the product path; -> (per wave) "one of my outputs came out
+// NaN", which makes the kernel run the band again with EXACT = true — see atrous_band in svgf_atrous_lds.h.
+template <int ST, bool EXACT>
+__device__ __forceinline__ bool fused_band(const Geo& g, const AtrousArgs& a, char* smem, int x0, int band, int j0, int j1, int nrows) {
     constexpr int CB = ST == 0 ? 16 : 8;
     constexpr int TD = 3;                          // tap pipeline depth (99 registers; LDS allows two workgroups per CU = four waves per SIMD)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* const aA = (f32x4*)smem;                                  // ring A: iteration 0's input
     f32x4* const bA = aA + kFRA * kFWA;                              // ring B: iteration 0's output = iteration 1's input
     f32x2* const aL = (f32x2*)(bA + kFRB * kFT0);
@@ -69,19 +70,6 @@ __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArg
     const int rg = __builtin_amdgcn_readfirstlane((t >> 7) & 1);                 // row of the step's pair
     const int wig = __builtin_amdgcn_readfirstlane((t >> 6) & 1);                // 64-column half of the row
 
-    // tile order: x tile fastest, XCD-aware groups (svgf_device.h); the frame is walked bottom-up: what the temporal launch wrote
-    // last is still in the Infinity Cache when it is read first
-    const int xtiles = (g.W + kFT1 - 1) / kFT1;
-    const int ntiles = xtiles * nbands;
-    int v = xcd_tile(xgroup, xrot);
-    if (v >= ntiles) return;
-    v = ntiles - 1 - v;
-    const int x0 = (v % xtiles) * kFT1;
-    const int band = v / xtiles;
-    const int nrows = g.ye - g.yb;                 // iteration-1 rows
-    const int j0 = band * band_rows;
-    if (j0 >= nrows) return;
-    const int j1 = min(nrows, j0 + band_rows);
     const int n1 = (j1 - j0 + 1) >> 1;             // iteration-1 steps; iteration 0 runs n1 + 4 steps (rows j0-4 .. j1+3), the loop n1 + 5
     const int K0 = n1 + 4;
 
@@ -96,6 +84,7 @@ __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArg
         ref01 = __builtin_amdgcn_readfirstlane(n.x); refz = __builtin_amdgcn_readfirstlane(n.y & 0xffffu);
     }
     if (t < 2 * (kFRA + kFRB)) flagA[t] = 0u;
+    unsigned long long nan_out = 0ull;             // lanes whose output held a NaN (EXACT = false)
     const float phi_n = a.phi_normal;              // != 0 (launcher)
     const float inv_phi_c = hw_rcp(a.phi_colour) * kLog2e;     // log2(e) / PhiColour
 
@@ -109,8 +98,8 @@ __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArg
         const int hx = lane < 2 ? gx - 2 : gx + kFT0 - 2;         // lanes 0,1: columns x0-6, x0-5; lanes 2,3: x0+124, x0+125
         const int hli = lane < 2 ? lane : kFT0 + lane;
         const bool own_ok = gx >= 0 && gx < g.W, halo_ok = has_halo && hx >= 0 && hx < g.W;
-        const unsigned vo_c = own_ok ? (unsigned)gx * CB : kOob, vo_m = own_ok ? (unsigned)gx * 16u + m_off : kOob, vo_n = own_ok ? ((unsigned)gx << n_shift) + n_off : kOob;
-        const unsigned vh_c = halo_ok ? (unsigned)hx * CB : kOob, vh_m = halo_ok ? (unsigned)hx * 16u + m_off : kOob, vh_n = halo_ok ? ((unsigned)hx << n_shift) + n_off : kOob;
+        const unsigned vo_c = own_ok ? (unsigned)gx * CB : kOob, vo_m = own_ok ? (unsigned)gx * 16u : kOob, vo_n = own_ok ? ((unsigned)gx << n_shift) + n_off : kOob;
+        const unsigned vh_c = halo_ok ? (unsigned)hx * CB : kOob, vh_m = halo_ok ? (unsigned)hx * 16u : kOob, vh_n = halo_ok ? ((unsigned)hx << n_shift) + n_off : kOob;
         // the feedback texel belongs to the tile whose iteration-1 columns hold it
         const unsigned vo_fb = (own_ok && col >= kFReach1 && col < kFT0 - kFReach1) ? (unsigned)gx * CB : kOob;
         // ... and to the band whose iteration-1 rows hold it; the first / last band also own the 4 rows beyond the launch rows
@@ -124,15 +113,14 @@ __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArg
             const bool rok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows;
             const int srow = rok ? yl * g.W : 0;
             const PlaneRsrc rs = plane_rsrc(a, npx, CB, n_shift, rok);
-            raw_load<ST, true>(st.o, rs, vo_c, vo_m, vo_n, srow, n_shift);
-            if (halo_wave) raw_load<ST, false>(st.h, rs, vh_c, vh_m, vh_n, srow, n_shift);
+            raw_load<ST, true>(st.o, rs, vo_c, vo_m, vo_n, srow, n_shift, m_off);
+            if (halo_wave) raw_load<ST, false>(st.h, rs, vh_c, vh_m, vh_n, srow, n_shift, m_off);
         };
         auto commit = [&](int sl, const Staged& st) __attribute__((always_inline)) {
             int so = sl + rg; so = so >= kFRA ? so - kFRA : so;
-            bool differs = commit_px<ST, true>(st.o, aA, aL, aN, so * kFWA + oli, ref01, refz);
-            if (halo_wave) { if (has_halo) differs = commit_px<ST, false>(st.h, aA, aL, aN, so * kFWA + hli, ref01, refz) || differs; }
-            const bool wave_differs = __ballot(differs) != 0ull;
-            if (lane == 0) flagA[so * 2 + wig] = wave_differs ? 1u : 0u;
+            unsigned long long differs = commit_px<ST, true>(st.o, aA, aL, aN, so * kFWA + oli, ref01, refz);
+            if (halo_wave) differs |= commit_px<ST, false>(st.h, aA, aL, aN, so * kFWA + hli, ref01, refz, has_halo);
+            if (lane == 0) flagA[so * 2 + wig] = differs != 0ull ? kFlagNormal : 0u;
         };
         float dq0 = 0.f, dq1 = 0.f;
         __syncthreads();                                          // the flags are zero
@@ -165,21 +153,23 @@ __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArg
                 const TapCentre c = centre_setup<1>(aA[ci], aL[ci], aN[ci], dq0, inv_phi_c);
                 sky = c.sky;
                 const bool wave_has_surface = !(SVGF_FUSED_DIAG & 1) && wave_any(!sky);
-                const bool uniform = !a.no_fastpath && __ballot(lane < 2 * kFRA && flagA[lane < 2 * kFRA ? lane : 0] != 0u) == 0ull;
-                o = filter_px<1, TD>(aA, aL, aN, rowbase, c, phi_n, wave_has_surface, uniform);
+                const bool uniform = !EXACT && !a.no_fastpath && !wave_any(lane < 2 * kFRA && flagA[lane < 2 * kFRA ? lane : 0] != 0u);
+                o = filter_px<1, TD, EXACT>(aA, aL, aN, rowbase, c, phi_n, wave_has_surface, uniform);
+                if constexpr (!EXACT) nan_out |= lanes_where(__builtin_isunordered(o.x, o.w));
                 // ring B record: the texel iteration 1 would load from the plane iteration 0 stores (:618 unclamped, in the storage type;
-                // :586 imageLoad clamps)
+                // :586 imageLoad clamps — a NaN stays NaN, svgf_device.h)
                 float4 q = o;
                 if constexpr (ST == 1) { const float2 lo = unpack_h2(pack_h2(o.x, o.y)), hi = unpack_h2(pack_h2(o.z, o.w)); q = make_float4(lo.x, lo.y, hi.x, hi.y); }
-                q = make_float4(med01(q.x), med01(q.y), med01(q.z), med01(q.w));
+                const f32x2 q01 = clamp01_pk((f32x2){q.x, q.y}), q23 = clamp01_pk((f32x2){q.z, q.w});
+                q = make_float4(q01.x, q01.y, q23.x, q23.y);
                 const int bi = slotB * kFT0 + col;
                 bA[bi] = (f32x4){q.x, q.y, q.z, q.w};
                 bL[bi] = (f32x2){lum_exact(q.x, q.y, q.z), sky ? kSkyZ : c.lz.y};
                 bN[bi] = (f32x2){__uint_as_float(c.n01), c.nz};
                 bD[bi] = dq0;
                 const bool differs = !sky && (c.n01 != ref01 || __float_as_uint(c.nz) != refz_f);
-                const bool wave_differs = __ballot(differs) != 0ull;
-                if (lane == 0) flagB[slotB * 2 + wig] = wave_differs ? 1u : 0u;
+                const bool wave_differs = wave_any(differs);
+                if (lane == 0) flagB[slotB * 2 + wig] = wave_differs ? kFlagNormal : 0u;
             }
             lds_barrier();                                        // every wave is done reading ring A's two oldest rows
             if (more && !(SVGF_FUSED_DIAG & 4)) {
@@ -227,8 +217,9 @@ __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArg
                 const int ci = rowbase[2] + kFReach1;
                 const TapCentre c = centre_setup<2>(bA[ci], bL[ci], bN[ci], bD[ci], inv_phi_c);
                 const bool wave_has_surface = !(SVGF_FUSED_DIAG & 2) && wave_any(!c.sky);
-                const bool uniform = !a.no_fastpath && __ballot(lane < 2 * kFRB && flagB[lane < 2 * kFRB ? lane : 0] != 0u) == 0ull;
-                o = filter_px<2, TD>(bA, bL, bN, rowbase, c, phi_n, wave_has_surface, uniform);
+                const bool uniform = !EXACT && !a.no_fastpath && !wave_any(lane < 2 * kFRB && flagB[lane < 2 * kFRB ? lane : 0] != 0u);
+                o = filter_px<2, TD, EXACT>(bA, bL, bN, rowbase, c, phi_n, wave_has_surface, uniform);
+                if constexpr (!EXACT) nan_out |= lanes_where(__builtin_isunordered(o.x, o.w));
             }
             lds_barrier();
             if (active) {
@@ -249,6 +240,34 @@ __global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArg
             lds_barrier();
         }
     }
+    return nan_out != 0ull;
+}
+
+template <int ST>
+__global__ __launch_bounds__(512, 4) void atrous_fused12_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup, int xrot) {
+    keep_nan_in_clamps();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // tile order: x tile fastest, XCD-aware groups (svgf_device.h); the frame is walked bottom-up: what the temporal launch wrote
+    // last is still in the Infinity Cache when it is read first
+    const int xtiles = (g.W + kFT1 - 1) / kFT1;
+    const int ntiles = xtiles * nbands;
+    int v = xcd_tile(xgroup, xrot);
+    if (v >= ntiles) return;
+    v = ntiles - 1 - v;
+    const int x0 = (v % xtiles) * kFT1;
+    const int band = v / xtiles;
+    const int nrows = g.ye - g.yb;                 // iteration-1 rows
+    const int j0 = band * band_rows;
+    if (j0 >= nrows) return;
+    const int j1 = min(nrows, j0 + band_rows);
+    uint32_t* const nan_word = (uint32_t*)(smem + kFusedLds) - 1;    // the workgroup's "an output was NaN" word (last word of the allocation)
+    if (threadIdx.x == 0) *nan_word = 0u;          // (ordered before the waves' stores below by the band's barriers)
+    const bool nan_wave = fused_band<ST, false>(g, a, smem, x0, band, j0, j1, nrows);
+    if (nan_wave && (threadIdx.x & 63) == 0) *nan_word = 1u;
+    __syncthreads();
+    if (*nan_word == 0u) return;                   // every frame without a NaN
+    __syncthreads();
+    (void)fused_band<ST, true>(g, a, smem, x0, band, j0, j1, nrows);
 }
 
 // The launch rows of Geo are ITERATION 1's rows; iteration 0 runs on them and kFReach1 rows beyond on either side (inside the

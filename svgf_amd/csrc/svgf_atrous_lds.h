@@ -28,44 +28,40 @@ constexpr int kTapDepth = 3;             // LDS reads run this many taps ahead o
 // workgroups per CU anyway.
 constexpr int atrous_waves(int S) { return S <= 8 ? 5 : 4; }
 
-template <int ST, int S>
-__global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup, int xrot) {
+struct AtrousLds { f32x4* recA; f32x2* recL; f32x2* recN; uint32_t* nflag; uint32_t* nref; };
+
+// One workgroup streaming down its band: decimated rows [j0, j1) of the residue whose row j is global row ybase + S*j, columns
+// [x0, x0 + kTX).  EXACT = false is the product path.  -> (per wave) "one of my outputs came out NaN".
+//
+// NaN.  The reference's clamp keeps a NaN texel (svgf_device.h), and so do the records here.  The reference's weight then stays FINITE —
+// `max(weightLillum, 0.0)` in Filter.cuh:424 is CUDA's fmax, which drops the NaN — and the NaN reaches the sums through the channels
+// that hold it (:608); a sky centre is copied whatever its taps hold (:554-558).  The fast taps fold |dl| / phi_l into one FMA of the
+// exponent: a NaN luminance makes their weight, and with it ALL FOUR channels of the output, NaN (and copy a sky centre through
+// weights that are exactly 0 — but 0 x NaN is not 0).  So any NaN in a pixel's window shows in its fast-path output — as a NaN in
+// every channel, or (a NaN variance only) in the variance channel — and costs the product path ONE compare per output.  The
+// kernel then runs the band again with EXACT = true: the general taps in the form that evaluates the luminance term as the
+// reference does (taps24<.., kTapsNaN>) and a select for the sky centres.  A workgroup whose texels are all finite never gets there.
+template <int ST, int S, bool EXACT>
+__device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, const AtrousLds& L, int x0, int j0, int j1, int ybase) {
     constexpr int TX = kTX;
     constexpr int WL = TX + 4 * S;                 // staged columns per ring row
     constexpr int CB = ST == 0 ? 16 : 8;           // bytes per colour texel
     constexpr int NH = 4 * S;                      // halo pixels per ring row: all staged by wave 0 of the row group (lanes 0..NH-1);
                                                    // spread over the waves, every wave paid the halo's ~20 VALU + 3 loads for a few lanes
     static_assert(NH >= 1 && NH <= 64, "halo does not fit one wave");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* recA = (f32x4*)smem;
-    f32x2* recL = (f32x2*)(recA + kRing * WL);     // 8-byte records, contiguous: conflict-free ds_read_b64 (64 banks)
-    f32x2* recN = recL + kRing * WL;
-    uint32_t* nflag = (uint32_t*)(recN + kRing * WL);              // [kRing][8]
-    uint32_t* nref = nflag + kRing * 8;                            // {(nx,ny) bits, nz bits}
+    f32x4* const recA = L.recA;
+    f32x2* const recL = L.recL;
+    f32x2* const recN = L.recN;
+    uint32_t* const nflag = L.nflag;
 
-    const int t = threadIdx.x;
+    int t = threadIdx.x;
+    // (the second pass derives its per-lane constants from a thread index the compiler cannot identify with the first pass's: shared
+    // between the two passes they would stay live through the product loop, which has no register to spare — it spilled)
+    if constexpr (EXACT) asm volatile("" : "+v"(t));
     const int lane = t & 63;
     const int col = t % TX;
     const int rg = __builtin_amdgcn_readfirstlane(t / TX);          // row group: wave-uniform -> scalar
     const int wig = __builtin_amdgcn_readfirstlane((t % TX) >> 6);  // wave index inside its row group
-    // tile order v = (residue, band, x tile), x fastest.  Step 1 walks the frame bottom-up: what the temporal launch wrote last is
-    // still in the 256 MB Infinity Cache when it is read first (-4.5 % for that launch).  Later steps sweep the frame once per row
-    // residue; of the six direction patterns tried for them, only "step 8 backwards too" measured better than all forwards (-1.5 to
-    // -3 % for that launch, -0.7 % for step 16 after it; steps 2 and 4 backwards are 1-4 % slower: profiles/r03_small_experiments.txt)
-    const int xtiles = (g.W + TX - 1) / TX;
-    const int ntiles = xtiles * nbands * S;
-    int v = xcd_tile(xgroup, xrot);
-    if (v >= ntiles) return;                       // padding of the last groups
-    if (S == 1 || S == 8) v = ntiles - 1 - v;
-    const int x0 = (v % xtiles) * TX;
-    const int band = (v / xtiles) % nbands;
-    const int rv = v / (xtiles * nbands);          // row residue (relative to g.yb) this workgroup owns
-    const int nrows = g.ye - g.yb;
-    const int nj = (nrows - rv + S - 1) / S;       // decimated rows of this residue
-    const int j0 = band * band_rows;
-    if (j0 >= nj) return;
-    const int j1 = min(nj, j0 + band_rows);
-    const int ybase = g.yb + rv;                   // global row of decimated index j: ybase + S*j
 
     // per-lane constants
     const int gx = x0 + col;                       // own column
@@ -76,8 +72,8 @@ __global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(
     const int hli = (lane < 2 * S) ? lane : TX + lane;
     const bool own_ok = gx < g.W, halo_ok = has_halo && hx >= 0 && hx < g.W;
     const GuideSel gs(a.guide != nullptr);
-    const unsigned vo_c = own_ok ? (unsigned)gx * CB : kOob, vo_m = own_ok ? (unsigned)gx * 16u + gs.m_off : kOob, vo_n = own_ok ? ((unsigned)gx << gs.n_shift) + gs.n_off : kOob;
-    const unsigned vh_c = halo_ok ? (unsigned)hx * CB : kOob, vh_m = halo_ok ? (unsigned)hx * 16u + gs.m_off : kOob, vh_n = halo_ok ? ((unsigned)hx << gs.n_shift) + gs.n_off : kOob;
+    const unsigned vo_c = own_ok ? (unsigned)gx * CB : kOob, vo_m = own_ok ? (unsigned)gx * 16u : kOob, vo_n = own_ok ? ((unsigned)gx << gs.n_shift) + gs.n_off : kOob;
+    const unsigned vh_c = halo_ok ? (unsigned)hx * CB : kOob, vh_m = halo_ok ? (unsigned)hx * 16u : kOob, vh_n = halo_ok ? ((unsigned)hx << gs.n_shift) + gs.n_off : kOob;
     const unsigned npx = (unsigned)g.rows * (unsigned)g.W;
 
     // A thread's share of one staged step: its own pixel of row (jn + rg), and a halo pixel on lanes < NH.  Buffer resources are
@@ -88,16 +84,15 @@ __global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(
         const bool rok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows;
         const int srow = rok ? yl * g.W : 0;
         const PlaneRsrc rs = plane_rsrc(a, npx, CB, gs.n_shift, rok);
-        raw_load<ST, true>(st.o, rs, vo_c, vo_m, vo_n, srow, gs.n_shift);
-        if (halo_wave) raw_load<ST, false>(st.h, rs, vh_c, vh_m, vh_n, srow, gs.n_shift);
+        raw_load<ST, true>(st.o, rs, vo_c, vo_m, vo_n, srow, gs.n_shift, gs.m_off);
+        if (halo_wave) raw_load<ST, false>(st.h, rs, vh_c, vh_m, vh_n, srow, gs.n_shift, gs.m_off);
     };
     uint32_t ref01 = 0, refz = 0;
     auto commit = [&](int sl, const Staged& st) __attribute__((always_inline)) {
         int so = sl + rg; so = so >= kRing ? so - kRing : so;                           // scalar
-        bool differs = commit_px<ST, true>(st.o, recA, recL, recN, so * WL + oli, ref01, refz);
-        if (halo_wave) { if (has_halo) differs = commit_px<ST, false>(st.h, recA, recL, recN, so * WL + hli, ref01, refz) || differs; }
-        const bool wave_differs = wave_any(differs);
-        if (lane == 0) nflag[so * 8 + wig] = wave_differs ? 1u : 0u;                    // a ring slot is always staged by the same waves
+        unsigned long long differs = commit_px<ST, true>(st.o, recA, recL, recN, so * WL + oli, ref01, refz);
+        if (halo_wave) differs |= commit_px<ST, false>(st.h, recA, recL, recN, so * WL + hli, ref01, refz, has_halo);
+        if (lane == 0) nflag[so * 8 + wig] = differs != 0ull ? kFlagNormal : 0u;        // a ring slot is always staged by the same waves
     };
 
     // ddepth of this thread's next two centres (rows j+rg and two rows further).  A staged row becomes a centre two steps after it
@@ -113,9 +108,9 @@ __global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(
         Staged st;
         fetch(j0 - 2 + r, st);
         if (rr == 0) {
-            if (t == 0) { nref[0] = st.o.n.x; nref[1] = st.o.n.y & 0xffffu; }
+            if (t == 0) { L.nref[0] = st.o.n.x; L.nref[1] = st.o.n.y & 0xffffu; }
             __syncthreads();
-            ref01 = nref[0]; refz = nref[1];
+            ref01 = L.nref[0]; refz = L.nref[1];
         }
         commit(r, st);
         if (r == 2) dq0 = __uint_as_float(st.o.zd.y);
@@ -130,6 +125,7 @@ __global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(
 #pragma unroll
     for (int k = 0; k < 5; k++) ref_base.e[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ref_base.e[k])));
     int slot0 = 0;
+    unsigned long long nan_out = 0ull;             // lanes whose output held a NaN (EXACT = false)
     Staged cs;                                     // the rows the NEXT step needs: requested at the start of a step, committed at its end
     for (int j = j0; j < j1; j += kRS) {
         const bool more = (j + kRS) < j1;
@@ -143,8 +139,9 @@ __global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(
         const TapCentre c = centre_setup<S>(recA[ci], recL[ci], recN[ci], dq0, inv_phi_c);
         const bool sky = c.sky;
         const bool wave_has_surface = wave_any(!sky);
-        const bool uniform = !a.no_fastpath && !wave_any(lane < kRing * 8 && nflag[lane < kRing * 8 ? lane : 0] != 0u);
-        const float4 o = filter_px<S, kTapDepth>(recA, recL, recN, rowbase, c, phi_n, wave_has_surface, uniform, &ref_base);
+        const bool uniform = !EXACT && !a.no_fastpath && !wave_any(lane < kRing * 8 && nflag[lane < kRing * 8 ? lane : 0] != 0u);
+        const float4 o = filter_px<S, kTapDepth, EXACT>(recA, recL, recN, rowbase, c, phi_n, wave_has_surface, uniform, &ref_base);
+        if constexpr (!EXACT) nan_out |= lanes_where(__builtin_isunordered(o.x, o.w));
 
         // Output values now, their stores AFTER the ring refill: hipcc's vmcnt bookkeeping cannot tell that the rows committed
         // below were fetched long before this step's stores, so stores issued first would be waited for.
@@ -171,12 +168,52 @@ __global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(
             }
         }
     }
+    return nan_out != 0ull;
+}
+
+template <int ST, int S>
+__global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup, int xrot) {
+    keep_nan_in_clamps();
+    constexpr int WL = kTX + 4 * S;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    AtrousLds L;
+    L.recA = (f32x4*)smem;
+    L.recL = (f32x2*)(L.recA + kRing * WL);        // 8-byte records, contiguous: conflict-free ds_read_b64 (64 banks)
+    L.recN = L.recL + kRing * WL;
+    L.nflag = (uint32_t*)(L.recN + kRing * WL);    // [kRing][8]
+    L.nref = L.nflag + kRing * 8;                  // {(nx,ny) bits, nz bits}, then the workgroup's "an output was NaN" word
+    // tile order v = (residue, band, x tile), x fastest.  Step 1 walks the frame bottom-up: what the temporal launch wrote last is
+    // still in the 256 MB Infinity Cache when it is read first (-4.5 % for that launch).  Later steps sweep the frame once per row
+    // residue; of the six direction patterns tried for them, only "step 8 backwards too" measured better than all forwards (-1.5 to
+    // -3 % for that launch, -0.7 % for step 16 after it; steps 2 and 4 backwards are 1-4 % slower: profiles/r03_small_experiments.txt)
+    const int xtiles = (g.W + kTX - 1) / kTX;
+    const int ntiles = xtiles * nbands * S;
+    int v = xcd_tile(xgroup, xrot);
+    if (v >= ntiles) return;                       // padding of the last groups
+    if (S == 1 || S == 8) v = ntiles - 1 - v;
+    const int x0 = (v % xtiles) * kTX;
+    const int band = (v / xtiles) % nbands;
+    const int rv = v / (xtiles * nbands);          // row residue (relative to g.yb) this workgroup owns
+    const int nrows = g.ye - g.yb;
+    const int nj = (nrows - rv + S - 1) / S;       // decimated rows of this residue
+    const int j0 = band * band_rows;
+    if (j0 >= nj) return;
+    const int j1 = min(nj, j0 + band_rows);
+    const int ybase = g.yb + rv;                   // global row of decimated index j: ybase + S*j
+
+    if (threadIdx.x == 0) L.nref[2] = 0u;          // (ordered before the waves' stores below by the band's barriers)
+    const bool nan_wave = atrous_band<ST, S, false>(g, a, L, x0, j0, j1, ybase);
+    if (nan_wave && (threadIdx.x & 63) == 0) L.nref[2] = 1u;
+    __syncthreads();
+    if (L.nref[2] == 0u) return;                   // every frame without a NaN
+    __syncthreads();                               // (the band's prologue writes the flag words again)
+    (void)atrous_band<ST, S, true>(g, a, L, x0, j0, j1, ybase);
 }
 
 template <int ST, int S>
 hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     constexpr int WL = kTX + 4 * S;
-    constexpr size_t lds = (size_t)kRing * WL * kRecBytes + (kRing * 8 + 2) * sizeof(uint32_t);
+    constexpr size_t lds = (size_t)kRing * WL * kRecBytes + (kRing * 8 + 3) * sizeof(uint32_t);
     static std::atomic<unsigned long long> attr_done{0};
     if (hipError_t e = allow_dynamic_lds(atrous_lds_kernel<ST, S>, lds, attr_done); e != hipSuccess) return e;
     // Bands are sized so that (x tiles) x (S residues) x (bands) is FOUR times the resident slots of the chip (LDS: 160 KiB per CU;

@@ -49,11 +49,18 @@ __device__ __forceinline__ UniBase uni_base(uint32_t n01, float nz, float phi_n)
     return u;
 }
 
-template <int CS, int D, bool UNI>
+// MODE: kTapsGeneral, kTapsUniform (the uniform-normal path), or kTapsNaN — the general path in the form that treats a NaN the way
+// the reference does (a band that is run again because a NaN showed in its output, svgf_atrous_lds.h): a NaN luminance
+// difference counts as 0 — `max(weightLillum, 0.0)` in :424 is CUDA's fmax, which drops the NaN — so the weight stays finite and the
+// NaN reaches the sums only through the channels that hold it (:608); saturate(n.n') of a NaN is 0.  The other two paths fold
+// |dl| / phi_l into one FMA of the exponent, which makes the weight — and with it all four channels — NaN.
+constexpr int kTapsGeneral = 0, kTapsUniform = 1, kTapsNaN = 2;
+template <int CS, int D, int MODE>
 __device__ __forceinline__ void taps24(const f32x4* recA, const f32x2* recL, const f32x2* recN, const int (&rowbase)[5], const TapCentre& c, float phi_n,
                                        float& sw, f32x2& srg, f32x2& sbv, const UniBase* shared_base) {
     // shared_base: the workgroup's reference normal's values, computed once (every surface centre of a uniform wave carries exactly
     // those normal bits, so they are what uni_base(c.n01, c.nz) would give); null: per pixel
+    constexpr bool UNI = MODE == kTapsUniform;
     UniBase ub;
     if constexpr (UNI) ub = shared_base ? *shared_base : uni_base(c.n01, c.nz, phi_n);
     const float (&ebase)[5] = ub.e;
@@ -84,10 +91,13 @@ __device__ __forceinline__ void taps24(const f32x4* recA, const f32x2* recL, con
             e = ebase[kernel_class(axx, ayy)];
         } else {
             const f32x2 N = qN[t];
-            const float d = clamp01(fmaf(N.y, c.nz, dot2_h2(__float_as_uint(N.x), c.n01)));
+            float d = fmaf(N.y, c.nz, dot2_h2(__float_as_uint(N.x), c.n01));
+            if constexpr (MODE == kTapsNaN) d = clamp01_ref(d != d ? 0.0f : d);          // (the wave runs with keep_nan_in_clamps())
+            else d = clamp01(d);
             e = fmaf(hw_log2(d), phi_n, klog2(axx, ayy));
         }
-        e = fmaf(-fabsf(dlz.x), c.il, e);
+        if constexpr (MODE == kTapsNaN) e -= fmaxf(fabsf(dlz.x) * c.il, 0.0f);          // fmax(NaN, 0) = 0, :424
+        else e = fmaf(-fabsf(dlz.x), c.il, e);
         e = fmaf(-fabsf(dlz.y), c.iz[len_class(xx, yy)], e);
         const float w = hw_exp2(e);
         const f32x2 ww = {w, w * w};                                                     // weights of (b, variance): :604-608
@@ -99,15 +109,19 @@ __device__ __forceinline__ void taps24(const f32x4* recA, const f32x2* recL, con
 }
 
 // One pixel: taps + normalisation (:554-558,567-568,615).  `wave_has_surface` (a wave whose centres are all sky has nothing to
-// filter) and `uniform` are wave-uniform.
-template <int CS, int D>
+// filter) and `uniform` are wave-uniform.  EXACT: the band is run again because a NaN showed in its output (svgf_atrous_lds.h).
+template <int CS, int D, bool EXACT = false>
 __device__ __forceinline__ float4 filter_px(const f32x4* recA, const f32x2* recL, const f32x2* recN, const int (&rowbase)[5], const TapCentre& c, float phi_n,
                                             bool wave_has_surface, bool uniform, const UniBase* shared_base = nullptr) {
     float sw = 1.0f;                                                                     // :567
     f32x2 srg = {c.A.x, c.A.y}, sbv = {c.A.z, c.A.w};                                    // :568
     if (wave_has_surface) {
-        if (uniform) taps24<CS, D, true>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv, shared_base);
-        else taps24<CS, D, false>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv, nullptr);
+        if constexpr (EXACT) {
+            taps24<CS, D, kTapsNaN>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv, nullptr);
+            // a sky centre is copied (:554-558): its taps' weights are exactly 0, but 0 x NaN is not
+            if (c.sky) { sw = 1.0f; srg = (f32x2){c.A.x, c.A.y}; sbv = (f32x2){c.A.z, c.A.w}; }
+        } else if (uniform) taps24<CS, D, kTapsUniform>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv, shared_base);
+        else taps24<CS, D, kTapsGeneral>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv, nullptr);
     }
     const float inv = hw_rcp(sw);                                                        // sw >= 1 (a sky centre: exactly 1, and the sums are its colour)
     return make_float4(srg.x * inv, srg.y * inv, sbv.x * inv, sbv.y * (inv * inv));      // :615

@@ -50,6 +50,7 @@ struct svgf_ctx {
     uint32_t* young_list = nullptr;        // scratch, temporal -> moments: indices of the pixels with history < 4 that need the spatial estimate
     unsigned* young_count = nullptr;       // two device counters used in turn (the temporal launch of a frame zeroes the next frame's)
     uint8_t* young_flags = nullptr;        // one flag per (row, 64-column segment): all 64 pixels need the estimate (listed nowhere)
+    uint32_t* nan_list = nullptr;          // scratch, temporal -> moments: the pixels whose accumulated colour / moments are NaN or inf (kNanListCap entries)
     int young_phase = 0;
     bool young_pending = false;            // a temporal launch appended to young_count[young_phase] and no moments launch has consumed it yet
     int vy0 = 0, vy1 = 0;                  // global rows of the previous-frame planes that hold valid state (svgf_set_valid_rows; default: all held)

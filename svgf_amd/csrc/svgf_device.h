@@ -46,8 +46,19 @@ template <> struct Store<1> {
     __device__ static __forceinline__ void st2(void* p, size_t i, float2 v) { ((uint32_t*)p)[i] = pack_h2(v.x, v.y); }
 };
 
-__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }          // NaN -> 0: saturate() of a dot product
 __device__ __forceinline__ float4 clamp01(float4 v) { return make_float4(clamp01(v.x), clamp01(v.y), clamp01(v.z), clamp01(v.w)); }
+// The reference's value clamp of imageLoad / imageStore (Filter.cuh:63-69,78-83) is glm::clamp = min(max(x, 0), 1) built from
+// (x < y) ? y : x comparisons: +-inf clamp to 1 / 0 and a NaN texel STAYS NaN (it then poisons the history through mix, :398, and the
+// a-trous sums channel by channel).  fminf / fmaxf, v_med3 and the hardware's result clamp in its default mode all turn a NaN into 0.
+// The kernels that clamp texels therefore clear MODE.DX10_CLAMP for the life of their waves (keep_nan_in_clamps, first statement):
+// with it cleared the `clamp` result modifier still maps +-inf and every finite value into [0, 1] and passes a NaN through — the
+// reference's clamp in ONE instruction (two values per instruction in its packed form), with nothing to detect and nothing to put back.
+// (MODE is per-wave state; nothing the compiler generates for these kernels depends on the bit except `saturate(n.n')` of the taps,
+// where a NaN can only come from a non-finite normal.)
+__device__ __forceinline__ void keep_nan_in_clamps() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 8, 1), 0" ::: "memory"); }
+__device__ __forceinline__ float clamp01_ref(float v) { float r; asm("v_max_f32 %0, %1, %1 clamp" : "=v"(r) : "v"(v)); return r; }   // needs keep_nan_in_clamps()
+__device__ __forceinline__ float4 clamp01_ref(float4 v) { return make_float4(clamp01_ref(v.x), clamp01_ref(v.y), clamp01_ref(v.z), clamp01_ref(v.w)); }
 
 // (z, dz) of a motion texel; depth 0 = sky sentinel (Filter.cuh:199-207)
 __device__ __forceinline__ void depth_of(float4 m, float& z, float& dz) {
@@ -86,7 +97,7 @@ __device__ __forceinline__ float inv_phi_l_log2e(float variance01, float k) { re
 // evaluated as exp2( phi_n*log2(sat(n.n')) - (max(|dl|*il,0) + |dz|*iz)*log2(e) ) with il = 1/phi_l,
 // iz = 1/phi_z precomputed per pixel; phi_n == 0 drops the normal term (pow(x,0) = 1 even at x = 0).
 __device__ __forceinline__ float edge_weight(float dl_abs, float il, float dz_abs, float iz, float ndot, float phi_n) {
-    const float d = clamp01(ndot);                                    // NaN -> 0 like saturate()
+    const float d = clamp01(ndot != ndot ? 0.0f : ndot);              // saturate(): NaN -> 0 (explicitly: some callers run with keep_nan_in_clamps())
     const float ln = (phi_n == 0.0f) ? 0.0f : phi_n * hw_log2(d);
     const float wl = fmaxf(dl_abs * il, 0.0f);                        // NaN (0*inf at phi_l = 0) -> 0 like fmax() in :424
     const float e = fmaf(-kLog2e, wl + dz_abs * iz, ln);
@@ -139,14 +150,16 @@ __device__ __forceinline__ PlaneRsrc plane_rsrc(const AtrousArgs& a, unsigned np
     return r;
 }
 
-// voff_*: the lane's constant byte offsets into the colour, depth and normal planes; srow: the row's scalar element offset yl*W.
+// voff_*: the lane's constant byte offsets into the colour, depth and normal planes (voff_m WITHOUT the position of {depth, ddepth}
+// inside the 16-byte texel, m_off: it travels in the scalar offset, so that with fp32 storage voff_m IS voff_c — one register less in
+// a loop that has none to spare); srow: the row's scalar element offset yl*W.
 template <int ST, bool DZ>
-__device__ __forceinline__ void raw_load(RawPx<ST, DZ>& r, const PlaneRsrc& rs, unsigned voff_c, unsigned voff_m, unsigned voff_n, int srow, unsigned n_shift) {
+__device__ __forceinline__ void raw_load(RawPx<ST, DZ>& r, const PlaneRsrc& rs, unsigned voff_c, unsigned voff_m, unsigned voff_n, int srow, unsigned n_shift, unsigned m_off) {
     constexpr int cb = ST == 0 ? 16 : 8;
     if constexpr (ST == 0) r.c = __builtin_amdgcn_raw_buffer_load_b128(rs.colour, voff_c, srow * cb, 0);
     else r.c = __builtin_amdgcn_raw_buffer_load_b64(rs.colour, voff_c, srow * cb, 0);
-    if constexpr (DZ) r.zd = __builtin_amdgcn_raw_buffer_load_b64(rs.motion, voff_m, srow * 16, 0);      // {depth, ddepth}
-    else r.zd = __builtin_amdgcn_raw_buffer_load_b32(rs.motion, voff_m, srow * 16, 0);                   // depth
+    if constexpr (DZ) r.zd = __builtin_amdgcn_raw_buffer_load_b64(rs.motion, voff_m, srow * 16 + (int)m_off, 0);      // {depth, ddepth}
+    else r.zd = __builtin_amdgcn_raw_buffer_load_b32(rs.motion, voff_m, srow * 16 + (int)m_off, 0);                   // depth
     r.n = __builtin_amdgcn_raw_buffer_load_b64(rs.normal, voff_n, srow << n_shift, 0);
 }
 
@@ -158,7 +171,8 @@ __device__ __forceinline__ bool wave_any(bool pred) { return __builtin_amdgcn_ba
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ float med01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }   // = min(max(v,0),1) for non-NaN v
-// the same for two values with ONE instruction: x * 1.0 with the result clamp of a packed multiply (hipcc emits one v_max .. clamp per value)
+// the reference's clamp (NaN kept: the kernel has called keep_nan_in_clamps()) for two values with ONE instruction: x * 1.0 with the result
+// clamp of a packed multiply
 __device__ __forceinline__ f32x2 clamp01_pk(f32x2 v) {
     f32x2 r;
     const f32x2 one = {1.0f, 1.0f};
@@ -166,22 +180,35 @@ __device__ __forceinline__ f32x2 clamp01_pk(f32x2 v) {
     return r;
 }
 
-// Convert a staged pixel into its LDS records; -> "a surface texel whose normal differs from the reference normal (ref01, refz)".
+// What a wave reports of a ring row it staged (the flag words of the streaming kernels): a surface texel's normal differs from the
+// workgroup's reference normal — no uniform-normal path while the row is in the ring.
+constexpr uint32_t kFlagNormal = 1u;
+
+// Convert a staged pixel into its LDS records (the kernel runs with keep_nan_in_clamps(): a NaN channel stays NaN in the colour record
+// and makes the luminance NaN).  -> the LANE MASK of "a surface texel whose normal differs from the reference normal (ref01, refz)".
+// A mask, not a per-lane bool: the ballot builtin folds into ONE compare, but a predicate that is an and / or of compares gets
+// materialised as 0 / 1 in a vector register and compared again — so every compare is balloted by itself and the masks are combined on
+// the scalar unit.  `store` masks the LDS writes only: everything else runs on every lane (the halo pass's idle lanes hold all-zero
+// texels: no depth, so they never differ).
+__device__ __forceinline__ unsigned long long lanes_where(bool single_compare) { return __builtin_amdgcn_ballot_w64(single_compare); }
 template <int ST, bool DZ>
-__device__ __forceinline__ bool commit_px(const RawPx<ST, DZ>& r, f32x4* recA, f32x2* recL, f32x2* recN, int at, uint32_t ref01, uint32_t refz) {
+__device__ __forceinline__ unsigned long long commit_px(const RawPx<ST, DZ>& r, f32x4* recA, f32x2* recL, f32x2* recN, int at, uint32_t ref01, uint32_t refz, bool store = true) {
     float4 c;
     if constexpr (ST == 0) c = make_float4(__uint_as_float(r.c.x), __uint_as_float(r.c.y), __uint_as_float(r.c.z), __uint_as_float(r.c.w));
     else { float2 lo = unpack_h2(r.c.x), hi = unpack_h2(r.c.y); c = make_float4(lo.x, lo.y, hi.x, hi.y); }
-    const f32x2 c01 = clamp01_pk((f32x2){c.x, c.y}), c23 = clamp01_pk((f32x2){c.z, c.w});    // imageLoad, :586
+    const f32x2 c01 = clamp01_pk((f32x2){c.x, c.y}), c23 = clamp01_pk((f32x2){c.z, c.w});    // imageLoad, :78-83,586
     c = make_float4(c01.x, c01.y, c23.x, c23.y);
     float z;
     if constexpr (DZ) z = __uint_as_float(r.zd.x); else z = __uint_as_float(r.zd);
     if (z == 0.0f) z = kSkyZ;                                           // GetDepth, :199-207
-    recA[at] = (f32x4){c.x, c.y, c.z, c.w};
-    recL[at] = (f32x2){lum_exact(c.x, c.y, c.z), z};
-    recN[at] = (f32x2){__uint_as_float(r.n.x), unpack_h2(r.n.y).x};
+    const float lum = lum_exact(c.x, c.y, c.z), nz = unpack_h2(r.n.y).x;
+    if (store) {
+        recA[at] = (f32x4){c.x, c.y, c.z, c.w};
+        recL[at] = (f32x2){lum, z};
+        recN[at] = (f32x2){__uint_as_float(r.n.x), nz};
+    }
     // a texel without depth (sky, or outside the frame) has weight 0 through the depth term whatever its normal
-    return z != kSkyZ && (r.n.x != ref01 || (r.n.y & 0xffffu) != refz);
+    return lanes_where(z != kSkyZ) & (lanes_where(r.n.x != ref01) | lanes_where((r.n.y & 0xffffu) != refz));
 }
 
 // log2 of the kernel weight K[|xx|]*K[|yy|] (:540,582), folded into the exponent

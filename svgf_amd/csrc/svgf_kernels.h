@@ -8,6 +8,11 @@ namespace svgf {
 // Local planes hold global rows [y0, y0+rows) of a W x H frame; a launch computes rows [yb, ye).
 struct Geo { int W, H, y0, rows, yb, ye; };
 
+// The young-pixel counters of a context are {young[2], non-finite[2]} (used in turn, frame by frame); the list of pixels whose temporal
+// result is not finite holds at most kNanListCap entries (more than that and the moments launch goes over every pixel instead).
+constexpr int kNanCounter = 2;
+constexpr unsigned kNanListCap = 1u << 16;
+
 struct TemporalArgs {
     const void* prev_colour; const void* radiance; void* colour_out;
     const float4* motion_c; const uint2* normal_c; const uint2* uv_c;
@@ -32,6 +37,8 @@ struct TemporalArgs {
                                  // motion_p / normal_p / uv_p (16 instead of 32 B per pixel), or null
     int guide_lo, guide_hi;      // global rows [guide_lo, guide_hi) whose guide texel this launch writes (>= the compute rows of Geo: a strip
                                  // needs the texels of every row it holds)
+    uint32_t* nan_list;          // with young_list: the local indices of the pixels whose temporal colour / moments are NaN or inf (counter:
+                                 // young_count[kNanCounter]); the moments launch redoes the zero-normal shortcut pixels around them
 };
 struct MomentsArgs {
     const void* colour; void* out; const void* mom; const float4* motion; const uint2* normal; const uint8_t* hist;
@@ -42,6 +49,8 @@ struct MomentsArgs {
     const uint32_t* young_list;   // with cold_only: TemporalArgs::young_list / young_count of the same frame — only listed pixels are visited
     const unsigned* young_count;
     const uint8_t* young_flags;   // TemporalArgs::young_flags: segments whose 64 pixels are all young
+    const uint32_t* nan_list;     // TemporalArgs::nan_list (counter: young_count[kNanCounter])
+    int no_fastpath;              // SVGF_VARIANT_LDS_GENERAL: the LDS-streaming kernel without its uniform-normal form (bit-identical, slower)
 };
 struct AtrousArgs {
     const void* in; void* out; void* feedback; const float4* motion; const uint2* normal;

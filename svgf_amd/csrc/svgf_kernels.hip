@@ -27,6 +27,7 @@
 #include "svgf_atrous_lds.h"
 #endif
 #include "svgf_atrous_fused.h"
+#include "svgf_moments_lds.h"
 
 namespace svgf {
 namespace {
@@ -38,7 +39,8 @@ namespace {
 // dependent fetches); rejected pixels simply discard them.
 template <int ST>
 __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs a) {
-    if (a.young_list && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) *a.young_count_next = 0u;
+    keep_nan_in_clamps();                                             // imageLoad / imageStore keep a NaN (svgf_device.h)
+    if (a.young_list && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) { a.young_count_next[0] = 0u; a.young_count_next[kNanCounter] = 0u; }
     // The grid covers the compute rows [yb, ye) and, where a guide plane is written, the rows [guide_lo, guide_hi) around them (a strip
     // holds more rows than it runs the temporal stage on: the later iterations' halos and the next frame's reprojection read their
     // guide texels too): a row outside the compute rows gets its guide texel and nothing else (a wave is one row: no divergence).
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
     ok = ok && in_strip;
     const size_t q = ok ? (size_t)ql * g.W + qx : idx;
 
-    const float4 c = clamp01(Store<ST>::ld4(a.radiance, idx));        // :370 imageLoad
+    const float4 c = clamp01_ref(Store<ST>::ld4(a.radiance, idx));    // :370 imageLoad (a NaN stays NaN)
     const uint2 nc_raw = a.normal_c[idx];
     const uint2 uc_raw = a.uv_c[idx];
     // What the test needs of the PREVIOUS G-buffer is {depth, normal, instance ID} at q.  The drivers kept exactly that when
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
         np_raw = a.normal_p[q];
         up_raw = a.uv_p[q];
     }
-    const float4 pc = clamp01(Store<ST>::ld4(a.prev_colour, q));      // :254 imageLoad
+    const float4 pc = clamp01_ref(Store<ST>::ld4(a.prev_colour, q));  // :254 imageLoad
     const int hp = a.hist_prev[q];                                    // :255
     const float2 pm = Store<ST>::ld2(a.mom_prev, q);                  // :256
 
@@ -118,7 +120,8 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
     // :401 imageStore.  sparse_colour (frame driver): iteration 0 of the wavelet filter overwrites this texel with its
     // feedback (:619-622) unless it has no depth; until then only the moments estimate of young pixels reads it
     // (the same predicate as the feedback store of atrous_*_kernel: GetDepth() == sentinel, i.e. depth 0 or literally 1e30f)
-    if (!a.sparse_colour || h < 4 || zc == kSkyZ) Store<ST>::st4(a.colour_out, idx, clamp01(o));
+    const float4 oc = clamp01_ref(o);                                 // imageStore, :63-69
+    if (!a.sparse_colour || h < 4 || zc == kSkyZ) Store<ST>::st4(a.colour_out, idx, oc);
     Store<ST>::st2(a.mom_cur, idx, m);                                // :402
     // Frame-driver fusion: for history >= 4 FilterMoments only copies this pixel into the filter buffer
     // (:521; store(load(x)) == x in both storage types), so it is written from here and the moments launch
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
     const bool young = h < 4;
     const bool zero_young = young && a.sky_zero && ((nc_raw.x & 0x7fff7fffu) | (nc_raw.y & 0x7fffu)) == 0u;
     if (a.passthrough_out) {
-        if (!young) Store<ST>::st4(a.passthrough_out, idx, clamp01(o));
+        if (!young) Store<ST>::st4(a.passthrough_out, idx, oc);
         else if (zero_young) Store<ST>::st4(a.passthrough_out, idx, make_float4(0.f, 0.f, 0.f, 0.f));
     }
     // ... and the moments launch is told where the remaining young pixels are: their indices are appended to a list, one
@@ -136,16 +139,30 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
     // young pixels, so the moments launch costs what they cost, however they are spread over the frame.
     if (a.young_list) {
         const bool listed = young && !zero_young;
-        const unsigned long long m = __ballot(listed);
-        const bool whole_wave = m == ~0ull;                 // all 64 pixels of the segment: flagged, not listed
-        if (m != 0ull && !whole_wave) {
-            const int lane = threadIdx.x, first = __builtin_ctzll(m);
+        const unsigned long long ym = __ballot(listed);
+        const bool whole_wave = ym == ~0ull;                // all 64 pixels of the segment: flagged, not listed
+        if (ym != 0ull && !whole_wave) {
+            const int lane = threadIdx.x, first = __builtin_ctzll(ym);
             unsigned base = 0;
-            if (lane == first) base = atomicAdd(a.young_count, (unsigned)__builtin_popcountll(m));
+            if (lane == first) base = atomicAdd(a.young_count, (unsigned)__builtin_popcountll(ym));
             base = __shfl(base, first);
-            if (listed) a.young_list[base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+            if (listed) a.young_list[base + (unsigned)__builtin_popcountll(ym & ((1ull << lane) - 1ull))] = (uint32_t)idx;
         }
         if (threadIdx.x == 0) a.young_flags[(size_t)(y - g.y0) * ((g.W + kBX - 1) / kBX) + blockIdx.x] = whole_wave ? 1 : 0;
+        // A pixel whose accumulated colour or moments are not finite (a NaN in the radiance, or in the history it reprojects onto:
+        // the reference's clamps keep it, :63-83,398) is listed as well.  The shortcut above is only right while a zero-normal pixel's
+        // 7x7 window is finite — its weights are exactly 0, and 0 x NaN is NaN in :498-499 — so the moments launch goes over the
+        // windows of the listed pixels again (moments_young_kernel).  Nothing but the test while every pixel is finite.
+        const unsigned long long bad = lanes_where(__builtin_isunordered(oc.x, oc.y)) | lanes_where(__builtin_isunordered(oc.z, m.x)) |
+                                       lanes_where(!(fabsf(m.x + m.y) < __builtin_inff()));     // (oc.w: fmax(0, NaN) = 0, :396)
+        if (bad != 0ull) {
+            const int lane = threadIdx.x, first = __builtin_ctzll(bad);
+            unsigned base = 0;
+            if (lane == first) base = atomicAdd(a.young_count + kNanCounter, (unsigned)__builtin_popcountll(bad));
+            base = __shfl(base, first);
+            const unsigned at = base + (unsigned)__builtin_popcountll(bad & ((1ull << lane) - 1ull));
+            if (((bad >> lane) & 1ull) && at < kNanListCap) a.nan_list[at] = (uint32_t)idx;
+        }
     }
 }
 
@@ -165,13 +182,11 @@ __device__ __forceinline__ void moments_pixel(const Geo& g, const MomentsArgs& a
     depth_of(a.motion[idx], zc, dzc);
     const uint2 nraw = a.normal[idx];
     const float3 nc = normal_of(nraw);
-    // A centre whose normal is exactly (0,0,0) — the G-buffer's cleared sky texels — has n.n' = 0 for every tap,
-    // so with phi_normal > 0 every weight is exp(..)*pow(0,phi_n) = 0: the sums stay 0, sumW clamps to 1e-6 and the
-    // result is exactly (0,0,0,0) (:505-516).  Same value, none of the 49 taps.
-    if (((nraw.x & 0x7fff7fffu) | (nraw.y & 0x7fffu)) == 0u && a.phi_normal > 0.0f) {
-        Store<ST>::st4(a.out, idx, make_float4(0.f, 0.f, 0.f, 0.f * (4.0f / h)));
-        return;
-    }
+    // A centre whose normal is exactly (0,0,0) — the G-buffer's cleared sky texels — has n.n' = 0 for every tap, so with
+    // phi_normal > 0 every weight is exp(..)*pow(0,phi_n) = 0 (edge_weight: exp2(-inf)): the sums are 0 x the taps, sumW clamps to
+    // 1e-6 and the result is (0,0,0,0) (:505-516) — unless a tap is NaN or inf, whose product with 0 is NaN
+    // (:498-499).  This kernel therefore takes no shortcut for such a centre; the frame driver's temporal launch does, and lists the
+    // non-finite pixels so that the windows around them are redone (moments_young_kernel).
     const float il = hw_rcp(a.phi_colour);                            // :460
     const float phi_d = fmaxf(dzc, 1e-8f) * 3.0f;                     // :461
     float sw = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sm1 = 0.f, sm2 = 0.f;
@@ -312,10 +327,7 @@ __device__ __forceinline__ void moments_group8(const Geo& g, const MomentsArgs& 
     if (!valid || j != 0) return;                                     // one lane of the group writes
     if (a.cold_only && !(h < 4.0f)) return;                           // already written by temporal_kernel (passthrough_out)
     if (!(h < 4.0f)) { Store<ST>::st4(a.out, idx, cc); return; }      // :521
-    if (((nraw.x & 0x7fff7fffu) | (nraw.y & 0x7fffu)) == 0u && a.phi_normal > 0.0f) {      // see moments_pixel
-        Store<ST>::st4(a.out, idx, make_float4(0.f, 0.f, 0.f, 0.f * (4.0f / h)));
-        return;
-    }
+    // (a zero-normal centre needs no special case: all its weights came out as exactly 0 above, see moments_pixel)
     sw = fmaxf(sw, 1e-6f);                                            // :505
     const float inv = 1.0f / sw;
     sm1 *= inv; sm2 *= inv;
@@ -388,10 +400,6 @@ __global__ __launch_bounds__(kBX* kBY) void moments3x3_shfl_kernel(Geo g, Moment
     float zc, dzc;
     depth_of(a.motion[idx], zc, dzc);
     const float3 nc = normal_of(make_uint2(cc.n01, cc.n2));
-    if (((cc.n01 & 0x7fff7fffu) | (cc.n2 & 0x7fffu)) == 0u && a.phi_normal > 0.0f) {          // see moments_pixel
-        Store<ST>::st4(a.out, idx, make_float4(0.f, 0.f, 0.f, 0.f * (4.0f / h)));
-        return;
-    }
     const float il = hw_rcp(a.phi_colour);                            // :460
     const float phi_d = fmaxf(dzc, 1e-8f) * 3.0f;                     // :461
     float sw = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sm1 = 0.f, sm2 = 0.f;
@@ -429,11 +437,41 @@ __global__ __launch_bounds__(kBX* kBY) void moments3x3_shfl_kernel(Geo g, Moment
 // (Bench pan, ~28 000 listed pixels + ~360 flagged segments per 4K frame: 0.051 -> 0.034 ms; nothing young: 0.0069 ms.  By parts,
 // tools/pan_moments_ab.sh: an empty launch 0.0069, the list alone 0.025, the flagged segments alone 0.029, a pass ~0.004 ms.)
 constexpr int kScanSplit = 2;
+constexpr int kNanBlocks = 32;                   // the last workgroups of the grid: the windows around non-finite pixels
 template <int ST>
 __global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a, int scan_blocks) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (blockIdx.x >= gridDim.x - kNanBlocks) {
+        // The temporal launch wrote exact zeros for young pixels with an all-zero normal (its zero-normal shortcut) — right unless a
+        // texel of the pixel's 7x7 window is NaN or inf (0 x NaN, :498-499).  It listed the pixels whose result is not finite: every
+        // pixel in the window of a listed pixel gets the full estimate here (moments_group8 has no shortcut; a pixel that is not
+        // young, or not in the launch rows, is left alone; a young pixel that is listed as young too is written twice with the same
+        // bits).  Nothing listed — every frame without a NaN — and these workgroups read one word.
+        const unsigned n = a.young_count[kNanCounter];
+        if (n == 0u) return;
+        const unsigned b = blockIdx.x - (gridDim.x - kNanBlocks), wave = b * 4u + (unsigned)w, nwaves = kNanBlocks * 4u;
+        if (n <= kNanListCap) {
+            for (unsigned i = wave; i < n; i += nwaves) {
+                const uint32_t p = a.nan_list[i];
+                const int px = (int)(p % (uint32_t)g.W), pyl = (int)(p / (uint32_t)g.W);
+#pragma unroll 1
+                for (int pass = 0; pass < 7; pass++) {
+                    const int k = pass * 8 + (lane >> 3), qx = px + k % 7 - 3, qyl = pyl + k / 7 - 3;
+                    const bool valid = k < 49 && qx >= 0 && qx < g.W && qyl >= 0 && qyl < g.rows;
+                    moments_group8<ST>(g, a, valid, valid ? (uint32_t)(qyl * g.W + qx) : 0u);
+                }
+            }
+        } else {                                    // the list overflowed (a frame full of NaN): every pixel of the launch rows
+            const unsigned first = (unsigned)(g.yb - g.y0) * (unsigned)g.W, last = (unsigned)(g.ye - g.y0) * (unsigned)g.W;
+            for (unsigned q0 = first + wave * 8u; q0 < last; q0 += nwaves * 8u) {
+                const unsigned q = q0 + ((unsigned)lane >> 3);
+                moments_group8<ST>(g, a, q < last, q < last ? q : 0u);
+            }
+        }
+        return;
+    }
     if ((int)blockIdx.x >= scan_blocks) {
-        const unsigned list_blocks = gridDim.x - (unsigned)scan_blocks, b = blockIdx.x - (unsigned)scan_blocks;
+        const unsigned list_blocks = gridDim.x - kNanBlocks - (unsigned)scan_blocks, b = blockIdx.x - (unsigned)scan_blocks;
         const unsigned n = *a.young_count, ngroups = (n + 7u) / 8u;
         for (unsigned grp = b + list_blocks * (unsigned)w; grp < ngroups; grp += list_blocks * 4u) {
             const unsigned i = grp * 8u + ((unsigned)lane >> 3);
@@ -476,11 +514,12 @@ __global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a
 // Kept as the simple variant (SVGF_VARIANT_DIRECT) the LDS-tiled kernel is A/B-tested against.
 template <int ST>
 __global__ __launch_bounds__(kBX* kBY) void atrous_direct_kernel(Geo g, AtrousArgs a) {
+    keep_nan_in_clamps();                                             // imageLoad keeps a NaN (svgf_device.h)
     const int x = blockIdx.x * kBX + threadIdx.x;
     const int y = g.yb + blockIdx.y * kBY + threadIdx.y;
     if (x >= g.W || y >= g.ye) return;
     const size_t idx = (size_t)(y - g.y0) * g.W + x;
-    const float4 c = clamp01(Store<ST>::ld4(a.in, idx));              // :543
+    const float4 c = clamp01_ref(Store<ST>::ld4(a.in, idx));          // :543 (a NaN stays NaN)
     float zc, dzc;
     depth_of(a.motion[idx], zc, dzc);                                 // :552
     if (zc == kSkyZ) { Store<ST>::st4(a.out, idx, c); return; }       // :554-558
@@ -500,7 +539,7 @@ __global__ __launch_bounds__(kBX* kBY) void atrous_direct_kernel(Geo g, AtrousAr
             const int px = x + xx * a.step;
             if (px < 0 || px >= g.W) continue;
             const size_t p = (size_t)(py - g.y0) * g.W + px;
-            const float4 q = clamp01(Store<ST>::ld4(a.in, p));        // :586
+            const float4 q = clamp01_ref(Store<ST>::ld4(a.in, p));    // :586
             float zp, dzp;
             depth_of(a.motion[p], zp, dzp);
             const float3 np = normal_of(a.normal[p]);
@@ -520,203 +559,6 @@ __global__ __launch_bounds__(kBX* kBY) void atrous_direct_kernel(Geo g, AtrousAr
 }
 
 
-
-// ------------------------------------------------------------------ moments (LDS streaming, cold frames) ----
-// Filter.cuh:430-525 for frames in which (nearly) every pixel is young (history < 4: the first three frames of a
-// sequence): the 7x7 window is served from an 8-row LDS ring exactly like the à-trous kernel's 5x5 window
-// (streaming down a band, 256 columns x 2 rows per step, one output per thread, rows fetched one step ahead), instead
-// of 49 x 4 gathers per pixel through L1.  Records are RAW (this stage does not clamp, :450,479):
-// A = {r,g,b,m1}, B = {luminance, depth, (nx,ny) halfs, nz}, C = m2.  Pixels with history >= 4 are a copy (:521).
-constexpr int kMR = 3;                       // window radius (the reference's, :465)
-constexpr int kMRing = kRS + 2 * kMR;        // 8 ring rows
-constexpr int kMTX = 256;
-
-__device__ __forceinline__ constexpr int len_class7(int xx, int yy) {   // |(xx,yy)|^2 in {1,2,4,5,8,9,10,13,18}
-    const int l2 = xx * xx + yy * yy;
-    return l2 == 1 ? 0 : l2 == 2 ? 1 : l2 == 4 ? 2 : l2 == 5 ? 3 : l2 == 8 ? 4 : l2 == 9 ? 5 : l2 == 10 ? 6 : l2 == 13 ? 7 : 8;
-}
-
-template <int ST>
-__global__ __launch_bounds__(kMTX* kRS, 4) void moments_lds_kernel(Geo g, MomentsArgs a, int band_rows) {
-    constexpr int TX = kMTX, WL = TX + 2 * kMR, CB = ST == 0 ? 16 : 8, MB = ST == 0 ? 8 : 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* recA = (f32x4*)smem;
-    f32x4* recB = recA + kMRing * WL;
-    float* recC = (float*)(recB + kMRing * WL);
-
-    const int t = threadIdx.x, lane = t & 63, col = t % TX;
-    const int rg = __builtin_amdgcn_readfirstlane(t / TX);
-    const int wig = __builtin_amdgcn_readfirstlane((t % TX) >> 6);
-    const int x0 = blockIdx.x * TX;
-    const int nrows = g.ye - g.yb;
-    const int j0 = blockIdx.y * band_rows;
-    if (j0 >= nrows) return;
-    const int j1 = min(nrows, j0 + band_rows);
-
-    const int gx = x0 + col, oli = col + kMR;
-    const bool has_halo = wig == 0 && lane < 2 * kMR;       // six halo pixels per row: lanes 0-5 of the row group's first wave
-    const int hx = (lane < kMR) ? x0 - kMR + lane : x0 + TX + lane - kMR;
-    const int hli = (lane < kMR) ? lane : TX + lane;
-    const bool own_ok = gx < g.W, halo_ok = has_halo && hx >= 0 && hx < g.W;
-    const unsigned vo = own_ok ? (unsigned)gx : 0u, vh = halo_ok ? (unsigned)hx : 0u;
-    const unsigned vo_c = own_ok ? vo * CB : kOob, vo_mo = own_ok ? vo * MB : kOob, vo_m = own_ok ? vo * 16u + 8u : kOob, vo_n = own_ok ? vo * 8u : kOob, vo_h = own_ok ? vo : kOob;
-    const unsigned vh_c = halo_ok ? vh * CB : kOob, vh_mo = halo_ok ? vh * MB : kOob, vh_m = halo_ok ? vh * 16u + 8u : kOob, vh_n = halo_ok ? vh * 8u : kOob;
-
-    const unsigned npx = (unsigned)g.rows * (unsigned)g.W;
-    auto mk = [](const void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); };
-    const __amdgpu_buffer_rsrc_t rs_c = mk(a.colour, npx * CB), rs_mo = mk(a.mom, npx * MB), rs_m = mk(a.motion, npx * 16u),
-                                 rs_n = mk(a.normal, npx * 8u), rs_h = mk(a.hist, npx), rs_out = mk(a.out, npx * CB);
-    const __amdgpu_buffer_rsrc_t rz_c = mk(a.colour, 0), rz_mo = mk(a.mom, 0), rz_m = mk(a.motion, 0), rz_n = mk(a.normal, 0);
-
-    struct Px { u32x4 c; u32x2 mo; unsigned z; u32x2 n; };
-    auto load_px = [&](Px& p, bool rok, int srow, unsigned o_c, unsigned o_mo, unsigned o_m, unsigned o_n) __attribute__((always_inline)) {
-        if (rok) {
-            if constexpr (ST == 0) { p.c = __builtin_amdgcn_raw_buffer_load_b128(rs_c, o_c, srow * CB, 0); p.mo = __builtin_amdgcn_raw_buffer_load_b64(rs_mo, o_mo, srow * MB, 0); }
-            else { const u32x2 c2 = __builtin_amdgcn_raw_buffer_load_b64(rs_c, o_c, srow * CB, 0); p.c = (u32x4){c2.x, c2.y, 0u, 0u}; p.mo = (u32x2){__builtin_amdgcn_raw_buffer_load_b32(rs_mo, o_mo, srow * MB, 0), 0u}; }
-            p.z = __builtin_amdgcn_raw_buffer_load_b32(rs_m, o_m, srow * 16, 0);
-            p.n = __builtin_amdgcn_raw_buffer_load_b64(rs_n, o_n, srow * 8, 0);
-        } else {
-            if constexpr (ST == 0) { p.c = __builtin_amdgcn_raw_buffer_load_b128(rz_c, o_c, 0, 0); p.mo = __builtin_amdgcn_raw_buffer_load_b64(rz_mo, o_mo, 0, 0); }
-            else { const u32x2 c2 = __builtin_amdgcn_raw_buffer_load_b64(rz_c, o_c, 0, 0); p.c = (u32x4){c2.x, c2.y, 0u, 0u}; p.mo = (u32x2){__builtin_amdgcn_raw_buffer_load_b32(rz_mo, o_mo, 0, 0), 0u}; }
-            p.z = __builtin_amdgcn_raw_buffer_load_b32(rz_m, o_m, 0, 0);
-            p.n = __builtin_amdgcn_raw_buffer_load_b64(rz_n, o_n, 0, 0);
-        }
-    };
-    auto row_of = [&](int j, bool& rok) __attribute__((always_inline)) {      // scalar: decimated == actual rows here
-        const int y = g.yb + j, yl = y - g.y0;
-        rok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows;
-        return rok ? yl * g.W : 0;
-    };
-    struct Staged { Px o, h; };
-    auto fetch = [&](int jn, Staged& st) __attribute__((always_inline)) {     // rows jn, jn+1: this wave's is jn+rg
-        bool rok; const int srow = row_of(jn + rg, rok);
-        load_px(st.o, rok, srow, vo_c, vo_mo, vo_m, vo_n);
-        load_px(st.h, rok, srow, vh_c, vh_mo, vh_m, vh_n);
-    };
-    auto commit_one = [&](const Px& p, int at) __attribute__((always_inline)) {
-        float4 c; float2 m;
-        if constexpr (ST == 0) { c = make_float4(__uint_as_float(p.c.x), __uint_as_float(p.c.y), __uint_as_float(p.c.z), __uint_as_float(p.c.w)); m = make_float2(__uint_as_float(p.mo.x), __uint_as_float(p.mo.y)); }
-        else { const float2 lo = unpack_h2(p.c.x), hi = unpack_h2(p.c.y); c = make_float4(lo.x, lo.y, hi.x, hi.y); m = unpack_h2(p.mo.x); }
-        float z = __uint_as_float(p.z);
-        if (z == 0.0f) z = kSkyZ;                                                   // GetDepth, :199-207
-        recA[at] = (f32x4){c.x, c.y, c.z, m.x};                                     // raw loads, :479-480
-        recB[at] = (f32x4){lum_exact(c.x, c.y, c.z), z, __uint_as_float(p.n.x), unpack_h2(p.n.y).x};
-        recC[at] = m.y;
-    };
-    auto commit = [&](int sl, const Staged& st) __attribute__((always_inline)) {
-        int so = sl + rg; so = so >= kMRing ? so - kMRing : so;
-        commit_one(st.o, so * WL + oli);
-        if (has_halo) commit_one(st.h, so * WL + hli);
-    };
-    // the centre's own history byte and ddepth come straight from the planes, one step ahead (L2 hits)
-    struct Centre { unsigned h; unsigned dz; };
-    auto fetch_centre = [&](int j, Centre& c) __attribute__((always_inline)) {
-        bool rok; const int srow = row_of(j + rg, rok);
-        if (rok) { c.h = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_h, vo_h, srow, 0); c.dz = __builtin_amdgcn_raw_buffer_load_b32(rs_m, own_ok ? vo * 16u + 12u : kOob, srow * 16, 0); }
-        else { c.h = 255u; c.dz = 0u; }
-    };
-
-#pragma unroll 1
-    for (int r = 0; r < kMRing; r += kRS) {               // ring rows 0..7 = rows j0-3 .. j0+4
-        Staged st;
-        fetch(j0 - kMR + r, st);
-        commit(r, st);
-    }
-    Centre cen, cen_next;
-    fetch_centre(j0, cen);
-    __syncthreads();
-
-    const float phi_n = a.phi_normal;                      // != 0 (launcher)
-    const float il = hw_rcp(a.phi_colour) * kLog2e;        // :460
-    int slot0 = 0;
-    for (int j = j0; j < j1; j += kRS) {
-        const bool more = (j + kRS) < j1;
-        Staged fs;
-        if (more) { fetch(j + kRS + kMR, fs); fetch_centre(j + kRS, cen_next); }       // rows j+5, j+6 enter the ring next step
-
-        int rowbase[2 * kMR + 1];
-#pragma unroll
-        for (int r = 0; r <= 2 * kMR; r++) { int sl = slot0 + rg + r; sl = sl >= kMRing ? sl - kMRing : sl; rowbase[r] = sl * WL + col; }
-        const f32x4 cB = recB[rowbase[kMR] + kMR];
-        const float lc = cB.x, zc = cB.y, ncz = cB.w;
-        const uint32_t nc01 = __float_as_uint(cB.z);
-        const float h = (float)cen.h;                                               // :442
-        const float dzc = zc == kSkyZ ? 0.0f : __uint_as_float(cen.dz);
-        const float izb = hw_rcp(fmaxf(dzc, 1e-8f) * 3.0f) * kLog2e;                // :461
-        const float iz[9] = {izb, izb * 0.70710678118654752f, izb * 0.5f, izb * 0.44721359549995794f, izb * 0.35355339059327376f,
-                             izb * 0.33333333333333333f, izb * 0.31622776601683794f, izb * 0.27735009811261456f, izb * 0.23570226039551584f};
-        float sw = 0.0f, sm2 = 0.0f;
-        f32x2 srg = {0.f, 0.f}, sbm = {0.f, 0.f};
-        const bool zero_normal = ((nc01 & 0x7fff7fffu) == 0u) && (ncz == 0.0f);     // cleared sky texel: every weight is 0 (see moments_kernel)
-        const bool need = (h < 4.0f) && !zero_normal && (j + rg < j1);
-        if (__ballot(need) != 0ull) {
-#pragma unroll
-            for (int r = 0; r <= 2 * kMR; r++) {
-                const int yy = r - kMR;
-                f32x4 tA[2 * kMR + 1], tB[2 * kMR + 1];
-                float tC[2 * kMR + 1];
-#pragma unroll
-                for (int k = 0; k <= 2 * kMR; k++) { tA[k] = recA[rowbase[r] + k]; tB[k] = recB[rowbase[r] + k]; tC[k] = recC[rowbase[r] + k]; }
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int xx = -kMR; xx <= kMR; xx++) {
-                    const f32x4 A = tA[xx + kMR], B = tB[xx + kMR];
-                    const float d = clamp01(fmaf(B.w, ncz, dot2_h2(__float_as_uint(B.z), nc01)));
-                    float e = hw_log2(d) * phi_n;
-                    e = fmaf(-fabsf(B.x - lc), il, e);
-                    if (xx != 0 || yy != 0) e = fmaf(-fabsf(B.y - zc), iz[len_class7(xx, yy)], e);   // phiDepth == 0 -> wZ = 0 at the centre, :420
-                    const float w = hw_exp2(e);
-                    sw += w;                                                         // :497-499
-                    srg = __builtin_elementwise_fma((f32x2){w, w}, (f32x2){A.x, A.y}, srg);
-                    sbm = __builtin_elementwise_fma((f32x2){w, w}, (f32x2){A.z, A.w}, sbm);
-                    sm2 = fmaf(w, tC[xx + kMR], sm2);
-                }
-                asm volatile("" : "+v"(sw), "+v"(srg), "+v"(sbm), "+v"(sm2) :: "memory");
-            }
-        }
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f * (4.0f / h));
-        if (!zero_normal) {
-            sw = fmaxf(sw, 1e-6f);                                                  // :505
-            const float inv = 1.0f / sw;
-            const float m1 = sbm.y * inv, m2 = sm2 * inv;
-            o = make_float4(srg.x * inv, srg.y * inv, sbm.x * inv, (m2 - m1 * m1) * (4.0f / h));   // :507-516
-        }
-        if (more) {
-            lds_barrier();
-            commit(slot0, fs);
-            slot0 += kRS; if (slot0 >= kMRing) slot0 -= kMRing;
-            lds_barrier();
-        }
-        if (j + rg < j1) {
-            const int srow = (g.yb + j + rg - g.y0) * g.W;
-            if (h < 4.0f) {
-                if constexpr (ST == 0) __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)}, rs_out, vo_c, srow * CB, 0);
-                else __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_h2(o.x, o.y), pack_h2(o.z, o.w)}, rs_out, vo_c, srow * CB, 0);
-            } else if (!a.cold_only) {                                              // :521 copy
-                if constexpr (ST == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_amdgcn_raw_buffer_load_b128(rs_c, vo_c, srow * CB, 0), rs_out, vo_c, srow * CB, 0);
-                else __builtin_amdgcn_raw_buffer_store_b64(__builtin_amdgcn_raw_buffer_load_b64(rs_c, vo_c, srow * CB, 0), rs_out, vo_c, srow * CB, 0);
-            }
-        }
-        cen = cen_next;
-    }
-}
-
-template <int ST>
-hipError_t launch_moments_lds(const Geo& g, const MomentsArgs& a, hipStream_t s) {
-    constexpr int WL = kMTX + 2 * kMR;
-    constexpr size_t lds = (size_t)kMRing * WL * 36;
-    static std::atomic<unsigned long long> attr_done{0};
-    if (hipError_t e = allow_dynamic_lds(moments_lds_kernel<ST>, lds, attr_done); e != hipSuccess) return e;
-    const int nrows = g.ye - g.yb, xtiles = (g.W + kMTX - 1) / kMTX;
-    int nbands = 2 * num_cus() / xtiles;                  // one resident round: 2 workgroups per CU (LDS)
-    if (nbands < 1) nbands = 1;
-    int band = (nrows + nbands - 1) / nbands;
-    if (band < 8) band = 8;
-    band = (band + kRS - 1) / kRS * kRS;
-    nbands = (nrows + band - 1) / band;
-    moments_lds_kernel<ST><<<dim3(xtiles, nbands), dim3(kMTX * kRS), lds, s>>>(g, a, band);
-    return hipGetLastError();
-}
 
 // ------------------------------------------------------------------ TAA + sRGB -----------------
 // filter::TAAFilterKernel (Filter.cuh:288-357): the stage application::Render runs right after the wavelet
@@ -940,8 +782,8 @@ hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, bool 
         if (scan > 4 * num_cus()) scan = 4 * num_cus();            // ... on at most one resident round
         const int walk = std::min(4 * num_cus(), std::max(1, nsegs / 16));   // the list holds at most 63 pixels per segment
         scan *= kScanSplit;
-        if (storage == 0) moments_young_kernel<0><<<scan + walk, 256, 0, s>>>(g, a, scan);
-        else moments_young_kernel<1><<<scan + walk, 256, 0, s>>>(g, a, scan);
+        if (storage == 0) moments_young_kernel<0><<<scan + walk + kNanBlocks, 256, 0, s>>>(g, a, scan);
+        else moments_young_kernel<1><<<scan + walk + kNanBlocks, 256, 0, s>>>(g, a, scan);
         return hipGetLastError();
     }
     const dim3 block(kBX, kBY), grid = grid_for(g);
