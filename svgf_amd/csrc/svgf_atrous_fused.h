@@ -118,8 +118,10 @@ __device__ __forceinline__ bool fused_band(const Geo& g, const AtrousArgs& a, ch
         };
         auto commit = [&](int sl, const Staged& st) __attribute__((always_inline)) {
             int so = sl + rg; so = so >= kFRA ? so - kFRA : so;
-            unsigned long long differs = commit_px<ST, true>(st.o, aA, aL, aN, so * kFWA + oli, ref01, refz);
-            if (halo_wave) differs |= commit_px<ST, false>(st.h, aA, aL, aN, so * kFWA + hli, ref01, refz, has_halo);
+            constexpr int noff = kFRA * kFWA * 8;
+            const int at_o = so * kFWA + oli, at_h = so * kFWA + hli;
+            unsigned long long differs = commit_px<ST, true>(st.o, lds_addr(aA) + at_o * 16, lds_addr(aL) + at_o * 8, noff, ref01, refz);
+            if (halo_wave) differs |= commit_px<ST, false>(st.h, lds_addr(aA) + at_h * 16, lds_addr(aL) + at_h * 8, noff, ref01, refz, has_halo);
             if (lane == 0) flagA[so * 2 + wig] = differs != 0ull ? kFlagNormal : 0u;
         };
         float dq0 = 0.f, dq1 = 0.f;
@@ -154,7 +156,7 @@ __device__ __forceinline__ bool fused_band(const Geo& g, const AtrousArgs& a, ch
                 sky = c.sky;
                 const bool wave_has_surface = !(SVGF_FUSED_DIAG & 1) && wave_any(!sky);
                 const bool uniform = !EXACT && !a.no_fastpath && !wave_any(lane < 2 * kFRA && flagA[lane < 2 * kFRA ? lane : 0] != 0u);
-                o = filter_px<1, TD, EXACT>(aA, aL, aN, rowbase, c, phi_n, wave_has_surface, uniform);
+                o = filter_px<1, TD, kFRA * kFWA * 8, EXACT>(rows_from_index(aA, aL, rowbase), c, phi_n, wave_has_surface, uniform);
                 if constexpr (!EXACT) nan_out |= lanes_where(__builtin_isunordered(o.x, o.w));
                 // ring B record: the texel iteration 1 would load from the plane iteration 0 stores (:618 unclamped, in the storage type;
                 // :586 imageLoad clamps — a NaN stays NaN, svgf_device.h)
@@ -218,7 +220,7 @@ __device__ __forceinline__ bool fused_band(const Geo& g, const AtrousArgs& a, ch
                 const TapCentre c = centre_setup<2>(bA[ci], bL[ci], bN[ci], bD[ci], inv_phi_c);
                 const bool wave_has_surface = !(SVGF_FUSED_DIAG & 2) && wave_any(!c.sky);
                 const bool uniform = !EXACT && !a.no_fastpath && !wave_any(lane < 2 * kFRB && flagB[lane < 2 * kFRB ? lane : 0] != 0u);
-                o = filter_px<2, TD, EXACT>(bA, bL, bN, rowbase, c, phi_n, wave_has_surface, uniform);
+                o = filter_px<2, TD, kFRB * kFT0 * 8, EXACT>(rows_from_index(bA, bL, rowbase), c, phi_n, wave_has_surface, uniform);
                 if constexpr (!EXACT) nan_out |= lanes_where(__builtin_isunordered(o.x, o.w));
             }
             lds_barrier();

@@ -28,7 +28,21 @@ constexpr int kTapDepth = 3;             // LDS reads run this many taps ahead o
 // workgroups per CU anyway.
 constexpr int atrous_waves(int S) { return S <= 8 ? 5 : 4; }
 
-struct AtrousLds { f32x4* recA; f32x2* recL; f32x2* recN; uint32_t* nflag; uint32_t* nref; };
+// LDS layout of a workgroup, as byte addresses (no generic pointers: an address-space cast of a pointer the compiler cannot see
+// through costs a null check per use): colour records (16 B x kRing x WL), {luminance, depth} records (8 B x ..), normal records
+// (8 B x ..), the ring rows' flag words [kRing][8], the reference normal {(nx,ny) bits, nz bits}, the "an output was NaN" word.
+template <int S> struct AtrousLds {
+    static constexpr int WL = kTX + 4 * S;
+    uint32_t a;                                                         // colour records
+    __device__ __forceinline__ uint32_t l() const { return a + kRing * WL * 16; }
+    static constexpr int NOFF = kRing * WL * 8;                         // bytes from a pixel's {luminance, depth} record to its normal record
+    __device__ __forceinline__ uint32_t flag(int i) const { return l() + 2 * NOFF + 4 * i; }
+    __device__ __forceinline__ uint32_t nref(int i) const { return flag(kRing * 8 + i); }
+    static constexpr size_t bytes = (size_t)kRing * WL * kRecBytes + (kRing * 8 + 3) * sizeof(uint32_t);
+};
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t lds_load(uint32_t addr) { return *(const lds_u32*)(uintptr_t)addr; }
+__device__ __forceinline__ void lds_store(uint32_t addr, uint32_t v) { *(lds_u32*)(uintptr_t)addr = v; }
 
 // One workgroup streaming down its band: decimated rows [j0, j1) of the residue whose row j is global row ybase + S*j, columns
 // [x0, x0 + kTX).  EXACT = false is the product path.  -> (per wave) "one of my outputs came out NaN".
@@ -42,17 +56,13 @@ struct AtrousLds { f32x4* recA; f32x2* recL; f32x2* recN; uint32_t* nflag; uint3
 // kernel then runs the band again with EXACT = true: the general taps in the form that evaluates the luminance term as the
 // reference does (taps24<.., kTapsNaN>) and a select for the sky centres.  A workgroup whose texels are all finite never gets there.
 template <int ST, int S, bool EXACT>
-__device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, const AtrousLds& L, int x0, int j0, int j1, int ybase) {
+__device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, const AtrousLds<S>& L, int x0, int j0, int j1, int ybase) {
     constexpr int TX = kTX;
     constexpr int WL = TX + 4 * S;                 // staged columns per ring row
     constexpr int CB = ST == 0 ? 16 : 8;           // bytes per colour texel
     constexpr int NH = 4 * S;                      // halo pixels per ring row: all staged by wave 0 of the row group (lanes 0..NH-1);
                                                    // spread over the waves, every wave paid the halo's ~20 VALU + 3 loads for a few lanes
     static_assert(NH >= 1 && NH <= 64, "halo does not fit one wave");
-    f32x4* const recA = L.recA;
-    f32x2* const recL = L.recL;
-    f32x2* const recN = L.recN;
-    uint32_t* const nflag = L.nflag;
 
     int t = threadIdx.x;
     // (the second pass derives its per-lane constants from a thread index the compiler cannot identify with the first pass's: shared
@@ -65,7 +75,6 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
 
     // per-lane constants
     const int gx = x0 + col;                       // own column
-    const int oli = col + 2 * S;                   // its LDS column
     const bool halo_wave = wig == 0;               // scalar
     const bool has_halo = halo_wave && lane < NH;  // this lane also stages one halo pixel per row of its row group
     const int hx = (lane < 2 * S) ? x0 - 2 * S + lane : x0 + TX + lane - 2 * S;
@@ -75,6 +84,9 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
     const unsigned vo_c = own_ok ? (unsigned)gx * CB : kOob, vo_m = own_ok ? (unsigned)gx * 16u : kOob, vo_n = own_ok ? ((unsigned)gx << gs.n_shift) + gs.n_off : kOob;
     const unsigned vh_c = halo_ok ? (unsigned)hx * CB : kOob, vh_m = halo_ok ? (unsigned)hx * 16u : kOob, vh_n = halo_ok ? ((unsigned)hx << gs.n_shift) + gs.n_off : kOob;
     const unsigned npx = (unsigned)g.rows * (unsigned)g.W;
+    constexpr int NOFF = AtrousLds<S>::NOFF;
+    const uint32_t colA = L.a + (uint32_t)col * 16u, colL = L.l() + (uint32_t)col * 8u;    // this column's records of ring row 0
+    const uint32_t haloA = L.a + (uint32_t)hli * 16u, haloL = L.l() + (uint32_t)hli * 8u;   // ... and of its halo pixel
 
     // A thread's share of one staged step: its own pixel of row (jn + rg), and a halo pixel on lanes < NH.  Buffer resources are
     // built where they are used (a scalar select of num_records) instead of being kept in SGPRs for the whole kernel.
@@ -90,9 +102,10 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
     uint32_t ref01 = 0, refz = 0;
     auto commit = [&](int sl, const Staged& st) __attribute__((always_inline)) {
         int so = sl + rg; so = so >= kRing ? so - kRing : so;                           // scalar
-        unsigned long long differs = commit_px<ST, true>(st.o, recA, recL, recN, so * WL + oli, ref01, refz);
-        if (halo_wave) differs |= commit_px<ST, false>(st.h, recA, recL, recN, so * WL + hli, ref01, refz, has_halo);
-        if (lane == 0) nflag[so * 8 + wig] = differs != 0ull ? kFlagNormal : 0u;        // a ring slot is always staged by the same waves
+        // (own pixel: column + 2S of the ring row — a scalar added to the column's address, no register of its own)
+        unsigned long long differs = commit_px<ST, true>(st.o, colA + (uint32_t)(so * (WL * 16) + 2 * S * 16), colL + (uint32_t)(so * (WL * 8) + 2 * S * 8), NOFF, ref01, refz);
+        if (halo_wave) differs |= commit_px<ST, false>(st.h, haloA + (uint32_t)(so * (WL * 16)), haloL + (uint32_t)(so * (WL * 8)), NOFF, ref01, refz, has_halo);
+        if (lane == 0) lds_store(L.flag(so * 8 + wig), differs != 0ull ? kFlagNormal : 0u);   // a ring slot is always staged by the same waves
     };
 
     // ddepth of this thread's next two centres (rows j+rg and two rows further).  A staged row becomes a centre two steps after it
@@ -101,16 +114,16 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
     // prologue: two ring rows at a time, three dependent rounds of memory latency.  (All six rows requested at once measure the
     // same at 4K and 1 % slower at 1080p: profiles/r03_small_experiments.txt.)  Rows j0, j0+1 (always inside the frame) go first:
     // thread 0's pixel of row j0 is the workgroup's reference normal.
-    if (t < kRing * 8) nflag[t] = 0u;
+    if (t < kRing * 8) lds_store(L.flag(0) + 4 * t, 0u);
 #pragma unroll 1
     for (int rr = 0; rr < kRing; rr += kRS) {
         const int r = rr == 0 ? 2 : (rr == 2 ? 0 : rr);
         Staged st;
         fetch(j0 - 2 + r, st);
         if (rr == 0) {
-            if (t == 0) { L.nref[0] = st.o.n.x; L.nref[1] = st.o.n.y & 0xffffu; }
+            if (t == 0) { lds_store(L.nref(0), st.o.n.x); lds_store(L.nref(1), st.o.n.y & 0xffffu); }
             __syncthreads();
-            ref01 = L.nref[0]; refz = L.nref[1];
+            ref01 = lds_load(L.nref(0)); refz = lds_load(L.nref(1));
         }
         commit(r, st);
         if (r == 2) dq0 = __uint_as_float(st.o.zd.y);
@@ -132,15 +145,18 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
         if (more) fetch(j + kRS + 2, cs);
 
         // this thread's centre is ring row 2+rg, its taps ring rows rg .. rg+4, columns oli-2S .. oli+2S
-        int rowbase[5];
+        TapRows rows;
 #pragma unroll
-        for (int r = 0; r < 5; r++) { int sl = slot0 + rg + r; sl = sl >= kRing ? sl - kRing : sl; rowbase[r] = sl * WL + col; }   // scalar + lane constant
-        const int ci = rowbase[2] + 2 * S;
-        const TapCentre c = centre_setup<S>(recA[ci], recL[ci], recN[ci], dq0, inv_phi_c);
+        for (int r = 0; r < 5; r++) {
+            int sl = slot0 + rg + r; sl = sl >= kRing ? sl - kRing : sl;                 // scalar
+            rows.a[r] = colA + (uint32_t)(sl * (WL * 16)); rows.l[r] = colL + (uint32_t)(sl * (WL * 8));
+        }
+        const uint32_t ca = rows.a[2] + 2 * S * 16, cl = rows.l[2] + 2 * S * 8;
+        const TapCentre c = centre_setup<S>(lds_read_a(ca), lds_read_l(cl), lds_read_l(cl + NOFF), dq0, inv_phi_c);
         const bool sky = c.sky;
         const bool wave_has_surface = wave_any(!sky);
-        const bool uniform = !EXACT && !a.no_fastpath && !wave_any(lane < kRing * 8 && nflag[lane < kRing * 8 ? lane : 0] != 0u);
-        const float4 o = filter_px<S, kTapDepth, EXACT>(recA, recL, recN, rowbase, c, phi_n, wave_has_surface, uniform, &ref_base);
+        const bool uniform = !EXACT && !a.no_fastpath && !wave_any(lane < kRing * 8 && lds_load(L.flag(0) + 4 * (lane < kRing * 8 ? lane : 0)) != 0u);
+        const float4 o = filter_px<S, kTapDepth, NOFF, EXACT>(rows, c, phi_n, wave_has_surface, uniform, &ref_base);
         if constexpr (!EXACT) nan_out |= lanes_where(__builtin_isunordered(o.x, o.w));
 
         // Output values now, their stores AFTER the ring refill: hipcc's vmcnt bookkeeping cannot tell that the rows committed
@@ -174,14 +190,8 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
 template <int ST, int S>
 __global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup, int xrot) {
     keep_nan_in_clamps();
-    constexpr int WL = kTX + 4 * S;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    AtrousLds L;
-    L.recA = (f32x4*)smem;
-    L.recL = (f32x2*)(L.recA + kRing * WL);        // 8-byte records, contiguous: conflict-free ds_read_b64 (64 banks)
-    L.recN = L.recL + kRing * WL;
-    L.nflag = (uint32_t*)(L.recN + kRing * WL);    // [kRing][8]
-    L.nref = L.nflag + kRing * 8;                  // {(nx,ny) bits, nz bits}, then the workgroup's "an output was NaN" word
+    const AtrousLds<S> L{lds_addr(smem)};
     // tile order v = (residue, band, x tile), x fastest.  Step 1 walks the frame bottom-up: what the temporal launch wrote last is
     // still in the 256 MB Infinity Cache when it is read first (-4.5 % for that launch).  Later steps sweep the frame once per row
     // residue; of the six direction patterns tried for them, only "step 8 backwards too" measured better than all forwards (-1.5 to
@@ -201,19 +211,18 @@ __global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(
     const int j1 = min(nj, j0 + band_rows);
     const int ybase = g.yb + rv;                   // global row of decimated index j: ybase + S*j
 
-    if (threadIdx.x == 0) L.nref[2] = 0u;          // (ordered before the waves' stores below by the band's barriers)
+    if (threadIdx.x == 0) lds_store(L.nref(2), 0u);    // (ordered before the waves' stores below by the band's barriers)
     const bool nan_wave = atrous_band<ST, S, false>(g, a, L, x0, j0, j1, ybase);
-    if (nan_wave && (threadIdx.x & 63) == 0) L.nref[2] = 1u;
+    if (nan_wave && (threadIdx.x & 63) == 0) lds_store(L.nref(2), 1u);
     __syncthreads();
-    if (L.nref[2] == 0u) return;                   // every frame without a NaN
+    if (lds_load(L.nref(2)) == 0u) return;         // every frame without a NaN
     __syncthreads();                               // (the band's prologue writes the flag words again)
     (void)atrous_band<ST, S, true>(g, a, L, x0, j0, j1, ybase);
 }
 
 template <int ST, int S>
 hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
-    constexpr int WL = kTX + 4 * S;
-    constexpr size_t lds = (size_t)kRing * WL * kRecBytes + (kRing * 8 + 3) * sizeof(uint32_t);
+    constexpr size_t lds = AtrousLds<S>::bytes;
     static std::atomic<unsigned long long> attr_done{0};
     if (hipError_t e = allow_dynamic_lds(atrous_lds_kernel<ST, S>, lds, attr_done); e != hipSuccess) return e;
     // Bands are sized so that (x tiles) x (S residues) x (bands) is FOUR times the resident slots of the chip (LDS: 160 KiB per CU;

@@ -12,6 +12,23 @@
 namespace svgf {
 namespace {
 
+// LDS BYTE addresses of a thread's five tap rows (its own column's record in each): A = the colour records (16 B), L = the
+// {luminance, depth} records (8 B); a row's normal record sits NOFF bytes behind its L record (same stride).  Byte addresses, built as
+// (per-lane constant) + (per-row scalar): one v_add per row and plane per step — index arithmetic (row * width + column, then x16 and
+// x8) cost three.  Tap (row r, column cc) is an immediate offset from there.
+struct TapRows { uint32_t a[5], l[5]; };
+__device__ __forceinline__ f32x4 lds_read_a(uint32_t addr) { return *(const lds_f32x4*)(uintptr_t)addr; }
+// volatile: keeps these as single ds_read_b64 (2 LDS cycles each); merged into ds_read2_b64 they take 8
+__device__ __forceinline__ f32x2 lds_read_l(uint32_t addr) { return *(const volatile lds_f32x2*)(uintptr_t)addr; }
+// the same from record indices (row * width + column) into planes recA / recL
+__device__ __forceinline__ TapRows rows_from_index(const f32x4* recA, const f32x2* recL, const int (&rowbase)[5]) {
+    TapRows t;
+    const uint32_t ba = lds_addr(recA), bl = lds_addr(recL);
+#pragma unroll
+    for (int r = 0; r < 5; r++) { t.a[r] = ba + (uint32_t)rowbase[r] * 16u; t.l[r] = bl + (uint32_t)rowbase[r] * 8u; }
+    return t;
+}
+
 // What a thread keeps of its centre pixel (the set-up of :543-568).
 struct TapCentre {
     f32x4 A;             // clamped colour + variance
@@ -55,9 +72,8 @@ __device__ __forceinline__ UniBase uni_base(uint32_t n01, float nz, float phi_n)
 // NaN reaches the sums only through the channels that hold it (:608); saturate(n.n') of a NaN is 0.  The other two paths fold
 // |dl| / phi_l into one FMA of the exponent, which makes the weight — and with it all four channels — NaN.
 constexpr int kTapsGeneral = 0, kTapsUniform = 1, kTapsNaN = 2;
-template <int CS, int D, int MODE>
-__device__ __forceinline__ void taps24(const f32x4* recA, const f32x2* recL, const f32x2* recN, const int (&rowbase)[5], const TapCentre& c, float phi_n,
-                                       float& sw, f32x2& srg, f32x2& sbv, const UniBase* shared_base) {
+template <int CS, int D, int MODE, int NOFF>
+__device__ __forceinline__ void taps24(const TapRows& rows, const TapCentre& c, float phi_n, float& sw, f32x2& srg, f32x2& sbv, const UniBase* shared_base) {
     // shared_base: the workgroup's reference normal's values, computed once (every surface centre of a uniform wave carries exactly
     // those normal bits, so they are what uni_base(c.n01, c.nz) would give); null: per pixel
     constexpr bool UNI = MODE == kTapsUniform;
@@ -70,10 +86,9 @@ __device__ __forceinline__ void taps24(const f32x4* recA, const f32x2* recL, con
     auto issue = [&](int t) __attribute__((always_inline)) {
         if (t == 12) return;                                                             // the centre itself is no tap (:584)
         const int r = t / 5, cc = t % 5;
-        qA[t] = recA[rowbase[r] + cc * CS];
-        // volatile: keeps these as single ds_read_b64 (2 LDS cycles each); merged into ds_read2_b64 they take 8
-        qL[t] = ((const volatile lds_f32x2*)recL)[rowbase[r] + cc * CS];
-        if (!UNI) qN[t] = ((const volatile lds_f32x2*)recN)[rowbase[r] + cc * CS];
+        qA[t] = lds_read_a(rows.a[r] + cc * CS * 16);
+        qL[t] = lds_read_l(rows.l[r] + cc * CS * 8);
+        if (!UNI) qN[t] = lds_read_l(rows.l[r] + cc * CS * 8 + NOFF);
     };
 #pragma unroll
     for (int t = 0; t < D; t++) issue(t);
@@ -110,18 +125,17 @@ __device__ __forceinline__ void taps24(const f32x4* recA, const f32x2* recL, con
 
 // One pixel: taps + normalisation (:554-558,567-568,615).  `wave_has_surface` (a wave whose centres are all sky has nothing to
 // filter) and `uniform` are wave-uniform.  EXACT: the band is run again because a NaN showed in its output (svgf_atrous_lds.h).
-template <int CS, int D, bool EXACT = false>
-__device__ __forceinline__ float4 filter_px(const f32x4* recA, const f32x2* recL, const f32x2* recN, const int (&rowbase)[5], const TapCentre& c, float phi_n,
-                                            bool wave_has_surface, bool uniform, const UniBase* shared_base = nullptr) {
+template <int CS, int D, int NOFF, bool EXACT = false>
+__device__ __forceinline__ float4 filter_px(const TapRows& rows, const TapCentre& c, float phi_n, bool wave_has_surface, bool uniform, const UniBase* shared_base = nullptr) {
     float sw = 1.0f;                                                                     // :567
     f32x2 srg = {c.A.x, c.A.y}, sbv = {c.A.z, c.A.w};                                    // :568
     if (wave_has_surface) {
         if constexpr (EXACT) {
-            taps24<CS, D, kTapsNaN>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv, nullptr);
+            taps24<CS, D, kTapsNaN, NOFF>(rows, c, phi_n, sw, srg, sbv, nullptr);
             // a sky centre is copied (:554-558): its taps' weights are exactly 0, but 0 x NaN is not
             if (c.sky) { sw = 1.0f; srg = (f32x2){c.A.x, c.A.y}; sbv = (f32x2){c.A.z, c.A.w}; }
-        } else if (uniform) taps24<CS, D, kTapsUniform>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv, shared_base);
-        else taps24<CS, D, kTapsGeneral>(recA, recL, recN, rowbase, c, phi_n, sw, srg, sbv, nullptr);
+        } else if (uniform) taps24<CS, D, kTapsUniform, NOFF>(rows, c, phi_n, sw, srg, sbv, shared_base);
+        else taps24<CS, D, kTapsGeneral, NOFF>(rows, c, phi_n, sw, srg, sbv, nullptr);
     }
     const float inv = hw_rcp(sw);                                                        // sw >= 1 (a sky centre: exactly 1, and the sums are its colour)
     return make_float4(srg.x * inv, srg.y * inv, sbv.x * inv, sbv.y * (inv * inv));      // :615

@@ -79,7 +79,12 @@ __device__ __forceinline__ float dot3_exact(float3 a, float3 b) { return (a.x * 
 __device__ __forceinline__ float dot3_fma(float3 a, float3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 // CalculateLuminance, Filter.cuh:260-263, in the reference's operation order: where the temporal variance is 0 the
 // a-trous weights amplify a one-ulp luminance difference ~1e4 times (Tolerance), so no FMA here
-__device__ __forceinline__ float lum_exact(float r, float g, float b) { return 0.2126f * r + 0.7152f * g + 0.0722f * b; }
+__device__ __forceinline__ float lum_exact(float r, float g, float b) {
+    float pr = 0.2126f * r, pg = 0.7152f * g;
+    asm("" : "+v"(pr));      // (keeps hipcc from pairing two of the three products into one v_pk_mul_f32 behind two v_mov: 6 issue slots instead of 2)
+    asm("" : "+v"(pg));
+    return pr + pg + 0.0722f * b;
+}
 __device__ __forceinline__ float mix_exact(float x, float y, float a) { return x * (1.0f - a) + y * a; }   // glm::mix
 
 __device__ __forceinline__ float hw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -191,8 +196,10 @@ constexpr uint32_t kFlagNormal = 1u;
 // the scalar unit.  `store` masks the LDS writes only: everything else runs on every lane (the halo pass's idle lanes hold all-zero
 // texels: no depth, so they never differ).
 __device__ __forceinline__ unsigned long long lanes_where(bool single_compare) { return __builtin_amdgcn_ballot_w64(single_compare); }
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+// addr_a / addr_l: LDS byte addresses of the pixel's colour and {luminance, depth} records; its normal record sits noff bytes behind the latter.
 template <int ST, bool DZ>
-__device__ __forceinline__ unsigned long long commit_px(const RawPx<ST, DZ>& r, f32x4* recA, f32x2* recL, f32x2* recN, int at, uint32_t ref01, uint32_t refz, bool store = true) {
+__device__ __forceinline__ unsigned long long commit_px(const RawPx<ST, DZ>& r, uint32_t addr_a, uint32_t addr_l, int noff, uint32_t ref01, uint32_t refz, bool store = true) {
     float4 c;
     if constexpr (ST == 0) c = make_float4(__uint_as_float(r.c.x), __uint_as_float(r.c.y), __uint_as_float(r.c.z), __uint_as_float(r.c.w));
     else { float2 lo = unpack_h2(r.c.x), hi = unpack_h2(r.c.y); c = make_float4(lo.x, lo.y, hi.x, hi.y); }
@@ -203,13 +210,14 @@ __device__ __forceinline__ unsigned long long commit_px(const RawPx<ST, DZ>& r, 
     if (z == 0.0f) z = kSkyZ;                                           // GetDepth, :199-207
     const float lum = lum_exact(c.x, c.y, c.z), nz = unpack_h2(r.n.y).x;
     if (store) {
-        recA[at] = (f32x4){c.x, c.y, c.z, c.w};
-        recL[at] = (f32x2){lum, z};
-        recN[at] = (f32x2){__uint_as_float(r.n.x), nz};
+        *(lds_f32x4*)(uintptr_t)addr_a = (f32x4){c.x, c.y, c.z, c.w};
+        *(lds_f32x2*)(uintptr_t)addr_l = (f32x2){lum, z};
+        *(lds_f32x2*)(uintptr_t)(addr_l + noff) = (f32x2){__uint_as_float(r.n.x), nz};
     }
     // a texel without depth (sky, or outside the frame) has weight 0 through the depth term whatever its normal
     return lanes_where(z != kSkyZ) & (lanes_where(r.n.x != ref01) | lanes_where((r.n.y & 0xffffu) != refz));
 }
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
 
 // log2 of the kernel weight K[|xx|]*K[|yy|] (:540,582), folded into the exponent
 __device__ __forceinline__ constexpr float klog2(int axx, int ayy) {
