@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--frames-in-flight", type=int, choices=[1, 2], default=1,
                     help="2: svgf_set_frames_in_flight(2) - iterations 1.. of a frame on a side stream beside the next frame's temporal launch (bit-identical results; "
                          "a frame's result is ordered on the stream one call later)")
+    ap.add_argument("--no-prev-guide", action="store_true", help="leave svgf_set_prev_guide off (the ABI's default): the reprojection test reads the three planes of the "
+                                                                 "previous G-buffer instead of the guide plane the previous frame kept (+16 B/px)")
     ap.add_argument("--prime-ms", type=float, default=400.0, help="untimed load before the first timed frame: at least this long ...")
     ap.add_argument("--prime-frames", type=int, default=600, help="... and at least this many frames, --warmup included (DESIGN.md 6: the post-idle clock ramp and the "
                                                                    "one-off stall of a process's first ~4 000 stream operations belong in front of the timed region; 0 / 0 for smoke runs)")
@@ -187,7 +189,7 @@ class FramePool:
 
 
 # ------------------------------------------------------------------ single GPU -----------------
-def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, device, cold_frames=0, fuse=False, windows=5, in_flight=1, prime=(400.0, 600)):
+def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, device, cold_frames=0, fuse=False, windows=5, in_flight=1, prime=(400.0, 600), prev_guide=True):
     """-> dict(ms_per_step = median over `windows` timed windows of `steps` frames each (sync, K frames, sync), windows_ms, stage_ms[list],
     ms_no_events: one more window without the per-stage HIP events, ...)."""
     import torch
@@ -195,7 +197,7 @@ def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, de
     d = F.Denoiser(W, H, F.Params(storage=storage, steps=iters, variant=variant), device=device.index or 0)
     d.set_iteration_fusion(fuse)
     d.set_frames_in_flight(in_flight)
-    d.set_prev_guide(True)     # the pools hand over last frame's current G-buffer, untouched, as `prev` (tests/test_bench_inputs.py): the precondition of svgf_set_prev_guide
+    d.set_prev_guide(prev_guide)   # the pools hand over last frame's current G-buffer, untouched, as `prev` (tests/test_bench_inputs.py): the precondition of svgf_set_prev_guide
     n = 0
     for _ in range(PRIME_FRAMES + warmup):
         d.Render(*pool.frame(n))
@@ -259,6 +261,69 @@ def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, de
                 in_flight=in_flight)
 
 
+def run_interactive(pool: FramePool, W, H, storage, iters, variant, device, producer_target_ms=4.0, frames=48):
+    """The regime the reference runs in: ONE denoise per displayed frame between other work of the same GPU — application::Render path-traces
+    the frame (App.cu:550) and then calls the three filter methods on the same stream (App.cu:552-556).  Neither the sustained headline
+    (back-to-back frames) nor an idle device between frames is that.  Two figures, both the sum of the library's per-stage HIP events:
+      interleaved: producer, denoise, producer, denoise ... on one stream, where the producer is a memory-bound stand-in for the path tracer
+                   (in-place passes over a 1 GiB buffer, their number calibrated to ~producer_target_ms);
+      isolated:    denoise, host sleep of 5 ms (the device idles and leaves its sustained clocks), denoise ...
+    -> dict(interleaved_ms, producer_ms, isolated_ms, ...)."""
+    import torch
+    from svgf_amd import filter as F
+    d = F.Denoiser(W, H, F.Params(storage=storage, steps=iters, variant=variant), device=device.index or 0)
+    d.set_prev_guide(True)
+    n = 0
+    for _ in range(PRIME_FRAMES):
+        d.Render(*pool.frame(n)); n += 1
+    buf = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=device).fill_(1.0)
+
+    def producer(passes):
+        for _ in range(passes):
+            buf.mul_(1.0000001)                      # 2 GiB of HBM traffic per pass
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    producer(4); torch.cuda.synchronize(device)
+    e0.record(); producer(8); e1.record(); torch.cuda.synchronize(device)
+    per_pass = e0.elapsed_time(e1) / 8
+    passes = max(1, int(round(producer_target_ms / per_pass)))
+    # warm: the same alternation, untimed
+    for _ in range(16):
+        producer(passes); d.Render(*pool.frame(n)); n += 1
+    torch.cuda.synchronize(device)
+    d.timing_enable(1)
+    pe = []
+    for k in range(frames):
+        if k % 8 == 0:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); producer(passes); b.record(); pe.append((a, b))
+        else:
+            producer(passes)
+        d.Render(*pool.frame(n)); n += 1
+    torch.cuda.synchronize(device)
+    ms, fr = d.timing_read()
+    interleaved = sum(ms) / max(fr, 1)
+    stages_i = [m / max(fr, 1) for m in ms]
+    producer_ms = sum(x.elapsed_time(y) for x, y in pe) / len(pe)
+    iso = []
+    for k in range(24):
+        d.Render(*pool.frame(n)); n += 1
+        torch.cuda.synchronize(device)
+        ms_k, _ = d.timing_read()
+        if k >= 4:
+            iso.append(sum(ms_k))
+        time.sleep(0.005)
+    d.timing_enable(False)
+    d.close()
+    del buf
+    iso.sort()
+    return {"interleaved_ms": round(interleaved, 4), "producer_ms": round(producer_ms, 3), "producer": f"{passes} in-place passes over a 1 GiB fp32 buffer on the same stream "
+            f"({per_pass:.3f} ms each: memory-bound, as the path tracer of App.cu:550 is)", "interleaved_stage_ms": [round(x, 4) for x in stages_i],
+            "isolated_ms": round(iso[len(iso) // 2], 4), "isolated_ms_min": round(iso[0], 4), "isolated_ms_max": round(iso[-1], 4),
+            "isolated": "one frame at a time, 5 ms of host sleep between frames (the device idles): median / min / max of 20 frames",
+            "note": "sum of the stage times between the library's HIP events (the denoise alone, whatever surrounds it); the headline ms_per_step is sustained "
+                    "back-to-back throughput, which an interactive renderer does not see"}
+
+
 def timing_fields(r):
     """What the judge asked to see next to ms_per_step: the spread of the windows, the sum of the stage times (events make the frames that
     carry them slower, so it exceeds ms_per_step), and what the events cost."""
@@ -316,6 +381,12 @@ def roofline_block(W, H, storage, iters, stage_ms, variant="auto", fused=False):
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5),
             "traffic": traffic, "traffic_source": src}
+    # the launch's second bound: its vector ALUs (the kernel is co-limited: DESIGN.md 3.3).  Like `traffic`, from the PMC passes of the same sources.
+    busy, bsrc = measured_traffic(W, H, storage, "atrous_valu_busy") if variant != "direct" and not fused else (None, None)
+    if busy is not None:
+        ipp, _ = measured_traffic(W, H, storage, "atrous_insts_valu_per_px")
+        roof["secondary"] = {"bound": "valu", "valu_busy": busy, "insts_valu_per_px": ipp, "source": bsrc,
+                             "what": "valu_busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) per launch; insts_valu_per_px = SQ_INSTS_VALU / (pixels / 64)"}
 
     def rate(px_bytes, ms):
         return round(px_bytes * P / (ms * 1e-3) / 1e9, 1) if ms > 0 else None
@@ -509,7 +580,8 @@ def main():
         fuse = bool(args.fuse)
         for m in motions:
             res[m] = run_single(FramePool(scene, storage, m), W, H, storage, iters, args.variant, args.steps, args.warmup, device,
-                                cold_frames=5 if (m == "static" and not args.no_extra) else 0, fuse=fuse, windows=args.windows, in_flight=args.frames_in_flight, prime=(args.prime_ms, args.prime_frames))
+                                cold_frames=5 if (m == "static" and not args.no_extra) else 0, fuse=fuse, windows=args.windows, in_flight=args.frames_in_flight, prime=(args.prime_ms, args.prime_frames),
+                                prev_guide=not args.no_prev_guide)
         head = motions[0]
         r = res[head]
         ms = r["ms_per_step"]
@@ -525,7 +597,9 @@ def main():
                                    f"G-buffer in distinct planes (ping-ponged), 1-spp noise, seed 0x5356474600000001",
                        "width": W, "height": H, "storage": storage, "atrous_iterations": iters, "variant": args.variant, "motion": head,
                        "iterations_0_and_1_in_one_launch": r["fused"], "frames_in_flight": r["in_flight"],
-                       "prev_guide": "on (svgf_set_prev_guide: the previous G-buffer's planes are last frame's current ones, not rewritten in between - as in the reference, App.cu:374)"},
+                       "prev_guide": "off (the ABI's default: the previous G-buffer's three planes are read)" if args.no_prev_guide else
+                                     "on (svgf_set_prev_guide, opt-in: the previous G-buffer's planes are last frame's current ones, not rewritten in between - as in the "
+                                     "reference, App.cu:374; also.prev_guide_off is the same run with the ABI's default)"},
             **timing_fields(r),
             "roofline": roof,
             "pass_roofline": pass_block(W, H, storage, iters, ms, r["fused"]),
@@ -572,6 +646,24 @@ def main():
                                                  "frac_of_8TBps": pass_block(W, H, "f16", iters, r3["ms_per_step"])["frac_of_8TBps"],
                                                  "atrous_avg_launch_ms": roof3["avg_launch_ms"] if roof3 else None,
                                                  "atrous_roofline_frac": roof3["frac"] if roof3 else None}
+        if not args.no_extra and not args.no_prev_guide and wl == "4k":
+            # the ABI's default: svgf_set_prev_guide off (the host has not vouched for the previous G-buffer's planes)
+            r6 = run_single(FramePool(scene, storage, "static"), W, H, storage, iters, args.variant, max(args.steps, 20), args.warmup, device, fuse=fuse, windows=args.windows, prime=(args.prime_ms, args.prime_frames), prev_guide=False)
+            roof6, st6 = roofline_block(W, H, storage, iters, r6["stage_ms"], args.variant, r6["fused"])
+            line.setdefault("also", {})["prev_guide_off"] = {
+                "ms_per_step": round(r6["ms_per_step"], 4), "ms_per_step_min": round(min(r6["windows_ms"]), 4), "ms_per_step_max": round(max(r6["windows_ms"]), 4),
+                "Mpixels/s": round(W * H / (r6["ms_per_step"] * 1e-3) / 1e6, 1), "frac_of_8TBps": pass_block(W, H, storage, iters, r6["ms_per_step"])["frac_of_8TBps"],
+                "temporal_ms": st6["temporal+moments"]["temporal_ms"] if st6 else None,
+                "note": "the ABI's default configuration: the reprojection test reads motion / normal / uv of the previous G-buffer (32 B/px) instead of the kept guide plane (16 B/px)"}
+        if not args.no_extra and wl == "4k" and iters == 5:
+            # the GUI's range is 0-10 iterations (GUI.cpp:988), step = 1 << i (App.cu:502): steps 32 and 64 run through the LDS kernel too
+            r7 = run_single(FramePool(scene, storage, "static"), W, H, storage, 7, args.variant, max(args.steps, 20), args.warmup, device, fuse=fuse, windows=3, prime=(args.prime_ms, args.prime_frames),
+                            prev_guide=not args.no_prev_guide)
+            line.setdefault("also", {})["seven_iterations"] = {"ms_per_step": round(r7["ms_per_step"], 4), "Mpixels/s": round(W * H / (r7["ms_per_step"] * 1e-3) / 1e6, 1),
+                                                               "atrous_launch_ms_by_step": {str(1 << i): round(r7["stage_ms"][2 + i], 5) for i in range(7)},
+                                                               "note": "temporal + moments + 7 a-trous iterations (steps 1..64), all LDS-streaming launches"}
+        if not args.no_extra and wl == "4k" and args.frames_in_flight == 1:
+            line.setdefault("also", {})["interactive"] = run_interactive(FramePool(scene, storage, "static"), W, H, storage, iters, args.variant, device)
         if not args.no_extra and args.variant == "auto" and wl == "4k":
             # the synthetic scene is piecewise planar: 68-87 % of the a-trous waves take the uniform-normal fast path (8 instead of 13
             # vector instructions per tap, same results).  What geometry without planar regions would cost: the fast path switched off.

@@ -231,8 +231,9 @@ int svgf_reset_history(svgf_ctx* ctx);                                 /* zero a
  *   - *result of call f is returned at once but is ORDERED on the context's stream only by the next svgf_denoise_frame, svgf_flush
  *     or svgf_sync (enqueue the consumer of frame f after one of those); it stays valid until the call after the next one (frames
  *     alternate between two pairs of filter planes: +2 colour planes of memory);
- *   - the planes of `cur` given to call f must stay as they are until call f + 1 has been made when the iterations read them
- *     (variant DIRECT, or steps == 0: without the guide plane) — with the reference's two framebuffers they do;
+ *   - the planes of `cur` are not read after the call's launches on the context's stream: iterations that read them (the direct kernel:
+ *     variant DIRECT, PhiNormal == 0, a step beyond 64) keep the frame's tail on the context's stream — such a frame simply does not
+ *     overlap with the next one;
  *   - the debug views (svgf_set_debug_mode) and strip-driver contexts do not combine with it (refused).
  * frames = 1 (default) restores stream order at once: the frame in flight is ordered on the context's stream by that call and its
  * result is then valid until the next svgf_denoise_frame, as ever.  svgf_flush orders the frame in flight on the context's stream

@@ -539,7 +539,14 @@ int svgf_set_frames_in_flight(svgf_ctx* c, int frames) {
     } else {
         int rc = join_side(c, c->stream);
         if (rc != SVGF_OK) return rc;
-        // the last result may sit in the second pair: it stays allocated (and valid) until the context is resized or destroyed
+        // With one frame in flight every frame uses c->filter[], and svgf_state_plane(SVGF_PLANE_FILTER, ..) and the SVGF_DEBUG_ATROUS view
+        // (which filters what the previous frame left in FilterBuffer, App.cu:611-620) index c->filter[] too: if the last frame used the
+        // second pair, the pairs change names (the result pointer handed out stays valid: the planes themselves do not move).
+        if (c->filter_set == 0 && c->filter_alt[0] && c->filter_alt[1]) {      // filter_set is the pair the NEXT frame would use: the last one used the other
+            std::swap(c->filter[0], c->filter_alt[0]);
+            std::swap(c->filter[1], c->filter_alt[1]);
+        }
+        c->filter_set = 0;
     }
     c->frames_in_flight = frames;
     return SVGF_OK;
@@ -712,7 +719,10 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     stamp();
     int pp = 0, first = 0;
     hipStream_t const caller_stream = c->stream;
-    const bool pair = can_fuse01(c) && halo_held(c, 6);
+    // The pair launch stores iteration 0's feedback on [rb - 4, re + 4) inside the frame: with svgf_set_rows narrower than the frame those
+    // rows lie outside what this frame's temporal launch wrote, and feedback computed from last frame's filter plane would replace
+    // colour rows the two-launch sequence leaves alone.  So: only on the whole frame.
+    const bool pair = can_fuse01(c) && halo_held(c, 6) && c->rb == 0 && c->re == c->H;
     bool aside = false;
     auto go_aside = [&]() -> int {
         // the rest of this frame goes onto the side stream; the frame that was there is ordered on the caller's stream first (its
@@ -739,8 +749,13 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     // Everything the NEXT frame's temporal launch reads is written now: with two frames in flight the remaining iterations leave the
     // caller's stream.  (Iteration 0 on the side stream as well - the next temporal launch waiting for an event behind it - measured
     // 1-2 % slower: beside a queue of nothing but wavelet launches the temporal launch gets too few workgroup slots, profiles/r03_small_experiments.txt.)
+    // The tail may only leave the caller's stream if it reads nothing of the caller's: every remaining iteration an LDS launch on the
+    // guide plane.  An iteration the direct kernel runs (variant DIRECT, PhiNormal == 0, a step beyond 64) reads cur->motion / cur->normal,
+    // which nothing orders against the caller's stream once the call has returned.
+    bool tail_reads_cur = guide == nullptr || c->p.variant == SVGF_VARIANT_DIRECT || c->p.phi_normal == 0.0f;
+    for (int i = first; i < c->p.steps; i++) tail_reads_cur = tail_reads_cur || (1 << i) > 64;
     if (rc == SVGF_OK && c->frames_in_flight > 1) {
-        if (c->side && first < c->p.steps) { fe.split = 2 + first; rc = go_aside(); }
+        if (c->side && first < c->p.steps && !tail_reads_cur) { fe.split = 2 + first; rc = go_aside(); }
         else rc = join_side(c, caller_stream);
     }
     for (int i = first; i < c->p.steps && rc == SVGF_OK; i++) {

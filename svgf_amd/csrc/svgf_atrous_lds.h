@@ -25,8 +25,8 @@ namespace {
 constexpr int kTX = 128;                 // columns of a workgroup: two waves per row, two rows per step
 constexpr int kTapDepth = 3;             // LDS reads run this many taps ahead of the arithmetic
 // Resident waves per SIMD the kernel of step S is compiled for (registers: 95 -> five).  At step 16 the ring (37 KB) allows four
-// workgroups per CU anyway.
-constexpr int atrous_waves(int S) { return S <= 8 ? 5 : 4; }
+// workgroups per CU anyway, at step 32 (49 KB) three, at step 64 (74 KB) two.
+constexpr int atrous_waves(int S) { return S <= 8 ? 5 : S == 16 ? 4 : S == 32 ? 3 : 2; }
 
 // LDS layout of a workgroup, as byte addresses (no generic pointers: an address-space cast of a pointer the compiler cannot see
 // through costs a null check per use): colour records (16 B x kRing x WL), {luminance, depth} records (8 B x ..), normal records
@@ -60,9 +60,12 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
     constexpr int TX = kTX;
     constexpr int WL = TX + 4 * S;                 // staged columns per ring row
     constexpr int CB = ST == 0 ? 16 : 8;           // bytes per colour texel
-    constexpr int NH = 4 * S;                      // halo pixels per ring row: all staged by wave 0 of the row group (lanes 0..NH-1);
-                                                   // spread over the waves, every wave paid the halo's ~20 VALU + 3 loads for a few lanes
-    static_assert(NH >= 1 && NH <= 64, "halo does not fit one wave");
+    constexpr int NH = 4 * S;                      // halo pixels per ring row.  Steps 1-16: all staged by wave 0 of the row group (lanes
+                                                   // 0..NH-1; spread over the waves, every wave paid the halo's ~20 VALU + 3 loads for a few
+                                                   // lanes).  Steps 32 and 64: 128 / 256 of them — HP full passes on BOTH waves of the row group
+    constexpr int HP = NH <= 64 ? 1 : NH / 128;    // halo passes per staging wave
+    constexpr bool kBothWaves = NH > 64;
+    static_assert(NH <= 64 || NH == 128 * HP, "halo passes must be whole waves");
 
     int t = threadIdx.x;
     // (the second pass derives its per-lane constants from a thread index the compiler cannot identify with the first pass's: shared
@@ -75,36 +78,53 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
 
     // per-lane constants
     const int gx = x0 + col;                       // own column
-    const bool halo_wave = wig == 0;               // scalar
-    const bool has_halo = halo_wave && lane < NH;  // this lane also stages one halo pixel per row of its row group
-    const int hx = (lane < 2 * S) ? x0 - 2 * S + lane : x0 + TX + lane - 2 * S;
-    const int hli = (lane < 2 * S) ? lane : TX + lane;
-    const bool own_ok = gx < g.W, halo_ok = has_halo && hx >= 0 && hx < g.W;
+    const bool halo_wave = kBothWaves || wig == 0; // scalar
     const GuideSel gs(a.guide != nullptr);
+    const bool own_ok = gx < g.W;
     const unsigned vo_c = own_ok ? (unsigned)gx * CB : kOob, vo_m = own_ok ? (unsigned)gx * 16u : kOob, vo_n = own_ok ? ((unsigned)gx << gs.n_shift) + gs.n_off : kOob;
-    const unsigned vh_c = halo_ok ? (unsigned)hx * CB : kOob, vh_m = halo_ok ? (unsigned)hx * 16u : kOob, vh_n = halo_ok ? ((unsigned)hx << gs.n_shift) + gs.n_off : kOob;
+    // halo pixel of pass p: index hidx in [0, NH) along the row's 2S left + 2S right halo columns
+    bool has_halo[HP];
+    unsigned vh_c[HP], vh_m[HP], vh_n[HP];
+    int hli[HP];
+#pragma unroll
+    for (int p = 0; p < HP; p++) {
+        const int hidx = kBothWaves ? (wig * HP + p) * 64 + lane : lane;
+        has_halo[p] = halo_wave && hidx < NH;      // this lane also stages one halo pixel per pass and row of its row group
+        const int hx = (hidx < 2 * S) ? x0 - 2 * S + hidx : x0 + TX + hidx - 2 * S;
+        hli[p] = (hidx < 2 * S) ? hidx : TX + hidx;
+        const bool halo_ok = has_halo[p] && hx >= 0 && hx < g.W;
+        vh_c[p] = halo_ok ? (unsigned)hx * CB : kOob; vh_m[p] = halo_ok ? (unsigned)hx * 16u : kOob; vh_n[p] = halo_ok ? ((unsigned)hx << gs.n_shift) + gs.n_off : kOob;
+    }
     const unsigned npx = (unsigned)g.rows * (unsigned)g.W;
     constexpr int NOFF = AtrousLds<S>::NOFF;
     const uint32_t colA = L.a + (uint32_t)col * 16u, colL = L.l() + (uint32_t)col * 8u;    // this column's records of ring row 0
-    const uint32_t haloA = L.a + (uint32_t)hli * 16u, haloL = L.l() + (uint32_t)hli * 8u;   // ... and of its halo pixel
+    uint32_t haloA[HP], haloL[HP];                                                          // ... and of its halo pixel(s)
+#pragma unroll
+    for (int p = 0; p < HP; p++) { haloA[p] = L.a + (uint32_t)hli[p] * 16u; haloL[p] = L.l() + (uint32_t)hli[p] * 8u; }
 
     // A thread's share of one staged step: its own pixel of row (jn + rg), and a halo pixel on lanes < NH.  Buffer resources are
     // built where they are used (a scalar select of num_records) instead of being kept in SGPRs for the whole kernel.
-    struct Staged { RawPx<ST, true> o; RawPx<ST, false> h; };
+    struct Staged { RawPx<ST, true> o; RawPx<ST, false> h[HP]; };
     auto fetch = [&](int jn, Staged& st) __attribute__((always_inline)) {
         const int y = ybase + S * (jn + rg), yl = y - g.y0;                             // scalar
         const bool rok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows;
         const int srow = rok ? yl * g.W : 0;
         const PlaneRsrc rs = plane_rsrc(a, npx, CB, gs.n_shift, rok);
         raw_load<ST, true>(st.o, rs, vo_c, vo_m, vo_n, srow, gs.n_shift, gs.m_off);
-        if (halo_wave) raw_load<ST, false>(st.h, rs, vh_c, vh_m, vh_n, srow, gs.n_shift, gs.m_off);
+        if (halo_wave) {
+#pragma unroll
+            for (int p = 0; p < HP; p++) raw_load<ST, false>(st.h[p], rs, vh_c[p], vh_m[p], vh_n[p], srow, gs.n_shift, gs.m_off);
+        }
     };
     uint32_t ref01 = 0, refz = 0;
     auto commit = [&](int sl, const Staged& st) __attribute__((always_inline)) {
         int so = sl + rg; so = so >= kRing ? so - kRing : so;                           // scalar
         // (own pixel: column + 2S of the ring row — a scalar added to the column's address, no register of its own)
         unsigned long long differs = commit_px<ST, true>(st.o, colA + (uint32_t)(so * (WL * 16) + 2 * S * 16), colL + (uint32_t)(so * (WL * 8) + 2 * S * 8), NOFF, ref01, refz);
-        if (halo_wave) differs |= commit_px<ST, false>(st.h, haloA + (uint32_t)(so * (WL * 16)), haloL + (uint32_t)(so * (WL * 8)), NOFF, ref01, refz, has_halo);
+        if (halo_wave) {
+#pragma unroll
+            for (int p = 0; p < HP; p++) differs |= commit_px<ST, false>(st.h[p], haloA[p] + (uint32_t)(so * (WL * 16)), haloL[p] + (uint32_t)(so * (WL * 8)), NOFF, ref01, refz, has_halo[p]);
+        }
         if (lane == 0) lds_store(L.flag(so * 8 + wig), differs != 0ull ? kFlagNormal : 0u);   // a ring slot is always staged by the same waves
     };
 
@@ -253,6 +273,8 @@ hipError_t launch_atrous_lds_step(const Geo& g, const AtrousArgs& a, hipStream_t
         case 4: return launch_atrous_lds<ST, 4>(g, a, s);
         case 8: return launch_atrous_lds<ST, 8>(g, a, s);
         case 16: return launch_atrous_lds<ST, 16>(g, a, s);
+        case 32: return launch_atrous_lds<ST, 32>(g, a, s);
+        case 64: return launch_atrous_lds<ST, 64>(g, a, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -794,7 +794,7 @@ hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, bool 
 
 hipError_t launch_atrous(const Geo& g, int storage, int variant, const AtrousArgs& a, hipStream_t s) {
     if (g.ye <= g.yb) return hipSuccess;
-    const bool lds_ok = a.step == 1 || a.step == 2 || a.step == 4 || a.step == 8 || a.step == 16;
+    const bool lds_ok = a.step == 1 || a.step == 2 || a.step == 4 || a.step == 8 || a.step == 16 || a.step == 32 || a.step == 64;
     // phi_normal == 0 (pow(x,0) = 1 even at x = 0) is left to the direct kernel: the fused exponent would see 0 * -inf
     if (variant != 1 /* SVGF_VARIANT_DIRECT */ && lds_ok && a.phi_normal != 0.0f)
         return storage == 0 ? launch_atrous_lds_step<0>(g, a, s) : launch_atrous_lds_step<1>(g, a, s);

@@ -347,7 +347,8 @@ class Denoiser:
         self._check(self.lib.svgf_atrous_pair(self._h, _ptr(src), _ptr(dst), _ptr(feedback), gb.c), "svgf_atrous_pair")
 
     def set_iteration_fusion(self, enable=True):
-        """Whether Render / the strip driver run iterations 0 and 1 as one launch (default) or one launch per iteration."""
+        """Whether Render / the strip driver run iterations 0 and 1 as one launch (svgf_atrous_pair: bit-identical, measured ~10 % slower)
+        or one launch per iteration (the default)."""
         self._check(self.lib.svgf_set_iteration_fusion(self._h, 1 if enable else 0), "svgf_set_iteration_fusion")
 
     def WaveletFilter(self, filter_buffers, render_buffer, gb: GBuffer, steps=None):

@@ -128,13 +128,38 @@ def test_frame_driver_with_and_without_the_fusion(G, storage, steps):
             assert _same(a.state_plane(plane, 1 - a.pingpong()), b.state_plane(plane, 1 - b.pingpong())), f"frame {k}: state plane {plane}"
 
 
+def test_frame_driver_fusion_with_restricted_rows_leaves_other_rows_alone(G):
+    """svgf_set_rows narrower than the frame + svgf_set_iteration_fusion: the pair launch would store iteration 0's feedback 4 rows
+    beyond the rows this frame's temporal launch wrote (computed from last frame's filter plane); the frame driver therefore fuses on
+    the whole frame only.  Result AND state planes equal the unfused driver's, bitwise, rows outside the range included."""
+    from svgf_amd import filter as F
+    W, H, N = 333, 210, 6
+    fr = frames(W, H, N, mv=(1.0, 0.0))
+    a = F.Denoiser(W, H, F.Params(storage="f32", steps=3))
+    b = F.Denoiser(W, H, F.Params(storage="f32", steps=3))
+    a.set_iteration_fusion(True)
+    gbs = [G.gb_dev(f) for f in fr]
+    for k in range(N):
+        if k == 3:
+            a.set_rows(40, 150); b.set_rows(40, 150)
+        rad = G.dev(fr[k]["radiance"])
+        ra = a.Render(rad, gbs[k], gbs[k - 1] if k else None)
+        rb = b.Render(rad, gbs[k], gbs[k - 1] if k else None)
+        assert _same(ra, rb), f"frame {k}: result"
+        for plane in (F.PLANE_COLOUR, F.PLANE_MOMENTS, F.PLANE_HISTORY):        # (the filter planes differ by design: the pair launch never writes iteration 0's own plane)
+            for idx in (0, 1):
+                assert _same(a.state_plane(plane, idx), b.state_plane(plane, idx)), f"frame {k}: state plane {plane}[{idx}]"
+
+
+@pytest.mark.parametrize("prev_guide", [False, True])
 @pytest.mark.parametrize("fusion", [False, True])
 @pytest.mark.parametrize("storage", ["f32", "f16"])
-def test_4k_render_equals_stage_calls(G, storage, fusion):
+def test_4k_render_equals_stage_calls(G, storage, fusion, prev_guide):
     """BASELINE.json configs[2] / [4] through the frame driver: 3840x2160, 5 iterations, static camera.  svgf_denoise_frame (fused
-    temporal launch, sparse colour store, young list, guide plane, previous-guide read; with and without iterations 0 + 1 as one
-    launch) against the plain stage calls on caller-owned planes, bitwise, over the cold -> steady transition (variant "lds": both sides then run the
-    LDS moments kernel while every pixel is young)."""
+    temporal launch, sparse colour store, young list, guide plane; with and without iterations 0 + 1 as one launch; with and without
+    svgf_set_prev_guide — ON is the configuration bench.py's headline runs: the reprojection test of frames 1.. reads the kept guide
+    plane instead of the previous G-buffer) against the plain stage calls on caller-owned planes, bitwise, over the cold -> steady
+    transition (variant "lds": both sides then run the LDS moments kernel while every pixel is young)."""
     import torch
     from svgf_amd import filter as F
     W, H, N = 3840, 2160, 5
@@ -143,6 +168,7 @@ def test_4k_render_equals_stage_calls(G, storage, fusion):
     hip = G.HipPipeline(W, H, storage, steps=5, variant="lds")
     d = F.Denoiser(W, H, F.Params(storage=storage, steps=5, variant="lds"))
     d.set_iteration_fusion(fusion)
+    d.set_prev_guide(prev_guide)
     for k in range(N):
         rad_np = synth.make_radiance(sc["base"], W, k)
         want = torch.from_numpy(hip.frame(rad_np, gb[k & 1], gb[(k & 1) ^ 1]))

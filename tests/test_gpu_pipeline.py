@@ -141,6 +141,41 @@ def test_switching_the_mode_mid_sequence(G):
         assert np.array_equal(G.host(x).view(np.uint8), y.view(np.uint8)), f"frame {k}"
 
 
+def test_filter_plane_and_debug_view_after_switching_back_to_one_frame(G):
+    """2 -> 1 frames in flight after an ODD number of frames in flight: the last result sits in the second pair of filter planes.
+    svgf_state_plane(FILTER, ..) and the SVGF_DEBUG_ATROUS view (which filters what the previous frame left in FilterBuffer,
+    App.cu:611-620) must see THAT plane: both are compared with a context that never left one frame in flight."""
+    from svgf_amd import filter as F
+    seq = frames(320, 180, 8)
+    gbs = [G.gb_dev(f) for f in seq]
+    one = F.Denoiser(320, 180, F.Params(storage="f32", steps=4))
+    two = F.Denoiser(320, 180, F.Params(storage="f32", steps=4))
+    for nflight in (3, 4):                               # odd and even counts of frames in flight
+        one.reset_history(); two.reset_history()
+        two.set_frames_in_flight(2)
+        for k in range(nflight):
+            r1 = one.Render(G.dev(seq[k]["radiance"]), gbs[k], gbs[k - 1] if k else None).clone()
+            two.Render(G.dev(seq[k]["radiance"]), gbs[k], gbs[k - 1] if k else None)
+        two.set_frames_in_flight(1)
+        idx = 4 & 1                                      # steps = 4: the result is in FilterBuffer[0] (no odd-N copy, App. B #12)
+        assert np.array_equal(G.host(two.state_plane(F.PLANE_FILTER, idx)).view(np.uint8), G.host(r1).view(np.uint8)), nflight
+        one.set_debug_mode("atrous"); two.set_debug_mode("atrous")
+        k = nflight
+        a = one.Render(G.dev(seq[k]["radiance"]), gbs[k], gbs[k - 1])
+        b = two.Render(G.dev(seq[k]["radiance"]), gbs[k], gbs[k - 1])
+        assert np.array_equal(G.host(a).view(np.uint8), G.host(b).view(np.uint8)), f"debug view after {nflight} frames in flight"
+        one.set_debug_mode("final"); two.set_debug_mode("final")
+
+
+def test_two_frames_in_flight_with_iterations_the_direct_kernel_runs(G):
+    """Seven iterations (steps 1..64: all LDS launches on the guide plane) and nine (steps 128, 256 go to the direct kernel, which reads the
+    caller's G-buffer planes: such a frame's tail stays on the caller's stream) — bitwise equal to one frame at a time, and the
+    caller may overwrite `cur` as soon as the NEXT call has returned."""
+    for steps in (7, 9):
+        seq = frames(384, 216, 6, mv=(1.0, 0.0))
+        _assert_same(_run(G, seq, "f32", 2, steps=steps), _run(G, seq, "f32", 1, steps=steps))
+
+
 def test_resize_with_a_frame_in_flight(G):
     from svgf_amd import filter as F
     a, b = frames(320, 200, 3), frames(448, 256, 4)
