@@ -24,6 +24,10 @@ namespace {
 
 constexpr int kTX = 128;                 // columns of a workgroup: two waves per row, two rows per step
 constexpr int kTapDepth = 3;             // LDS reads run this many taps ahead of the arithmetic
+constexpr int kAtrousOversubscribe = 4;   // workgroups per resident slot of the chip the bands are cut for ...
+constexpr int kAtrousMinBand = 8;         // ... but no band shorter than this many (decimated) rows: 4 more are fetched per band.  (Round 4 swept
+                                          // 2x / 4x and 8 / 12 / 16 rows on an 8K/8 strip, 1080p and 4K, interleaved on one device: 4x and 8 rows are
+                                          // best or equal everywhere, profiles/r04_small_experiments.txt)
 // Resident waves per SIMD the kernel of step S is compiled for (registers: 95 -> five).  At step 16 the ring (37 KB) allows four
 // workgroups per CU anyway, at step 32 (49 KB) three, at step 64 (74 KB) two.
 constexpr int atrous_waves(int S) { return S <= 8 ? 5 : S == 16 ? 4 : S == 32 ? 3 : 2; }
@@ -253,10 +257,10 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     const int nrows = g.ye - g.yb;
     const int njmax = (nrows + S - 1) / S;
     const int xtiles = (g.W + kTX - 1) / kTX;
-    int nbands = per_cu * num_cus() * 4 / (xtiles * S);
+    int nbands = per_cu * num_cus() * kAtrousOversubscribe / (xtiles * S);
     if (nbands < 1) nbands = 1;
     int band = (njmax + nbands - 1) / nbands;
-    if (band < 8) band = 8;
+    if (band < kAtrousMinBand) band = kAtrousMinBand;
     band = (band + kRS - 1) / kRS * kRS;
     nbands = (njmax + band - 1) / band;
     int xgroup;

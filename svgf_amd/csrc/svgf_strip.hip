@@ -460,15 +460,20 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
         return post_exchange(s, {{SVGF_PLANE_COLOUR, P}, {SVGF_PLANE_MOMENTS, P}, {SVGF_PLANE_HISTORY, P}}, {colour_held, g.ext_temporal, g.ext_temporal}, g.halo_state, true);
     };
     const auto& groups = s->local[0].g.groups;
+    // The exchange in front of iteration group g + 1 carries the rows within halo_group[g + 1] of every strip boundary of the LAST
+    // iteration of group g.  That iteration therefore produces those rows FIRST (two edge launches), the exchange is posted behind
+    // them, and the interior follows: the transfer runs beside the interior of the iteration that produced its rows — and has landed
+    // when the next group's first iteration, which waits for it and then covers all of its rows in one launch, starts.  (Round 3 posted
+    // the exchange after the WHOLE previous iteration and ran the next iteration's interior beside it: the tail of the producing
+    // iteration and the head of the consuming one were serialised with the transfer.)
+    bool posted = false;                              // an exchange of filter rows is in flight for the group about to start
     for (size_t gi = 0; gi < groups.size(); gi++) {
-        bool exchanged = false;
-        if (gi > 0 && s->world > 1) {
-            int rc = post_exchange(s, {{SVGF_PLANE_FILTER, pp[0]}}, {0}, s->local[0].g.halo_group[gi], false);
-            if (rc != SVGF_OK) return rc;
-            exchanged = true;
-        }
         for (size_t q = 0; q < groups[gi].size(); q++) {
             const int i = groups[gi][q];
+            if (q == 0 && posted) {
+                for (int k = 0; k < n; k++) { int rc = wait_exchange(s, s->local[k], false); if (rc != SVGF_OK) return rc; }
+                posted = false;
+            }
             // iterations 0 and 1 of one group: ONE launch on iteration 1's rows (svgf_atrous_pair); iteration 0 runs on 4 rows more
             // either side — grown(ext_atrous[0]) exactly — inside it
             if (i == 0 && q + 1 < groups[gi].size() && groups[gi][q + 1] == 1 && can_fuse01(s->local[0].ctx)) {
@@ -481,34 +486,48 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
                 int rc = post_state();
                 if (rc != SVGF_OK) return rc;
                 q++;
+                if (q + 1 == groups[gi].size() && gi + 1 < groups.size() && s->world > 1) {      // (a group of exactly {0, 1}: its output travels whole)
+                    rc = post_exchange(s, {{SVGF_PLANE_FILTER, pp[0]}}, {0}, s->local[0].g.halo_group[gi + 1], false);
+                    if (rc != SVGF_OK) return rc;
+                    posted = true;
+                }
                 continue;
+            }
+            const bool feeds_exchange = q + 1 == groups[gi].size() && gi + 1 < groups.size() && s->world > 1;
+            const int h = feeds_exchange ? s->local[0].g.halo_group[gi + 1] : 0;
+            std::vector<Rows> inner(n, Rows{0, 0});
+            bool split = feeds_exchange;
+            if (feeds_exchange) {
+                for (int k = 0; k < n; k++) {            // the rows the neighbours will need (the last iteration of a group runs on the owned rows)
+                    auto& l = s->local[k];
+                    const Rows rows = grown(l.g, s->H, l.g.ext_atrous[i]);
+                    const int lo = l.rank == 0 ? rows.a : std::min(rows.b, l.g.own0 + h);
+                    const int hi = l.rank == s->world - 1 ? rows.b : std::max(rows.a, l.g.own1 - h);
+                    inner[k] = Rows{lo, std::max(lo, hi)};
+                    if (hi <= lo) split = false;         // a strip shorter than its two edges: one launch, the exchange behind it
+                }
             }
             for (int k = 0; k < n; k++) {
                 auto& l = s->local[k];
-                const int P = l.ctx->pingpong;
                 const Rows rows = grown(l.g, s->H, l.g.ext_atrous[i]);
-                if (exchanged && q == 0) {
-                    // rows that need no neighbour data first (the transfer runs beside them), the edges after it has landed
-                    const int reach = 2 << i;
-                    const int lo = l.rank == 0 ? rows.a : std::max(rows.a, l.g.own0 + reach);
-                    const int hi = l.rank == s->world - 1 ? rows.b : std::min(rows.b, l.g.own1 - reach);
-                    if (hi > lo) {
-                        int rc = launch_atrous_rows(s, l, Rows{lo, hi}, pp[k], 1 - pp[k], P, &cur[k], i);
-                        if (rc == SVGF_OK) rc = wait_exchange(s, l, false);
-                        if (rc == SVGF_OK) rc = launch_atrous_rows(s, l, Rows{rows.a, lo}, pp[k], 1 - pp[k], P, &cur[k], i);
-                        if (rc == SVGF_OK) rc = launch_atrous_rows(s, l, Rows{hi, rows.b}, pp[k], 1 - pp[k], P, &cur[k], i);
-                        if (rc != SVGF_OK) return rc;
-                    } else {
-                        int rc = wait_exchange(s, l, false);
-                        if (rc == SVGF_OK) rc = launch_atrous_rows(s, l, rows, pp[k], 1 - pp[k], P, &cur[k], i);
-                        if (rc != SVGF_OK) return rc;
-                    }
-                } else {
-                    int rc = launch_atrous_rows(s, l, rows, pp[k], 1 - pp[k], P, &cur[k], i);
-                    if (rc != SVGF_OK) return rc;
-                }
-                pp[k] ^= 1;
+                int rc = SVGF_OK;
+                if (split) {
+                    rc = launch_atrous_rows(s, l, Rows{rows.a, inner[k].a}, pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], i);
+                    if (rc == SVGF_OK) rc = launch_atrous_rows(s, l, Rows{inner[k].b, rows.b}, pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], i);
+                } else rc = launch_atrous_rows(s, l, rows, pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], i);
+                if (rc != SVGF_OK) return rc;
             }
+            if (feeds_exchange) {
+                int rc = post_exchange(s, {{SVGF_PLANE_FILTER, 1 - pp[0]}}, {0}, h, false);
+                if (rc != SVGF_OK) return rc;
+                posted = true;
+            }
+            if (split) for (int k = 0; k < n; k++) {
+                auto& l = s->local[k];
+                int rc = launch_atrous_rows(s, l, inner[k], pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], i);
+                if (rc != SVGF_OK) return rc;
+            }
+            for (int k = 0; k < n; k++) pp[k] ^= 1;
             if (i == 0) { int rc = post_state(); if (rc != SVGF_OK) return rc; }   // this frame's state is final once iteration 0 has written the feedback colour
         }
     }

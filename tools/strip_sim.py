@@ -36,6 +36,9 @@ ap.add_argument("--warm-ms", type=float, default=400.0, help="untimed frames for
 ap.add_argument("--warm-frames", type=int, default=600, help="... and at least this many")
 ap.add_argument("--per-frame", action="store_true", help="print the device and host time of every frame")
 ap.add_argument("--driver", default="python", help="python = StripRunner; native = svgf_strip_* C driver if present")
+ap.add_argument("--aperiodic", action="store_true", help="keep the frame's real content in the halo rows (self-sent state is then inconsistent: see below)")
+ap.add_argument("--link-gbps", type=float, default=153.0, help="wire model: one xGMI link between neighbouring GPUs, per direction (MI355X: 7 links x ~153 GB/s)")
+ap.add_argument("--rccl-latency-us", type=float, default=-1.0, help="wire model: latency of one send/recv group; < 0 = measured here on the loop-back communicator")
 args = ap.parse_args(argv[1:])
 
 W, H = bench.WORKLOADS[args.workload]
@@ -64,6 +67,18 @@ torch.cuda.set_stream(side)
 params = F.Params(storage=args.storage, steps=5)
 geo = strips.Geometry.make(W, H, args.rank, args.world, 5, plan=args.plan, moments_radius=params.moments_radius, motion_reach=4)
 gb, rads = bench.make_inputs(W, H, args.storage, dev, row_begin=geo.y0, row_end=geo.y1)
+if args.comm == "self" and not args.aperiodic:
+    # Both neighbours are this rank: what arrives in the halo rows is this strip's OWN boundary rows.  With the frame's real content
+    # that is the wrong state for those rows (e.g. the history of sky texels under surface texels: pixels that are "young" again every
+    # frame — the moments launch of the strip then costs 33 us instead of ~5).  So the strip's inputs are made PERIODIC in y with the
+    # period of the owned rows: row y of the halo holds what row y -+ own of the strip holds, and a self-sent row IS the row a real
+    # neighbour would send.
+    own_rows = geo.own[1] - geo.own[0]
+    idx = torch.arange(geo.y0, geo.y1, device=dev)
+    idx = (geo.own[0] - geo.y0) + torch.remainder(idx - geo.own[0], own_rows)
+    take = lambda t: (t.view(torch.int16)[idx].contiguous().view(torch.uint16) if t.dtype == torch.uint16 else t[idx].contiguous())   # noqa: E731 (no uint16 gather in torch)
+    gb = F.GBuffer(take(gb.motion), take(gb.normal), take(gb.uv))
+    rads = [take(r) for r in rads]
 gb2 = F.GBuffer(gb.motion.clone(), gb.normal.clone(), gb.uv.clone())      # current / previous G-buffer in distinct planes
 gbs = [gb, gb2]
 if args.driver == "native":
@@ -118,6 +133,76 @@ own = geo.own[1] - geo.own[0]
 print(f"{W}x{H} strip {args.rank}/{args.world} ({own} rows, held {geo.y1 - geo.y0}), plan {geo.plan}, comm {args.comm}/{args.post}, stream {args.stream}, driver {args.driver}: "
       f"{t / args.steps * 1e3:.4f} ms/frame (host enqueue {t_host / args.steps * 1e3:.4f} ms) -> "
       f"{W * own / (t / args.steps) / 1e6:.0f} Mpx/s per GPU, x{args.world} = {W * own * args.world / (t / args.steps) / 1e6:.0f} Mpx/s")
+
+
+def rccl_group_latency_us(n=200):
+    """GPU time of one RCCL group {ncclSend, ncclRecv} of 4 KiB to and from this rank itself on one stream (a loop-back communicator of the
+    library's own, librccl called directly): launch + protocol latency, no wire.  The host enqueues the groups while the device is
+    still busy with a queue of GEMMs, so that the time between the two events is the device's."""
+    import ctypes as C
+    lib = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+    for f in (lib.ncclSend, lib.ncclRecv):
+        f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        f.restype = C.c_int
+    c2 = strips.rccl_comm(1, 0, 0)
+    st = torch.cuda.Stream(device=dev)
+    a, b = torch.zeros(4096, device=dev, dtype=torch.int8), torch.zeros(4096, device=dev, dtype=torch.int8)
+    xx = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    h = C.c_void_p(st.cuda_stream)
+
+    def group():
+        lib.ncclGroupStart()
+        rc = lib.ncclSend(C.c_void_p(a.data_ptr()), 4096, 0, 0, c2, h) | lib.ncclRecv(C.c_void_p(b.data_ptr()), 4096, 0, 0, c2, h)
+        lib.ncclGroupEnd()
+        assert rc == 0
+    with torch.cuda.stream(st):
+        for _ in range(20):
+            group()
+        torch.cuda.synchronize()
+        for _ in range(40):
+            xx @ xx
+        x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        x0.record()
+        for _ in range(n):
+            group()
+        x1.record()
+        torch.cuda.synchronize()
+    us = x0.elapsed_time(x1) * 1e3 / n
+    F.load_library().svgf_rccl_comm_destroy(c2)
+    return us
+
+
+def wire_model(ms_frame):
+    """What the xGMI wire would add to the loop-back figure.  Per exchange: bytes per boundary and direction / link bandwidth + 2 x the
+    latency of an RCCL group (send side and receive side), against the WINDOW in which the transfer runs beside compute: the state
+    exchange is posted after iteration 0 and waited for at the start of the next frame (window: iterations 1..); the filter rows in
+    front of iteration group g are posted behind the two edge launches of the iteration that produces them and waited for when group g
+    starts (window: that iteration's interior).  Stage shares of the frame: temporal + moments 0.29, an iteration 0.142 (the one-GPU
+    stage table of bench.py).  exposed = max(0, wire - window)."""
+    cb, mb = (16, 8) if args.storage == "f32" else (8, 4)
+    lat = args.rccl_latency_us if args.rccl_latency_us >= 0 else rccl_group_latency_us()
+    it_ms = 0.142 * ms_frame
+    own = geo.own[1] - geo.own[0]
+    colour_held = geo.ext_atrous[0] if geo.steps else geo.ext_temporal
+    ex = []
+    state_bytes = W * ((geo.halo_state - colour_held) * cb + (geo.halo_state - geo.ext_temporal) * (mb + 1))
+    ex.append(("state (colour, moments, history)", state_bytes, (geo.steps - 1) * it_ms))
+    for gi in range(1, len(geo.groups)):
+        h = geo.halo_group[gi]
+        ex.append((f"filter rows in front of iterations {geo.groups[gi]}", W * h * cb, it_ms * max(0, own - 2 * h) / own))
+    total = 0.0
+    lines = []
+    for name, nbytes, window in ex:
+        wire = nbytes / (args.link_gbps * 1e9) * 1e3 + 2 * lat * 1e-3
+        exposed = max(0.0, wire - window)
+        total += exposed
+        lines.append(f"    {name}: {nbytes / 1e6:.2f} MB per boundary and direction, wire {wire * 1e3:.1f} us, window {window * 1e3:.0f} us, exposed {exposed * 1e3:.1f} us")
+    print(f"  wire model ({args.link_gbps:.0f} GB/s per direction, RCCL group latency {lat:.1f} us {'(measured on the loop-back communicator)' if args.rccl_latency_us < 0 else '(given)'}):")
+    print("\n".join(lines))
+    print(f"  with wire: {ms_frame + total:.4f} ms/frame (without: {ms_frame:.4f}) -> x{args.world} = {W * own * args.world / ((ms_frame + total) * 1e-3) / 1e6:.0f} Mpx/s")
+
+
+wire_model(t / args.steps * 1e3)
 if args.driver == "native":
     drv.sync()
     drv.close()
