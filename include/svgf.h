@@ -34,6 +34,16 @@
  *    or beyond -150): any real depth derivative.  The LDS kernels also copy a sky CENTRE through the taps (its depth enters
  *    them as -1e30, so that every one of its weights is exactly 0 and the normalisation multiplies its own colour by rcp(1)):
  *    the same bound, on the sky texel's own ddepth.
+ *  - Non-finite input.  The reference's imageLoad / imageStore clamp is glm::clamp = min(max(x, 0), 1) built from `(x < y) ? y : x`
+ *    (Filter.cuh:63-69,78-83): +inf clamps to 1, -inf to 0, and a NaN texel STAYS NaN.  It then poisons the history through mix (:398) for
+ *    as long as the pixel keeps reprojecting onto it, reaches the wavelet sums channel by channel (the weight itself stays finite:
+ *    `max(weightLillum, 0.0)` in :424 is CUDA's fmax, which drops the NaN; a sky centre is copied whatever its neighbours hold) and turns
+ *    the zero-weight sums FilterMoments forms for zero-normal (sky) texels into NaN (0 x NaN, :498-499).  svgf_temporal, svgf_moments,
+ *    svgf_atrous, svgf_atrous_pair, svgf_denoise_frame and the strip driver reproduce exactly that (tests/test_gpu_nonfinite.py: NaN
+ *    masks identical to the oracle's, finite values within the stage tolerances): a host that wants its NaNs healed must clean the
+ *    radiance before the temporal stage — the reference does not, and neither does this library.  Not covered: NaN / inf in the
+ *    G-buffer planes (depth, normal, motion), and svgf_taa, which reads a NaN texel as 0 (the reference's TAA tests the result for NaN
+ *    and writes black, Filter.cuh:351; the outcome differs in the neighbours' min / max).
  *  - Strips: a context may hold only rows [y0, y0+rows) of a WxH frame (multi-GPU row strips);
  *    "inside the frame" tests always use the global frame, so strip results are bit-identical
  *    to the whole-frame result as long as the halo rows hold valid data.
@@ -176,8 +186,9 @@ int svgf_atrous(svgf_ctx* ctx, const void* in, void* out, void* feedback, const 
  * rows (SVGF_ERR_HALO otherwise).  `in`, `out` and `feedback` are three different planes.  Needs variant != SVGF_VARIANT_DIRECT
  * and PhiNormal != 0.  Measured on MI355X the pair launch is ~10 % SLOWER than the two launches it replaces (the iterations are
  * bound by their tap arithmetic, not by the 48 B/px the fusion saves: DESIGN.md 3.3c), so svgf_denoise_frame and the strip driver
- * use it only after svgf_set_iteration_fusion(ctx, 1) (default 0; same results either way; with steps >= 2, and in the strip driver
- * where the halo plan keeps iterations 0 and 1 in one group). */
+ * use it only after svgf_set_iteration_fusion(ctx, 1) (default 0; same results either way; with steps >= 2; svgf_denoise_frame fuses on the
+ * WHOLE frame only — with svgf_set_rows narrower than the frame the feedback rows beyond the range would be computed from rows this
+ * frame's temporal launch did not write — and the strip driver where the halo plan keeps iterations 0 and 1 in one group). */
 int svgf_atrous_pair(svgf_ctx* ctx, const void* in, void* out, void* feedback, const svgf_gbuffer* gbuf);
 int svgf_set_iteration_fusion(svgf_ctx* ctx, int enable);
 
