@@ -63,7 +63,8 @@ def main(tag):
         ("hbm_traffic.json", "HBM bytes per launch from this round's PMC passes (`tools/make_traffic.py`), stamped with the hash of the kernel sources; `bench.py` attaches it (`roofline.traffic`, `traffic_source`) only when the sources it runs hash to the same value"),
         (f"{tag}_strip_sim_8k_over_8.txt", "`tools/strip_sim.py --driver native`, plans ghost / grouped / per-iteration: the middle strip of an 8K/8 partition with loop-back RCCL groups"),
         (f"{tag}_fused_pair_ablations.txt", "iterations 0 + 1 as one launch: A/B against two launches, its knobs, what it is made of; the fp16 half-record experiment"),
-        (f"{tag}_small_experiments.txt", "the other `tools/abn.sh` blocks of the round (restructured kernel vs round 2's, exponent bases per workgroup, one-round prologue, the young-pixel moments launch and its counters)"),
+        (f"{tag}_small_experiments.txt", "the `tools/abn.sh` / `tools/strip_ab.sh` blocks of the round (interleaved A/B of prebuilt twins on one device)"),
+        (f"{tag}_cold_frames.txt", "`tools/cold_frames.py`: per-frame stage times over the cold -> steady transition (fp32, fp16)"),
         (f"{tag}_repeat_suite_prefix.txt", "`tools/repeat_suite_prefix.py 200`: the tests around the spot where two round-2 suite runs hung, 200 times in one process"),
         (f"{tag}_pytest_gpu.txt", "summary line of `pytest tests -q -m gpu` in the same call as the bench lines"),
         (f"{tag}_pytest_gpu_soak.txt", "five more full `pytest tests -q -m gpu` runs in one call at the final sources (the round-2 suite abort: not seen)"),
@@ -99,7 +100,18 @@ def main(tag):
         if "pan" in b:
             notes.append(f"* pan ({b['pan']['mv']}): {b['pan']['ms_per_step']} ms per frame, moments launch {b['pan']['moments_ms'] * 1e3:.1f} us.")
         for k, v in (b.get("also") or {}).items():
-            notes.append(f"* also `{k}`: {v['ms_per_step']} ms per frame, {v['Mpixels/s']} Mpixel/s, pass frac {v.get('frac_of_8TBps')}, à-trous launch {v.get('atrous_avg_launch_ms')} ms (frac {v.get('atrous_roofline_frac')}).")
+            if k == "interactive":
+                notes.append(f"* also `interactive` (one denoise per displayed frame, sum of the stage events): **{v['interleaved_ms']} ms** between a {v['producer_ms']} ms memory-bound producer "
+                             f"on the same stream; **{v['isolated_ms']} ms** ({v['isolated_ms_min']}-{v['isolated_ms_max']}) with the device idle for 5 ms between frames.")
+            elif k == "seven_iterations":
+                notes.append(f"* also `seven_iterations` (steps 1..64, all LDS launches): {v['ms_per_step']} ms per frame; a-trous launch by step (ms): {v['atrous_launch_ms_by_step']}.")
+            elif "ms_per_step" in v:
+                notes.append(f"* also `{k}`: {v['ms_per_step']} ms per frame, {v['Mpixels/s']} Mpixel/s, pass frac {v.get('frac_of_8TBps')}, à-trous launch {v.get('atrous_avg_launch_ms')} ms (frac {v.get('atrous_roofline_frac')}).")
+        sec = (r or {}).get("secondary")
+        if sec:
+            notes.append(f"* `roofline.secondary` (the launch's second bound, from `{sec.get('source')}`): valu_busy **{sec['valu_busy']}**, {sec['insts_valu_per_px']} vector instructions per pixel.")
+        if b.get("cold_frames_ms"):
+            notes.append(f"* cold frames after a reset (ms, one frame at a time): {b['cold_frames_ms']['after_reset']}.")
         c = b.get("cpu_baseline")
         if c:
             notes.append(f"* cpu_baseline: {c['value']} Mpixel/s on {c['cores']} threads, {c['single_thread_value']} on one; configs[0] (256x256, one iteration, scalar C++ loop): "
@@ -144,4 +156,4 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r03")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r04")
