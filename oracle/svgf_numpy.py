@@ -90,7 +90,8 @@ def temporal(prev_colour, cur, gb_cur, gb_prev, hist_prev, mom_prev, *, depth_th
     m = np.stack([L, L * L], -1)
     a = alpha[..., None]
     m2 = mp * (f32(1) - a) + m * a
-    var = np.maximum(f32(0), m2[..., 1] - m2[..., 0] * m2[..., 0])
+    # :396 max(0.f, x): CUDA's max(float, float) is fmaxf (and glm::max(0, x) = (0 < x) ? x : 0): a NaN x gives 0 — np.fmax, not np.maximum
+    var = np.fmax(f32(0), m2[..., 1] - m2[..., 0] * m2[..., 0])
     c2 = cp * (f32(1) - a) + c * a
     out = _clamp01(np.concatenate([c2, var[..., None]], -1)).astype(sdt)
     return out, h.astype(np.uint8), m2.astype(sdt)
@@ -149,7 +150,8 @@ def atrous(src, gb, *, step, phi_colour, phi_normal):
     zc, dzc = _depth(gb["motion"])
     nc = _normal(gb["normal"])
     sky = zc == SKY_Z
-    phi_l = (np.float64(f32(phi_colour)) * np.sqrt(np.maximum(0.0, (f32(1e-10) + var).astype(np.float64)))).astype(np.float32)
+    # :562 max(0.0, eps + variance): the double literal selects CUDA's fmax, which drops a NaN variance (phi_l = 0: only equal luminances pass)
+    phi_l = (np.float64(f32(phi_colour)) * np.sqrt(np.fmax(0.0, (f32(1e-10) + var).astype(np.float64)))).astype(np.float32)
     phi_d = np.maximum(dzc, f32(1e-6)) * f32(step)
     Y, X = np.mgrid[0:H, 0:W]
     S = np.ones((H, W), np.float32)

@@ -280,3 +280,104 @@ def test_albedo_demodulation_matches_numpy_and_round_trips(oracle, storage):
     tol = 2e-7 if storage == "f32" else 2e-3
     assert np.abs(m.astype(np.float64) - x.astype(np.float64))[..., :3].max() <= tol * 2
     assert np.array_equal(d[0, :5, :3].astype(np.float32), (x[0, :5, :3].astype(np.float32) / np.float32(1e-3)).astype(dt).astype(np.float32))
+
+
+# ---------------------------------------------------------------- non-finite input ----------------------------------------------------------
+# What the reference does with NaN / inf texels (Filter.cuh:63-83: glm::clamp keeps a NaN; :424: CUDA's fmax drops it; :498-499, :608: 0 x NaN
+# = NaN): hand-derivable known answers, and the independently written NumPy restatement on poisoned planes.  The GPU suite
+# (tests/test_gpu_nonfinite.py) holds the HIP kernels to this behaviour.
+def _poison(rng, plane, n=10):
+    H, W, C = plane.shape
+    for v in (np.nan, np.inf, -np.inf):
+        for ch in range(C):
+            for _ in range(n):
+                plane[rng.integers(H), rng.integers(W), ch] = v
+
+
+def _same_nonfinite(a, b, what):
+    a32, b32 = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    assert np.array_equal(np.isnan(a32), np.isnan(b32)), f"{what}: NaN masks differ"
+    inf = np.isinf(b32)
+    assert np.array_equal(a32[inf], b32[inf]), f"{what}: infinities differ"
+    return np.isfinite(b32)
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_nonfinite_stages_match_numpy(oracle, storage):
+    W, H = 101, 67
+    rng = np.random.default_rng(91)
+    dt = CDT[storage]
+    f0, f1 = synth.make_frame(W, H, 3, mv=(1.0, 0.0)), synth.make_frame(W, H, 4, mv=(1.0, 0.0))
+    # temporal: bit exact, NaN where the restatement has NaN
+    prev, mom_prev, hist_prev = _temporal_state(W, H, storage, rng)
+    cur = (f1["radiance"] * 1.3 - 0.1).astype(dt)
+    _poison(rng, cur); _poison(rng, prev); _poison(rng, mom_prev, 5)
+    out = np.zeros_like(cur); hist = np.zeros((H, W), np.uint8); mom = np.zeros((H, W, 2), dt)
+    oracle.temporal(W, H, storage, prev, cur, out, gbuf(f1), gbuf(f0), hist_prev, hist, mom, mom_prev,
+                    depth_threshold=0.8, normal_threshold=0.9, history_base=24, mesh_id_test=1)
+    w_out, w_hist, w_mom = snp.temporal(prev, cur, gbuf(f1), gbuf(f0), hist_prev, mom_prev, depth_threshold=0.8, normal_threshold=0.9, history_base=24)
+    assert np.array_equal(hist, w_hist)
+    for got, want, name in ((out, w_out, "colour"), (mom, w_mom, "moments")):
+        fin = _same_nonfinite(got, want, f"temporal {name}")
+        u = np.uint32 if storage == "f32" else np.uint16
+        assert np.array_equal(got.view(u)[fin], want.view(u)[fin]), f"temporal {name}: finite bits"
+    assert np.isnan(out.astype(np.float32)).any() and not np.isinf(out.astype(np.float32)).any()       # +-inf clamps, NaN stays
+    # moments
+    col = rng.uniform(0, 1, (H, W, 4)).astype(dt); mo = rng.uniform(0, 1, (H, W, 2)).astype(dt)
+    hi = rng.integers(1, 8, (H, W)).astype(np.uint8)
+    _poison(rng, col, 4); _poison(rng, mo, 3)
+    got = np.zeros_like(col)
+    oracle.moments(W, H, storage, col, got, mo, gbuf(f1), hi, phi_colour=10.0, phi_normal=128.0)
+    with np.errstate(all="ignore"):
+        want = snp.moments(col, mo, gbuf(f1), hi, phi_colour=10.0, phi_normal=128.0)
+    fin = _same_nonfinite(got, want, "moments")
+    assert np.abs(got.astype(np.float64)[fin] - want.astype(np.float64)[fin]).max() <= (1e-4 if storage == "f32" else 2e-3)
+    # a-trous
+    src = np.concatenate([f1["radiance"][..., :3] * 1.2 - 0.05, rng.uniform(-0.01, 0.05, (H, W, 1)).astype(np.float32)], -1).astype(dt)
+    _poison(rng, src, 5)
+    for step in (1, 4):
+        o = np.zeros_like(src); fb = np.full_like(src, 7)
+        oracle.atrous(W, H, storage, src, o, fb, gbuf(f1), step=step, phi_colour=10.0, phi_normal=128.0, iteration=0)
+        with np.errstate(all="ignore"):
+            w, wfb = snp.atrous(src, gbuf(f1), step=step, phi_colour=10.0, phi_normal=128.0)
+        fin = _same_nonfinite(o, w, f"a-trous step {step}")
+        assert np.abs(o.astype(np.float64)[fin] - w.astype(np.float64)[fin]).max() <= (1e-5 if storage == "f32" else 2e-3)
+        assert (np.isnan(o.astype(np.float32)).sum(-1) == 1).any()       # a NaN in one channel reaches one channel of its neighbours
+
+
+def test_kat_nonfinite_by_hand(oracle):
+    """5x5 frame, one flat surface (depth 2, ddepth 0.1, normal (0,0,-1)), constant colour 0.25, variance 0.  By hand:
+      * temporal: radiance {NaN, +inf, -inf, 0.5} at one pixel, no history -> colour {NaN, 1, 0}, luminance NaN -> moments NaN, variance
+        max(0, NaN) = 0 (Filter.cuh:396);
+      * a-trous: a NaN in the GREEN channel of the centre texel (2,2): every pixel of the 5x5 window has it as a tap with a FINITE weight
+        (fmax drops the NaN luminance difference, :424), so exactly the green channel of all 25 pixels is NaN, and red / blue / variance
+        are the filtered constants (0.25 / 0.25 / 0 — a weighted mean of equal values);
+      * moments: a zero-normal (sky) centre with a NaN in its window: all weights 0, sums 0 x NaN = NaN in that channel, 0 in the others."""
+    W = H = 5
+    motion = np.zeros((H, W, 4), np.float32); motion[..., 2] = 2.0; motion[..., 3] = 0.1
+    normal = np.zeros((H, W, 4), np.uint16); normal[..., 2] = np.float16(-1.0).view(np.uint16)
+    uv = np.zeros((H, W, 4), np.uint16)
+    gb = {"motion": motion, "normal": normal, "uv": uv}
+    # temporal
+    rad = np.full((H, W, 4), 0.25, np.float32); rad[2, 2] = (np.nan, np.inf, -np.inf, 0.5)
+    z4, z2, zh = np.zeros((H, W, 4), np.float32), np.zeros((H, W, 2), np.float32), np.zeros((H, W), np.uint8)
+    out, hist, mom = np.zeros_like(rad), np.zeros((H, W), np.uint8), np.zeros((H, W, 2), np.float32)
+    oracle.temporal(W, H, "f32", z4, rad, out, gb, gb, zh, hist, mom, z2, depth_threshold=0.8, normal_threshold=0.9, history_base=24)
+    assert np.isnan(out[2, 2, 0]) and out[2, 2, 1] == 1.0 and out[2, 2, 2] == 0.0 and out[2, 2, 3] == 0.0
+    assert np.isnan(mom[2, 2]).all() and np.isfinite(np.delete(out.reshape(-1, 4), 12, 0)).all()
+    # a-trous
+    src = np.zeros((H, W, 4), np.float32); src[..., :3] = 0.25; src[2, 2, 1] = np.nan
+    o = np.zeros_like(src)
+    oracle.atrous(W, H, "f32", src, o, None, gb, step=1, phi_colour=10.0, phi_normal=128.0, iteration=1)
+    assert np.isnan(o[..., 1]).all() and np.isfinite(o[..., (0, 2, 3)]).all()
+    np.testing.assert_allclose(o[..., (0, 2)], 0.25, rtol=1e-6)
+    assert np.all(o[..., 3] == 0)
+    # moments: a sky texel at (0,0) whose window holds the NaN
+    n2 = normal.copy(); n2[0, 0] = 0
+    m2 = motion.copy(); m2[0, 0, 2] = 0.0
+    col = np.full((H, W, 4), 0.25, np.float32); col[1, 1, 2] = np.nan
+    mo = np.full((H, W, 2), 0.1, np.float32)
+    hist1 = np.ones((H, W), np.uint8)
+    om = np.zeros_like(col)
+    oracle.moments(W, H, "f32", col, om, mo, {"motion": m2, "normal": n2, "uv": uv}, hist1, phi_colour=10.0, phi_normal=128.0)
+    assert om[0, 0, 0] == 0 and om[0, 0, 1] == 0 and np.isnan(om[0, 0, 2]) and om[0, 0, 3] == 0
