@@ -1,7 +1,7 @@
 // svgf_moments_lds.h — the spatial estimate of young pixels (filter::FilterMoments, Filter.cuh:430-525) as an LDS-streaming kernel
 // for frames in which (nearly) every pixel is young (history < 4: the first three frames of a sequence, after a reset, a resize, a
 // camera cut).  The 7x7 window is served from an 8-row LDS ring exactly like the a-trous kernel's 5x5 window (svgf_atrous_lds.h):
-// a workgroup streams down a band, 256 columns x 2 rows per step, one output per thread, rows fetched one step ahead — instead of
+// a workgroup streams down a band, 128 columns x 2 rows per step, one output per thread, rows fetched one step ahead — instead of
 // 49 x 4 gathers per pixel through L1.
 //
 // Records are RAW (this stage does not clamp, :450,479), 36 B per staged pixel in four planes:
@@ -28,8 +28,10 @@ namespace {
 
 constexpr int kMR = 3;                       // window radius (the reference's, :465)
 constexpr int kMRing = kRS + 2 * kMR;        // 8 ring rows
-constexpr int kMTX = 256;
+constexpr int kMTX = 128;                    // columns of a workgroup (two waves per row; round 4: 256 -> 128 and four resident rounds of
+                                             // workgroups instead of one: -13 % per launch, profiles/r04_small_experiments.txt block 5)
 constexpr int kMTapDepth = 3;                // LDS reads run this many taps ahead of the arithmetic
+constexpr int kMRounds = 4;                  // workgroups per resident slot of the chip the bands are cut for
 constexpr int kMRecBytes = 36;
 
 __device__ __forceinline__ constexpr int len_class7(int xx, int yy) {   // |(xx,yy)|^2 in {1,2,4,5,8,9,10,13,18}
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(kMTX* kRS, 4) void moments_lds_kernel(Geo g, Moment
     f32x2* recL = (f32x2*)(recA + kMRing * WL);
     f32x2* recN = recL + kMRing * WL;
     float* recC = (float*)(recN + kMRing * WL);
-    uint32_t* mflag = (uint32_t*)(recC + kMRing * WL);     // [kMRing][4]: what each of the four waves of a row group reported of its ring row,
+    uint32_t* mflag = (uint32_t*)(recC + kMRing * WL);     // [kMRing][4]: what each wave of a row group reported of its ring row (two of the four words are used),
     constexpr int kBadWord = kMRing * 4;                   // then the workgroup's sticky "a NaN / inf was staged" word
     uint32_t* nref = mflag + kBadWord + 1;                 // the workgroup's reference normal {(nx,ny) bits, nz half bits}
 
@@ -264,7 +266,8 @@ hipError_t launch_moments_lds(const Geo& g, const MomentsArgs& a, hipStream_t s)
     static std::atomic<unsigned long long> attr_done{0};
     if (hipError_t e = allow_dynamic_lds(moments_lds_kernel<ST>, lds, attr_done); e != hipSuccess) return e;
     const int nrows = g.ye - g.yb, xtiles = (g.W + kMTX - 1) / kMTX;
-    int nbands = 2 * num_cus() / xtiles;                  // one resident round: 2 workgroups per CU (LDS)
+    constexpr int per_cu = (int)((160 * 1024) / lds);
+    int nbands = kMRounds * per_cu * num_cus() / xtiles;                        // resident rounds x workgroups per CU (LDS: 38.6 KB each, four per CU)
     if (nbands < 1) nbands = 1;
     int band = (nrows + nbands - 1) / nbands;
     if (band < 8) band = 8;
