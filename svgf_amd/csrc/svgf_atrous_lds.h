@@ -35,8 +35,8 @@ constexpr int atrous_waves(int S) { return S <= 8 ? 5 : S == 16 ? 4 : S == 32 ? 
 // LDS layout of a workgroup, as byte addresses (no generic pointers: an address-space cast of a pointer the compiler cannot see
 // through costs a null check per use): colour records (16 B x kRing x WL), {luminance, depth} records (8 B x ..), normal records
 // (8 B x ..), the ring rows' flag words [kRing][8], the reference normal {(nx,ny) bits, nz bits}, the "an output was NaN" word.
-template <int S> struct AtrousLds {
-    static constexpr int WL = kTX + 4 * S;
+template <int S, int TX> struct AtrousLds {
+    static constexpr int WL = TX + 4 * S;
     uint32_t a;                                                         // colour records
     __device__ __forceinline__ uint32_t l() const { return a + kRing * WL * 16; }
     static constexpr int NOFF = kRing * WL * 8;                         // bytes from a pixel's {luminance, depth} record to its normal record
@@ -59,17 +59,17 @@ __device__ __forceinline__ void lds_store(uint32_t addr, uint32_t v) { *(lds_u32
 // every channel, or (a NaN variance only) in the variance channel — and costs the product path ONE compare per output.  The
 // kernel then runs the band again with EXACT = true: the general taps in the form that evaluates the luminance term as the
 // reference does (taps24<.., kTapsNaN>) and a select for the sky centres.  A workgroup whose texels are all finite never gets there.
-template <int ST, int S, bool EXACT>
-__device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, const AtrousLds<S>& L, int x0, int j0, int j1, int ybase) {
-    constexpr int TX = kTX;
+template <int ST, int S, int TX, bool EXACT>
+__device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, const AtrousLds<S, TX>& L, int x0, int j0, int j1, int ybase) {
     constexpr int WL = TX + 4 * S;                 // staged columns per ring row
     constexpr int CB = ST == 0 ? 16 : 8;           // bytes per colour texel
     constexpr int NH = 4 * S;                      // halo pixels per ring row.  Steps 1-16: all staged by wave 0 of the row group (lanes
                                                    // 0..NH-1; spread over the waves, every wave paid the halo's ~20 VALU + 3 loads for a few
                                                    // lanes).  Steps 32 and 64: 128 / 256 of them — HP full passes on BOTH waves of the row group
-    constexpr int HP = NH <= 64 ? 1 : NH / 128;    // halo passes per staging wave
+    constexpr int WPR = TX / 64;                   // waves per row group
+    constexpr int HP = NH <= 64 ? 1 : NH / (64 * WPR);    // halo passes per staging wave
     constexpr bool kBothWaves = NH > 64;
-    static_assert(NH <= 64 || NH == 128 * HP, "halo passes must be whole waves");
+    static_assert(NH <= 64 || NH == 64 * WPR * HP, "halo passes must be whole waves");
 
     int t = threadIdx.x;
     // (the second pass derives its per-lane constants from a thread index the compiler cannot identify with the first pass's: shared
@@ -100,7 +100,7 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
         vh_c[p] = halo_ok ? (unsigned)hx * CB : kOob; vh_m[p] = halo_ok ? (unsigned)hx * 16u : kOob; vh_n[p] = halo_ok ? ((unsigned)hx << gs.n_shift) + gs.n_off : kOob;
     }
     const unsigned npx = (unsigned)g.rows * (unsigned)g.W;
-    constexpr int NOFF = AtrousLds<S>::NOFF;
+    constexpr int NOFF = AtrousLds<S, TX>::NOFF;
     const uint32_t colA = L.a + (uint32_t)col * 16u, colL = L.l() + (uint32_t)col * 8u;    // this column's records of ring row 0
     uint32_t haloA[HP], haloL[HP];                                                          // ... and of its halo pixel(s)
 #pragma unroll
@@ -211,21 +211,21 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
     return nan_out != 0ull;
 }
 
-template <int ST, int S>
-__global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup, int xrot) {
+template <int ST, int S, int TX>
+__global__ __launch_bounds__(TX * kRS, atrous_waves(S)) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup, int xrot) {
     keep_nan_in_clamps();
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const AtrousLds<S> L{lds_addr(smem)};
+    const AtrousLds<S, TX> L{lds_addr(smem)};
     // tile order v = (residue, band, x tile), x fastest.  Step 1 walks the frame bottom-up: what the temporal launch wrote last is
     // still in the 256 MB Infinity Cache when it is read first (-4.5 % for that launch).  Later steps sweep the frame once per row
     // residue; of the six direction patterns tried for them, only "step 8 backwards too" measured better than all forwards (-1.5 to
     // -3 % for that launch, -0.7 % for step 16 after it; steps 2 and 4 backwards are 1-4 % slower: profiles/r03_small_experiments.txt)
-    const int xtiles = (g.W + kTX - 1) / kTX;
+    const int xtiles = (g.W + TX - 1) / TX;
     const int ntiles = xtiles * nbands * S;
     int v = xcd_tile(xgroup, xrot);
     if (v >= ntiles) return;                       // padding of the last groups
     if (S == 1 || S == 8) v = ntiles - 1 - v;
-    const int x0 = (v % xtiles) * kTX;
+    const int x0 = (v % xtiles) * TX;
     const int band = (v / xtiles) % nbands;
     const int rv = v / (xtiles * nbands);          // row residue (relative to g.yb) this workgroup owns
     const int nrows = g.ye - g.yb;
@@ -236,27 +236,27 @@ __global__ __launch_bounds__(kTX * kRS, atrous_waves(S)) void atrous_lds_kernel(
     const int ybase = g.yb + rv;                   // global row of decimated index j: ybase + S*j
 
     if (threadIdx.x == 0) lds_store(L.nref(2), 0u);    // (ordered before the waves' stores below by the band's barriers)
-    const bool nan_wave = atrous_band<ST, S, false>(g, a, L, x0, j0, j1, ybase);
+    const bool nan_wave = atrous_band<ST, S, TX, false>(g, a, L, x0, j0, j1, ybase);
     if (nan_wave && (threadIdx.x & 63) == 0) lds_store(L.nref(2), 1u);
     __syncthreads();
     if (lds_load(L.nref(2)) == 0u) return;         // every frame without a NaN
     __syncthreads();                               // (the band's prologue writes the flag words again)
-    (void)atrous_band<ST, S, true>(g, a, L, x0, j0, j1, ybase);
+    (void)atrous_band<ST, S, TX, true>(g, a, L, x0, j0, j1, ybase);
 }
 
-template <int ST, int S>
-hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
-    constexpr size_t lds = AtrousLds<S>::bytes;
+template <int ST, int S, int TX>
+hipError_t launch_atrous_lds_tx(const Geo& g, const AtrousArgs& a, hipStream_t s) {
+    constexpr size_t lds = AtrousLds<S, TX>::bytes;
     static std::atomic<unsigned long long> attr_done{0};
-    if (hipError_t e = allow_dynamic_lds(atrous_lds_kernel<ST, S>, lds, attr_done); e != hipSuccess) return e;
+    if (hipError_t e = allow_dynamic_lds(atrous_lds_kernel<ST, S, TX>, lds, attr_done); e != hipSuccess) return e;
     // Bands are sized so that (x tiles) x (S residues) x (bands) is FOUR times the resident slots of the chip (LDS: 160 KiB per CU;
     // registers: atrous_waves(S) waves per SIMD): workgroups that take a fast path (all sky, uniform normals) make room for others
     // instead of idling until the slowest one of a single round finishes (A/B on one device: 2x -3..5 %, 4x another -1.5 %, 6x worse).
-    constexpr int per_cu_lds = (int)((160 * 1024) / lds), per_cu_waves = atrous_waves(S);      // 4-wave workgroups
+    constexpr int per_cu_lds = (int)((160 * 1024) / lds), per_cu_waves = atrous_waves(S) * 4 / (TX * kRS / 64);      // workgroups of TX * kRS / 64 waves
     constexpr int per_cu = per_cu_lds < per_cu_waves ? per_cu_lds : per_cu_waves;
     const int nrows = g.ye - g.yb;
     const int njmax = (nrows + S - 1) / S;
-    const int xtiles = (g.W + kTX - 1) / kTX;
+    const int xtiles = (g.W + TX - 1) / TX;
     int nbands = per_cu * num_cus() * kAtrousOversubscribe / (xtiles * S);
     if (nbands < 1) nbands = 1;
     int band = (njmax + nbands - 1) / nbands;
@@ -265,9 +265,15 @@ hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) {
     nbands = (njmax + band - 1) / band;
     int xgroup;
     const dim3 grid = xcd_grid(xtiles * nbands * S, S <= 2 ? 16 : (S == 16 ? 2 : 1), xgroup);     // groups per XCD: A/B per step on one device (4K)
-    atrous_lds_kernel<ST, S><<<grid, dim3(kTX * kRS), lds, s>>>(g, a, band, nbands, xgroup, 3);
+    atrous_lds_kernel<ST, S, TX><<<grid, dim3(TX * kRS), lds, s>>>(g, a, band, nbands, xgroup, 3);
     return hipGetLastError();
 }
+
+// (The tile width is a template parameter because 64-column two-wave workgroups were tried for small launches — 1080p frames, strips —
+// where they cut twice as many tiles in x and so allow bands twice as tall: parity-green and 3-5 % SLOWER at 1080p, on an 8K/8 strip
+// and at 4K, profiles/r04_small_experiments.txt block 6.)
+template <int ST, int S>
+hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) { return launch_atrous_lds_tx<ST, S, kTX>(g, a, s); }
 
 template <int ST>
 hipError_t launch_atrous_lds_step(const Geo& g, const AtrousArgs& a, hipStream_t s) {
