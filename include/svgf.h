@@ -58,7 +58,7 @@
 extern "C" {
 #endif
 
-#define SVGF_ABI_VERSION 4
+#define SVGF_ABI_VERSION 5
 
 enum svgf_status {
     SVGF_OK = 0,
@@ -337,6 +337,12 @@ int svgf_strips_layout(const svgf_strips* s, int local_index, svgf_strip_layout*
 int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gbuffer* cur, const svgf_gbuffer* prev, const void** results);
 /* Wait for the last frame's state exchange and the streams; SVGF_ERR_HALO if a reprojection left a strip (see svgf_sync). */
 int svgf_strips_sync(svgf_strips* s);
+/* Two frames in flight for the strips — svgf_set_frames_in_flight for the driver's contexts: with frames = 2, iterations 1.. of a frame
+ * (their halo exchanges included) run on a stream of the driver's own beside the NEXT frame's temporal launch; results are bit-identical.
+ * results[k] of call f is ORDERED on the rank's compute stream only by call f + 1 or svgf_strips_sync — enqueue its consumer after one of
+ * those — and stays valid until call f + 2 (frames alternate between two pairs of filter planes); cur[k] is not read after the call has
+ * returned (a frame whose iterations would read it — the direct kernel — keeps its tail on the compute stream).  Default 1. */
+int svgf_strips_set_frames_in_flight(svgf_strips* s, int frames);
 /* HIP events around the a-trous launches of the first local rank on every n-th frame (0 = off); read: launches, their summed
  * ms, the pixels they covered in all iterations and in iteration 0 (for the roofline's algorithmic bytes). */
 int svgf_strips_timing_enable(svgf_strips* s, int every);

@@ -102,6 +102,12 @@ struct svgf_strips {
         ncclComm_t comm = nullptr;
         hipStream_t compute = nullptr, comm_stream = nullptr;
         bool own_comm_stream = false;
+        // svgf_strips_set_frames_in_flight(2): iterations 1.. of a frame run on `side` beside the next frame's temporal launch; `cur` is the stream
+        // the launches, the exchanges' ready records and their waits go to at the moment (compute, or side for a frame's tail)
+        hipStream_t side = nullptr, cur = nullptr;
+        hipEvent_t ev_first = nullptr, ev_tail = nullptr;     // iteration 0 of the frame being enqueued is on `compute`; the end of the tail in flight on `side`
+        bool tail_pending = false;                            // ... which `compute` has not been made to wait for yet
+        void* filter_alt[2] = {nullptr, nullptr};
         hipEvent_t ready = nullptr, halo_done = nullptr, state_done = nullptr;
         bool state_pending = false;
         // the host never runs more than kMaxAhead frames ahead of the device: frame f waits for the end of frame f - kMaxAhead.  With ~100
@@ -115,6 +121,7 @@ struct svgf_strips {
     };
     std::vector<Local> local;
     int timing_every = 0, timing_base = 0, frame_no = 0;       // timed: frames timing_base, timing_base + every, ...
+    int frames_in_flight = 1;
     double t_ms = 0, t_px_iter = 0, t_px_fb = 0;
     int t_launches = 0;
     std::string err;
@@ -199,7 +206,7 @@ int post_exchange(svgf_strips* s, const std::vector<std::pair<int, int>>& planes
     // receives into.  Loop-back: every virtual rank shares one communication stream, which then waits for all of them.
     for (auto& l : s->local) {
         DeviceGuard dg(l.device);
-        SVGF_SHIP(s, hipEventRecord(l.ready, l.compute));
+        SVGF_SHIP(s, hipEventRecord(l.ready, l.cur));
     }
     for (auto& l : s->local) {
         DeviceGuard dg(l.device);
@@ -245,7 +252,7 @@ int post_exchange(svgf_strips* s, const std::vector<std::pair<int, int>>& planes
 
 int wait_exchange(svgf_strips* s, svgf_strips::Local& l, bool is_state) {
     DeviceGuard dg(l.device);
-    SVGF_SHIP(s, hipStreamWaitEvent(l.compute, is_state ? l.state_done : l.halo_done, 0));
+    SVGF_SHIP(s, hipStreamWaitEvent(l.cur, is_state ? l.state_done : l.halo_done, 0));
     if (is_state) l.state_pending = false;
     return SVGF_OK;
 }
@@ -261,7 +268,7 @@ int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src
     if (timed) {
         SVGF_SHIP(s, hipEventCreate(&e0));
         if (hipError_t e = hipEventCreate(&e1); e != hipSuccess) { (void)hipEventDestroy(e0); return sfail(s, SVGF_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
-        if (hipError_t e = hipEventRecord(e0, l.compute); e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return sfail(s, SVGF_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e)); }
+        if (hipError_t e = hipEventRecord(e0, l.cur); e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return sfail(s, SVGF_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e)); }
     }
     const void* guide = use_guide(c) ? c->guide : nullptr;
     int rc = pair ? atrous_pair_impl(c, c->filter[src], c->filter[dst], c->colour[P], cur, guide)
@@ -271,7 +278,7 @@ int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src
         return sfail(s, rc, c->err);
     }
     if (timed) {
-        if (hipError_t e = hipEventRecord(e1, l.compute); e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return sfail(s, SVGF_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e)); }
+        if (hipError_t e = hipEventRecord(e1, l.cur); e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return sfail(s, SVGF_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e)); }
         l.tev.push_back(e0); l.tev.push_back(e1);
         l.tbytes_px.push_back((double)(rows.b - rows.a) * s->W);
         l.titer.push_back(pair ? -1 : i);
@@ -362,6 +369,7 @@ int svgf_strips_create(svgf_strips** out, int width, int height, int world, cons
         if (l.rank < 0 || l.rank >= world) { cleanup(); return SVGF_ERR_INVALID; }
         make_geo(width, height, l.rank, world, params->steps, s->plan, params->moments_radius, motion_reach, l.g);
         l.compute = compute_streams ? (hipStream_t)compute_streams[k] : nullptr;
+        l.cur = l.compute;
         l.comm = comms ? (ncclComm_t)comms[s->loopback ? 0 : k] : nullptr;
         svgf_strip st{l.g.y0, l.g.y1 - l.g.y0, l.g.own0, l.g.own1};
         rc = svgf_create_strip(&l.ctx, width, height, &st, params, l.device, l.compute);
@@ -388,7 +396,12 @@ void svgf_strips_destroy(svgf_strips* s) {
     for (auto& l : s->local) {
         DeviceGuard dg(l.device);
         if (l.comm_stream) (void)hipStreamSynchronize(l.comm_stream);
-        if (l.ctx) { (void)hipStreamSynchronize(l.compute); l.ctx->strip_drv = nullptr; svgf_destroy(l.ctx); }
+        if (l.side) (void)hipStreamSynchronize(l.side);
+        if (l.ctx) { (void)hipStreamSynchronize(l.compute); l.ctx->stream = l.compute; l.ctx->strip_drv = nullptr; svgf_destroy(l.ctx); }
+        for (void* p : l.filter_alt) if (p) (void)hipFree(p);
+        if (l.ev_first) (void)hipEventDestroy(l.ev_first);
+        if (l.ev_tail) (void)hipEventDestroy(l.ev_tail);
+        if (l.side) (void)hipStreamDestroy(l.side);
         for (auto e : l.tev) (void)hipEventDestroy(e);
         for (auto e : l.frame_done) if (e) (void)hipEventDestroy(e);
         if (l.ready) (void)hipEventDestroy(l.ready);
@@ -428,6 +441,18 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
         int rc0 = alloc_state(c);                 // svgf_denoise_frame's lazy allocation (exact size, zeroed)
         if (rc0 == SVGF_OK) rc0 = alloc_flags(c);
         if (rc0 != SVGF_OK) return sfail(s, rc0, c->err);
+        if (s->frames_in_flight > 1) {
+            // Two frames in flight: frames alternate between two pairs of filter planes (the context's pointers are swapped, so that every helper
+            // keeps saying c->filter[]); the pair this frame takes over was last used by the frame before the previous one, whose tail the
+            // filter stream was made to wait for in the previous call (go_aside).
+            for (int i = 0; i < 2; i++) {
+                if (!l.filter_alt[i]) {
+                    SVGF_SHIP(s, hipMalloc(&l.filter_alt[i], colour_bytes(c)));
+                    SVGF_SHIP(s, hipMemsetAsync(l.filter_alt[i], 0, colour_bytes(c), l.compute));
+                }
+                std::swap(c->filter[i], l.filter_alt[i]);
+            }
+        }
         // previous-frame state halo: posted by the PREVIOUS frame right after its iteration 0
         if (l.state_pending) { int rc = wait_exchange(s, l, true); if (rc != SVGF_OK) return rc; }
     }
@@ -459,6 +484,31 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
         // moments / history ext_temporal rows beyond (bit-identical to the owner's)
         return post_exchange(s, {{SVGF_PLANE_COLOUR, P}, {SVGF_PLANE_MOMENTS, P}, {SVGF_PLANE_HISTORY, P}}, {colour_held, g.ext_temporal, g.ext_temporal}, g.halo_state, true);
     };
+    // Two frames in flight: everything the NEXT frame's temporal launch reads is written once iteration 0 has stored the feedback colour and
+    // the state exchange is posted; the remaining iterations (their exchanges included) go to the side stream.  Only when they read nothing
+    // of the caller's: LDS launches on the guide plane (the direct kernel reads cur[k], which the caller may rewrite after this call).
+    bool tail_ok = s->frames_in_flight > 1 && s->steps > 1;
+    for (int k = 0; k < n && tail_ok; k++) {
+        const svgf_ctx* c = s->local[k].ctx;
+        tail_ok = use_guide(c) && c->p.variant != SVGF_VARIANT_DIRECT && c->p.phi_normal != 0.0f && (1 << (s->steps - 1)) <= 64;
+    }
+    bool aside = false;
+    auto go_aside = [&]() -> int {
+        if (!tail_ok || aside) return SVGF_OK;
+        for (int k = 0; k < n; k++) {
+            auto& l = s->local[k];
+            DeviceGuard dg(l.device);
+            SVGF_SHIP(s, hipEventRecord(l.ev_first, l.compute));
+            // the frame that was on the side stream is ordered on the filter stream first: its result may be consumed after this call, its
+            // pair of planes reused by the next one
+            if (l.tail_pending) { SVGF_SHIP(s, hipStreamWaitEvent(l.compute, l.ev_tail, 0)); l.tail_pending = false; }
+            SVGF_SHIP(s, hipStreamWaitEvent(l.side, l.ev_first, 0));
+            l.cur = l.side;
+            l.ctx->stream = l.side;
+        }
+        aside = true;
+        return SVGF_OK;
+    };
     const auto& groups = s->local[0].g.groups;
     // The exchange in front of iteration group g + 1 carries the rows within halo_group[g + 1] of every strip boundary of the LAST
     // iteration of group g.  That iteration therefore produces those rows FIRST (two edge launches), the exchange is posted behind
@@ -484,6 +534,7 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
                     pp[k] ^= 1;
                 }
                 int rc = post_state();
+                if (rc == SVGF_OK) rc = go_aside();
                 if (rc != SVGF_OK) return rc;
                 q++;
                 if (q + 1 == groups[gi].size() && gi + 1 < groups.size() && s->world > 1) {      // (a group of exactly {0, 1}: its output travels whole)
@@ -528,7 +579,11 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
                 if (rc != SVGF_OK) return rc;
             }
             for (int k = 0; k < n; k++) pp[k] ^= 1;
-            if (i == 0) { int rc = post_state(); if (rc != SVGF_OK) return rc; }   // this frame's state is final once iteration 0 has written the feedback colour
+            if (i == 0) {                             // this frame's state is final once iteration 0 has written the feedback colour
+                int rc = post_state();
+                if (rc == SVGF_OK) rc = go_aside();
+                if (rc != SVGF_OK) return rc;
+            }
         }
     }
     if (!s->steps) { int rc = post_state(); if (rc != SVGF_OK) return rc; }
@@ -539,7 +594,16 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
             DeviceGuard dg(l.device);
             hipEvent_t& done = l.frame_done[s->frame_no % kMaxAhead];
             if (!done) SVGF_SHIP(s, hipEventCreateWithFlags(&done, hipEventDisableTiming));
-            SVGF_SHIP(s, hipEventRecord(done, l.compute));
+            SVGF_SHIP(s, hipEventRecord(done, l.cur));
+            if (l.cur != l.compute) {             // the end of this frame's tail on the side stream
+                SVGF_SHIP(s, hipEventRecord(l.ev_tail, l.cur));
+                l.tail_pending = true;
+            } else if (l.tail_pending) {          // this frame never left the filter stream: the one in flight is ordered behind it now
+                SVGF_SHIP(s, hipStreamWaitEvent(l.compute, l.ev_tail, 0));
+                l.tail_pending = false;
+            }
+            l.cur = l.compute;
+            c->stream = l.compute;
         }
         c->rb = c->strip.own_begin; c->re = c->strip.own_end;
         if (results) results[k] = c->filter[pp[k]];
@@ -549,6 +613,31 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
         if (c->frames_since_reset < (1 << 30)) c->frames_since_reset++;
     }
     s->frame_no++;
+    return SVGF_OK;
+}
+
+// Two frames in flight for the strips (svgf.h): 2 = iterations 1.. of a frame on a side stream of every local rank, beside the next frame's
+// temporal launch; 1 = back to one frame at a time (waits for what is in flight).
+int svgf_strips_set_frames_in_flight(svgf_strips* s, int frames) {
+    if (!s) return SVGF_ERR_INVALID;
+    if (frames != 1 && frames != 2) return sfail(s, SVGF_ERR_INVALID, "svgf_strips_set_frames_in_flight: 1 or 2");
+    if (frames == s->frames_in_flight) return SVGF_OK;
+    for (auto& l : s->local) {
+        DeviceGuard dg(l.device);
+        if (frames == 2) {
+            if (!l.side) {                        // at the filter stream's priority (a default-priority stream beside a high-priority one is starved)
+                int prio = 0;
+                (void)hipStreamGetPriority(l.compute, &prio);
+                SVGF_SHIP(s, hipStreamCreateWithPriority(&l.side, hipStreamNonBlocking, prio));
+            }
+            if (!l.ev_first) SVGF_SHIP(s, hipEventCreateWithFlags(&l.ev_first, hipEventDisableTiming));
+            if (!l.ev_tail) SVGF_SHIP(s, hipEventCreateWithFlags(&l.ev_tail, hipEventDisableTiming));
+        } else if (l.tail_pending) {              // back to one frame at a time: the filter stream waits for the tail in flight
+            SVGF_SHIP(s, hipStreamWaitEvent(l.compute, l.ev_tail, 0));
+            l.tail_pending = false;
+        }
+    }
+    s->frames_in_flight = frames;
     return SVGF_OK;
 }
 
@@ -563,7 +652,9 @@ int svgf_strips_sync(svgf_strips* s) {
         unsigned long long n = 0;
         int rc = read_halo_violations(l.ctx, &n, 1);
         if (rc != SVGF_OK) return sfail(s, rc, l.ctx->err);
+        if (l.tail_pending) { SVGF_SHIP(s, hipStreamWaitEvent(l.compute, l.ev_tail, 0)); l.tail_pending = false; }
         SVGF_SHIP(s, hipStreamSynchronize(l.compute));
+        if (l.side) SVGF_SHIP(s, hipStreamSynchronize(l.side));
         SVGF_SHIP(s, hipStreamSynchronize(l.comm_stream));
         total += n;
     }

@@ -30,9 +30,9 @@ EXPORTS = [
     "svgf_import_gbuffer_pitched", "svgf_import_gbuffer_array", "svgf_export_to_array",
     "svgf_strips_plan", "svgf_rccl_unique_id", "svgf_rccl_comm_init", "svgf_rccl_comm_destroy", "svgf_rccl_comm_count", "svgf_strips_create", "svgf_strips_destroy",
     "svgf_strips_last_error", "svgf_strips_context", "svgf_strips_layout", "svgf_strips_frame", "svgf_strips_sync",
-    "svgf_strips_timing_enable", "svgf_strips_timing_read",
+    "svgf_strips_timing_enable", "svgf_strips_timing_read", "svgf_strips_set_frames_in_flight",
 ]
-ABI_VERSION = 4
+ABI_VERSION = 5
 DEBUG_MODE = {"final": 0, "temporal": 1, "atrous": 2}
 HALO_PLAN = {"auto": 0, "ghost": 1, "grouped": 2, "per-iteration": 3}
 HALO_PLAN_NAME = {v: k for k, v in HALO_PLAN.items()}
@@ -181,6 +181,7 @@ def load_library():
     lib.svgf_strips_layout.argtypes = [vp, ip, C.POINTER(StripLayoutC)]
     lib.svgf_strips_frame.argtypes = [vp, C.POINTER(vp), C.POINTER(GBufferC), C.POINTER(GBufferC), C.POINTER(vp)]
     lib.svgf_strips_sync.argtypes = [vp]
+    lib.svgf_strips_set_frames_in_flight.argtypes = [vp, ip]
     lib.svgf_strips_timing_enable.argtypes = [vp, ip]
     lib.svgf_strips_timing_read.argtypes = [vp, C.POINTER(ip), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     _lib = lib

@@ -507,6 +507,11 @@ class NativeStrips:
         for k in range(self.n):
             self._check(self.lib.svgf_set_prev_guide(self.lib.svgf_strips_context(self._h, k), 1 if enable else 0))
 
+    def set_frames_in_flight(self, frames=2):
+        """svgf_strips_set_frames_in_flight: 2 = iterations 1.. of a frame on a side stream beside the next frame's temporal launch (same bits;
+        a frame's result is ordered on the compute stream two calls later, or by sync())."""
+        self._check(self.lib.svgf_strips_set_frames_in_flight(self._h, int(frames)), "svgf_strips_set_frames_in_flight")
+
     def set_iteration_fusion(self, enable=True):
         """Iterations 0 and 1 as one launch on every local strip (where the halo plan keeps them in one group)."""
         for k in range(self.n):

@@ -74,6 +74,53 @@ def test_native_strip_driver_over_rccl_loopback(G, loop_comm, plan, storage):
     drv.close()
 
 
+@pytest.mark.parametrize("plan", ["per-iteration", "grouped", "ghost"])
+def test_native_strip_driver_with_two_frames_in_flight(G, loop_comm, plan):
+    """svgf_strips_set_frames_in_flight(2): iterations 1.. of a frame — their halo exchanges included — on a side stream of every
+    rank beside the next frame's temporal launch, frames alternating between two pairs of filter planes.  Six frames of a panning
+    sequence WITHOUT a synchronisation in between (result f is read after call f + 1, or after the final sync): bitwise equal to
+    the single-context frames, history included; then back to one frame in flight, and one frame more."""
+    import torch
+    from svgf_amd import filter as F
+    from svgf_amd import strips
+    W, H, world, N = 320, 420, 3, 7
+    storage = "f32"
+    fr = frames(W, H, N, mv=(1.0, -2.5))
+    params = F.Params(storage=storage, steps=5)
+    whole = G.HipPipeline(W, H, storage, steps=5)
+    side = torch.cuda.Stream(priority=-1)
+    drv = strips.NativeStrips(W, H, world, params, list(range(world)), [0] * world, streams=[side.cuda_stream] * world, comms=[loop_comm],
+                              plan=plan, motion_reach=3, loopback=True)
+    drv.set_frames_in_flight(2)
+    gbs = [G.gb_dev(f) for f in fr]
+    want = [whole.frame(fr[k]["radiance"], gbs[k], gbs[max(k - 1, 0)]) for k in range(N)]
+    torch.cuda.synchronize()
+    inputs = [[_strip_inputs(G, fr[k], lay, storage) for lay in drv.layouts] for k in range(N)]       # every frame's planes stay alive and untouched
+    outs, got = {}, {}
+
+    def collect(k):          # on the ranks' compute stream: ordered behind frame k by call k + 1
+        with torch.cuda.stream(side):
+            got[k] = [drv.owned(r, o).clone() for r, o in enumerate(outs[k])]
+    for k in range(N - 1):
+        outs[k] = drv.frame([c[0] for c in inputs[k]], [c[1] for c in inputs[k]], [p[1] for p in inputs[k - 1]] if k else None)
+        if k >= 1:
+            collect(k - 1)
+    drv.sync()
+    collect(N - 2)
+    drv.set_frames_in_flight(1)
+    k = N - 1
+    outs[k] = drv.frame([c[0] for c in inputs[k]], [c[1] for c in inputs[k]], [p[1] for p in inputs[k - 1]])
+    drv.sync()
+    collect(k)
+    torch.cuda.synchronize()
+    for k in range(N):
+        g = np.concatenate([G.host(t) for t in got[k]], 0)
+        assert np.array_equal(g.view(np.uint8), want[k].view(np.uint8)), f"plan {plan}: frame {k}"
+    hist = np.concatenate([G.host(drv.owned(r, drv.state_plane(r, F.PLANE_HISTORY, 1 - drv.pingpong(r)))) for r in range(world)], 0)
+    assert np.array_equal(hist, whole.taps["hist"])
+    drv.close()
+
+
 def test_config4_8k_as_eight_strips_of_540_rows(G, loop_comm):
     """BASELINE.json configs[3]: 7680x4320 fp32 cut into 8 strips x 540 rows (plan auto = ghost, 69-row halo), two frames through
     the C++ strip driver with its RCCL exchanges, bitwise against the whole frame on the same device."""

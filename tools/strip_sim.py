@@ -36,6 +36,7 @@ ap.add_argument("--warm-ms", type=float, default=400.0, help="untimed frames for
 ap.add_argument("--warm-frames", type=int, default=600, help="... and at least this many")
 ap.add_argument("--per-frame", action="store_true", help="print the device and host time of every frame")
 ap.add_argument("--driver", default="python", help="python = StripRunner; native = svgf_strip_* C driver if present")
+ap.add_argument("--in-flight", type=int, default=1, help="native driver: svgf_strips_set_frames_in_flight")
 ap.add_argument("--aperiodic", action="store_true", help="keep the frame's real content in the halo rows (self-sent state is then inconsistent: see below)")
 ap.add_argument("--link-gbps", type=float, default=153.0, help="wire model: one xGMI link between neighbouring GPUs, per direction (MI355X: 7 links x ~153 GB/s)")
 ap.add_argument("--rccl-latency-us", type=float, default=-1.0, help="wire model: latency of one send/recv group; < 0 = measured here on the loop-back communicator")
@@ -86,6 +87,7 @@ if args.driver == "native":
     comm = strips.rccl_comm(1, 0, 0)
     drv = strips.NativeStrips(W, H, args.world, params, [args.rank], [0], streams=[side.cuda_stream], comms=[comm], plan=geo.plan, motion_reach=4, loopback=True)
     drv.set_prev_guide(True)          # the previous G-buffer below IS last frame's current one, untouched
+    drv.set_frames_in_flight(args.in_flight)
     frame = lambda k: drv.frame([rads[k % len(rads)]], [gbs[k & 1]], [gbs[(k & 1) ^ 1]])      # noqa: E731
 else:
     stages = strips.HipStages(geo, params, dev)
@@ -130,7 +132,7 @@ if args.per_frame:       # device time between the ends of consecutive frames, a
     for i in range(0, len(dev_ms) if args.steps <= 200 else 0, 10):
         print(f"frames {i:4d}..: device " + " ".join(f"{v:.2f}" for v in dev_ms[i:i + 10]) + "   host " + " ".join(f"{v:.2f}" for v in host_ms[i:i + 10]))
 own = geo.own[1] - geo.own[0]
-print(f"{W}x{H} strip {args.rank}/{args.world} ({own} rows, held {geo.y1 - geo.y0}), plan {geo.plan}, comm {args.comm}/{args.post}, stream {args.stream}, driver {args.driver}: "
+print(f"{W}x{H} strip {args.rank}/{args.world} ({own} rows, held {geo.y1 - geo.y0}), plan {geo.plan}, comm {args.comm}/{args.post}, stream {args.stream}, driver {args.driver}{', two frames in flight' if args.in_flight == 2 else ''}: "
       f"{t / args.steps * 1e3:.4f} ms/frame (host enqueue {t_host / args.steps * 1e3:.4f} ms) -> "
       f"{W * own / (t / args.steps) / 1e6:.0f} Mpx/s per GPU, x{args.world} = {W * own * args.world / (t / args.steps) / 1e6:.0f} Mpx/s")
 
