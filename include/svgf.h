@@ -41,9 +41,9 @@
  *    the zero-weight sums FilterMoments forms for zero-normal (sky) texels into NaN (0 x NaN, :498-499).  svgf_temporal, svgf_moments,
  *    svgf_atrous, svgf_atrous_pair, svgf_denoise_frame and the strip driver reproduce exactly that (tests/test_gpu_nonfinite.py: NaN
  *    masks identical to the oracle's, finite values within the stage tolerances): a host that wants its NaNs healed must clean the
- *    radiance before the temporal stage — the reference does not, and neither does this library.  Not covered: NaN / inf in the
- *    G-buffer planes (depth, normal, motion), and svgf_taa, which reads a NaN texel as 0 (the reference's TAA tests the result for NaN
- *    and writes black, Filter.cuh:351; the outcome differs in the neighbours' min / max).
+ *    radiance before the temporal stage — the reference does not, and neither does this library.  svgf_taa likewise: a NaN texel goes
+ *    through glm's min / max position by position (Filter.cuh:330-338) and the NaN test of :351 writes the pixel black.  Not covered:
+ *    NaN / inf in the G-buffer planes (depth, normal, motion).
  *  - Strips: a context may hold only rows [y0, y0+rows) of a WxH frame (multi-GPU row strips);
  *    "inside the frame" tests always use the global frame, so strip results are bit-identical
  *    to the whole-frame result as long as the halo rows hold valid data.

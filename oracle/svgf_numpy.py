@@ -210,19 +210,24 @@ def taa(filtered, history):
     def samp(img, uu, vv):
         return img[_tex(vv, H), _tex(uu, W)]
     last = samp(hist, u, v)
-    mix = np.minimum(last[..., 3], f32(0.5))[..., None]
+    mix = np.fmin(last[..., 3], f32(0.5))[..., None]            # :302 min(float, double literal): CUDA's overload is fmin (a NaN alpha gives 0.5)
     in0 = samp(inp, u, v)[..., :3]
-    aa = np.sqrt((last[..., :3] * last[..., :3]) * (f32(1) - mix) + (in0 * in0) * mix).astype(np.float32)
+    with np.errstate(all="ignore"):
+        aa = np.sqrt((last[..., :3] * last[..., :3]) * (f32(1) - mix) + (in0 * in0) * mix).astype(np.float32)
     offs = [(0, 0), (1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, 1), (1, -1), (-1, -1)]
     ys = [_enc(samp(inp, u + f32(a) * iw if a else u, v + f32(b) * ih if b else v)[..., :3]) for a, b in offs]
     ya = _enc(aa)
-    mn = np.minimum(np.minimum(np.minimum(ys[0], ys[1]), np.minimum(ys[2], ys[3])), ys[4])
-    mx = np.maximum(np.maximum(np.maximum(ys[0], ys[1]), np.maximum(ys[2], ys[3])), ys[4])
-    mn2 = np.minimum(np.minimum(np.minimum(ys[5], ys[6]), np.minimum(ys[7], ys[8])), mn)
-    mx2 = np.maximum(np.maximum(np.maximum(ys[5], ys[6]), np.maximum(ys[7], ys[8])), mx)
-    mn = mn * f32(0.5) + mn2 * f32(0.5)
-    mx = mx * f32(0.5) + mx2 * f32(0.5)
-    ya = np.minimum(np.maximum(ya, mn), mx)
+    # :330-338 glm::min / glm::max on vec3: (y < x) ? y : x and (x < y) ? y : x per component — what a NaN does depends on its position
+    gmin = lambda a, b: np.where(b < a, b, a)      # noqa: E731
+    gmax = lambda a, b: np.where(a < b, b, a)      # noqa: E731
+    with np.errstate(all="ignore"):
+        mn = gmin(gmin(gmin(ys[0], ys[1]), gmin(ys[2], ys[3])), ys[4])
+        mx = gmax(gmax(gmax(ys[0], ys[1]), gmax(ys[2], ys[3])), ys[4])
+        mn2 = gmin(gmin(gmin(ys[5], ys[6]), gmin(ys[7], ys[8])), mn)
+        mx2 = gmax(gmax(gmax(ys[5], ys[6]), gmax(ys[7], ys[8])), mx)
+        mn = mn * f32(0.5) + mn2 * f32(0.5)
+        mx = mx * f32(0.5) + mx2 * f32(0.5)
+        ya = gmin(gmax(ya, mn), mx)
     with np.errstate(all="ignore"):
         r = (ya[..., 0] * f32(1) + ya[..., 1] * f32(0)) + ya[..., 2] * f32(1.13983)
         g = (ya[..., 0] * f32(1) + ya[..., 1] * f32(-0.39465)) + ya[..., 2] * f32(-0.58060)

@@ -332,7 +332,7 @@ void taa(const Geo& g, const void* input, const void* history, void* out, int nt
                 const float u = (float)x * inv_w, v = (float)y * inv_h;   // :296
                 float last[4]; sample(history, u, v, last);               // :299
                 float aa[3] = {last[0], last[1], last[2]};
-                const float mix_rate = (float)std::min((double)last[3], 0.5);   // :302
+                const float mix_rate = (float)std::fmin((double)last[3], 0.5);  // :302 min(float, double literal): CUDA's overload is fmin (a NaN alpha gives 0.5)
                 float in[9][4];
                 sample(input, u, v, in[0]);                               // :305
                 for (int k = 0; k < 3; k++) aa[k] = std::sqrt(mixf(aa[k] * aa[k], in[0][k] * in[0][k], mix_rate));   // :307-308

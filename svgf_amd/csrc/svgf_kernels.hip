@@ -580,8 +580,44 @@ __device__ __forceinline__ float to_srgb(float c) {                     // :145-
     return (c <= 0.0031308f) ? 12.92f * c : 1.055f * hw_exp2(hw_log2(c) * (1.0f / 2.4f)) - 0.055f;
 }
 
+// :330-338: the neighbourhood clamp of the blended colour `ya` in YUV: y[0] the centre, y[1..4] the plus-shaped and y[5..8] the diagonal
+// neighbours.  EXACT: glm's min / max, `(y < x) ? y : x` and `(x < y) ? y : x`, in the reference's association — what a NaN does there
+// depends on its position (min(a, NaN) = a, min(NaN, b) = NaN); taken by a wave that holds a NaN (the reference's clamps keep a NaN texel,
+// :78-83, and :351 then turns the pixel black — but its neighbours' min / max have seen it).  Otherwise fminf / fmaxf: the same values.
+template <bool EXACT>
+__device__ __forceinline__ float3 taa_clamp(float3 ya, const float3 (&y)[9]) {
+    auto mn2 = [](float a, float b) { return EXACT ? ((b < a) ? b : a) : fminf(a, b); };
+    auto mx2 = [](float a, float b) { return EXACT ? ((a < b) ? b : a) : fmaxf(a, b); };
+    float r[3];
+    const float yav[3] = {ya.x, ya.y, ya.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        auto ch = [&](int i) { return k == 0 ? y[i].x : (k == 1 ? y[i].y : y[i].z); };
+        float mn, mx, mnd, mxd;
+        if constexpr (EXACT) {
+            mn = mn2(mn2(mn2(ch(0), ch(1)), mn2(ch(2), ch(3))), ch(4));
+            mx = mx2(mx2(mx2(ch(0), ch(1)), mx2(ch(2), ch(3))), ch(4));
+            mnd = mn2(mn2(mn2(ch(5), ch(6)), mn2(ch(7), ch(8))), mn);
+            mxd = mx2(mx2(mx2(ch(5), ch(6)), mx2(ch(7), ch(8))), mx);
+        } else {
+            mn = mx = ch(0);
+#pragma unroll
+            for (int i = 1; i <= 4; i++) { mn = fminf(mn, ch(i)); mx = fmaxf(mx, ch(i)); }
+            mnd = mn; mxd = mx;
+#pragma unroll
+            for (int i = 5; i <= 8; i++) { mnd = fminf(mnd, ch(i)); mxd = fmaxf(mxd, ch(i)); }
+        }
+        mn = mix_exact(mn, mnd, 0.5f);                                        // :332-335
+        mx = mix_exact(mx, mxd, 0.5f);
+        r[k] = mn2(mx2(yav[k], mn), mx);                                      // :338 clamp = min(max(x, lo), hi)
+    }
+    return make_float3(r[0], r[1], r[2]);
+}
+__device__ __forceinline__ bool any_nan3(float3 v) { return __builtin_isunordered(v.x, v.y) | (v.z != v.z); }
+
 template <int ST>
 __global__ __launch_bounds__(kBX* kBY) void taa_kernel(Geo g, const void* filtered, const void* history, void* out) {
+    keep_nan_in_clamps();                                                 // imageLoad keeps a NaN (svgf_device.h)
     const int x = blockIdx.x * kBX + threadIdx.x;
     const int y = g.yb + blockIdx.y * kBY + threadIdx.y;
     if (x >= g.W || y >= g.ye) return;
@@ -589,46 +625,31 @@ __global__ __launch_bounds__(kBX* kBY) void taa_kernel(Geo g, const void* filter
     const float u = (float)x * iw, v = (float)y * ih;                    // :296
     const int sx[3] = {tex_coord(u - iw, g.W), tex_coord(u, g.W), tex_coord(u + iw, g.W)};
     const int sy[3] = {tex_coord(v - ih, g.H), tex_coord(v, g.H), tex_coord(v + ih, g.H)};
-    auto at = [&](const void* img, int ix, int iy) { return clamp01(Store<ST>::ld4(img, (size_t)(sy[iy] - g.y0) * g.W + sx[ix])); };
+    auto at = [&](const void* img, int ix, int iy) { return clamp01_ref(Store<ST>::ld4(img, (size_t)(sy[iy] - g.y0) * g.W + sx[ix])); };
     const float4 last = at(history, 1, 1);                                // :299
-    const float mix = fminf(last.w, 0.5f);                                // :302
+    const float mix = fminf(last.w, 0.5f);                                // :302 (CUDA's min(float, double) is fmin: a NaN alpha gives 0.5)
     const float4 c0 = at(filtered, 1, 1);                                 // :305
     float3 aa = make_float3(sqrtf(mix_exact(last.x * last.x, c0.x * c0.x, mix)), sqrtf(mix_exact(last.y * last.y, c0.y * c0.y, mix)),
                             sqrtf(mix_exact(last.z * last.z, c0.z * c0.z, mix)));   // :307-308
     float3 ya = enc_yuv(aa);                                              // :319
-    // :310-317,320-335: plus-shaped and diagonal neighbourhoods
-    float3 mn, mx, mnd, mxd;
-    {
-        const float3 y0_ = enc_yuv(make_float3(c0.x, c0.y, c0.z));
-        mn = y0_; mx = y0_;
-        const int px[4] = {2, 0, 1, 1}, py[4] = {1, 1, 2, 0};
+    // :310-317,320-328: the centre, the plus-shaped and the diagonal neighbours
+    float3 nbv[9];
+    const int nx[9] = {1, 2, 0, 1, 1, 2, 0, 2, 0}, ny[9] = {1, 1, 1, 2, 0, 2, 2, 0, 0};
+    bool nan_in = any_nan3(ya);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float4 c = at(filtered, px[k], py[k]);
-            const float3 yk = enc_yuv(make_float3(c.x, c.y, c.z));
-            mn = make_float3(fminf(mn.x, yk.x), fminf(mn.y, yk.y), fminf(mn.z, yk.z));
-            mx = make_float3(fmaxf(mx.x, yk.x), fmaxf(mx.y, yk.y), fmaxf(mx.z, yk.z));
-        }
-        mnd = mn; mxd = mx;
-        const int dx[4] = {2, 0, 2, 0}, dy[4] = {2, 2, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float4 c = at(filtered, dx[k], dy[k]);
-            const float3 yk = enc_yuv(make_float3(c.x, c.y, c.z));
-            mnd = make_float3(fminf(mnd.x, yk.x), fminf(mnd.y, yk.y), fminf(mnd.z, yk.z));
-            mxd = make_float3(fmaxf(mxd.x, yk.x), fmaxf(mxd.y, yk.y), fmaxf(mxd.z, yk.z));
-        }
+    for (int k = 0; k < 9; k++) {
+        const float4 c = k == 0 ? c0 : at(filtered, nx[k], ny[k]);
+        nbv[k] = enc_yuv(make_float3(c.x, c.y, c.z));
+        nan_in = nan_in | any_nan3(nbv[k]);
     }
-    mn = make_float3(mix_exact(mn.x, mnd.x, 0.5f), mix_exact(mn.y, mnd.y, 0.5f), mix_exact(mn.z, mnd.z, 0.5f));
-    mx = make_float3(mix_exact(mx.x, mxd.x, 0.5f), mix_exact(mx.y, mxd.y, 0.5f), mix_exact(mx.z, mxd.z, 0.5f));
-    ya = make_float3(fminf(fmaxf(ya.x, mn.x), mx.x), fminf(fmaxf(ya.y, mn.y), mx.y), fminf(fmaxf(ya.z, mn.z), mx.z));   // :338
+    ya = wave_any(nan_in) ? taa_clamp<true>(ya, nbv) : taa_clamp<false>(ya, nbv);
     // :277-285; pow(x, 0.5) = sqrt(x), NaN for negative x
     float r = sqrtf((ya.x * 1.0f + ya.y * 0.0f) + ya.z * 1.13983f);
     float gg = sqrtf((ya.x * 1.0f + ya.y * -0.39465f) + ya.z * -0.58060f);
     float b = sqrtf((ya.x * 1.0f + ya.y * 2.03211f) + ya.z * 0.0f);
     if (r != r || gg != gg || b != b) { r = 0.f; gg = 0.f; b = 0.f; }     // :351
     const float4 o = make_float4(to_srgb(r), to_srgb(gg), to_srgb(b), 1.0f);   // :353
-    Store<ST>::st4(out, (size_t)(y - g.y0) * g.W + x, clamp01(o));        // :355 imageStore
+    Store<ST>::st4(out, (size_t)(y - g.y0) * g.W + x, clamp01_ref(o));   // :355 imageStore
 }
 
 // The same stage with the neighbourhood's YUV values computed ONCE per texel: a workgroup covers 64 x 8 pixels, encodes
@@ -638,15 +659,19 @@ __global__ __launch_bounds__(kBX* kBY) void taa_kernel(Geo g, const void* filter
 constexpr int kTaaW = 68, kTaaH = 12, kTaaRows = 8;
 template <int ST>
 __global__ __launch_bounds__(kBX* kBY) void taa_lds_kernel(Geo g, const void* filtered, const void* history, void* out) {
+    keep_nan_in_clamps();                                                 // imageLoad keeps a NaN (svgf_device.h)
     __shared__ float4 yuv[kTaaH][kTaaW];                                  // 16-B records: one ds_read_b128 per neighbour
+    __shared__ uint32_t wave_nan[kBY];                                    // per wave: a texel it staged holds a NaN in YUV (-> the workgroup clamps with glm's min / max)
     const int x0 = blockIdx.x * kBX, yb = g.yb + blockIdx.y * kTaaRows;
+    bool staged_nan = false;
     auto stage = [&](int lx, int ly) {
         const int gx = x0 - 3 + lx, gy = yb - 3 + ly;
         float3 e = make_float3(0.f, 0.f, 0.f);
         if (gx >= 0 && gx < g.W && gy >= 0 && gy < g.H && gy >= g.y0 && gy < g.y0 + g.rows) {
-            const float4 c = clamp01(Store<ST>::ld4(filtered, (size_t)(gy - g.y0) * g.W + gx));
+            const float4 c = clamp01_ref(Store<ST>::ld4(filtered, (size_t)(gy - g.y0) * g.W + gx));
             e = enc_yuv(make_float3(c.x, c.y, c.z));
         }
+        staged_nan = staged_nan | any_nan3(e);
         yuv[ly][lx] = make_float4(e.x, e.y, e.z, 0.f);
     };
 #pragma unroll
@@ -655,7 +680,10 @@ __global__ __launch_bounds__(kBX* kBY) void taa_lds_kernel(Geo g, const void* fi
         const int id = threadIdx.y * kBX + threadIdx.x;                                   // columns 64..67
         if (id < (kTaaW - kBX) * kTaaH) stage(kBX + (id & 3), id >> 2);
     }
+    { const bool w = wave_any(staged_nan); if (threadIdx.x == 0) wave_nan[threadIdx.y] = w ? 1u : 0u; }
     __syncthreads();
+    const bool tile_exact = (wave_nan[0] | wave_nan[1] | wave_nan[2] | wave_nan[3]) != 0u;
+    static_assert(kBY == 4, "one flag word per wave");
     const int x = x0 + threadIdx.x;
     if (x >= g.W) return;
     const float iw = 1.0f / (float)g.W, ih = 1.0f / (float)g.H;
@@ -669,38 +697,24 @@ __global__ __launch_bounds__(kBX* kBY) void taa_lds_kernel(Geo g, const void* fi
         const int sy[3] = {tex_coord(v - ih, g.H), tex_coord(v, g.H), tex_coord(v + ih, g.H)};
         auto nb = [&](int ix, int iy) { const float4 e = yuv[sy[iy] - (yb - 3)][sx[ix] - (x0 - 3)]; return make_float3(e.x, e.y, e.z); };
         const size_t ci = (size_t)(sy[1] - g.y0) * g.W + sx[1];
-        const float4 last = clamp01(Store<ST>::ld4(history, ci));         // :299
-        const float mix = fminf(last.w, 0.5f);                            // :302
-        const float4 c0 = clamp01(Store<ST>::ld4(filtered, ci));          // :305
+        const float4 last = clamp01_ref(Store<ST>::ld4(history, ci));     // :299
+        const float mix = fminf(last.w, 0.5f);                            // :302 (CUDA's min(float, double) is fmin)
+        const float4 c0 = clamp01_ref(Store<ST>::ld4(filtered, ci));      // :305
         float3 aa = make_float3(sqrtf(mix_exact(last.x * last.x, c0.x * c0.x, mix)), sqrtf(mix_exact(last.y * last.y, c0.y * c0.y, mix)),
                                 sqrtf(mix_exact(last.z * last.z, c0.z * c0.z, mix)));   // :307-308
         float3 ya = enc_yuv(aa);                                          // :319
-        float3 mn, mx, mnd, mxd;
-        mn = nb(1, 1); mx = mn;
-        const int px[4] = {2, 0, 1, 1}, py[4] = {1, 1, 2, 0};
+        const int nx[9] = {1, 2, 0, 1, 1, 2, 0, 2, 0}, ny[9] = {1, 1, 1, 2, 0, 2, 2, 0, 0};
+        float3 nbv[9];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float3 yk = nb(px[k], py[k]);
-            mn = make_float3(fminf(mn.x, yk.x), fminf(mn.y, yk.y), fminf(mn.z, yk.z));
-            mx = make_float3(fmaxf(mx.x, yk.x), fmaxf(mx.y, yk.y), fmaxf(mx.z, yk.z));
-        }
-        mnd = mn; mxd = mx;
-        const int dx[4] = {2, 0, 2, 0}, dy[4] = {2, 2, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float3 yk = nb(dx[k], dy[k]);
-            mnd = make_float3(fminf(mnd.x, yk.x), fminf(mnd.y, yk.y), fminf(mnd.z, yk.z));
-            mxd = make_float3(fmaxf(mxd.x, yk.x), fmaxf(mxd.y, yk.y), fmaxf(mxd.z, yk.z));
-        }
-        mn = make_float3(mix_exact(mn.x, mnd.x, 0.5f), mix_exact(mn.y, mnd.y, 0.5f), mix_exact(mn.z, mnd.z, 0.5f));
-        mx = make_float3(mix_exact(mx.x, mxd.x, 0.5f), mix_exact(mx.y, mxd.y, 0.5f), mix_exact(mx.z, mxd.z, 0.5f));
-        ya = make_float3(fminf(fmaxf(ya.x, mn.x), mx.x), fminf(fmaxf(ya.y, mn.y), mx.y), fminf(fmaxf(ya.z, mn.z), mx.z));   // :338
+        for (int k = 0; k < 9; k++) nbv[k] = nb(nx[k], ny[k]);
+        // (taa_kernel takes the exact form per wave; a tile that holds a NaN takes it for all its waves: for NaN-free values the two forms agree)
+        ya = (tile_exact || wave_any(any_nan3(ya))) ? taa_clamp<true>(ya, nbv) : taa_clamp<false>(ya, nbv);
         float rr = sqrtf((ya.x * 1.0f + ya.y * 0.0f) + ya.z * 1.13983f);
         float gg = sqrtf((ya.x * 1.0f + ya.y * -0.39465f) + ya.z * -0.58060f);
         float bb = sqrtf((ya.x * 1.0f + ya.y * 2.03211f) + ya.z * 0.0f);
         if (rr != rr || gg != gg || bb != bb) { rr = 0.f; gg = 0.f; bb = 0.f; }     // :351
         const float4 o = make_float4(to_srgb(rr), to_srgb(gg), to_srgb(bb), 1.0f);  // :353
-        Store<ST>::st4(out, (size_t)(y - g.y0) * g.W + x, clamp01(o));    // :355 imageStore
+        Store<ST>::st4(out, (size_t)(y - g.y0) * g.W + x, clamp01_ref(o));    // :355 imageStore
     }
 }
 

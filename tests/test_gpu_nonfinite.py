@@ -275,3 +275,34 @@ def test_nonfinite_list_overflow(G, oracle):
     assert np.array_equal(np.isnan(got), np.isnan(want))
     sky = fr[5]["region"] == synth.SKY
     assert np.isnan(want[sky]).any()
+
+
+@pytest.mark.parametrize("variant", ["auto", "direct"])
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_taa_nonfinite(G, oracle, storage, variant):
+    """svgf_taa (the LDS-tiled kernel and the per-pixel one) on planes that hold NaN / +-inf, in the filtered frame and in the history
+    (alpha included): the reference keeps a NaN through imageLoad, its glm min / max see it position by position (:330-338), the NaN
+    test of :351 writes black.  Against the oracle within the stage's tolerance — and the same set of black pixels."""
+    from svgf_amd import filter as F
+    W, H = 333, 207
+    rng = np.random.default_rng(81)
+    dt = CDT[storage]
+    f = synth.make_frame(W, H, 0)
+    filt = np.concatenate([f["base"] * 1.1, np.ones((H, W, 1), np.float32)], -1).astype(dt)
+    hist = rng.uniform(0, 1, (H, W, 4)).astype(dt)
+    poison(rng, filt, f["region"], n_per_kind=8)
+    poison(rng, hist, f["region"], n_per_kind=6)
+    want = np.zeros_like(filt)
+    oracle.taa(W, H, storage, filt, hist, want)
+    d = F.Denoiser(W, H, F.Params(storage=storage, variant=variant))
+    out = d.new_colour()
+    d.TAA(G.dev(filt), G.dev(hist), out)
+    got = G.host(out)
+    assert not np.isnan(got.astype(np.float32)).any()
+    black_w, black_g = (want[..., :3].astype(np.float32) == 0).all(-1), (got[..., :3].astype(np.float32) == 0).all(-1)
+    assert black_w.sum() >= 20 and np.array_equal(black_w, black_g), "black (NaN-guarded) pixels differ"
+    if storage == "f32":
+        assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= 2e-6
+    else:
+        from tests.helpers import half_ulp_diff
+        assert half_ulp_diff(got, want).max() <= 1

@@ -381,3 +381,27 @@ def test_kat_nonfinite_by_hand(oracle):
     om = np.zeros_like(col)
     oracle.moments(W, H, "f32", col, om, mo, {"motion": m2, "normal": n2, "uv": uv}, hist1, phi_colour=10.0, phi_normal=128.0)
     assert om[0, 0, 0] == 0 and om[0, 0, 1] == 0 and np.isnan(om[0, 0, 2]) and om[0, 0, 3] == 0
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_taa_nonfinite_matches_numpy(oracle, storage):
+    """The stage after the path on poisoned planes: imageLoad keeps a NaN, glm's min / max see it position by position (:330-338), the
+    NaN test of :351 turns the pixel black.  C++ oracle against the NumPy restatement: identical bits except where one of them is NaN
+    (none: the stage ends in the NaN test and a clamp)."""
+    W, H = 97, 61
+    rng = np.random.default_rng(93)
+    dt = CDT[storage]
+    f = synth.make_frame(W, H, 0)
+    filt = np.concatenate([f["base"] * 1.1, np.ones((H, W, 1), np.float32)], -1).astype(dt)
+    hist = rng.uniform(0, 1, (H, W, 4)).astype(dt)
+    _poison(rng, filt, 8); _poison(rng, hist, 6)
+    got = np.zeros_like(filt)
+    oracle.taa(W, H, storage, filt, hist, got)
+    want = snp.taa(filt, hist)
+    assert not np.isnan(got.astype(np.float32)).any() and not np.isnan(want.astype(np.float32)).any()
+    black = (got[..., :3].astype(np.float32) == 0).all(-1)
+    assert black.sum() >= 3 * 8, "the poisoned texels must have turned pixels black"
+    if storage == "f32":
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=3e-7)
+    else:
+        assert half_ulp_diff(got, want).max() <= 1
