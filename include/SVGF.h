@@ -103,6 +103,7 @@ public:
     int HistoryLength = 24;
     float PhiColour = 10.0f;
     float PhiNormal = 128.0f;
+    int NanPolicy = SVGF_NAN_REFERENCE;             // SVGF_NAN_ZERO: the temporal stage reads a NaN radiance / history channel as 0 (an extension, svgf.h)
 
     svgfDenoiser(uint32_t Width, uint32_t Height, int Storage = SVGF_F16, int Device = 0, hipStream_t Stream = nullptr) {
         Buffers.Storage = Storage;
@@ -180,6 +181,7 @@ private:
         svgf_default_params(&p);
         p.steps = SpatialFilterSteps; p.depth_threshold = DepthThreshold; p.normal_threshold = NormalThreshold;
         p.history_base = HistoryLength; p.phi_colour = PhiColour; p.phi_normal = PhiNormal; p.storage = Buffers.Storage;
+        p.nan_policy = NanPolicy;
         check(svgf_set_params(Ctx, &p), "svgf_set_params");
     }
     void check(int rc, const char* what) {

@@ -100,7 +100,17 @@ typedef struct svgf_params {
     int   storage;           /* svgf_storage                                                                   */
     int   mesh_id_test;      /* 1 = compare instance IDs as Filter.cuh:245-247 intends, 0 = the de-facto no-op */
     int   variant;           /* svgf_variant                                                                   */
+    int   nan_policy;        /* svgf_nan_policy: SVGF_NAN_REFERENCE (default) or SVGF_NAN_ZERO                 */
 } svgf_params;
+
+/* What the temporal stage does with a NaN in the radiance it is given or in the history it reprojects onto ("Non-finite input" above).
+ *   SVGF_NAN_REFERENCE  what the reference does: the NaN stays (Filter.cuh:63-83), settles in the history, and — through iteration 0's
+ *                       feedback — reaches two more pixels in every direction with every frame: a single NaN texel ends up covering every
+ *                       connected surface (the reference has no protection; its path tracer avoids producing them, PathTrace.cuh:338).
+ *   SVGF_NAN_ZERO       an extension: svgf_temporal / svgf_temporal_moments / svgf_denoise_frame / the strip driver read a NaN channel of
+ *                       the radiance, of the previous colour and of the previous moments as 0, so that nothing behind the temporal stage
+ *                       ever sees one.  With finite input the two policies give the same bits. */
+enum svgf_nan_policy { SVGF_NAN_REFERENCE = 0, SVGF_NAN_ZERO = 1 };
 
 /* Rows of the global frame this context's planes hold, and the rows it owns (computes by default). */
 typedef struct svgf_strip {

@@ -38,6 +38,7 @@ int check_params(svgf_ctx* c, const svgf_params* p) {
     if (p->storage != SVGF_F32 && p->storage != SVGF_F16) return fail(c, SVGF_ERR_INVALID, "storage must be SVGF_F32 or SVGF_F16");
     if (p->moments_radius < 0 || p->moments_radius > 3) return fail(c, SVGF_ERR_INVALID, "moments_radius must be in [0,3]");
     if (p->variant < SVGF_VARIANT_AUTO || p->variant > SVGF_VARIANT_LDS_GENERAL) return fail(c, SVGF_ERR_INVALID, "unknown variant");
+    if (p->nan_policy != SVGF_NAN_REFERENCE && p->nan_policy != SVGF_NAN_ZERO) return fail(c, SVGF_ERR_INVALID, "unknown nan_policy");
     return SVGF_OK;
 }
 
@@ -220,7 +221,7 @@ int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, vo
                          std::max(c->vy0, c->strip.y0) - c->strip.y0, std::min(c->vy1, c->strip.y0 + c->strip.rows) - c->strip.y0, (uint4*)guide_out,
                          (const uint4*)guide_prev,
                          c->strip.y0, c->strip.y0 + c->strip.rows,       // the guide texels of every row held (a strip runs the stage on fewer)
-                         passthrough_out ? c->nan_list : nullptr};
+                         passthrough_out ? c->nan_list : nullptr, c->p.nan_policy == SVGF_NAN_ZERO};
     if (c->re <= c->rb) return SVGF_OK;             // nothing to launch: the young list and its counters stay as they are
     SVGF_HIP(c, svgf::launch_temporal(geo_of(c), c->p.storage, a, c->stream));
     if (passthrough_out) c->young_pending = true;
@@ -338,6 +339,7 @@ void svgf_default_params(svgf_params* p) {
     p->storage = SVGF_F16;        // Filter.cuh:15-16
     p->mesh_id_test = 1;          // the test Filter.cuh:245-247 intends; 0 = what the reference's binary does (see svgf.h)
     p->variant = SVGF_VARIANT_AUTO;
+    p->nan_policy = SVGF_NAN_REFERENCE;  // what Filter.cuh does with a NaN texel (svgf.h)
 }
 
 const char* svgf_status_string(int s) {

@@ -39,6 +39,7 @@ struct TemporalArgs {
                                  // needs the texels of every row it holds)
     uint32_t* nan_list;          // with young_list: the local indices of the pixels whose temporal colour / moments are NaN or inf (counter:
                                  // young_count[kNanCounter]); the moments launch redoes the zero-normal shortcut pixels around them
+    int heal_nan;                // svgf_params::nan_policy == SVGF_NAN_ZERO: a NaN channel of the radiance / previous colour / previous moments reads as 0
 };
 struct MomentsArgs {
     const void* colour; void* out; const void* mom; const float4* motion; const uint2* normal; const uint8_t* hist;

@@ -69,7 +69,9 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
     ok = ok && in_strip;
     const size_t q = ok ? (size_t)ql * g.W + qx : idx;
 
-    const float4 c = clamp01_ref(Store<ST>::ld4(a.radiance, idx));    // :370 imageLoad (a NaN stays NaN)
+    float4 c = clamp01_ref(Store<ST>::ld4(a.radiance, idx));          // :370 imageLoad (a NaN stays NaN)
+    auto healed = [](float v) { return v != v ? 0.0f : v; };          // SVGF_NAN_ZERO (an extension, svgf.h): a NaN channel reads as 0
+    if (a.heal_nan) c = make_float4(healed(c.x), healed(c.y), healed(c.z), healed(c.w));
     const uint2 nc_raw = a.normal_c[idx];
     const uint2 uc_raw = a.uv_c[idx];
     // What the test needs of the PREVIOUS G-buffer is {depth, normal, instance ID} at q.  The drivers kept exactly that when
@@ -86,9 +88,10 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
         np_raw = a.normal_p[q];
         up_raw = a.uv_p[q];
     }
-    const float4 pc = clamp01_ref(Store<ST>::ld4(a.prev_colour, q));  // :254 imageLoad
+    float4 pc = clamp01_ref(Store<ST>::ld4(a.prev_colour, q));        // :254 imageLoad
     const int hp = a.hist_prev[q];                                    // :255
-    const float2 pm = Store<ST>::ld2(a.mom_prev, q);                  // :256
+    float2 pm = Store<ST>::ld2(a.mom_prev, q);                        // :256
+    if (a.heal_nan) { pc = make_float4(healed(pc.x), healed(pc.y), healed(pc.z), healed(pc.w)); pm = make_float2(healed(pm.x), healed(pm.y)); }
 
     float zc, dzc, zp, dzp;
     depth_of(mc, zc, dzc);
@@ -158,7 +161,10 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
         if (bad != 0ull) {
             const int lane = threadIdx.x, first = __builtin_ctzll(bad);
             unsigned base = 0;
-            if (lane == first) base = atomicAdd(a.young_count + kNanCounter, (unsigned)__builtin_popcountll(bad));
+            // (once the list has overflowed the counter says so and stays: no wave appends any more — a frame full of NaN would otherwise
+            // queue 130 000 atomics on one word)
+            if (lane == first) base = __hip_atomic_load(a.young_count + kNanCounter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > kNanListCap
+                                          ? kNanListCap : atomicAdd(a.young_count + kNanCounter, (unsigned)__builtin_popcountll(bad));
             base = __shfl(base, first);
             const unsigned at = base + (unsigned)__builtin_popcountll(bad & ((1ull << lane) - 1ull));
             if (((bad >> lane) & 1ull) && at < kNanListCap) a.nan_list[at] = (uint32_t)idx;
@@ -437,46 +443,50 @@ __global__ __launch_bounds__(kBX* kBY) void moments3x3_shfl_kernel(Geo g, Moment
 // (Bench pan, ~28 000 listed pixels + ~360 flagged segments per 4K frame: 0.051 -> 0.034 ms; nothing young: 0.0069 ms.  By parts,
 // tools/pan_moments_ab.sh: an empty launch 0.0069, the list alone 0.025, the flagged segments alone 0.029, a pass ~0.004 ms.)
 constexpr int kScanSplit = 2;
-constexpr int kNanBlocks = 32;                   // the last workgroups of the grid: the windows around non-finite pixels
 template <int ST>
 __global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a, int scan_blocks) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (blockIdx.x >= gridDim.x - kNanBlocks) {
+    if ((int)blockIdx.x >= scan_blocks) {
+        const unsigned list_blocks = gridDim.x - (unsigned)scan_blocks, b = blockIdx.x - (unsigned)scan_blocks;
+        const unsigned n = *a.young_count, ngroups = (n + 7u) / 8u;
+        for (unsigned grp = b + list_blocks * (unsigned)w; grp < ngroups; grp += list_blocks * 4u) {
+            const unsigned i = grp * 8u + ((unsigned)lane >> 3);
+            const bool valid = i < n;
+            moments_group8<ST>(g, a, valid, valid ? a.young_list[i] : 0u);
+        }
         // The temporal launch wrote exact zeros for young pixels with an all-zero normal (its zero-normal shortcut) — right unless a
         // texel of the pixel's 7x7 window is NaN or inf (0 x NaN, :498-499).  It listed the pixels whose result is not finite: every
-        // pixel in the window of a listed pixel gets the full estimate here (moments_group8 has no shortcut; a pixel that is not
-        // young, or not in the launch rows, is left alone; a young pixel that is listed as young too is written twice with the same
-        // bits).  Nothing listed — every frame without a NaN — and these workgroups read one word.
-        const unsigned n = a.young_count[kNanCounter];
-        if (n == 0u) return;
-        const unsigned b = blockIdx.x - (gridDim.x - kNanBlocks), wave = b * 4u + (unsigned)w, nwaves = kNanBlocks * 4u;
-        if (n <= kNanListCap) {
-            for (unsigned i = wave; i < n; i += nwaves) {
+        // shortcut pixel in the window of a listed pixel gets the full estimate here (moments_group8 has no shortcut).  Nothing listed —
+        // every frame without a NaN — and this is one more word read by the list workgroups.
+        const unsigned nn = a.young_count[kNanCounter];
+        if (nn == 0u) return;
+        const unsigned wave = b * 4u + (unsigned)w, nwaves = list_blocks * 4u;
+        auto shortcut_px = [&](bool valid, uint32_t q) {             // young, with an all-zero normal
+            const uint2 nq = a.normal[q];
+            return valid && a.hist[q] < 4 && ((nq.x & 0x7fff7fffu) | (nq.y & 0x7fffu)) == 0u;
+        };
+        if (nn <= kNanListCap) {
+            for (unsigned i = wave; i < nn; i += nwaves) {
                 const uint32_t p = a.nan_list[i];
                 const int px = (int)(p % (uint32_t)g.W), pyl = (int)(p / (uint32_t)g.W);
 #pragma unroll 1
                 for (int pass = 0; pass < 7; pass++) {
                     const int k = pass * 8 + (lane >> 3), qx = px + k % 7 - 3, qyl = pyl + k / 7 - 3;
                     const bool valid = k < 49 && qx >= 0 && qx < g.W && qyl >= 0 && qyl < g.rows;
-                    moments_group8<ST>(g, a, valid, valid ? (uint32_t)(qyl * g.W + qx) : 0u);
+                    const uint32_t q = valid ? (uint32_t)(qyl * g.W + qx) : 0u;
+                    const bool need = shortcut_px(valid, q);         // (a NaN pixel on a surface far from the sky costs two small loads per pass)
+                    if (!wave_any(need)) continue;
+                    moments_group8<ST>(g, a, need, q);
                 }
             }
-        } else {                                    // the list overflowed (a frame full of NaN): every pixel of the launch rows
+        } else {                                    // the list overflowed (a frame full of NaN): every shortcut pixel of the launch rows
             const unsigned first = (unsigned)(g.yb - g.y0) * (unsigned)g.W, last = (unsigned)(g.ye - g.y0) * (unsigned)g.W;
             for (unsigned q0 = first + wave * 8u; q0 < last; q0 += nwaves * 8u) {
-                const unsigned q = q0 + ((unsigned)lane >> 3);
-                moments_group8<ST>(g, a, q < last, q < last ? q : 0u);
+                const unsigned q = q0 + ((unsigned)lane >> 3), qs = q < last ? q : first;
+                const bool need = shortcut_px(q < last, qs);
+                if (!wave_any(need)) continue;
+                moments_group8<ST>(g, a, need, qs);
             }
-        }
-        return;
-    }
-    if ((int)blockIdx.x >= scan_blocks) {
-        const unsigned list_blocks = gridDim.x - kNanBlocks - (unsigned)scan_blocks, b = blockIdx.x - (unsigned)scan_blocks;
-        const unsigned n = *a.young_count, ngroups = (n + 7u) / 8u;
-        for (unsigned grp = b + list_blocks * (unsigned)w; grp < ngroups; grp += list_blocks * 4u) {
-            const unsigned i = grp * 8u + ((unsigned)lane >> 3);
-            const bool valid = i < n;
-            moments_group8<ST>(g, a, valid, valid ? a.young_list[i] : 0u);
         }
         return;
     }
@@ -796,8 +806,8 @@ hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, bool 
         if (scan > 4 * num_cus()) scan = 4 * num_cus();            // ... on at most one resident round
         const int walk = std::min(4 * num_cus(), std::max(1, nsegs / 16));   // the list holds at most 63 pixels per segment
         scan *= kScanSplit;
-        if (storage == 0) moments_young_kernel<0><<<scan + walk + kNanBlocks, 256, 0, s>>>(g, a, scan);
-        else moments_young_kernel<1><<<scan + walk + kNanBlocks, 256, 0, s>>>(g, a, scan);
+        if (storage == 0) moments_young_kernel<0><<<scan + walk, 256, 0, s>>>(g, a, scan);
+        else moments_young_kernel<1><<<scan + walk, 256, 0, s>>>(g, a, scan);
         return hipGetLastError();
     }
     const dim3 block(kBX, kBY), grid = grid_for(g);

@@ -18,6 +18,7 @@ from . import build as _build
 SVGF_F32, SVGF_F16 = 0, 1
 STORAGE = {"f32": SVGF_F32, "f16": SVGF_F16}
 VARIANT = {"auto": 0, "direct": 1, "lds": 2, "lds-general": 3}
+NAN_POLICY = {"reference": 0, "zero": 1}
 PLANE_COLOUR, PLANE_MOMENTS, PLANE_FILTER, PLANE_HISTORY = 0, 1, 2, 3
 MAX_STEPS = 10
 
@@ -50,7 +51,7 @@ class GBufferC(C.Structure):
 class ParamsC(C.Structure):
     _fields_ = [("steps", C.c_int), ("depth_threshold", C.c_float), ("normal_threshold", C.c_float),
                 ("history_base", C.c_int), ("phi_colour", C.c_float), ("phi_normal", C.c_float),
-                ("moments_radius", C.c_int), ("storage", C.c_int), ("mesh_id_test", C.c_int), ("variant", C.c_int)]
+                ("moments_radius", C.c_int), ("storage", C.c_int), ("mesh_id_test", C.c_int), ("variant", C.c_int), ("nan_policy", C.c_int)]
 
 
 class CameraC(C.Structure):
@@ -80,11 +81,12 @@ class Params:
     storage: str = "f16"
     mesh_id_test: int = 1
     variant: str = "auto"
+    nan_policy: str = "reference"         # "reference": a NaN texel stays NaN, as in Filter.cuh; "zero": the temporal stage reads it as 0 (svgf.h)
 
     def to_c(self) -> ParamsC:
         return ParamsC(self.steps, self.depth_threshold, self.normal_threshold, self.history_base, self.phi_colour,
                        self.phi_normal, self.moments_radius, STORAGE[self.storage], self.mesh_id_test,
-                       VARIANT[self.variant])
+                       VARIANT[self.variant], NAN_POLICY[self.nan_policy])
 
 
 _lib = None

@@ -35,6 +35,7 @@ def test_default_params_match_reference_defaults():
     assert (p.steps, p.history_base, p.moments_radius) == (3, 24, 3)
     assert (round(p.depth_threshold, 6), round(p.normal_threshold, 6), p.phi_colour, p.phi_normal) == (0.8, 0.9, 10.0, 128.0)
     assert p.storage == F.SVGF_F16
+    assert p.nan_policy == 0 and F.NAN_POLICY["reference"] == 0      # a NaN texel behaves as in Filter.cuh unless the host asks otherwise
 
 
 def test_no_cpu_fallback():

@@ -306,3 +306,57 @@ def test_taa_nonfinite(G, oracle, storage, variant):
     else:
         from tests.helpers import half_ulp_diff
         assert half_ulp_diff(got, want).max() <= 1
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_nan_policy_zero_reads_a_nan_as_zero(G, oracle, storage):
+    """svgf_params::nan_policy = SVGF_NAN_ZERO (an extension): the temporal stage reads a NaN channel of the radiance, of the previous colour
+    and of the previous moments as 0.  (i) The stage call on poisoned planes == the oracle on the same planes with every NaN replaced by
+    0, bit for bit.  (ii) A free-running sequence through svgf_denoise_frame with NaN radiance in most frames never shows a NaN and stays
+    within the free-running bounds of the oracle fed the cleaned radiance.  (iii) With finite input the two policies give the same bits."""
+    from svgf_amd import filter as F
+    W, H = 331, 203
+    dt = CDT[storage]
+    rng = np.random.default_rng(95)
+    f0, f1 = synth.make_frame(W, H, 3, mv=(1.0, 0.0)), synth.make_frame(W, H, 4, mv=(1.0, 0.0))
+    prev = rng.uniform(-0.1, 1.2, (H, W, 4)).astype(dt)
+    mom_prev = rng.uniform(0, 1, (H, W, 2)).astype(dt)
+    hist_prev = rng.integers(0, 40, (H, W)).astype(np.uint8)
+    cur = (f1["radiance"] * 1.3 - 0.1).astype(dt)
+    poison(rng, cur, f1["region"]); poison(rng, prev, f0["region"]); poison(rng, mom_prev, f0["region"], channels=2)
+    clean = lambda a: np.where(np.isnan(a.astype(np.float32)), dt(0), a).astype(dt)     # noqa: E731
+    out = np.zeros_like(cur); hist = np.zeros((H, W), np.uint8); mom = np.zeros((H, W, 2), dt)
+    oracle.temporal(W, H, storage, clean(prev), clean(cur), out, gbuf(f1), gbuf(f0), hist_prev, hist, mom, clean(mom_prev),
+                    depth_threshold=0.8, normal_threshold=0.9, history_base=24, mesh_id_test=1)
+    d = F.Denoiser(W, H, F.Params(storage=storage, nan_policy="zero"))
+    o_col, o_hist, o_mom = d.new_colour(), d.new_history(), d.new_moments()
+    d.TemporalFilter(G.dev(prev), G.dev(cur), o_col, G.gb_dev(f1), G.gb_dev(f0), G.dev(hist_prev), o_hist, o_mom, G.dev(mom_prev))
+    assert np.array_equal(G.host(o_hist), hist)
+    assert np.array_equal(G.host(o_col).view(np.uint8), out.view(np.uint8)) and np.array_equal(G.host(o_mom).view(np.uint8), mom.view(np.uint8))
+    # (ii)
+    Wf, Hf, N = 256, 144, 8
+    fr = frames(Wf, Hf, N, mv=(-2.5, 1.5))
+    rads = []
+    for k in range(N):
+        r = fr[k]["radiance"].copy()
+        if k != 3:
+            poison(rng, r, fr[k]["region"], n_per_kind=2, channels=3)
+        rads.append(r)
+    ref = oracle.Pipeline(Wf, Hf, storage, steps=5, nthreads=8)
+    dz = F.Denoiser(Wf, Hf, F.Params(storage=storage, steps=5, nan_policy="zero"))
+    gbs = [G.gb_dev(f) for f in fr]
+    tight, loose, frac = (2e-5, 5e-4, 1e-3) if storage == "f32" else (1e-3, 2e-2, 2e-3)
+    for k in range(N):
+        kp = max(k - 1, 0)
+        want = ref.frame(np.where(np.isnan(rads[k]), np.float32(0), rads[k]), gbuf(fr[k]), gbuf(fr[kp])).astype(np.float64)
+        got = G.host(dz.Render(G.dev(rads[k].astype(G.NPDT[storage])), gbs[k], gbs[kp] if k else None)).astype(np.float64)
+        assert not np.isnan(got).any(), f"frame {k}: a NaN came through"
+        assert np.array_equal(G.host(dz.state_plane(F.PLANE_HISTORY, 1 - dz.pingpong())), ref.taps["hist"]), f"frame {k}: history"
+        err = np.abs(got - want)[..., :3]
+        assert err.max() <= loose and (err > tight + 1e-5 * np.abs(want[..., :3])).mean() <= frac, f"frame {k}: {err.max():.3e}"
+    # (iii)
+    a, b = F.Denoiser(Wf, Hf, F.Params(storage=storage, steps=3)), F.Denoiser(Wf, Hf, F.Params(storage=storage, steps=3, nan_policy="zero"))
+    for k in range(4):
+        rad = G.dev(fr[k]["radiance"].astype(G.NPDT[storage]))
+        ra, rb = a.Render(rad, gbs[k], gbs[k - 1] if k else None), b.Render(rad, gbs[k], gbs[k - 1] if k else None)
+        assert np.array_equal(G.host(ra).view(np.uint8), G.host(rb).view(np.uint8)), k
