@@ -436,6 +436,7 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
         svgf_ctx* c = l.ctx;
         DeviceGuard dg(l.device);
         if (!radiance[k]) return sfail(s, SVGF_ERR_INVALID, "svgf_strips_frame: null radiance");
+        l.cur = l.compute; c->stream = l.compute;      // (a frame that failed behind its go_aside leaves them on the side stream)
         if (l.frame_done.empty()) l.frame_done.assign(kMaxAhead, nullptr);
         if (hipEvent_t old = l.frame_done[s->frame_no % kMaxAhead]) SVGF_SHIP(s, hipEventSynchronize(old));   // the end of frame f - kMaxAhead
         int rc0 = alloc_state(c);                 // svgf_denoise_frame's lazy allocation (exact size, zeroed)
