@@ -261,6 +261,25 @@ int svgf_reset_history(svgf_ctx* ctx);                                 /* zero a
  * without waiting for it; svgf_reset_history / svgf_resize / svgf_destroy wait for or order it themselves. */
 int svgf_set_frames_in_flight(svgf_ctx* ctx, int frames);
 int svgf_flush(svgf_ctx* ctx);
+/* Stream capture — a host that records its frame into a hipGraph (hipStreamBeginCapture on the context's stream) can record
+ * svgf_denoise_frame and the stage calls with it: in steady state they only enqueue (kernel launches, two 4-byte memsets on an error
+ * path, with two frames in flight the driver's own event record / wait pairs, which take the side stream into the capture and back).
+ * What a graph replays is what the captured calls enqueued, so:
+ *   - capture an EVEN number of svgf_denoise_frame calls: the context ping-pongs its state, guide and (two frames in flight) filter
+ *     planes per frame, and the second call leaves it where the first one found it;
+ *   - the planes passed to the captured calls (radiance, cur, prev, and whatever consumes *result) are the ones every replay reads and
+ *     writes: the host refills them, normally by nodes of the same graph;
+ *   - the first three frames after svgf_create / svgf_resize / svgf_reset_history cannot be captured (the first one allocates, all
+ *     three run the cold-start moments kernel): under capture they are refused with SVGF_ERR_INVALID and record nothing — enqueue
+ *     them directly; tunables, row ranges, debug mode and the switches are those in force at capture time;
+ *   - with two frames in flight: svgf_flush before hipStreamBeginCapture (a frame enqueued before the capture cannot be joined inside
+ *     it: refused) and again before hipStreamEndCapture (the side stream must be back on the captured one);
+ *   - per-stage timing skips captured frames; svgf_sync / svgf_halo_violations / svgf_timing_read wait for the device and are not
+ *     capturable, as any synchronising call; the strip driver (svgf_strips_frame) is not capturable.
+ * Replayed frames equal directly enqueued ones bit for bit (tests/test_gpu_graph.py).  Measured (tools/graph_replay.py): with one
+ * frame in flight a replay costs the device what the calls cost (the launches are not host-bound: 7 us against 30 us of host time
+ * per frame, no device time saved); with two frames in flight the cross-stream edges of a graph are cheaper than the event waits of
+ * the calls: -5 % at 1080p and -9 % at 720p against one frame in flight enqueued call by call. */
 /* The sequences application::Render runs in its debug views (SVGFDebugOutput, App.cu:545-649) on the same state:
  *   SVGF_DEBUG_FINAL     TemporalFilter, FilterMoments, WaveletFilter (App.cu:552-556)                  — the default
  *   SVGF_DEBUG_TEMPORAL  TemporalFilter only; *result = the temporally accumulated colour (App.cu:602-609)

@@ -102,11 +102,26 @@ int alloc_flags(svgf_ctx* c) {
     return SVGF_OK;
 }
 
+// Stream capture (svgf.h): 0 while the context's stream is not being captured, else a number that names the capture.
+int capture_of(svgf_ctx* c, unsigned long long* id) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long n = 0;
+    *id = 0;
+    if (!c->stream) return SVGF_OK;                 // the legacy default stream cannot be captured
+    SVGF_HIP(c, hipStreamGetCaptureInfo(c->stream, &st, &n));
+    if (st == hipStreamCaptureStatusInvalidated) return fail(c, SVGF_ERR_HIP, "the capture of the context's stream has been invalidated (hipStreamEndCapture will report it)");
+    if (st == hipStreamCaptureStatusActive) *id = n | (1ull << 63);
+    return SVGF_OK;
+}
+
 bool is_strip(const svgf_ctx* c) { return c->strip.y0 != 0 || c->strip.rows != c->H; }
 
 // the violation counter of a strip context (a whole-frame context cannot lose a reprojection: it holds every row)
 int alloc_halo_counter(svgf_ctx* c) {
     if (c->halo_violations || !is_strip(c)) return SVGF_OK;
+    unsigned long long cap = 0;
+    if (int rc = capture_of(c, &cap); rc != SVGF_OK) return rc;
+    if (cap) return fail(c, SVGF_ERR_INVALID, "the context's stream is being captured and a strip context's first temporal launch allocates: enqueue one before the capture begins");
     SVGF_HIP(c, hipMalloc((void**)&c->halo_violations, sizeof(unsigned)));
     SVGF_HIP(c, hipMemsetAsync(c->halo_violations, 0, sizeof(unsigned), c->stream));
     return SVGF_OK;
@@ -645,6 +660,21 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     // First frame: state is zero, so reprojecting onto the current G-buffer gives h = 1, alpha = 1 —
     // the same result as the reference's rejection against its cleared previous framebuffer.
     if (!prev) prev = cur;
+    // Under stream capture a call records launches, it cannot allocate; and what a graph replays is what THIS call enqueues — the
+    // cold-start moments kernel of the first three frames after a reset would be replayed for ever.
+    unsigned long long cap = 0;
+    rc = capture_of(c, &cap);
+    if (rc != SVGF_OK) return rc;
+    if (cap) {
+        const bool allocates = !c->have_state || !(c->young_list && c->young_count && c->young_flags && c->nan_list) ||
+                               (c->frames_in_flight > 1 && !(c->filter_alt[0] && c->filter_alt[1])) || (is_strip(c) && !c->halo_violations);
+        if (allocates || c->frames_since_reset < 3)
+            return fail(c, SVGF_ERR_INVALID, "svgf_denoise_frame: the context's stream is being captured and this frame cannot be: the first three frames after "
+                                             "svgf_create / svgf_resize / svgf_reset_history allocate and take the cold-start path - enqueue them before the capture begins");
+        if (c->in_flight && c->in_flight_capture != cap)
+            return fail(c, SVGF_ERR_INVALID, "svgf_denoise_frame: the context's stream is being captured while a frame enqueued before the capture is still in flight: "
+                                             "svgf_flush before hipStreamBeginCapture");
+    }
     rc = alloc_state(c);
     if (rc == SVGF_OK) rc = alloc_flags(c);
     if (rc == SVGF_OK) rc = alloc_alt(c);
@@ -655,7 +685,7 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     if (c->frames_in_flight > 1) c->filter_set ^= 1;
 
     svgf_ctx::FrameEvents fe;
-    const bool timed = c->timing > 0 && (c->timing_phase++ % c->timing) == 0;
+    const bool timed = !cap && c->timing > 0 && (c->timing_phase++ % c->timing) == 0;     // (events of a captured frame are graph nodes: nothing to read back)
     auto stamp = [&]() {                            // on c->stream AS IT IS when called (the side stream for the tail of a frame in flight)
         if (!timed) return;
         hipEvent_t e = take_event(c);
@@ -767,7 +797,7 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     if (aside) {
         // (also after a failed launch: whatever did get onto the side stream must be waited for before its planes are touched again)
         hipError_t e = hipEventRecord(c->ev_done, c->side);
-        if (e == hipSuccess) c->in_flight = true; else if (rc == SVGF_OK) rc = hip_fail(c, e, "hipEventRecord");
+        if (e == hipSuccess) { c->in_flight = true; c->in_flight_capture = cap; } else if (rc == SVGF_OK) rc = hip_fail(c, e, "hipEventRecord");
         c->stream = caller_stream;
     }
     if (rc != SVGF_OK) return bail(rc);

@@ -47,6 +47,7 @@ struct svgf_ctx {
     void* filter_alt[2] = {nullptr, nullptr};
     int filter_set = 0;                    // which pair the NEXT frame uses (toggles per frame while frames_in_flight == 2)
     bool in_flight = false;                // a frame's tail is on `side` and `stream` has not been made to wait for it yet
+    unsigned long long in_flight_capture = 0;   // ... and the stream capture that tail was recorded in (0: none; svgf.h, Stream capture)
     uint32_t* young_list = nullptr;        // scratch, temporal -> moments: indices of the pixels with history < 4 that need the spatial estimate
     unsigned* young_count = nullptr;       // two device counters used in turn (the temporal launch of a frame zeroes the next frame's)
     uint8_t* young_flags = nullptr;        // one flag per (row, 64-column segment): all 64 pixels need the estimate (listed nowhere)

@@ -1,0 +1,168 @@
+"""GPU tests of the frame driver under HIP stream capture (include/svgf.h, "Stream capture"): a host that records its whole frame into a
+hipGraph can record svgf_denoise_frame with it.  The context ping-pongs its state planes, so a graph holds an EVEN number of frames
+(the second one leaves the context where the first one found it); the inputs of the captured frames live at fixed addresses and are
+refilled before each replay.  Every frame of a replayed sequence — and the state it leaves — equals the directly enqueued one's, bit
+for bit."""
+import numpy as np
+import pytest
+
+from tests.helpers import frames
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from tests import gpu_helpers
+    return gpu_helpers
+
+
+def _state(G, d):
+    from svgf_amd import filter as F
+    q = 1 - d.pingpong()
+    return {"hist": G.host(d.state_plane(F.PLANE_HISTORY, q)), "moments": G.host(d.state_plane(F.PLANE_MOMENTS, q)),
+            "colour": G.host(d.state_plane(F.PLANE_COLOUR, q))}
+
+
+def _direct(G, seq, storage, **kw):
+    import torch
+    from svgf_amd import filter as F
+    H, W = seq[0]["radiance"].shape[:2]
+    d = F.Denoiser(W, H, F.Params(storage=storage, steps=kw.get("steps", 5), variant=kw.get("variant", "auto")))
+    d.set_prev_guide(kw.get("prev_guide", False))
+    d.set_iteration_fusion(kw.get("fusion", False))
+    gbs = [G.gb_dev(f) for f in seq]
+    outs = [G.host(d.Render(G.dev(f["radiance"].astype(G.NPDT[storage])), gbs[k], gbs[k - 1] if k else None)) for k, f in enumerate(seq)]
+    torch.cuda.synchronize()
+    return outs, _state(G, d)
+
+
+def _replayed(G, seq, storage, warm=4, in_flight=1, **kw):
+    """Frames [0, warm) enqueued directly (the first call after svgf_create allocates, the first three take the cold-start path: not
+    capturable), then ONE capture of two frames
+    reading their inputs from two fixed slots, replayed for the rest of the sequence."""
+    import torch
+    from svgf_amd import filter as F
+    H, W = seq[0]["radiance"].shape[:2]
+    assert warm % 2 == 0 and (len(seq) - warm) % 2 == 0
+    s = torch.cuda.Stream()
+    d = F.Denoiser(W, H, F.Params(storage=storage, steps=kw.get("steps", 5), variant=kw.get("variant", "auto")), stream=s.cuda_stream)
+    d.set_prev_guide(kw.get("prev_guide", False))
+    d.set_iteration_fusion(kw.get("fusion", False))
+    d.set_frames_in_flight(in_flight)
+    dt = G.NPDT[storage]
+    # The two input slots (frame k lives in slot k % 2: the previous G-buffer of a frame is the other slot) and a staging copy of each:
+    # the captured sequence is { write slot 0, denoise, write slot 1, denoise } - the copies stand for the host's renderer.
+    names = ("radiance", "motion", "normal", "uv")
+    cast = lambda f, n: f[n].astype(dt) if n == "radiance" else f[n]     # noqa: E731
+    slot = [{n: G.dev(cast(seq[k], n)) for n in names} for k in (0, 1)]
+    stage = [{n: torch.empty_like(slot[k][n]) for n in names} for k in (0, 1)]
+    gb = [F.GBuffer(slot[k]["motion"], slot[k]["normal"], slot[k]["uv"]) for k in (0, 1)]
+    res = [torch.empty_like(d.new_colour()) for _ in (0, 1)]
+
+    def fill(k):
+        for n in names:
+            stage[k % 2][n].copy_(G.dev(cast(seq[k], n)))
+
+    def render(j, first):
+        for n in names:
+            slot[j][n].copy_(stage[j][n])
+        return d.Render(slot[j]["radiance"], gb[j], gb[1 - j] if (first + j) else None)
+
+    def two_frames(first):
+        v0 = render(0, first)
+        if in_flight == 1:
+            res[0].copy_(v0)                            # the next call may write the plane this view shows
+        v1 = render(1, first)
+        if in_flight == 2:
+            res[0].copy_(v0)                            # two in flight: ordered on the stream by the call for the next frame (svgf.h)
+            d.flush()                                   # ... and the graph ends with every frame it holds ordered on the captured stream
+        res[1].copy_(v1)
+
+    outs = []
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        for k in range(0, warm, 2):
+            fill(k)
+            fill(k + 1)
+            two_frames(k)
+            s.synchronize()
+            outs += [G.host(res[0]), G.host(res[1])]
+    d.sync()
+    g = torch.cuda.CUDAGraph()
+    fill(warm)
+    fill(warm + 1)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s):
+        two_frames(warm)
+    for k in range(warm, len(seq), 2):
+        fill(k)
+        fill(k + 1)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        outs += [G.host(res[0]), G.host(res[1])]
+    st = _state(G, d)
+    del g
+    d.close()
+    return outs, st
+
+
+def _assert_same(a, b):
+    (oa, sa), (ob, sb) = a, b
+    assert len(oa) == len(ob)
+    for k, (x, y) in enumerate(zip(oa, ob)):
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), f"frame {k}"
+    for name in sa:
+        assert np.array_equal(sa[name].view(np.uint8), sb[name].view(np.uint8)), name
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+@pytest.mark.parametrize("kw", [dict(), dict(prev_guide=True), dict(fusion=True), dict(variant="direct"), dict(steps=7)],
+                         ids=lambda kw: "-".join(f"{k}={v}" for k, v in kw.items()) or "default")
+def test_captured_frames_replay_bitwise(G, storage, kw):
+    seq = frames(384, 216, 10, mv=(1.5, -0.5))
+    _assert_same(_replayed(G, seq, storage, **kw), _direct(G, seq, storage, **kw))
+
+
+def test_captured_frames_with_two_in_flight(G):
+    """The side stream joins the capture through the driver's own events; svgf_flush before the capture ends joins it back."""
+    seq = frames(640, 360, 10, mv=(0.5, 1.0))
+    _assert_same(_replayed(G, seq, "f32", in_flight=2), _direct(G, seq, "f32"))
+
+
+def test_frames_that_cannot_be_captured_are_refused(G):
+    """The first svgf_denoise_frame after svgf_create / svgf_resize allocates, and the first three after a reset run the cold-start
+    moments kernel (a graph would replay it for ever): under capture they fail with an error of the library's own, record nothing,
+    and the context stays usable.  The fourth frame is captured."""
+    import torch
+    from svgf_amd import filter as F
+    seq = frames(128, 64, 6)
+    s = torch.cuda.Stream()
+    d = F.Denoiser(128, 64, F.Params(storage="f32", steps=2), stream=s.cuda_stream)
+    rad, gbs = [G.dev(f["radiance"]) for f in seq], [G.gb_dev(f) for f in seq]
+    res = torch.empty_like(d.new_colour())
+    torch.cuda.synchronize()
+    want, _ = _direct(G, seq, "f32", steps=2)
+
+    def attempt(k):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            res.copy_(d.Render(rad[k], gbs[k], gbs[k - 1] if k else None))
+        return g
+
+    for k in range(3):
+        with pytest.raises(F.SvgfError, match="captured"):
+            attempt(k)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s):
+            out = d.Render(rad[k], gbs[k], gbs[k - 1] if k else None)          # ... enqueued directly instead
+            assert np.array_equal(G.host(out), want[k]), f"frame {k}"
+    g = attempt(3)
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(G.host(res), want[3])
+    del g
+    d.close()
