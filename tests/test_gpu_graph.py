@@ -2,7 +2,7 @@
 hipGraph can record svgf_denoise_frame with it.  The context ping-pongs its state planes, so a graph holds an EVEN number of frames
 (the second one leaves the context where the first one found it); the inputs of the captured frames live at fixed addresses and are
 refilled before each replay.  Every frame of a replayed sequence — and the state it leaves — equals the directly enqueued one's, bit
-for bit."""
+for bit.  Also here: two contexts driven from two host threads, and two contexts interleaved on one stream."""
 import numpy as np
 import pytest
 
@@ -166,3 +166,71 @@ def test_frames_that_cannot_be_captured_are_refused(G):
     assert np.array_equal(G.host(res), want[3])
     del g
     d.close()
+
+
+def test_two_contexts_from_two_host_threads(G):
+    """Two contexts of one process, each driven by a host thread of its own on a stream of its own (ctypes drops the GIL inside the
+    library): the library keeps no state outside a context that the calls of another could disturb.  Each sequence equals the one a
+    single thread produces."""
+    import threading
+    import torch
+    from svgf_amd import filter as F
+    seqs = {"a": frames(320, 200, 12, mv=(1.0, 0.5)), "b": frames(448, 136, 12, mv=(-0.5, 2.0))}
+    stor = {"a": "f32", "b": "f16"}
+    want = {k: _direct(G, seqs[k], stor[k])[0] for k in seqs}
+    got, errs = {}, []
+    start = threading.Barrier(2)
+
+    def work(k):
+        try:
+            seq, st = seqs[k], stor[k]
+            H, W = seq[0]["radiance"].shape[:2]
+            with torch.cuda.device(0):
+                s = torch.cuda.Stream()
+                d = F.Denoiser(W, H, F.Params(storage=st, steps=5), stream=s.cuda_stream)
+                with torch.cuda.stream(s):
+                    gbs = [G.gb_dev(f) for f in seq]
+                    rads = [G.dev(f["radiance"].astype(G.NPDT[st])) for f in seq]
+                    s.synchronize()
+                    start.wait()
+                    outs = [d.Render(rads[i], gbs[i], gbs[i - 1] if i else None).clone() for i in range(len(seq))]
+                    s.synchronize()
+                got[k] = [G.host(o) for o in outs]
+                d.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, repr(e)))
+            start.abort()
+
+    th = [threading.Thread(target=work, args=(k,)) for k in seqs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for k in seqs:
+        for i, (x, y) in enumerate(zip(got[k], want[k])):
+            assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), f"context {k}, frame {i}"
+
+
+def test_two_contexts_interleaved_on_one_stream(G):
+    """Diffuse and specular, say: two contexts of the same size fed alternately on one stream share nothing but the stream."""
+    import torch
+    from svgf_amd import filter as F
+    sa, sb = frames(384, 216, 8, mv=(0.5, 0.5)), frames(384, 216, 8, mv=(0.5, 0.5), noise="mul")
+    wa, wb = _direct(G, sa, "f32")[0], _direct(G, sb, "f32")[0]
+    da, db = F.Denoiser(384, 216, F.Params(storage="f32", steps=5)), F.Denoiser(384, 216, F.Params(storage="f32", steps=5))
+    da.set_frames_in_flight(2)                       # ... one of them with its tail on a side stream
+    ga, gb_ = [G.gb_dev(f) for f in sa], [G.gb_dev(f) for f in sb]
+    oa, ob, waiting = [], [], None
+    for i in range(8):
+        va = da.Render(G.dev(sa[i]["radiance"]), ga[i], ga[i - 1] if i else None)
+        if waiting is not None:
+            oa.append(G.host(waiting))
+        waiting = va
+        ob.append(G.host(db.Render(G.dev(sb[i]["radiance"]), gb_[i], gb_[i - 1] if i else None)))
+    da.flush()
+    oa.append(G.host(waiting))
+    torch.cuda.synchronize()
+    for i in range(8):
+        assert np.array_equal(oa[i].view(np.uint8), wa[i].view(np.uint8)), f"a, frame {i}"
+        assert np.array_equal(ob[i].view(np.uint8), wb[i].view(np.uint8)), f"b, frame {i}"
