@@ -107,6 +107,10 @@ def main(tag):
                 notes.append(f"* also `seven_iterations` (steps 1..64, all LDS launches): {v['ms_per_step']} ms per frame; a-trous launch by step (ms): {v['atrous_launch_ms_by_step']}.")
             elif "ms_per_step" in v:
                 notes.append(f"* also `{k}`: {v['ms_per_step']} ms per frame, {v['Mpixels/s']} Mpixel/s, pass frac {v.get('frac_of_8TBps')}, à-trous launch {v.get('atrous_avg_launch_ms')} ms (frac {v.get('atrous_roofline_frac')}).")
+                g = v.get("hip_graph")
+                if g:
+                    notes.append(f"* also `{k}.hip_graph` (four frames captured once and replayed, ms per frame): one frame in flight {g['calls_1_in_flight_ms']} by calls / {g['graph_1_in_flight_ms']} replayed; "
+                                 f"two in flight {g['calls_2_in_flight_ms']} / **{g['graph_2_in_flight_ms']}** (without stage events the calls read {v.get('ms_per_step_without_stage_events')}).")
         sec = (r or {}).get("secondary")
         if sec:
             notes.append(f"* `roofline.secondary` (the launch's second bound, from `{sec.get('source')}`): valu_busy **{sec['valu_busy']}**, {sec['insts_valu_per_px']} vector instructions per pixel.")
