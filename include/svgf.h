@@ -273,7 +273,8 @@ int svgf_flush(svgf_ctx* ctx);
  *     three run the cold-start moments kernel): under capture they are refused with SVGF_ERR_INVALID and record nothing — enqueue
  *     them directly; tunables, row ranges, debug mode and the switches are those in force at capture time;
  *   - with two frames in flight: svgf_flush before hipStreamBeginCapture (a frame enqueued before the capture cannot be joined inside
- *     it: refused) and again before hipStreamEndCapture (the side stream must be back on the captured one);
+ *     it: refused) and again before hipStreamEndCapture (the side stream must be back on the captured one: HIP refuses to end a capture
+ *     with unjoined work, and on ROCm 7.2 leaves its streams unusable afterwards);
  *   - per-stage timing skips captured frames; svgf_sync / svgf_halo_violations / svgf_timing_read wait for the device and are not
  *     capturable, as any synchronising call; the strip driver (svgf_strips_frame) is not capturable.
  * Replayed frames equal directly enqueued ones bit for bit (tests/test_gpu_graph.py).  Measured (tools/graph_replay.py): with one

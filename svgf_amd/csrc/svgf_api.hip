@@ -154,8 +154,16 @@ int alloc_alt(svgf_ctx* c) {
 
 int join_side(svgf_ctx* c, hipStream_t onto) {
     if (!c->in_flight) return SVGF_OK;
+    if (c->in_flight_capture) {
+        // the tail was recorded in a stream capture.  If that capture is over it ended without svgf_flush, i.e. hipStreamEndCapture refused
+        // it (unjoined work) and nothing of it will ever run: there is nothing to wait for, and its event must not be waited on.
+        unsigned long long cap = 0;
+        if (int rc = capture_of(c, &cap); rc != SVGF_OK) return rc;
+        if (cap != c->in_flight_capture) { c->in_flight = false; c->in_flight_capture = 0; return SVGF_OK; }
+    }
     SVGF_HIP(c, hipStreamWaitEvent(onto, c->ev_done, 0));
     c->in_flight = false;
+    c->in_flight_capture = 0;
     return SVGF_OK;
 }
 
@@ -671,7 +679,7 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
         if (allocates || c->frames_since_reset < 3)
             return fail(c, SVGF_ERR_INVALID, "svgf_denoise_frame: the context's stream is being captured and this frame cannot be: the first three frames after "
                                              "svgf_create / svgf_resize / svgf_reset_history allocate and take the cold-start path - enqueue them before the capture begins");
-        if (c->in_flight && c->in_flight_capture != cap)
+        if (c->in_flight && c->in_flight_capture == 0)      // (a tail left behind by an abandoned capture is dropped by join_side)
             return fail(c, SVGF_ERR_INVALID, "svgf_denoise_frame: the context's stream is being captured while a frame enqueued before the capture is still in flight: "
                                              "svgf_flush before hipStreamBeginCapture");
     }

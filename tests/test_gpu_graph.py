@@ -234,3 +234,40 @@ def test_two_contexts_interleaved_on_one_stream(G):
     for i in range(8):
         assert np.array_equal(oa[i].view(np.uint8), wa[i].view(np.uint8)), f"a, frame {i}"
         assert np.array_equal(ob[i].view(np.uint8), wb[i].view(np.uint8)), f"b, frame {i}"
+
+
+def test_capture_with_two_frames_in_flight_needs_a_flush_first(G):
+    """A frame enqueued before the capture cannot be joined inside it: refused (nothing recorded) until svgf_flush has ordered it.
+    (The other half of the contract - svgf_flush before hipStreamEndCapture - is enforced by HIP itself, which refuses a capture with
+    unjoined work and, on ROCm 7.2, leaves the streams unusable: not something a test of this process can survive.)"""
+    import torch
+    from svgf_amd import filter as F
+    seq = frames(256, 128, 8, mv=(0.5, 0.5))
+    want, _ = _direct(G, seq, "f32")
+    s = torch.cuda.Stream()
+    d = F.Denoiser(256, 128, F.Params(storage="f32", steps=5), stream=s.cuda_stream)
+    d.set_frames_in_flight(2)
+    rad, gbs = [G.dev(f["radiance"]) for f in seq], [G.gb_dev(f) for f in seq]
+    res = [torch.empty_like(d.new_colour()) for _ in (0, 1)]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        for k in range(4):
+            d.Render(rad[k], gbs[k], gbs[k - 1] if k else None)          # frame 3's tail is in flight now
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(F.SvgfError, match="svgf_flush"):
+        with torch.cuda.graph(g, stream=s):
+            d.Render(rad[4], gbs[4], gbs[3])
+    torch.cuda.synchronize()
+    d.flush()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        v4 = d.Render(rad[4], gbs[4], gbs[3])
+        v5 = d.Render(rad[5], gbs[5], gbs[4])
+        res[0].copy_(v4)
+        d.flush()
+        res[1].copy_(v5)
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(G.host(res[0]), want[4]) and np.array_equal(G.host(res[1]), want[5])
+    del g
+    d.close()
