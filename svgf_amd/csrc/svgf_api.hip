@@ -81,20 +81,25 @@ hipEvent_t take_event(svgf_ctx* c) {
 }
 
 int alloc_flags(svgf_ctx* c) {
-    if (c->young_list && c->young_count && c->young_flags && c->nan_list) return SVGF_OK;
-    // all four or none: a failed allocation leaves nothing behind that a later call would mistake for a complete set
+    if (c->young_masks && c->young_list && c->young_count && c->nan_count && c->nan_list) return SVGF_OK;
+    // all or none: a failed allocation leaves nothing behind that a later call would mistake for a complete set
     auto drop = [&]() {
+        if (c->young_masks) (void)hipFree(c->young_masks);
         if (c->young_list) (void)hipFree(c->young_list);
         if (c->young_count) (void)hipFree(c->young_count);
-        if (c->young_flags) (void)hipFree(c->young_flags);
+        if (c->nan_count) (void)hipFree(c->nan_count);
         if (c->nan_list) (void)hipFree(c->nan_list);
-        c->young_list = nullptr; c->young_count = nullptr; c->young_flags = nullptr; c->nan_list = nullptr;
+        c->young_masks = nullptr; c->young_list = nullptr; c->young_count = nullptr; c->nan_count = nullptr; c->nan_list = nullptr;
     };
     drop();
-    hipError_t e = hipMalloc((void**)&c->young_list, (size_t)c->strip.rows * c->W * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&c->young_count, 4 * sizeof(unsigned));          // {young[2], non-finite[2]} (svgf_kernels.h: kNanCounter)
-    if (e == hipSuccess) e = hipMemsetAsync(c->young_count, 0, 4 * sizeof(unsigned), c->stream);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->young_flags, (size_t)c->strip.rows * ((c->W + 63) / 64));
+    const size_t nmasks = (size_t)c->strip.rows * ((c->W + 63) / 64);
+    hipError_t e = hipMalloc((void**)&c->young_masks, nmasks * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(c->young_masks, 0, nmasks * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->young_list, std::min((size_t)c->strip.rows * c->W, svgf::kYoungListEntries) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->young_count, 2 * svgf::kYoungCounterStride * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(c->young_count, 0, 2 * svgf::kYoungCounterStride * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->nan_count, 2 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemsetAsync(c->nan_count, 0, 2 * sizeof(unsigned), c->stream);
     if (e == hipSuccess) e = hipMalloc((void**)&c->nan_list, (size_t)svgf::kNanListCap * sizeof(uint32_t));
     if (e != hipSuccess) { drop(); return hip_fail(c, e, "alloc_flags"); }
     c->young_phase = 0;
@@ -181,11 +186,12 @@ void free_state(svgf_ctx* c) {
     if (c->guide_prev) (void)hipFree(c->guide_prev);
     c->guide = c->guide_prev = nullptr;
     c->guide_prev_valid = false;
+    if (c->young_masks) (void)hipFree(c->young_masks);
     if (c->young_list) (void)hipFree(c->young_list);
     if (c->young_count) (void)hipFree(c->young_count);
-    if (c->young_flags) (void)hipFree(c->young_flags);
+    if (c->nan_count) (void)hipFree(c->nan_count);
     if (c->nan_list) (void)hipFree(c->nan_list);
-    c->young_list = nullptr; c->young_count = nullptr; c->young_flags = nullptr; c->nan_list = nullptr;
+    c->young_masks = nullptr; c->young_list = nullptr; c->young_count = nullptr; c->nan_count = nullptr; c->nan_list = nullptr;
     c->have_state = false;
 }
 
@@ -231,21 +237,24 @@ int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, vo
     if (prev_colour == colour_out || hist_prev == hist_cur || moments_prev == moments_cur)
         return fail(c, SVGF_ERR_INVALID, "svgf_temporal: previous and current state planes must differ (App. B #1)");
     if (passthrough_out && c->young_pending) {      // the lists of an earlier launch were never consumed (an error in between): start them again
-        SVGF_HIP(c, hipMemsetAsync(c->young_count + c->young_phase, 0, sizeof(unsigned), c->stream));
-        SVGF_HIP(c, hipMemsetAsync(c->young_count + svgf::kNanCounter + c->young_phase, 0, sizeof(unsigned), c->stream));
+        SVGF_HIP(c, hipMemsetAsync(c->young_count + c->young_phase * svgf::kYoungCounterStride, 0, svgf::kYoungCounterStride * sizeof(unsigned long long), c->stream));
+        SVGF_HIP(c, hipMemsetAsync(c->nan_count + c->young_phase, 0, sizeof(unsigned), c->stream));
     }
     svgf::TemporalArgs a{prev_colour, radiance, colour_out,
                          (const float4*)cur->motion, (const uint2*)cur->normal, (const uint2*)cur->uv,
                          (const float4*)prev->motion, (const uint2*)prev->normal, (const uint2*)prev->uv,
                          hist_prev, hist_cur, moments_cur, moments_prev,
                          c->p.depth_threshold, c->p.normal_threshold, c->p.history_base, c->p.mesh_id_test, passthrough_out,
-                         passthrough_out ? c->young_list : nullptr, passthrough_out ? c->young_count + c->young_phase : nullptr,
-                         passthrough_out ? c->young_count + (c->young_phase ^ 1) : nullptr, passthrough_out ? c->young_flags : nullptr, sparse_colour, c->p.phi_normal > 0.0f, c->halo_violations,
+                         passthrough_out ? c->young_masks : nullptr, passthrough_out ? c->young_list : nullptr,
+                         passthrough_out ? c->young_count + c->young_phase * svgf::kYoungCounterStride : nullptr,
+                         passthrough_out ? c->young_count + (c->young_phase ^ 1) * svgf::kYoungCounterStride : nullptr,
+                         sparse_colour, c->p.phi_normal > 0.0f, c->halo_violations,
                          std::max(c->vy0, c->strip.y0) - c->strip.y0, std::min(c->vy1, c->strip.y0 + c->strip.rows) - c->strip.y0, (uint4*)guide_out,
                          (const uint4*)guide_prev,
                          c->strip.y0, c->strip.y0 + c->strip.rows,       // the guide texels of every row held (a strip runs the stage on fewer)
-                         passthrough_out ? c->nan_list : nullptr, c->p.nan_policy == SVGF_NAN_ZERO};
-    if (c->re <= c->rb) return SVGF_OK;             // nothing to launch: the young list and its counters stay as they are
+                         passthrough_out ? c->nan_list : nullptr, passthrough_out ? c->nan_count + c->young_phase : nullptr,
+                         passthrough_out ? c->nan_count + (c->young_phase ^ 1) : nullptr, c->p.nan_policy == SVGF_NAN_ZERO};
+    if (c->re <= c->rb) return SVGF_OK;             // nothing to launch: the young masks and the counters stay as they are
     SVGF_HIP(c, svgf::launch_temporal(geo_of(c), c->p.storage, a, c->stream));
     if (passthrough_out) c->young_pending = true;
     return SVGF_OK;
@@ -260,8 +269,9 @@ int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments
     if (rc != SVGF_OK) return rc;
     svgf::MomentsArgs a{colour, out, moments, (const float4*)g->motion, (const uint2*)g->normal, hist,
                         c->p.phi_colour, c->p.phi_normal, c->p.moments_radius, cold_only, dense, sparse_colour,
-                        cold_only ? c->young_list : nullptr, cold_only ? c->young_count + c->young_phase : nullptr, cold_only ? c->young_flags : nullptr,
-                        cold_only ? c->nan_list : nullptr, c->p.variant == SVGF_VARIANT_LDS_GENERAL};
+                        cold_only ? c->young_masks : nullptr, cold_only ? c->young_list : nullptr, cold_only ? c->young_count + c->young_phase * svgf::kYoungCounterStride : nullptr,
+                        cold_only ? c->nan_list : nullptr, cold_only ? c->nan_count + c->young_phase : nullptr,
+                        c->p.variant == SVGF_VARIANT_LDS_GENERAL};
     if (c->re <= c->rb) {
         // No moments rows.  If the temporal launch of this frame did run (young_pending), its list is dropped: the counter pair still
         // has to turn over, because that launch zeroed the OTHER counter for the next frame.
@@ -674,7 +684,7 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     rc = capture_of(c, &cap);
     if (rc != SVGF_OK) return rc;
     if (cap) {
-        const bool allocates = !c->have_state || !(c->young_list && c->young_count && c->young_flags && c->nan_list) ||
+        const bool allocates = !c->have_state || !(c->young_masks && c->young_list && c->young_count && c->nan_count && c->nan_list) ||
                                (c->frames_in_flight > 1 && !(c->filter_alt[0] && c->filter_alt[1])) || (is_strip(c) && !c->halo_violations);
         if (allocates || c->frames_since_reset < 3)
             return fail(c, SVGF_ERR_INVALID, "svgf_denoise_frame: the context's stream is being captured and this frame cannot be: the first three frames after "

@@ -48,12 +48,13 @@ struct svgf_ctx {
     int filter_set = 0;                    // which pair the NEXT frame uses (toggles per frame while frames_in_flight == 2)
     bool in_flight = false;                // a frame's tail is on `side` and `stream` has not been made to wait for it yet
     unsigned long long in_flight_capture = 0;   // ... and the stream capture that tail was recorded in (0: none; svgf.h, Stream capture)
-    uint32_t* young_list = nullptr;        // scratch, temporal -> moments: indices of the pixels with history < 4 that need the spatial estimate
-    unsigned* young_count = nullptr;       // two device counters used in turn (the temporal launch of a frame zeroes the next frame's)
-    uint8_t* young_flags = nullptr;        // one flag per (row, 64-column segment): all 64 pixels need the estimate (listed nowhere)
+    unsigned long long* young_masks = nullptr;   // scratch, temporal -> moments: per (row, 64-column segment) the lanes whose pixel (history < 4) needs the spatial estimate
+    uint32_t* young_list = nullptr;        // ... and the indices of the pixels of the partly young segments (svgf::kYoungListEntries)
+    unsigned long long* young_count = nullptr;   // ... two {appends, pixels} counters used in turn (the temporal launch of a frame zeroes the next frame's)
+    unsigned* nan_count = nullptr;         // two device counters of nan_list used in turn (the temporal launch of a frame zeroes the next frame's)
     uint32_t* nan_list = nullptr;          // scratch, temporal -> moments: the pixels whose accumulated colour / moments are NaN or inf (kNanListCap entries)
     int young_phase = 0;
-    bool young_pending = false;            // a temporal launch appended to young_count[young_phase] and no moments launch has consumed it yet
+    bool young_pending = false;            // a temporal launch wrote the masks / appended to nan_count[young_phase] and no moments launch has consumed them yet
     int vy0 = 0, vy1 = 0;                  // global rows of the previous-frame planes that hold valid state (svgf_set_valid_rows; default: all held)
     unsigned* halo_violations = nullptr;   // strips: device counter of reprojections that left the rows this strip holds (temporal_kernel)
     int pingpong = 0;                      // PingPongInx, App.cu:374

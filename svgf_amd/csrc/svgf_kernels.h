@@ -8,10 +8,19 @@ namespace svgf {
 // Local planes hold global rows [y0, y0+rows) of a W x H frame; a launch computes rows [yb, ye).
 struct Geo { int W, H, y0, rows, yb, ye; };
 
-// The young-pixel counters of a context are {young[2], non-finite[2]} (used in turn, frame by frame); the list of pixels whose temporal
-// result is not finite holds at most kNanListCap entries (more than that and the moments launch goes over every pixel instead).
-constexpr int kNanCounter = 2;
+// The list of pixels whose temporal result is not finite holds at most kNanListCap entries (more than that and the moments launch goes over
+// every pixel instead); its two counters are used in turn, frame by frame.
 constexpr unsigned kNanListCap = 1u << 16;
+// The young-pixel list takes at most kYoungAppendCap appends (one per wave that holds young pixels; same-address atomics retire at ~11 ns each on
+// this part: 8 192 of them are 0.09 ms spread over a 0.19 ms launch).  A frame with more such waves — thin geometry under motion: every wave
+// holds a few young pixels — stops appending, and the moments launch works from the per-segment lane masks instead.  Its counter is 64 bits:
+// {appends, pixels}.
+constexpr unsigned kYoungAppendCap = 8192;
+constexpr size_t kYoungListEntries = (size_t)kYoungAppendCap * 63;
+// "The cap is reached" is a word of its own, 128 bytes behind its counter: a wave reads THAT before it appends — a load of the counter's own
+// line between the atomics makes each of them cost 50 instead of 11 ns (tools/ubench/atomic_one_address.hip), a load of a line nobody
+// writes is free.  A context holds two {counter, flag} pairs, kYoungCounterStride 64-bit words apart.
+constexpr int kYoungFlagOffset = 16, kYoungCounterStride = 32;
 
 struct TemporalArgs {
     const void* prev_colour; const void* radiance; void* colour_out;
@@ -20,11 +29,11 @@ struct TemporalArgs {
     const uint8_t* hist_prev; uint8_t* hist_cur; void* mom_cur; const void* mom_prev;
     float depth_thr, normal_thr; int history_base; int mesh_id_test;
     void* passthrough_out;   // frame driver only: where history >= 4 the moments stage is a copy (Filter.cuh:521) — write it here directly
-    uint32_t* young_list;    // with passthrough_out: the local indices (row * W + x) of the pixels that still need the moments estimate ...
-    unsigned* young_count;   // ... and how many there are (device counter, appended to with one atomic per wave); the OTHER counter of the
-    unsigned* young_count_next;   // context's pair is zeroed by this launch for the next frame
-    uint8_t* young_flags;    // ... except that a wave whose 64 pixels ALL need it sets one flag per (local row, 64-column segment) instead
-                             // (frames after a reset: every wave — 130 000 appends to one counter would serialise)
+    unsigned long long* young_masks;   // with passthrough_out: which pixels still need the moments estimate — one 64-bit lane mask per (local row,
+                             // 64-column segment), stored by the wave that computes the segment ...
+    uint32_t* young_list;    // ... and, for the waves that hold SOME young pixels (disocclusions are sparse: frame borders under a pan, silhouettes),
+    unsigned long long* young_count;        // their local indices (row * W + x) appended to a list: one 64-bit atomic per wave on {appends, pixels}, at most
+    unsigned long long* young_count_next;   // kYoungAppendCap of them per frame (above).  The OTHER counter of the context's pair is zeroed by this launch.
     int sparse_colour;       // with passthrough_out and >= 1 a-trous iteration: colour_out is only stored where the iteration-0 feedback
                              // will not overwrite it or the moments estimate reads it (young pixels, depth-0 texels)
     int sky_zero;            // with passthrough_out: PhiNormal > 0, so a young pixel with an all-zero normal filters to exactly 0 (written here)
@@ -37,8 +46,9 @@ struct TemporalArgs {
                                  // motion_p / normal_p / uv_p (16 instead of 32 B per pixel), or null
     int guide_lo, guide_hi;      // global rows [guide_lo, guide_hi) whose guide texel this launch writes (>= the compute rows of Geo: a strip
                                  // needs the texels of every row it holds)
-    uint32_t* nan_list;          // with young_list: the local indices of the pixels whose temporal colour / moments are NaN or inf (counter:
-                                 // young_count[kNanCounter]); the moments launch redoes the zero-normal shortcut pixels around them
+    uint32_t* nan_list;          // with young_masks: the local indices of the pixels whose temporal colour / moments are NaN or inf, appended with one
+    unsigned* nan_count;         // atomic per wave that holds any (none in a frame without a NaN); the moments launch redoes the zero-normal shortcut
+    unsigned* nan_count_next;    // pixels around them.  The OTHER counter of the context's pair is zeroed by this launch for the next frame
     int heal_nan;                // svgf_params::nan_policy == SVGF_NAN_ZERO: a NaN channel of the radiance / previous colour / previous moments reads as 0
 };
 struct MomentsArgs {
@@ -47,10 +57,11 @@ struct MomentsArgs {
     int cold_only;           // 1: pixels with history >= 4 were already written by the temporal stage (passthrough_out)
     int dense;               // 1: (nearly) every pixel has history < 4 (first frames of a sequence): use the LDS-streaming kernel
     int sparse_colour;            // TemporalArgs::sparse_colour of the same frame: an old, non-sky neighbour's colour is in `out`
-    const uint32_t* young_list;   // with cold_only: TemporalArgs::young_list / young_count of the same frame — only listed pixels are visited
-    const unsigned* young_count;
-    const uint8_t* young_flags;   // TemporalArgs::young_flags: segments whose 64 pixels are all young
-    const uint32_t* nan_list;     // TemporalArgs::nan_list (counter: young_count[kNanCounter])
+    const unsigned long long* young_masks;   // with cold_only: TemporalArgs::young_masks / young_list / young_count of the same frame — only those pixels are visited
+    const uint32_t* young_list;
+    const unsigned long long* young_count;
+    const uint32_t* nan_list;     // TemporalArgs::nan_list / nan_count of the same frame
+    const unsigned* nan_count;
     int no_fastpath;              // SVGF_VARIANT_LDS_GENERAL: the LDS-streaming kernel without its uniform-normal form (bit-identical, slower)
 };
 struct AtrousArgs {

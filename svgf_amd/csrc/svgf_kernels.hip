@@ -13,6 +13,7 @@
 #include "svgf_kernels.h"
 
 #include <algorithm>
+#include <numeric>
 #include <atomic>
 #include <vector>
 #include <cstdio>
@@ -40,7 +41,7 @@ namespace {
 template <int ST>
 __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs a) {
     keep_nan_in_clamps();                                             // imageLoad / imageStore keep a NaN (svgf_device.h)
-    if (a.young_list && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) { a.young_count_next[0] = 0u; a.young_count_next[kNanCounter] = 0u; }
+    if (a.young_masks && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) { a.young_count_next[0] = 0ull; a.young_count_next[kYoungFlagOffset] = 0ull; a.nan_count_next[0] = 0u; }
     // The grid covers the compute rows [yb, ye) and, where a guide plane is written, the rows [guide_lo, guide_hi) around them (a strip
     // holds more rows than it runs the temporal stage on: the later iterations' halos and the next frame's reprojection read their
     // guide texels too): a row outside the compute rows gets its guide texel and nothing else (a wave is one row: no divergence).
@@ -137,21 +138,27 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
         if (!young) Store<ST>::st4(a.passthrough_out, idx, oc);
         else if (zero_young) Store<ST>::st4(a.passthrough_out, idx, make_float4(0.f, 0.f, 0.f, 0.f));
     }
-    // ... and the moments launch is told where the remaining young pixels are: their indices are appended to a list, one
-    // atomic per wave that holds any (disocclusions are sparse: frame borders under a pan, silhouettes).  The list is dense in
-    // young pixels, so the moments launch costs what they cost, however they are spread over the frame.
-    if (a.young_list) {
+    // ... and the moments launch is told where the remaining young pixels are.  Every wave (one 64-column segment of a row) stores its lane
+    // mask; a wave that holds SOME young pixels also appends their indices to a list, one atomic per wave (disocclusions are sparse: frame
+    // borders under a pan, silhouettes) — the list is dense in young pixels, so the moments launch spreads them evenly over its waves
+    // however they are spread over the frame.  A wave whose 64 pixels are ALL young appends nothing (its mask says it all: after a reset every
+    // wave is one), and no wave appends once kYoungAppendCap have (svgf_kernels.h: the moments launch then works from the masks alone).
+    if (a.young_masks) {
         const bool listed = young && !zero_young;
         const unsigned long long ym = __ballot(listed);
-        const bool whole_wave = ym == ~0ull;                // all 64 pixels of the segment: flagged, not listed
-        if (ym != 0ull && !whole_wave) {
+        if (threadIdx.x == 0)                                             // (lane 0 is always inside the frame; lanes beyond W have left: their bits are 0)
+            a.young_masks[(size_t)(y - g.y0) * ((g.W + kBX - 1) / kBX) + blockIdx.x] = ym;
+        if (ym != 0ull && ym != ~0ull) {
             const int lane = threadIdx.x, first = __builtin_ctzll(ym);
-            unsigned base = 0;
-            if (lane == first) base = atomicAdd(a.young_count, (unsigned)__builtin_popcountll(ym));
+            unsigned base = ~0u;
+            if (lane == first && __hip_atomic_load(a.young_count + kYoungFlagOffset, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) {
+                const unsigned long long old = atomicAdd(a.young_count, (1ull << 32) | (unsigned long long)__builtin_popcountll(ym));
+                if ((unsigned)(old >> 32) < kYoungAppendCap) base = (unsigned)old;       // (appends 0 .. cap-1 own their entries: < cap x 63 pixels)
+                else __hip_atomic_store(a.young_count + kYoungFlagOffset, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             base = __shfl(base, first);
-            if (listed) a.young_list[base + (unsigned)__builtin_popcountll(ym & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+            if (listed && base != ~0u) a.young_list[base + (unsigned)__builtin_popcountll(ym & ((1ull << lane) - 1ull))] = (uint32_t)idx;
         }
-        if (threadIdx.x == 0) a.young_flags[(size_t)(y - g.y0) * ((g.W + kBX - 1) / kBX) + blockIdx.x] = whole_wave ? 1 : 0;
         // A pixel whose accumulated colour or moments are not finite (a NaN in the radiance, or in the history it reprojects onto:
         // the reference's clamps keep it, :63-83,398) is listed as well.  The shortcut above is only right while a zero-normal pixel's
         // 7x7 window is finite — its weights are exactly 0, and 0 x NaN is NaN in :498-499 — so the moments launch goes over the
@@ -163,8 +170,8 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
             unsigned base = 0;
             // (once the list has overflowed the counter says so and stays: no wave appends any more — a frame full of NaN would otherwise
             // queue 130 000 atomics on one word)
-            if (lane == first) base = __hip_atomic_load(a.young_count + kNanCounter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > kNanListCap
-                                          ? kNanListCap : atomicAdd(a.young_count + kNanCounter, (unsigned)__builtin_popcountll(bad));
+            if (lane == first) base = __hip_atomic_load(a.nan_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > kNanListCap
+                                          ? kNanListCap : atomicAdd(a.nan_count, (unsigned)__builtin_popcountll(bad));
             base = __shfl(base, first);
             const unsigned at = base + (unsigned)__builtin_popcountll(bad & ((1ull << lane) - 1ull));
             if (((bad >> lane) & 1ull) && at < kNanListCap) a.nan_list[at] = (uint32_t)idx;
@@ -219,7 +226,7 @@ __device__ __forceinline__ void moments_pixel(const Geo& g, const MomentsArgs& a
             mq[k] = a.motion[p[k]];
             mp[k] = Store<ST>::ld2(a.mom, p[k]);                      // :480
             nq[k] = a.normal[p[k]];                                   // :483
-            hq[k] = a.sparse_colour ? (int)a.hist[p[k]] : 0;
+            hq[k] = (int)a.hist[p[k]];        // (unconditional: a load inside a branch is waited for at the end of the branch — one memory round per tap row)
         }
 #pragma unroll
         for (int k = 0; k <= 2 * RM; k++) {
@@ -282,11 +289,15 @@ __device__ __forceinline__ void moments_group8(const Geo& g, const MomentsArgs& 
     for (int r = 0; r < NW; r++) {
         const int yy = r - RM, py = y + yy, px = x + xx;
         ok[r] = valid && j < NW && yy >= -R && yy <= R && py >= 0 && py < g.H && xx >= -R && xx <= R && px >= 0 && px < g.W;   // :473
-        const size_t p = ok[r] ? (size_t)(py - g.y0) * g.W + px : idx;                 // a tap that does not exist reads the centre and is dropped
+        // A tap that does not exist reads the nearest texel the strip holds and is dropped.  (Not the centre: a select between the tap's and the
+        // centre's address makes the compiler load the taps under a branch whose other arm is the centre's DATA — every tap load then waits
+        // for the centre's: two dependent memory rounds per pass instead of one.)
+        const int pyc = min(max(py, g.y0), g.y0 + g.rows - 1), pxc = min(max(px, 0), g.W - 1);
+        const size_t p = (size_t)(pyc - g.y0) * g.W + pxc;
         tz[r] = ((const float*)a.motion)[p * 4 + 2];
         tm[r] = Store<ST>::ld2(a.mom, p);                                              // :480
         tn[r] = a.normal[p];                                                           // :483
-        th[r] = a.sparse_colour ? (int)a.hist[p] : 0;
+        th[r] = (int)a.hist[p];                                                        // (unconditional: see moments_pixel)
         ca[r] = Store<ST>::ld4(a.colour, p);                                           // :479 raw ...
         cb[r] = Store<ST>::ld4(a.sparse_colour ? (const void*)a.out : a.colour, p);    // ... or, for an old non-sky texel, where the temporal launch put it
     }
@@ -321,6 +332,8 @@ __device__ __forceinline__ void moments_group8(const Geo& g, const MomentsArgs& 
     for (int r = 0; r < NW; r++) {
 #pragma unroll
         for (int c = 0; c < NW; c++) {
+            // (all of a row's shuffles issued before its seven taps are accumulated shortens a pass, but costs 40 registers and a third of the
+            // resident waves: slower for this launch, whose passes are spread one per wave - profiles/r04_small_experiments.txt block 9)
             const float w = __shfl(tw[r], base + c), c0 = __shfl(t0[r], base + c), c1 = __shfl(t1[r], base + c), c2 = __shfl(t2[r], base + c);
             const float m1 = __shfl(tm[r].x, base + c), m2 = __shfl(tm[r].y, base + c);
             if ((okc[c] >> r) & 1u) {
@@ -434,88 +447,123 @@ __global__ __launch_bounds__(kBX* kBY) void moments3x3_shfl_kernel(Geo g, Moment
 }
 
 // Steady state inside the frame driver: the temporal launch already copied every pixel with history >= 4 and told this launch where
-// the young ones are: the LIST (indices appended wave by wave) and, for a 64-pixel segment whose pixels are ALL young, one FLAG.
-// Both are served by moments_group8, eight pixels per wave-pass.  List waves take eight consecutive entries per pass.  A scan
-// workgroup reads 256 flags (segment s belongs to scan slot s mod (scan_blocks / 2): a row of flagged segments spreads over as many
-// slots), shares the four ballots through LDS, and the eight waves of the slot's TWO workgroups take one eighth of every flagged
-// segment each: one pass instead of one wave's fourteen dependent rounds (one workgroup per slot, two passes per wave: +0.004 ms
-// under the bench pan).  Scan workgroups come first in the grid: theirs are the longer chains.
-// (Bench pan, ~28 000 listed pixels + ~360 flagged segments per 4K frame: 0.051 -> 0.034 ms; nothing young: 0.0069 ms.  By parts,
-// tools/pan_moments_ab.sh: an empty launch 0.0069, the list alone 0.025, the flagged segments alone 0.029, a pass ~0.004 ms.)
+// the young ones are: one 64-bit lane mask per (row, 64-column segment), and the LIST of the pixels of the partly young segments.
+// All are served by moments_group8, eight pixels per wave-pass — a launch of a few thousand passes, bound by their latency: it wants them
+// spread over all resident waves, one each.
+//  * List workgroups: eight consecutive entries per pass, group g to wave g mod (waves).
+//  * Scan workgroups: 256 masks each (segment s belongs to scan slot s mod (scan_blocks / 2): a row of all-young segments — the rows that
+//    have just entered the frame under a vertical pan — spreads over as many slots); the segments whose mask is FULL are shared through LDS
+//    as four ballots, and the eight waves of the slot's TWO workgroups take one eighth of each.  Scan workgroups come first in the grid:
+//    theirs are the longer chains.
+//  * A frame whose list is over its cap (svgf_kernels.h; thin geometry under motion, or half the frame disoccluded): the list is ignored,
+//    a scan workgroup compacts the young pixels of ITS 256 masks into a list in LDS and its waves take eight entries per pass.
+// (Bench pan, ~28 000 listed pixels + ~300 all-young segments per 4K frame: 0.051 ms in round 2, 0.034 in round 3 (eight lanes per pixel,
+// two workgroups per slot), 0.028 now (the window loads of a pass in ONE memory round, not eight); nothing young: 0.007 ms.)
 constexpr int kScanSplit = 2;
 template <int ST>
 __global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a, int scan_blocks) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if ((int)blockIdx.x >= scan_blocks) {
-        const unsigned list_blocks = gridDim.x - (unsigned)scan_blocks, b = blockIdx.x - (unsigned)scan_blocks;
-        const unsigned n = *a.young_count, ngroups = (n + 7u) / 8u;
-        for (unsigned grp = b + list_blocks * (unsigned)w; grp < ngroups; grp += list_blocks * 4u) {
-            const unsigned i = grp * 8u + ((unsigned)lane >> 3);
-            const bool valid = i < n;
-            moments_group8<ST>(g, a, valid, valid ? a.young_list[i] : 0u);
-        }
-        // The temporal launch wrote exact zeros for young pixels with an all-zero normal (its zero-normal shortcut) — right unless a
-        // texel of the pixel's 7x7 window is NaN or inf (0 x NaN, :498-499).  It listed the pixels whose result is not finite: every
-        // shortcut pixel in the window of a listed pixel gets the full estimate here (moments_group8 has no shortcut).  Nothing listed —
-        // every frame without a NaN — and this is one more word read by the list workgroups.
-        const unsigned nn = a.young_count[kNanCounter];
-        if (nn == 0u) return;
-        const unsigned wave = b * 4u + (unsigned)w, nwaves = list_blocks * 4u;
-        auto shortcut_px = [&](bool valid, uint32_t q) {             // young, with an all-zero normal
-            const uint2 nq = a.normal[q];
-            return valid && a.hist[q] < 4 && ((nq.x & 0x7fff7fffu) | (nq.y & 0x7fffu)) == 0u;
-        };
-        if (nn <= kNanListCap) {
-            for (unsigned i = wave; i < nn; i += nwaves) {
-                const uint32_t p = a.nan_list[i];
-                const int px = (int)(p % (uint32_t)g.W), pyl = (int)(p / (uint32_t)g.W);
-#pragma unroll 1
-                for (int pass = 0; pass < 7; pass++) {
-                    const int k = pass * 8 + (lane >> 3), qx = px + k % 7 - 3, qyl = pyl + k / 7 - 3;
-                    const bool valid = k < 49 && qx >= 0 && qx < g.W && qyl >= 0 && qyl < g.rows;
-                    const uint32_t q = valid ? (uint32_t)(qyl * g.W + qx) : 0u;
-                    const bool need = shortcut_px(valid, q);         // (a NaN pixel on a surface far from the sky costs two small loads per pass)
-                    if (!wave_any(need)) continue;
-                    moments_group8<ST>(g, a, need, q);
-                }
-            }
-        } else {                                    // the list overflowed (a frame full of NaN): every shortcut pixel of the launch rows
-            const unsigned first = (unsigned)(g.yb - g.y0) * (unsigned)g.W, last = (unsigned)(g.ye - g.y0) * (unsigned)g.W;
-            for (unsigned q0 = first + wave * 8u; q0 < last; q0 += nwaves * 8u) {
-                const unsigned q = q0 + ((unsigned)lane >> 3), qs = q < last ? q : first;
-                const bool need = shortcut_px(q < last, qs);
-                if (!wave_any(need)) continue;
-                moments_group8<ST>(g, a, need, qs);
-            }
-        }
-        return;
-    }
-    constexpr int F = kScanSplit;                   // workgroups that share the flags of one scan slot: each takes 8 / F octants of a flagged segment
-    const int part = (int)blockIdx.x % F, bid = (int)blockIdx.x / F;
-    scan_blocks /= F;
-    __shared__ unsigned long long masks[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = threadIdx.x;
+    __shared__ unsigned long long full[4];
+    __shared__ uint16_t slist[256 * 64];            // over the cap only: {thread that read the segment's mask, lane of the pixel}: 14 bits
+    __shared__ int swave[4];
     const int nseg = (g.W + kBX - 1) / kBX;
-    const int first = (g.yb - g.y0) * nseg, last = (g.ye - g.y0) * nseg;             // flag range of the launch rows
-    for (int base = first; base + bid < last; base += scan_blocks * 256) {   // (uniform over the workgroup)
-        const int sidx = base + (w * 64 + lane) * scan_blocks + bid;
-        const unsigned long long m = __ballot(sidx < last && a.young_flags[sidx] != 0);
-        if (lane == 0) masks[w] = m;
-        __syncthreads();
-#pragma unroll 1
-        for (int ww = 0; ww < 4; ww++) {
-            unsigned long long mm = masks[ww];
-            while (mm) {
-                const int bit = __builtin_ctzll(mm);
-                mm &= mm - 1;
-                const int seg = base + (ww * 64 + bit) * scan_blocks + bid, yl = seg / nseg;
-#pragma unroll 1
-                for (int o = part * (8 / F) + w; o < (part + 1) * (8 / F); o += 4) {     // this wave's eighth(s) of the segment
-                    const int x = (seg % nseg) * kBX + o * 8 + (lane >> 3);
-                    moments_group8<ST>(g, a, x < g.W, (uint32_t)(yl * g.W + (x < g.W ? x : 0)));
-                }
+    const int first = (g.yb - g.y0) * nseg, last = (g.ye - g.y0) * nseg;             // mask range of the launch rows
+    if ((int)blockIdx.x >= scan_blocks) {
+        const unsigned long long counted = *a.young_count;
+        if ((unsigned)(counted >> 32) < kYoungAppendCap) {
+            const unsigned list_blocks = gridDim.x - (unsigned)scan_blocks, b = blockIdx.x - (unsigned)scan_blocks;
+            const unsigned n = (unsigned)counted, ngroups = (n + 7u) / 8u;
+            for (unsigned grp = b + list_blocks * (unsigned)w; grp < ngroups; grp += list_blocks * 4u) {
+                const unsigned i = grp * 8u + ((unsigned)lane >> 3);
+                const bool valid = i < n;
+                moments_group8<ST>(g, a, valid, valid ? a.young_list[i] : 0u);
             }
         }
-        __syncthreads();
+    } else {
+        constexpr int F = kScanSplit;               // workgroups that share the masks of one scan slot
+        const int part = (int)blockIdx.x % F, bid = (int)blockIdx.x / F, nslots = scan_blocks / F;
+        for (int base = first; base + bid < last; base += nslots * 256) {    // (uniform over the workgroup)
+            const int sidx = base + t * nslots + bid;
+            unsigned long long m = sidx < last ? a.young_masks[sidx] : 0ull;          // (requested together with the counter: one memory round)
+            const bool overflow = (unsigned)(*a.young_count >> 32) >= kYoungAppendCap;   // (uniform over the launch)
+            if (!overflow) {
+                // the all-young segments of the slot; each of the slot's 4 F waves takes 8 / F octants of every one
+                const unsigned long long fm = __ballot(m == ~0ull);
+                if (lane == 0) full[w] = fm;
+                __syncthreads();
+#pragma unroll 1
+                for (int ww = 0; ww < 4; ww++) {
+                    unsigned long long mm = full[ww];
+                    while (mm) {
+                        const int bit = __builtin_ctzll(mm);
+                        mm &= mm - 1;
+                        const int seg = base + (ww * 64 + bit) * nslots + bid, yl = seg / nseg;
+#pragma unroll 1
+                        for (int o = part * (8 / F) + w; o < (part + 1) * (8 / F); o += 4) {
+                            const int x = (seg % nseg) * kBX + o * 8 + (lane >> 3);
+                            moments_group8<ST>(g, a, x < g.W, (uint32_t)(yl * g.W + (x < g.W ? x : 0)));
+                        }
+                    }
+                }
+            } else {
+                // the list is void: every young pixel of the slot's masks, compacted into LDS (by each of the slot's workgroups for itself),
+                // eight entries per pass, the passes dealt out over the slot's 4 F waves
+                const int k = __builtin_popcountll(m);
+                int inc = k;                                                  // inclusive scan over the wave
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d); if (lane >= d) inc += v; }
+                if (lane == 63) swave[w] = inc;
+                __syncthreads();
+                int off = inc - k, total = 0;
+#pragma unroll
+                for (int ww = 0; ww < 4; ww++) { const int n = swave[ww]; if (ww < w) off += n; total += n; }
+                while (m) { slist[off++] = (uint16_t)((t << 6) | __builtin_ctzll(m)); m &= m - 1; }
+                __syncthreads();
+                const int npass = (total + 7) >> 3;
+#pragma unroll 1
+                for (int it = part * 4 + w; it < npass; it += 4 * F) {        // (uniform over the wave)
+                    const int i = it * 8 + (lane >> 3);
+                    const bool valid = i < total;
+                    const int e = slist[valid ? i : 0], seg = base + (e >> 6) * nslots + bid;
+                    moments_group8<ST>(g, a, valid, (uint32_t)((seg / nseg) * g.W + (seg % nseg) * kBX + (e & 63)));
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // The temporal launch wrote exact zeros for young pixels with an all-zero normal (its zero-normal shortcut) — right unless a
+    // texel of the pixel's 7x7 window is NaN or inf (0 x NaN, :498-499).  It listed the pixels whose result is not finite: every
+    // shortcut pixel in the window of a listed pixel gets the full estimate here (moments_group8 has no shortcut).  Nothing listed —
+    // every frame without a NaN — and this is one word read per wave.
+    const unsigned nn = *a.nan_count;
+    if (nn == 0u) return;
+    const unsigned wave = blockIdx.x * 4u + (unsigned)w, nwaves = gridDim.x * 4u;
+    auto shortcut_px = [&](bool valid, uint32_t q) {             // young, with an all-zero normal
+        const uint2 nq = a.normal[q];
+        return valid && a.hist[q] < 4 && ((nq.x & 0x7fff7fffu) | (nq.y & 0x7fffu)) == 0u;
+    };
+    if (nn <= kNanListCap) {
+        for (unsigned i = wave; i < nn; i += nwaves) {
+            const uint32_t p = a.nan_list[i];
+            const int px = (int)(p % (uint32_t)g.W), pyl = (int)(p / (uint32_t)g.W);
+#pragma unroll 1
+            for (int pass = 0; pass < 7; pass++) {
+                const int k = pass * 8 + (lane >> 3), qx = px + k % 7 - 3, qyl = pyl + k / 7 - 3;
+                const bool valid = k < 49 && qx >= 0 && qx < g.W && qyl >= 0 && qyl < g.rows;
+                const uint32_t q = valid ? (uint32_t)(qyl * g.W + qx) : 0u;
+                const bool need = shortcut_px(valid, q);         // (a NaN pixel on a surface far from the sky costs two small loads per pass)
+                if (!wave_any(need)) continue;
+                moments_group8<ST>(g, a, need, q);
+            }
+        }
+    } else {                                    // the list overflowed (a frame full of NaN): every shortcut pixel of the launch rows
+        const unsigned firstp = (unsigned)(g.yb - g.y0) * (unsigned)g.W, lastp = (unsigned)(g.ye - g.y0) * (unsigned)g.W;
+        for (unsigned q0 = firstp + wave * 8u; q0 < lastp; q0 += nwaves * 8u) {
+            const unsigned q = q0 + ((unsigned)lane >> 3), qs = q < lastp ? q : firstp;
+            const bool need = shortcut_px(q < lastp, qs);
+            if (!wave_any(need)) continue;
+            moments_group8<ST>(g, a, need, qs);
+        }
     }
 }
 
@@ -800,9 +848,9 @@ hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, bool 
         else moments3x3_shfl_kernel<1><<<grid, block, 0, s>>>(g, a);
         return hipGetLastError();
     }
-    if (a.cold_only && a.young_list) {
+    if (a.cold_only && a.young_masks) {
         const int nsegs = (g.ye - g.yb) * ((g.W + kBX - 1) / kBX);
-        int scan = (nsegs + 255) / 256;                            // >= one flag per lane and load ...
+        int scan = (nsegs + 255) / 256;                            // >= one mask per lane and load ...
         if (scan > 4 * num_cus()) scan = 4 * num_cus();            // ... on at most one resident round
         const int walk = std::min(4 * num_cus(), std::max(1, nsegs / 16));   // the list holds at most 63 pixels per segment
         scan *= kScanSplit;

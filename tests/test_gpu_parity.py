@@ -260,6 +260,34 @@ def test_frame_driver_equals_stage_calls(G, storage):
     assert np.array_equal(G.host(d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong())), hip.taps["hist"])
 
 
+@pytest.mark.parametrize("period,storage", [(8, "f32"), (2, "f16"), (64, "f32")])
+def test_frame_driver_when_every_wave_holds_young_pixels(G, period, storage):
+    """Thin geometry under motion: every `period`-th column fails the reprojection test in every frame (the two G-buffers the frames
+    alternate between disagree on its normals), so EVERY wave of the temporal launch holds young pixels — more waves than the young
+    list takes appends from (svgf_kernels.h: kYoungAppendCap = 8192).  The temporal launch stops appending and the moments launch
+    works from the per-segment masks: still the stage sequence's results, bit for bit."""
+    from svgf_amd import filter as F
+    W, H, N = 1024, 800, 6                                  # 16 x 800 = 12 800 waves, ~8 % of them sky
+    fr = frames(W, H, 2, mv=(0.0, 0.0))
+    gbn = []
+    for k in (0, 1):
+        n = fr[0]["normal"].copy()
+        if k:
+            n.view(np.int16)[:, ::period, 0:3] ^= np.int16(-32768)      # the sign of the normal, in one of the two G-buffers
+        gbn.append(G.F.GBuffer(G.dev(fr[0]["motion"]), G.dev(n), G.dev(fr[0]["uv"])))
+    hip = G.HipPipeline(W, H, storage, steps=3, variant="direct")
+    d = F.Denoiser(W, H, F.Params(storage=storage, steps=3, variant="direct"))
+    for k in range(N):
+        rad = fr[k % 2]["radiance"]
+        a = hip.frame(rad, gbn[k % 2], gbn[(k + 1) % 2] if k else gbn[0])
+        b = G.host(d.Render(G.dev(rad.astype(G.NPDT[storage])), gbn[k % 2], gbn[(k + 1) % 2] if k else None))
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), k
+    hist = G.host(d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong()))
+    assert np.array_equal(hist, hip.taps["hist"])
+    surface = fr[0]["motion"][..., 2] != 0
+    assert (hist[:, ::period][surface[:, ::period]] == 1).all() and (hist[:, 1::period][surface[:, 1::period]] >= 4).mean() > 0.9
+
+
 @pytest.mark.parametrize("params", [
     dict(steps=0), dict(steps=1), dict(steps=5, phi_normal=0.0), dict(steps=3, history_base=2), dict(steps=3, history_base=4),
     dict(steps=2, mesh_id_test=0, normal_threshold=0.0), dict(steps=3, moments_radius=1), dict(steps=4, depth_threshold=0.0, phi_colour=0.5),
