@@ -81,7 +81,7 @@ hipEvent_t take_event(svgf_ctx* c) {
 }
 
 int alloc_flags(svgf_ctx* c) {
-    if (c->young_masks && c->young_list && c->young_count && c->nan_count && c->nan_list) return SVGF_OK;
+    if (c->young_masks && c->young_list && c->young_count && c->nan_count && c->nan_list && c->sample_count && c->estimate_host) return SVGF_OK;
     // all or none: a failed allocation leaves nothing behind that a later call would mistake for a complete set
     auto drop = [&]() {
         if (c->young_masks) (void)hipFree(c->young_masks);
@@ -89,7 +89,10 @@ int alloc_flags(svgf_ctx* c) {
         if (c->young_count) (void)hipFree(c->young_count);
         if (c->nan_count) (void)hipFree(c->nan_count);
         if (c->nan_list) (void)hipFree(c->nan_list);
+        if (c->sample_count) (void)hipFree(c->sample_count);
+        if (c->estimate_host) (void)hipHostFree(c->estimate_host);
         c->young_masks = nullptr; c->young_list = nullptr; c->young_count = nullptr; c->nan_count = nullptr; c->nan_list = nullptr;
+        c->sample_count = nullptr; c->estimate_host = nullptr;
     };
     drop();
     const size_t nmasks = (size_t)c->strip.rows * ((c->W + 63) / 64);
@@ -101,6 +104,10 @@ int alloc_flags(svgf_ctx* c) {
     if (e == hipSuccess) e = hipMalloc((void**)&c->nan_count, 2 * sizeof(unsigned));
     if (e == hipSuccess) e = hipMemsetAsync(c->nan_count, 0, 2 * sizeof(unsigned), c->stream);
     if (e == hipSuccess) e = hipMalloc((void**)&c->nan_list, (size_t)svgf::kNanListCap * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->sample_count, 64 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemsetAsync(c->sample_count, 0, 64 * sizeof(unsigned), c->stream);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->estimate_host, 64, hipHostMallocMapped);
+    if (e == hipSuccess) { c->estimate_host[0] = 0u; c->dense_moments = false; }
     if (e != hipSuccess) { drop(); return hip_fail(c, e, "alloc_flags"); }
     c->young_phase = 0;
     c->young_pending = false;
@@ -191,7 +198,10 @@ void free_state(svgf_ctx* c) {
     if (c->young_count) (void)hipFree(c->young_count);
     if (c->nan_count) (void)hipFree(c->nan_count);
     if (c->nan_list) (void)hipFree(c->nan_list);
+    if (c->sample_count) (void)hipFree(c->sample_count);
+    if (c->estimate_host) (void)hipHostFree(c->estimate_host);
     c->young_masks = nullptr; c->young_list = nullptr; c->young_count = nullptr; c->nan_count = nullptr; c->nan_list = nullptr;
+    c->sample_count = nullptr; c->estimate_host = nullptr;
     c->have_state = false;
 }
 
@@ -245,7 +255,7 @@ int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, vo
                          (const float4*)prev->motion, (const uint2*)prev->normal, (const uint2*)prev->uv,
                          hist_prev, hist_cur, moments_cur, moments_prev,
                          c->p.depth_threshold, c->p.normal_threshold, c->p.history_base, c->p.mesh_id_test, passthrough_out,
-                         passthrough_out ? c->young_masks : nullptr, passthrough_out ? c->young_list : nullptr,
+                         passthrough_out ? c->young_masks : nullptr, passthrough_out && !c->dense_now ? c->young_list : nullptr,
                          passthrough_out ? c->young_count + c->young_phase * svgf::kYoungCounterStride : nullptr,
                          passthrough_out ? c->young_count + (c->young_phase ^ 1) * svgf::kYoungCounterStride : nullptr,
                          sparse_colour, c->p.phi_normal > 0.0f, c->halo_violations,
@@ -253,7 +263,9 @@ int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, vo
                          (const uint4*)guide_prev,
                          c->strip.y0, c->strip.y0 + c->strip.rows,       // the guide texels of every row held (a strip runs the stage on fewer)
                          passthrough_out ? c->nan_list : nullptr, passthrough_out ? c->nan_count + c->young_phase : nullptr,
-                         passthrough_out ? c->nan_count + (c->young_phase ^ 1) : nullptr, c->p.nan_policy == SVGF_NAN_ZERO};
+                         passthrough_out ? c->nan_count + (c->young_phase ^ 1) : nullptr,
+                         passthrough_out ? c->sample_count + c->young_phase * 32 : nullptr, passthrough_out ? c->sample_count + (c->young_phase ^ 1) * 32 : nullptr,
+                         passthrough_out ? c->estimate_host : nullptr, c->p.nan_policy == SVGF_NAN_ZERO};
     if (c->re <= c->rb) return SVGF_OK;             // nothing to launch: the young masks and the counters stay as they are
     SVGF_HIP(c, svgf::launch_temporal(geo_of(c), c->p.storage, a, c->stream));
     if (passthrough_out) c->young_pending = true;
@@ -513,6 +525,15 @@ int svgf_set_debug_mode(svgf_ctx* c, int mode) {
     return SVGF_OK;
 }
 
+int svgf_set_adaptive_moments(svgf_ctx* c, int enable) {
+    if (!c) return SVGF_ERR_INVALID;
+    c->adaptive_moments = enable != 0;
+    if (!enable) c->dense_moments = false;
+    return SVGF_OK;
+}
+
+int svgf_adaptive_moments_state(const svgf_ctx* c) { return c && c->dense_moments ? 1 : 0; }
+
 int svgf_set_prev_guide(svgf_ctx* c, int enable) {
     if (!c) return SVGF_ERR_INVALID;
     c->prev_guide_enabled = enable != 0;
@@ -530,8 +551,9 @@ int svgf_temporal(svgf_ctx* c, const void* prev_colour, const void* radiance, vo
 int svgf_moments(svgf_ctx* c, const void* colour, void* out, const void* moments, const svgf_gbuffer* g, const uint8_t* hist) {
     if (!c) return SVGF_ERR_INVALID;
     DeviceGuard dg(c->device);
-    // stage call: history is unknown to the host, so the per-pixel kernel — unless the caller asks for the LDS variant
-    return moments_impl(c, colour, out, moments, g, hist, 0, c->p.variant == SVGF_VARIANT_LDS || c->p.variant == SVGF_VARIANT_LDS_GENERAL, 0);
+    // stage call: every pixel is visited — the LDS-streaming kernel (variant DIRECT, a radius other than 3 or PhiNormal == 0: the per-pixel one).
+    // The frame driver's young-pixel launch evaluates its taps as whichever of the two this call runs does (moments_group8): bit-identical results.
+    return moments_impl(c, colour, out, moments, g, hist, 0, c->p.variant != SVGF_VARIANT_DIRECT, 0);
 }
 
 int svgf_temporal_moments(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, void* filter_out,
@@ -684,7 +706,7 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     rc = capture_of(c, &cap);
     if (rc != SVGF_OK) return rc;
     if (cap) {
-        const bool allocates = !c->have_state || !(c->young_masks && c->young_list && c->young_count && c->nan_count && c->nan_list) ||
+        const bool allocates = !c->have_state || !(c->young_masks && c->young_list && c->young_count && c->nan_count && c->nan_list && c->sample_count && c->estimate_host) ||
                                (c->frames_in_flight > 1 && !(c->filter_alt[0] && c->filter_alt[1])) || (is_strip(c) && !c->halo_violations);
         if (allocates || c->frames_since_reset < 3)
             return fail(c, SVGF_ERR_INVALID, "svgf_denoise_frame: the context's stream is being captured and this frame cannot be: the first three frames after "
@@ -749,7 +771,23 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     }
     // With at least one wavelet iteration the temporal result in colour[P] is dead where iteration 0's feedback will
     // overwrite it (:619-622): it is only stored for young pixels (the moments estimate reads them) and depth-0 texels.
-    const int sparse = c->p.steps >= 1;
+    // Which kernel serves the young pixels.  The first three frames after a reset have history <= 3 everywhere: the LDS-streaming kernel, which
+    // visits every pixel (0.21 ms per 4K frame, whatever is young).  Afterwards the young-pixel launch, which costs what the young pixels cost
+    // (0.005 ms for none, 0.03 under a pan, 0.5 for 12 % of the frame, 1.6 for half of it) — unless a recent frame's SAMPLE of young pixels
+    // (temporal_kernel, one wave in 64; read here without synchronising: it is a few frames old) says that more than 8 % of the frame are young:
+    // fast camera motion, a cut without a reset.  Back below 5 %.  Both kernels evaluate the estimate on the same bits (moments_group8,
+    // ARITH = 1), so the choice — and the timing it depends on — changes nothing but the frame time.
+    const bool cold = c->frames_since_reset < 3 && c->p.variant != SVGF_VARIANT_DIRECT;
+    bool crowded = false;
+    if (!cold && c->adaptive_moments && c->estimate_host && c->p.variant != SVGF_VARIANT_DIRECT && c->p.moments_radius == 3 && c->p.phi_normal != 0.0f && c->re > c->rb) {
+        const double est = 64.0 * (double)*(volatile unsigned*)c->estimate_host / ((double)c->W * (double)(c->re - c->rb));
+        if (est > 0.08) c->dense_moments = true;
+        else if (est < 0.05) c->dense_moments = false;
+        crowded = c->dense_moments;
+    }
+    // (a crowded frame keeps every pixel's temporal colour: the streaming kernel reads its taps from one plane)
+    const int sparse = c->p.steps >= 1 && !crowded;
+    c->dense_now = cold || crowded;                  // (the temporal launch of such a frame appends to no list)
     // The temporal launch also writes the filter buffer where history >= 4 (there FilterMoments is a copy), the
     // moments launch then only works on young pixels: same planes, 32 B/px less traffic in steady state.
     // ... and repacks what the wavelet iterations read of the G-buffer ({depth, ddepth, normal}: 16 B instead of 24 B of lines per
@@ -761,10 +799,11 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     void* guide = use_guide(c) ? c->guide : nullptr;
     rc = temporal_impl(c, c->colour[1 - P], radiance, c->colour[P], cur, prev, c->hist[1 - P], c->hist[P],
                        c->moments[P], c->moments[1 - P], F[0], sparse, guide, prev_guide_for(c, cur, prev));  // App.cu:552
+    c->dense_now = false;                           // (the stage calls on this context keep their lists)
     if (rc != SVGF_OK) return bail(rc);
     stamp();
     // the first three frames after a reset have history <= 3 everywhere: the LDS-streaming moments kernel
-    rc = moments_impl(c, c->colour[P], F[0], c->moments[P], cur, c->hist[P], 1, c->frames_since_reset < 3 && c->p.variant != SVGF_VARIANT_DIRECT, sparse);   // App.cu:554 (current moments: App. B #4)
+    rc = moments_impl(c, c->colour[P], F[0], c->moments[P], cur, c->hist[P], 1, cold || crowded, sparse);   // App.cu:554 (current moments: App. B #4)
     if (rc != SVGF_OK) return bail(rc);
     stamp();
     int pp = 0, first = 0;

@@ -52,6 +52,11 @@ struct svgf_ctx {
     uint32_t* young_list = nullptr;        // ... and the indices of the pixels of the partly young segments (svgf::kYoungListEntries)
     unsigned long long* young_count = nullptr;   // ... two {appends, pixels} counters used in turn (the temporal launch of a frame zeroes the next frame's)
     unsigned* nan_count = nullptr;         // two device counters of nan_list used in turn (the temporal launch of a frame zeroes the next frame's)
+    unsigned* sample_count = nullptr;      // two device counters (128 B apart) used in turn: the sampled number of young pixels of a frame (TemporalArgs::sample_count)
+    unsigned* estimate_host = nullptr;     // host-mapped: the latest sample a temporal launch has published (read without synchronising: some frames old)
+    bool adaptive_moments = true;          // svgf_set_adaptive_moments
+    bool dense_moments = false;            // the frame driver's current choice (hysteresis)
+    bool dense_now = false;                // the frame being enqueued is served by the streaming kernel (a cold or a crowded frame)
     uint32_t* nan_list = nullptr;          // scratch, temporal -> moments: the pixels whose accumulated colour / moments are NaN or inf (kNanListCap entries)
     int young_phase = 0;
     bool young_pending = false;            // a temporal launch wrote the masks / appended to nan_count[young_phase] and no moments launch has consumed them yet

@@ -41,7 +41,13 @@ namespace {
 template <int ST>
 __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs a) {
     keep_nan_in_clamps();                                             // imageLoad / imageStore keep a NaN (svgf_device.h)
-    if (a.young_masks && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) { a.young_count_next[0] = 0ull; a.young_count_next[kYoungFlagOffset] = 0ull; a.nan_count_next[0] = 0u; }
+    if (a.young_masks && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) {
+        a.young_count_next[0] = 0ull; a.young_count_next[kYoungFlagOffset] = 0ull; a.nan_count_next[0] = 0u;
+        if (a.sample_count) {                       // last frame's sample is final: to the host (no answer awaited), and its counter starts again
+            __hip_atomic_store(a.estimate_host, a.sample_prev[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            a.sample_prev[0] = 0u;
+        }
+    }
     // The grid covers the compute rows [yb, ye) and, where a guide plane is written, the rows [guide_lo, guide_hi) around them (a strip
     // holds more rows than it runs the temporal stage on: the later iterations' halos and the next frame's reprojection read their
     // guide texels too): a row outside the compute rows gets its guide texel and nothing else (a wave is one row: no divergence).
@@ -148,7 +154,10 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
         const unsigned long long ym = __ballot(listed);
         if (threadIdx.x == 0)                                             // (lane 0 is always inside the frame; lanes beyond W have left: their bits are 0)
             a.young_masks[(size_t)(y - g.y0) * ((g.W + kBX - 1) / kBX) + blockIdx.x] = ym;
-        if (ym != 0ull && ym != ~0ull) {
+        // one wave in 64 (hashed over segment and row: columns and rows of young pixels are sampled like anything else) reports how many it holds
+        if (a.sample_count && ym != 0ull && threadIdx.x == 0 && (((unsigned)blockIdx.x * 29u + (unsigned)y * 13u) & 63u) == 0u)
+            (void)__hip_atomic_fetch_add(a.sample_count, (unsigned)__builtin_popcountll(ym), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.young_list && ym != 0ull && ym != ~0ull) {                 // (no list for a frame the streaming kernel will serve)
             const int lane = threadIdx.x, first = __builtin_ctzll(ym);
             unsigned base = ~0u;
             if (lane == first && __hip_atomic_load(a.young_count + kYoungFlagOffset, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) {
@@ -266,7 +275,13 @@ __device__ __forceinline__ void moments_pixel(const Geo& g, const MomentsArgs& a
 // that holds them (__shfl = ds_bpermute: no memory), so the sums are accumulated in exactly the order — and to exactly the bits —
 // of moments_pixel.  The colour of a tap is fetched from BOTH planes it can live in (the choice depends on the tap's own depth /
 // history texel), which keeps every load of the window independent: one round of memory latency for the taps.
-template <int ST>
+// ARITH = 0: the tap weight as moments_pixel evaluates it (variant DIRECT, a radius other than 3, PhiNormal == 0: the stage calls then run
+// moments_pixel).  ARITH = 1: as moments_lds_kernel evaluates it (svgf_moments_lds.h, moments_taps49: the fused exponent on the same
+// bits) — the kernel the default variants run for a frame full of young pixels, so that which of the two serves a frame is a matter of
+// speed alone: the frame driver may switch between them from frame to frame without a bit of the results changing (finite input; a
+// workgroup of the streaming kernel that has staged a NaN evaluates ALL its luminance terms the reference's way, :424, this one only
+// the NaN ones).
+template <int ST, int ARITH>
 __device__ __forceinline__ void moments_group8(const Geo& g, const MomentsArgs& a, bool valid, uint32_t pix) {
     constexpr int RM = 3, NW = 2 * RM + 1;
     const int lane = threadIdx.x & 63, j = lane & 7, base = lane & ~7;
@@ -307,6 +322,9 @@ __device__ __forceinline__ void moments_group8(const Geo& g, const MomentsArgs& 
     const float3 nc = normal_of(nraw);
     const float il = hw_rcp(a.phi_colour);                            // :460
     const float phi_d = fmaxf(dzc, 1e-8f) * 3.0f;                     // :461
+    // ARITH = 1: moments_lds_kernel's centre (svgf_moments_lds.h)
+    const float ncz1 = unpack_h2(nraw.y).x, il1 = il * kLog2e;
+    const float izb1 = hw_rcp(fmaxf(zc == kSkyZ ? 0.0f : mc.w, 1e-8f) * 3.0f) * kLog2e;
     // this lane's seven taps: weight and the values the sums take from them
     float tw[NW], t0[NW], t1[NW], t2[NW];
     unsigned okbits = 0u;
@@ -320,7 +338,19 @@ __device__ __forceinline__ void moments_group8(const Geo& g, const MomentsArgs& 
         const float3 np = normal_of(tn[r]);
         const float len = sqrtf((float)(xx * xx + yy * yy));          // :488 (IEEE sqrt of a small integer: the value a constant would have)
         const float iz = (xx == 0 && yy == 0) ? 0.0f : hw_rcp(phi_d * len);   // phiDepth == 0 -> wZ = 0, :420
-        tw[r] = edge_weight(fabsf(lc - lum_exact(t0[r], t1[r], t2[r])), il, fabsf(zc - zp), iz, dot3_fma(nc, np), a.phi_normal);
+        if constexpr (ARITH == 0) {
+            tw[r] = edge_weight(fabsf(lc - lum_exact(t0[r], t1[r], t2[r])), il, fabsf(zc - zp), iz, dot3_fma(nc, np), a.phi_normal);
+        } else {
+            const int l2 = xx * xx + yy * yy;                         // moments_taps49's depth scale by tap distance (len_class7)
+            const float km = l2 == 1 ? 1.0f : l2 == 2 ? 0.70710678118654752f : l2 == 4 ? 0.5f : l2 == 5 ? 0.44721359549995794f : l2 == 8 ? 0.35355339059327376f
+                           : l2 == 9 ? 0.33333333333333333f : l2 == 10 ? 0.31622776601683794f : l2 == 13 ? 0.27735009811261456f : 0.23570226039551584f;
+            const float d = clamp01(fmaf(unpack_h2(tn[r].y).x, ncz1, dot2_h2(tn[r].x, nraw.x)));
+            float e = hw_log2(d) * a.phi_normal;
+            const float dl = lum_exact(t0[r], t1[r], t2[r]) - lc;
+            if (dl == dl) e = fmaf(-fabsf(dl), il1, e);               // a NaN luminance: max(|dl| / phi_l, 0.0) is CUDA's fmax, which drops it (:424)
+            if (l2 != 0) e = fmaf(-fabsf(zp - zc), l2 == 1 ? izb1 : izb1 * km, e);
+            tw[r] = hw_exp2(e);
+        }
         okbits |= ok[r] ? 1u << r : 0u;
     }
     // the 49 taps in the reference's order; every lane of the group accumulates the same sums
@@ -460,7 +490,7 @@ __global__ __launch_bounds__(kBX* kBY) void moments3x3_shfl_kernel(Geo g, Moment
 // (Bench pan, ~28 000 listed pixels + ~300 all-young segments per 4K frame: 0.051 ms in round 2, 0.034 in round 3 (eight lanes per pixel,
 // two workgroups per slot), 0.028 now (the window loads of a pass in ONE memory round, not eight); nothing young: 0.007 ms.)
 constexpr int kScanSplit = 2;
-template <int ST>
+template <int ST, int ARITH>
 __global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a, int scan_blocks) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = threadIdx.x;
     __shared__ unsigned long long full[4];
@@ -476,7 +506,7 @@ __global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a
             for (unsigned grp = b + list_blocks * (unsigned)w; grp < ngroups; grp += list_blocks * 4u) {
                 const unsigned i = grp * 8u + ((unsigned)lane >> 3);
                 const bool valid = i < n;
-                moments_group8<ST>(g, a, valid, valid ? a.young_list[i] : 0u);
+                moments_group8<ST, ARITH>(g, a, valid, valid ? a.young_list[i] : 0u);
             }
         }
     } else {
@@ -501,7 +531,7 @@ __global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a
 #pragma unroll 1
                         for (int o = part * (8 / F) + w; o < (part + 1) * (8 / F); o += 4) {
                             const int x = (seg % nseg) * kBX + o * 8 + (lane >> 3);
-                            moments_group8<ST>(g, a, x < g.W, (uint32_t)(yl * g.W + (x < g.W ? x : 0)));
+                            moments_group8<ST, ARITH>(g, a, x < g.W, (uint32_t)(yl * g.W + (x < g.W ? x : 0)));
                         }
                     }
                 }
@@ -525,7 +555,7 @@ __global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a
                     const int i = it * 8 + (lane >> 3);
                     const bool valid = i < total;
                     const int e = slist[valid ? i : 0], seg = base + (e >> 6) * nslots + bid;
-                    moments_group8<ST>(g, a, valid, (uint32_t)((seg / nseg) * g.W + (seg % nseg) * kBX + (e & 63)));
+                    moments_group8<ST, ARITH>(g, a, valid, (uint32_t)((seg / nseg) * g.W + (seg % nseg) * kBX + (e & 63)));
                 }
             }
             __syncthreads();
@@ -553,7 +583,7 @@ __global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a
                 const uint32_t q = valid ? (uint32_t)(qyl * g.W + qx) : 0u;
                 const bool need = shortcut_px(valid, q);         // (a NaN pixel on a surface far from the sky costs two small loads per pass)
                 if (!wave_any(need)) continue;
-                moments_group8<ST>(g, a, need, q);
+                moments_group8<ST, ARITH>(g, a, need, q);
             }
         }
     } else {                                    // the list overflowed (a frame full of NaN): every shortcut pixel of the launch rows
@@ -562,7 +592,7 @@ __global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a
             const unsigned q = q0 + ((unsigned)lane >> 3), qs = q < lastp ? q : firstp;
             const bool need = shortcut_px(q < lastp, qs);
             if (!wave_any(need)) continue;
-            moments_group8<ST>(g, a, need, qs);
+            moments_group8<ST, ARITH>(g, a, need, qs);
         }
     }
 }
@@ -854,8 +884,10 @@ hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, bool 
         if (scan > 4 * num_cus()) scan = 4 * num_cus();            // ... on at most one resident round
         const int walk = std::min(4 * num_cus(), std::max(1, nsegs / 16));   // the list holds at most 63 pixels per segment
         scan *= kScanSplit;
-        if (storage == 0) moments_young_kernel<0><<<scan + walk, 256, 0, s>>>(g, a, scan);
-        else moments_young_kernel<1><<<scan + walk, 256, 0, s>>>(g, a, scan);
+        // the arithmetic of the kernel the stage calls / the dense frames of this configuration run (moments_group8)
+        const bool lds_arith = !direct && a.radius == kMR && a.phi_normal != 0.0f;
+        if (storage == 0) { if (lds_arith) moments_young_kernel<0, 1><<<scan + walk, 256, 0, s>>>(g, a, scan); else moments_young_kernel<0, 0><<<scan + walk, 256, 0, s>>>(g, a, scan); }
+        else { if (lds_arith) moments_young_kernel<1, 1><<<scan + walk, 256, 0, s>>>(g, a, scan); else moments_young_kernel<1, 0><<<scan + walk, 256, 0, s>>>(g, a, scan); }
         return hipGetLastError();
     }
     const dim3 block(kBX, kBY), grid = grid_for(g);

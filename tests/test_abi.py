@@ -23,7 +23,7 @@ def test_header_symbols_all_exported():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/svgf.h but not exported"
     assert sorted(F.EXPORTS) == syms
-    assert lib.svgf_abi_version() == F.ABI_VERSION == 5
+    assert lib.svgf_abi_version() == F.ABI_VERSION == 6
 
 
 def test_default_params_match_reference_defaults():

@@ -243,8 +243,8 @@ def test_pipeline_free_running(G, oracle, storage, mv, variant):
 @pytest.mark.parametrize("storage", ["f32", "f16"])
 def test_frame_driver_equals_stage_calls(G, storage):
     """svgf_denoise_frame (context-owned state, moments pass-through folded into the temporal launch) == the same
-    stages driven from outside, bitwise — with variant "direct", where both paths run the same kernels (the default
-    driver switches to the LDS moments kernel while the whole frame is young, which rounds differently)."""
+    stages driven from outside, bitwise — here with variant "direct" (the per-pixel kernels; the default variants, whose young-pixel
+    launch and LDS-streaming moments kernel evaluate the estimate on the same bits, are compared the same way in test_gpu_fused.py)."""
     from svgf_amd import filter as F
     W, H, N = 200, 120, 6
     fr = frames(W, H, N, mv=(1.0, 0.0))
@@ -286,6 +286,42 @@ def test_frame_driver_when_every_wave_holds_young_pixels(G, period, storage):
     assert np.array_equal(hist, hip.taps["hist"])
     surface = fr[0]["motion"][..., 2] != 0
     assert (hist[:, ::period][surface[:, ::period]] == 1).all() and (hist[:, 1::period][surface[:, 1::period]] >= 4).mean() > 0.9
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_adaptive_moments_switches_kernels_without_a_bit_changing(G, storage):
+    """A sequence that goes from calm to crowded and back (every 8th column disoccluded in every frame of the middle part: 12 % of the
+    surface pixels young): with the host waiting for every frame the sample of frame f reaches the driver at frame f + 2, which then
+    serves the young pixels with the LDS-streaming kernel instead of the young-pixel launch, and goes back when the frames calm down.
+    The frames equal those of a context that never switches, bit for bit."""
+    import torch
+    from svgf_amd import filter as F
+    W, H, N = 1024, 512, 22
+    fr = frames(W, H, 2, mv=(0.0, 0.0))
+    base = fr[0]["normal"]
+    flipped = base.copy()
+    flipped.view(np.int16)[:, ::8, 0:3] ^= np.int16(-32768)
+    mot, uv = G.dev(fr[0]["motion"]), G.dev(fr[0]["uv"])
+    calm = [G.F.GBuffer(mot, G.dev(base), uv), G.F.GBuffer(mot, G.dev(base.copy()), uv)]
+    crowd = [calm[0], G.F.GBuffer(mot, G.dev(flipped), uv)]
+    gb_of = lambda k: (crowd if 8 <= k < 15 else calm)[k % 2]          # noqa: E731
+    outs, modes = {}, []
+    for adaptive in (True, False):
+        d = F.Denoiser(W, H, F.Params(storage=storage, steps=3))
+        d.set_adaptive_moments(adaptive)
+        res = []
+        for k in range(N):
+            rad = G.dev(fr[k % 2]["radiance"].astype(G.NPDT[storage]))
+            res.append(G.host(d.Render(rad, gb_of(k), gb_of(k - 1) if k else None)))      # (G.host waits for the frame)
+            if adaptive:
+                modes.append(d.adaptive_moments_state())
+        outs[adaptive] = res
+        d.close()
+    # frames 0-2 are young all over (their samples keep the streaming kernel on until frame 5), 9-15 crowded (frame 9 is the first whose two
+    # G-buffers disagree; seen from frame 11 on), 18 is the first calm one again (seen at frame 20)
+    assert not any(modes[6:9]) and all(modes[11:17]) and not modes[-1], modes
+    for k in range(N):
+        assert np.array_equal(outs[True][k].view(np.uint8), outs[False][k].view(np.uint8)), k
 
 
 @pytest.mark.parametrize("params", [
