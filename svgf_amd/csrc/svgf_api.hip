@@ -774,15 +774,18 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     // Which kernel serves the young pixels.  The first three frames after a reset have history <= 3 everywhere: the LDS-streaming kernel, which
     // visits every pixel (0.21 ms per 4K frame, whatever is young).  Afterwards the young-pixel launch, which costs what the young pixels cost
     // (0.005 ms for none, 0.03 under a pan, 0.5 for 12 % of the frame, 1.6 for half of it) — unless a recent frame's SAMPLE of young pixels
-    // (temporal_kernel, one wave in 64; read here without synchronising: it is a few frames old) says that more than 8 % of the frame are young:
-    // fast camera motion, a cut without a reset.  Back below 5 %.  Both kernels evaluate the estimate on the same bits (moments_group8,
+    // (temporal_kernel, one wave in 64; read here without synchronising: it is a few frames old) says that more than 8 % of the frame are young
+    // (fast camera motion, a cut without a reset; back below 5 %) or that more waves hold young pixels than the list takes appends from (thin
+    // geometry under motion; back below half of that).  Both kernels evaluate the estimate on the same bits (moments_group8,
     // ARITH = 1), so the choice — and the timing it depends on — changes nothing but the frame time.
     const bool cold = c->frames_since_reset < 3 && c->p.variant != SVGF_VARIANT_DIRECT;
     bool crowded = false;
     if (!cold && c->adaptive_moments && c->estimate_host && c->p.variant != SVGF_VARIANT_DIRECT && c->p.moments_radius == 3 && c->p.phi_normal != 0.0f && c->re > c->rb) {
-        const double est = 64.0 * (double)*(volatile unsigned*)c->estimate_host / ((double)c->W * (double)(c->re - c->rb));
-        if (est > 0.08) c->dense_moments = true;
-        else if (est < 0.05) c->dense_moments = false;
+        const unsigned sample = *(volatile unsigned*)c->estimate_host;      // {waves that hold some young pixels: 12 bits, young pixels: 20 bits}, of one wave in 64
+        const double est = 64.0 * (double)(sample & 0xfffffu) / ((double)c->W * (double)(c->re - c->rb));
+        const unsigned appends = 64u * (sample >> 20);                      // what the list of such a frame takes (cap: svgf::kYoungAppendCap)
+        if (est > 0.08 || appends > svgf::kYoungAppendCap) c->dense_moments = true;
+        else if (est < 0.05 && appends < svgf::kYoungAppendCap / 2) c->dense_moments = false;
         crowded = c->dense_moments;
     }
     // (a crowded frame keeps every pixel's temporal colour: the streaming kernel reads its taps from one plane)

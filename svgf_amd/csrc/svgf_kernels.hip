@@ -155,8 +155,9 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
         if (threadIdx.x == 0)                                             // (lane 0 is always inside the frame; lanes beyond W have left: their bits are 0)
             a.young_masks[(size_t)(y - g.y0) * ((g.W + kBX - 1) / kBX) + blockIdx.x] = ym;
         // one wave in 64 (hashed over segment and row: columns and rows of young pixels are sampled like anything else) reports how many it holds
+        // (low 20 bits: young pixels; high 12: waves that hold some but not 64 — the ones that append to the list)
         if (a.sample_count && ym != 0ull && threadIdx.x == 0 && (((unsigned)blockIdx.x * 29u + (unsigned)y * 13u) & 63u) == 0u)
-            (void)__hip_atomic_fetch_add(a.sample_count, (unsigned)__builtin_popcountll(ym), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(a.sample_count, (unsigned)__builtin_popcountll(ym) + (ym != ~0ull ? 1u << 20 : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.young_list && ym != 0ull && ym != ~0ull) {                 // (no list for a frame the streaming kernel will serve)
             const int lane = threadIdx.x, first = __builtin_ctzll(ym);
             unsigned base = ~0u;
@@ -490,11 +491,25 @@ __global__ __launch_bounds__(kBX* kBY) void moments3x3_shfl_kernel(Geo g, Moment
 // (Bench pan, ~28 000 listed pixels + ~300 all-young segments per 4K frame: 0.051 ms in round 2, 0.034 in round 3 (eight lanes per pixel,
 // two workgroups per slot), 0.028 now (the window loads of a pass in ONE memory round, not eight); nothing young: 0.007 ms.)
 constexpr int kScanSplit = 2;
+
+// position of the r-th (0-based) set bit of m; r < popcount(m)
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, int r) {
+    unsigned w = (unsigned)m;
+    int pos = 0, c = __popc(w);
+    if (r >= c) { r -= c; w = (unsigned)(m >> 32); pos = 32; }
+    c = __popc(w & 0xffffu); if (r >= c) { r -= c; w >>= 16; pos += 16; }
+    c = __popc(w & 0xffu);   if (r >= c) { r -= c; w >>= 8;  pos += 8; }
+    c = __popc(w & 0xfu);    if (r >= c) { r -= c; w >>= 4;  pos += 4; }
+    c = __popc(w & 0x3u);    if (r >= c) { r -= c; w >>= 2;  pos += 2; }
+    return pos + (r >= (int)(w & 1u) ? 1 : 0);
+}
+
 template <int ST, int ARITH>
 __global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a, int scan_blocks) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = threadIdx.x;
     __shared__ unsigned long long full[4];
-    __shared__ uint16_t slist[256 * 64];            // over the cap only: {thread that read the segment's mask, lane of the pixel}: 14 bits
+    __shared__ unsigned long long smask[256];       // over the cap only: the slot's masks ...
+    __shared__ uint16_t sitem[256 * 8];             // ... and its work items {thread that read the segment's mask, which eight of its young pixels}
     __shared__ int swave[4];
     const int nseg = (g.W + kBX - 1) / kBX;
     const int first = (g.yb - g.y0) * nseg, last = (g.ye - g.y0) * nseg;             // mask range of the launch rows
@@ -536,26 +551,29 @@ __global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a
                     }
                 }
             } else {
-                // the list is void: every young pixel of the slot's masks, compacted into LDS (by each of the slot's workgroups for itself),
-                // eight entries per pass, the passes dealt out over the slot's 4 F waves
-                const int k = __builtin_popcountll(m);
-                int inc = k;                                                  // inclusive scan over the wave
+                // the list is void: every young pixel of the slot's masks, as items {segment, eight of its young pixels} in LDS (built by each of
+                // the slot's workgroups for itself), dealt out over the slot's 4 F waves.  A frame or two until the frame driver's sample says
+                // "crowded" and the streaming kernel takes over (svgf_set_adaptive_moments): eight pixels per pass only where a segment holds them.
+                const int np = (__builtin_popcountll(m) + 7) >> 3;            // passes this segment needs: 0 .. 8
+                int inc = np;                                                 // inclusive scan over the wave
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d); if (lane >= d) inc += v; }
                 if (lane == 63) swave[w] = inc;
+                smask[t] = m;
                 __syncthreads();
-                int off = inc - k, total = 0;
+                int off = inc - np, total = 0;
 #pragma unroll
                 for (int ww = 0; ww < 4; ww++) { const int n = swave[ww]; if (ww < w) off += n; total += n; }
-                while (m) { slist[off++] = (uint16_t)((t << 6) | __builtin_ctzll(m)); m &= m - 1; }
+                for (int q = 0; q < np; q++) sitem[off + q] = (uint16_t)((t << 3) | q);
                 __syncthreads();
-                const int npass = (total + 7) >> 3;
 #pragma unroll 1
-                for (int it = part * 4 + w; it < npass; it += 4 * F) {        // (uniform over the wave)
-                    const int i = it * 8 + (lane >> 3);
-                    const bool valid = i < total;
-                    const int e = slist[valid ? i : 0], seg = base + (e >> 6) * nslots + bid;
-                    moments_group8<ST, ARITH>(g, a, valid, (uint32_t)((seg / nseg) * g.W + (seg % nseg) * kBX + (e & 63)));
+                for (int it = part * 4 + w; it < total; it += 4 * F) {        // (uniform over the wave)
+                    const int e = sitem[it], tt = e >> 3;
+                    const unsigned long long mm = smask[tt];
+                    const int r = (e & 7) * 8 + (lane >> 3);
+                    const bool valid = r < __builtin_popcountll(mm);
+                    const int seg = base + tt * nslots + bid;
+                    moments_group8<ST, ARITH>(g, a, valid, (uint32_t)((seg / nseg) * g.W + (seg % nseg) * kBX + nth_set_bit(mm, valid ? r : 0)));
                 }
             }
             __syncthreads();
