@@ -165,6 +165,9 @@ public:
     // planes when `prev` is that G-buffer (svgf.h, svgf_set_prev_guide: off by default; the host vouches that it does not rewrite
     // Framebuffer[1 - PingPongInx] between two frames, as the reference does not).  The three stage calls above never use it.
     void SetPrevGuide(bool Enable) { check(svgf_set_prev_guide(Ctx, Enable ? 1 : 0), "svgf_set_prev_guide"); }
+    // svgf_denoise_frame serves a crowded frame (> 8 % young pixels by a sample of recent frames) with the LDS-streaming moments kernel instead
+    // of the young-pixel launch: same results, bounded frame time (svgf.h, svgf_set_adaptive_moments: on by default)
+    void SetAdaptiveMoments(bool Enable) { check(svgf_set_adaptive_moments(Ctx, Enable ? 1 : 0), "svgf_set_adaptive_moments"); }
     // application::EndFrame's share (App.cu:374): this frame's colour/moments/history become the previous frame's
     void EndFrame() {
         std::swap(Buffers.ColourBuffer, Buffers.HistoryBufferColour);

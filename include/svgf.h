@@ -303,11 +303,14 @@ int svgf_set_prev_guide(svgf_ctx* ctx, int enable);
  * over the young pixels alone (what they cost: 0.005 ms per 4K frame for none, 0.03 under a pan, 0.5 for 12 % of the frame, 1.6 for half of it) or the
  * LDS-streaming kernel over every pixel (0.21 ms whatever is young; always for the first three frames after a reset).  With enable = 1 (default)
  * the driver goes by a sample of the young pixels of a recent frame, which the temporal launch leaves in host-mapped memory (no synchronisation: it
- * is a few frames old): above 8 % of the frame the streaming kernel, back below 5 %.  Both evaluate the estimate on the same bits, so the choice
+ * is a few frames old): above 8 % of the frame — or with more waves holding young pixels than the young-pixel list takes appends from (16 384) — the
+ * streaming kernel, back below 5 % (and three quarters of that).  Both evaluate the estimate on the same bits, so the choice
  * never shows in the results (finite input; around a NaN texel the two round the luminance term differently, both within the stated tolerance).
  * enable = 0: the young-pixel launch whenever the frame is not one of the first three. */
 int svgf_set_adaptive_moments(svgf_ctx* ctx, int enable);
 int svgf_adaptive_moments_state(const svgf_ctx* ctx);                  /* 1: the last frame was served by the streaming kernel because of the sample */
+/* the latest sample as the driver reads it (x 64: an estimate of a recent frame's young pixels and of its waves that hold some); SVGF_ERR_INVALID before the first frame */
+int svgf_adaptive_moments_sample(const svgf_ctx* ctx, unsigned* young_pixels, unsigned* appending_waves);
 
 /* Texture / pitched adapters — what the reference gets from its CUDA <-> OpenGL mappings (CreateMapping, CudaUtil.h:68-99;
  * render targets Framebuffer.cpp:7-49): the G-buffer planes arrive as array-backed textures or pitched surfaces and are

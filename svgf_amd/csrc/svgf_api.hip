@@ -534,6 +534,14 @@ int svgf_set_adaptive_moments(svgf_ctx* c, int enable) {
 
 int svgf_adaptive_moments_state(const svgf_ctx* c) { return c && c->dense_moments ? 1 : 0; }
 
+int svgf_adaptive_moments_sample(const svgf_ctx* c, unsigned* young_pixels, unsigned* appending_waves) {
+    if (!c || !c->estimate_host) return SVGF_ERR_INVALID;
+    const unsigned sample = *(volatile unsigned*)c->estimate_host;
+    if (young_pixels) *young_pixels = 64u * (sample & 0xfffffu);
+    if (appending_waves) *appending_waves = 64u * (sample >> 20);
+    return SVGF_OK;
+}
+
 int svgf_set_prev_guide(svgf_ctx* c, int enable) {
     if (!c) return SVGF_ERR_INVALID;
     c->prev_guide_enabled = enable != 0;
@@ -776,7 +784,7 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     // (0.005 ms for none, 0.03 under a pan, 0.5 for 12 % of the frame, 1.6 for half of it) — unless a recent frame's SAMPLE of young pixels
     // (temporal_kernel, one wave in 64; read here without synchronising: it is a few frames old) says that more than 8 % of the frame are young
     // (fast camera motion, a cut without a reset; back below 5 %) or that more waves hold young pixels than the list takes appends from (thin
-    // geometry under motion; back below half of that).  Both kernels evaluate the estimate on the same bits (moments_group8,
+    // geometry under motion; back below three quarters of that: the bench pan's ~4 500 such waves must not keep a context there).  Both kernels evaluate the estimate on the same bits (moments_group8,
     // ARITH = 1), so the choice — and the timing it depends on — changes nothing but the frame time.
     const bool cold = c->frames_since_reset < 3 && c->p.variant != SVGF_VARIANT_DIRECT;
     bool crowded = false;
@@ -785,7 +793,7 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
         const double est = 64.0 * (double)(sample & 0xfffffu) / ((double)c->W * (double)(c->re - c->rb));
         const unsigned appends = 64u * (sample >> 20);                      // what the list of such a frame takes (cap: svgf::kYoungAppendCap)
         if (est > 0.08 || appends > svgf::kYoungAppendCap) c->dense_moments = true;
-        else if (est < 0.05 && appends < svgf::kYoungAppendCap / 2) c->dense_moments = false;
+        else if (est < 0.05 && appends < svgf::kYoungAppendCap / 4 * 3) c->dense_moments = false;
         crowded = c->dense_moments;
     }
     // (a crowded frame keeps every pixel's temporal colour: the streaming kernel reads its taps from one plane)

@@ -11,11 +11,12 @@ struct Geo { int W, H, y0, rows, yb, ye; };
 // The list of pixels whose temporal result is not finite holds at most kNanListCap entries (more than that and the moments launch goes over
 // every pixel instead); its two counters are used in turn, frame by frame.
 constexpr unsigned kNanListCap = 1u << 16;
-// The young-pixel list takes at most kYoungAppendCap appends (one per wave that holds young pixels; same-address atomics retire at ~11 ns each on
-// this part: 8 192 of them are 0.09 ms spread over a 0.19 ms launch).  A frame with more such waves — thin geometry under motion: every wave
-// holds a few young pixels — stops appending, and the moments launch works from the per-segment lane masks instead.  Its counter is 64 bits:
+// The young-pixel list takes at most kYoungAppendCap appends (one per wave that holds SOME young pixels; same-address atomics retire at ~11 ns each
+// on this part: the bench pan's 8 000 - 10 000 of them are 0.1 ms spread over a 0.19 ms launch — unseen —, 130 000 made it a 1.39 ms one).  A frame
+// with more such waves — thin geometry under motion: every wave holds a few young pixels — stops appending (a few thousand waves late: those already
+// past the test when the cap is reached), and the moments launch works from the per-segment lane masks instead.  Its counter is 64 bits:
 // {appends, pixels}.
-constexpr unsigned kYoungAppendCap = 8192;
+constexpr unsigned kYoungAppendCap = 16384;
 constexpr size_t kYoungListEntries = (size_t)kYoungAppendCap * 63;
 // "The cap is reached" is a word of its own, 128 bytes behind its counter: a wave reads THAT before it appends — a load of the counter's own
 // line between the atomics makes each of them cost 50 instead of 11 ns (tools/ubench/atomic_one_address.hip), a load of a line nobody

@@ -27,7 +27,7 @@ EXPORTS = [
     "svgf_create_strip", "svgf_destroy", "svgf_set_params", "svgf_set_stream", "svgf_set_rows", "svgf_temporal", "svgf_temporal_moments", "svgf_demodulate", "svgf_modulate",
     "svgf_moments", "svgf_atrous", "svgf_atrous_pair", "svgf_set_iteration_fusion", "svgf_taa", "svgf_pack_gbuffer", "svgf_denoise_frame", "svgf_reset_history", "svgf_set_frames_in_flight", "svgf_flush", "svgf_state_plane",
     "svgf_state_pingpong", "svgf_plane_bytes", "svgf_timing_enable", "svgf_timing_read",
-    "svgf_resize", "svgf_resize_strip", "svgf_get_size", "svgf_sync", "svgf_halo_violations", "svgf_set_valid_rows", "svgf_set_debug_mode", "svgf_set_prev_guide", "svgf_set_adaptive_moments", "svgf_adaptive_moments_state",
+    "svgf_resize", "svgf_resize_strip", "svgf_get_size", "svgf_sync", "svgf_halo_violations", "svgf_set_valid_rows", "svgf_set_debug_mode", "svgf_set_prev_guide", "svgf_set_adaptive_moments", "svgf_adaptive_moments_state", "svgf_adaptive_moments_sample",
     "svgf_import_gbuffer_pitched", "svgf_import_gbuffer_array", "svgf_export_to_array",
     "svgf_strips_plan", "svgf_rccl_unique_id", "svgf_rccl_comm_init", "svgf_rccl_comm_destroy", "svgf_rccl_comm_count", "svgf_strips_create", "svgf_strips_destroy",
     "svgf_strips_last_error", "svgf_strips_context", "svgf_strips_layout", "svgf_strips_frame", "svgf_strips_sync",
@@ -166,6 +166,7 @@ def load_library():
     lib.svgf_set_prev_guide.argtypes = [vp, ip]
     lib.svgf_set_adaptive_moments.argtypes = [vp, ip]
     lib.svgf_adaptive_moments_state.argtypes = [vp]
+    lib.svgf_adaptive_moments_sample.argtypes = [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     lib.svgf_set_valid_rows.argtypes = [vp, ip, ip]
     lib.svgf_import_gbuffer_pitched.argtypes = [vp, ip, vp, C.c_size_t, vp]
     lib.svgf_import_gbuffer_array.argtypes = [vp, ip, vp, vp]
@@ -322,6 +323,12 @@ class Denoiser:
 
     def adaptive_moments_state(self) -> bool:
         return bool(self.lib.svgf_adaptive_moments_state(self._h))
+
+    def adaptive_moments_sample(self):
+        """-> (estimated young pixels, estimated waves that hold some) of a recent frame, as the frame driver reads them."""
+        px, wv = C.c_uint(), C.c_uint()
+        self._check(self.lib.svgf_adaptive_moments_sample(self._h, C.byref(px), C.byref(wv)), "svgf_adaptive_moments_sample")
+        return px.value, wv.value
 
     def ImportPitched(self, plane, src_ptr, pitch_bytes, dst):
         self._check(self.lib.svgf_import_gbuffer_pitched(self._h, plane, C.c_void_p(src_ptr), pitch_bytes, _ptr(dst)), "svgf_import_gbuffer_pitched")
