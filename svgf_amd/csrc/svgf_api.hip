@@ -265,7 +265,7 @@ int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, vo
                          passthrough_out ? c->nan_list : nullptr, passthrough_out ? c->nan_count + c->young_phase : nullptr,
                          passthrough_out ? c->nan_count + (c->young_phase ^ 1) : nullptr,
                          passthrough_out ? c->sample_count + c->young_phase * 32 : nullptr, passthrough_out ? c->sample_count + (c->young_phase ^ 1) * 32 : nullptr,
-                         passthrough_out ? c->estimate_host : nullptr, c->p.nan_policy == SVGF_NAN_ZERO};
+                         passthrough_out ? c->estimate_host : nullptr, c->cold_now, c->p.nan_policy == SVGF_NAN_ZERO};
     if (c->re <= c->rb) return SVGF_OK;             // nothing to launch: the young masks and the counters stay as they are
     SVGF_HIP(c, svgf::launch_temporal(geo_of(c), c->p.storage, a, c->stream));
     if (passthrough_out) c->young_pending = true;
@@ -799,6 +799,7 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     // (a crowded frame keeps every pixel's temporal colour: the streaming kernel reads its taps from one plane)
     const int sparse = c->p.steps >= 1 && !crowded;
     c->dense_now = cold || crowded;                  // (the temporal launch of such a frame appends to no list)
+    c->cold_now = cold;                              // (... and of a cold one adds nothing to the sample)
     // The temporal launch also writes the filter buffer where history >= 4 (there FilterMoments is a copy), the
     // moments launch then only works on young pixels: same planes, 32 B/px less traffic in steady state.
     // ... and repacks what the wavelet iterations read of the G-buffer ({depth, ddepth, normal}: 16 B instead of 24 B of lines per
@@ -810,7 +811,7 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     void* guide = use_guide(c) ? c->guide : nullptr;
     rc = temporal_impl(c, c->colour[1 - P], radiance, c->colour[P], cur, prev, c->hist[1 - P], c->hist[P],
                        c->moments[P], c->moments[1 - P], F[0], sparse, guide, prev_guide_for(c, cur, prev));  // App.cu:552
-    c->dense_now = false;                           // (the stage calls on this context keep their lists)
+    c->dense_now = c->cold_now = false;             // (the stage calls on this context keep their lists)
     if (rc != SVGF_OK) return bail(rc);
     stamp();
     // the first three frames after a reset have history <= 3 everywhere: the LDS-streaming moments kernel

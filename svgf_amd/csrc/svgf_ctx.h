@@ -57,6 +57,7 @@ struct svgf_ctx {
     bool adaptive_moments = true;          // svgf_set_adaptive_moments
     bool dense_moments = false;            // the frame driver's current choice (hysteresis)
     bool dense_now = false;                // the frame being enqueued is served by the streaming kernel (a cold or a crowded frame)
+    bool cold_now = false;                 // ... it is one of the first three after a reset
     uint32_t* nan_list = nullptr;          // scratch, temporal -> moments: the pixels whose accumulated colour / moments are NaN or inf (kNanListCap entries)
     int young_phase = 0;
     bool young_pending = false;            // a temporal launch wrote the masks / appended to nan_count[young_phase] and no moments launch has consumed them yet

@@ -53,6 +53,8 @@ struct TemporalArgs {
     unsigned* sample_count;      // with young_masks: every 64th wave (hashed) adds the number of its young pixels here, fire and forget — what the frame
     unsigned* sample_prev;       // driver's choice between the young-pixel launch and the streaming kernel goes by (svgf_set_adaptive_moments).  This
     unsigned* estimate_host;     // launch publishes the PREVIOUS frame's sum (sample_prev, then zeroed) in host-mapped memory; all three may be null
+    int sample_off;              // a frame after a reset (every pixel young by construction): publishes, but adds nothing — its sample would say "crowded"
+                                 // two frames later, when nothing is
     int heal_nan;                // svgf_params::nan_policy == SVGF_NAN_ZERO: a NaN channel of the radiance / previous colour / previous moments reads as 0
 };
 struct MomentsArgs {

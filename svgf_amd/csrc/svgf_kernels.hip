@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
             a.young_masks[(size_t)(y - g.y0) * ((g.W + kBX - 1) / kBX) + blockIdx.x] = ym;
         // one wave in 64 (hashed over segment and row: columns and rows of young pixels are sampled like anything else) reports how many it holds
         // (low 20 bits: young pixels; high 12: waves that hold some but not 64 — the ones that append to the list)
-        if (a.sample_count && ym != 0ull && threadIdx.x == 0 && (((unsigned)blockIdx.x * 29u + (unsigned)y * 13u) & 63u) == 0u)
+        if (a.sample_count && !a.sample_off && ym != 0ull && threadIdx.x == 0 && (((unsigned)blockIdx.x * 29u + (unsigned)y * 13u) & 63u) == 0u)
             (void)__hip_atomic_fetch_add(a.sample_count, (unsigned)__builtin_popcountll(ym) + (ym != ~0ull ? 1u << 20 : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.young_list && ym != 0ull && ym != ~0ull) {                 // (no list for a frame the streaming kernel will serve)
             const int lane = threadIdx.x, first = __builtin_ctzll(ym);
