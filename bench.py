@@ -189,7 +189,7 @@ class FramePool:
 
 
 # ------------------------------------------------------------------ single GPU -----------------
-def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, device, cold_frames=0, fuse=False, windows=5, in_flight=1, prime=(400.0, 600), prev_guide=True):
+def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, device, cold_frames=0, fuse=False, windows=5, in_flight=1, prime=(400.0, 600), prev_guide=True, adaptive=True):
     """-> dict(ms_per_step = median over `windows` timed windows of `steps` frames each (sync, K frames, sync), windows_ms, stage_ms[list],
     ms_no_events: one more window without the per-stage HIP events, ...)."""
     import torch
@@ -197,6 +197,7 @@ def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, de
     d = F.Denoiser(W, H, F.Params(storage=storage, steps=iters, variant=variant), device=device.index or 0)
     d.set_iteration_fusion(fuse)
     d.set_frames_in_flight(in_flight)
+    d.set_adaptive_moments(adaptive)
     d.set_prev_guide(prev_guide)   # the pools hand over last frame's current G-buffer, untouched, as `prev` (tests/test_bench_inputs.py): the precondition of svgf_set_prev_guide
     n = 0
     for _ in range(PRIME_FRAMES + warmup):
@@ -717,6 +718,23 @@ def main():
             line.setdefault("also", {})["seven_iterations"] = {"ms_per_step": round(r7["ms_per_step"], 4), "Mpixels/s": round(W * H / (r7["ms_per_step"] * 1e-3) / 1e6, 1),
                                                                "atrous_launch_ms_by_step": {str(1 << i): round(r7["stage_ms"][2 + i], 5) for i in range(7)},
                                                                "note": "temporal + moments + 7 a-trous iterations (steps 1..64), all LDS-streaming launches"}
+        if not args.no_extra and wl == "4k" and args.frames_in_flight == 1 and storage == "f32":
+            # Heavy disocclusion: every 8th column of ONE of the two G-buffers the frames alternate between has its normals flipped, so those columns fail
+            # the reprojection test in every frame (12 % of the surface pixels young, some in EVERY wave of the temporal launch): what thin geometry under
+            # motion or a fast camera does to the young-pixel machinery (tools/young_worst_case.py)
+            import torch
+            cp = FramePool(scene, storage, "static")
+            cp.gb[1].normal.view(torch.int16)[:, ::8, 0:3] ^= -32768
+            crowd = {}
+            for name, ad in (("adaptive", True), ("young_pixel_launch_only", False)):
+                rc = run_single(cp, W, H, storage, iters, args.variant, max(args.steps, 20), args.warmup, device, fuse=fuse, windows=3, prime=(min(args.prime_ms, 150.0), min(args.prime_frames, 200)), adaptive=ad)
+                _, stc = roofline_block(W, H, storage, iters, rc["stage_ms"], args.variant, rc["fused"])
+                crowd[name] = {"ms_per_step": round(rc["ms_per_step"], 4), "temporal_ms": stc["temporal+moments"]["temporal_ms"] if stc else None,
+                               "moments_ms": stc["temporal+moments"]["moments_ms"] if stc else None, "young_fraction": round(rc["young_fraction"], 4)}
+            crowd["note"] = ("every 8th column disoccluded in every frame; adaptive (default): the frame driver serves such frames with the LDS-streaming moments kernel "
+                             "(svgf_set_adaptive_moments: same bits); young_pixel_launch_only: svgf_set_adaptive_moments(0); round 3's sources: 2.6 ms")
+            line.setdefault("also", {})["crowded_frames"] = crowd
+            del cp
         if not args.no_extra and wl == "4k" and args.frames_in_flight == 1:
             line.setdefault("also", {})["interactive"] = run_interactive(FramePool(scene, storage, "static"), W, H, storage, iters, args.variant, device)
         if not args.no_extra and args.variant == "auto" and wl == "4k":

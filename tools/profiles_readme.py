@@ -103,6 +103,10 @@ def main(tag):
             if k == "interactive":
                 notes.append(f"* also `interactive` (one denoise per displayed frame, sum of the stage events): **{v['interleaved_ms']} ms** between a {v['producer_ms']} ms memory-bound producer "
                              f"on the same stream; **{v['isolated_ms']} ms** ({v['isolated_ms_min']}-{v['isolated_ms_max']}) with the device idle for 5 ms between frames.")
+            elif k == "crowded_frames":
+                notes.append(f"* also `crowded_frames` (every 8th column disoccluded in every frame: 12 % of the surface pixels young, some in every wave): **{v['adaptive']['ms_per_step']} ms** per frame "
+                             f"(temporal {v['adaptive']['temporal_ms']}, moments {v['adaptive']['moments_ms']}: the streaming kernel by the sample); with `svgf_set_adaptive_moments(0)` "
+                             f"{v['young_pixel_launch_only']['ms_per_step']} ms (moments {v['young_pixel_launch_only']['moments_ms']}).")
             elif k == "seven_iterations":
                 notes.append(f"* also `seven_iterations` (steps 1..64, all LDS launches): {v['ms_per_step']} ms per frame; a-trous launch by step (ms): {v['atrous_launch_ms_by_step']}.")
             elif "ms_per_step" in v:
