@@ -306,7 +306,8 @@ int svgf_set_prev_guide(svgf_ctx* ctx, int enable);
  * is a few frames old): above 8 % of the frame — or with more waves holding young pixels than the young-pixel list takes appends from (16 384) — the
  * streaming kernel, back below 5 % (and three quarters of that).  Both evaluate the estimate on the same bits, so the choice
  * never shows in the results (finite input; around a NaN texel the two round the luminance term differently, both within the stated tolerance).
- * enable = 0: the young-pixel launch whenever the frame is not one of the first three. */
+ * enable = 0: the young-pixel launch whenever the frame is not one of the first three.  The strip driver's contexts (svgf_strips_context) choose the
+ * same way, every rank for itself: the results do not depend on it. */
 int svgf_set_adaptive_moments(svgf_ctx* ctx, int enable);
 int svgf_adaptive_moments_state(const svgf_ctx* ctx);                  /* 1: the last frame was served by the streaming kernel because of the sample */
 /* the latest sample as the driver reads it (x 64: an estimate of a recent frame's young pixels and of its waves that hold some); SVGF_ERR_INVALID before the first frame */

@@ -350,18 +350,42 @@ bool can_fuse01(const svgf_ctx* c) {
     return c->fuse01 && c->p.steps >= 2 && c->p.variant != SVGF_VARIANT_DIRECT && c->p.phi_normal != 0.0f;
 }
 
+// Which kernel serves this frame's young pixels (frame and strip drivers).  The first three frames after a reset have history <= 3 everywhere: the
+// LDS-streaming kernel, which visits every pixel (0.21 ms per 4K frame, whatever is young).  Afterwards the young-pixel launch, which costs what the
+// young pixels cost (0.005 ms for none, 0.03 under a pan, 0.5 for 12 % of the frame, 1.6 for half of it) — unless a recent frame's SAMPLE of young
+// pixels (temporal_kernel, one wave in 64; read here without synchronising: it is a few frames old) says that more than 8 % of the frame are young
+// (fast camera motion, a cut without a reset; back below 5 %) or that more waves hold young pixels than the list takes appends from (thin geometry
+// under motion; back below three quarters of that: the bench pan's 8 000 - 10 000 such waves must not keep a context there).  Both kernels evaluate
+// the estimate on the same bits (moments_group8, ARITH = 1), so the choice — and the timing it depends on — changes nothing but the frame time; the
+// ranks of a strip driver choose each for itself.  Rows: [c->rb, c->re) as they are when this is called (the temporal rows).
+void choose_moments_kernel(svgf_ctx* c, bool* cold, bool* crowded) {
+    *cold = c->frames_since_reset < 3 && c->p.variant != SVGF_VARIANT_DIRECT;
+    *crowded = false;
+    if (!*cold && c->adaptive_moments && c->estimate_host && c->p.variant != SVGF_VARIANT_DIRECT && c->p.moments_radius == 3 && c->p.phi_normal != 0.0f && c->re > c->rb) {
+        const unsigned sample = *(volatile unsigned*)c->estimate_host;      // {waves that hold some young pixels: 12 bits, young pixels: 20 bits}, of one wave in 64
+        const double est = 64.0 * (double)(sample & 0xfffffu) / ((double)c->W * (double)(c->re - c->rb));
+        const unsigned appends = 64u * (sample >> 20);                      // what the list of such a frame takes (cap: svgf::kYoungAppendCap)
+        if (est > 0.08 || appends > svgf::kYoungAppendCap) c->dense_moments = true;
+        else if (est < 0.05 && appends < svgf::kYoungAppendCap / 4 * 3) c->dense_moments = false;
+        *crowded = c->dense_moments;
+    }
+    c->dense_now = *cold || *crowded;               // (the temporal launch of such a frame appends to no list)
+    c->cold_now = *cold;                            // (... and of a cold one adds nothing to the sample)
+}
+
 int temporal_moments_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, void* filter_out,
                           const svgf_gbuffer* cur, const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur,
-                          void* moments_cur, const void* moments_prev, int mrb, int mre, int feedback_follows, void* guide_out, const void* guide_prev) {
+                          void* moments_cur, const void* moments_prev, int mrb, int mre, int feedback_follows, void* guide_out, const void* guide_prev, int dense) {
     if (!filter_out || filter_out == colour_out) return fail(c, SVGF_ERR_INVALID, "svgf_temporal_moments: filter_out must be a plane of its own");
     const int rb = c->rb, re = c->re;
     if (mrb == -1 && mre == -1) { mrb = rb; mre = re; }
     if (mrb < rb || mre > re || mrb > mre) return fail(c, SVGF_ERR_INVALID, "svgf_temporal_moments: moments rows outside the temporal rows");
     int rc = alloc_flags(c);
     if (rc == SVGF_OK) rc = temporal_impl(c, prev_colour, radiance, colour_out, cur, prev, hist_prev, hist_cur, moments_cur, moments_prev, filter_out, feedback_follows != 0, guide_out, guide_prev);
+    c->dense_now = c->cold_now = false;             // (a driver's choice for THIS frame, choose_moments_kernel: the stage calls keep their lists)
     if (rc != SVGF_OK) return rc;
     c->rb = mrb; c->re = mre;
-    rc = moments_impl(c, colour_out, filter_out, moments_cur, cur, hist_cur, 1, 0, feedback_follows != 0);
+    rc = moments_impl(c, colour_out, filter_out, moments_cur, cur, hist_cur, 1, dense, feedback_follows != 0);
     c->rb = rb; c->re = re;
     return rc;
 }
@@ -779,27 +803,10 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     }
     // With at least one wavelet iteration the temporal result in colour[P] is dead where iteration 0's feedback will
     // overwrite it (:619-622): it is only stored for young pixels (the moments estimate reads them) and depth-0 texels.
-    // Which kernel serves the young pixels.  The first three frames after a reset have history <= 3 everywhere: the LDS-streaming kernel, which
-    // visits every pixel (0.21 ms per 4K frame, whatever is young).  Afterwards the young-pixel launch, which costs what the young pixels cost
-    // (0.005 ms for none, 0.03 under a pan, 0.5 for 12 % of the frame, 1.6 for half of it) — unless a recent frame's SAMPLE of young pixels
-    // (temporal_kernel, one wave in 64; read here without synchronising: it is a few frames old) says that more than 8 % of the frame are young
-    // (fast camera motion, a cut without a reset; back below 5 %) or that more waves hold young pixels than the list takes appends from (thin
-    // geometry under motion; back below three quarters of that: the bench pan's ~4 500 such waves must not keep a context there).  Both kernels evaluate the estimate on the same bits (moments_group8,
-    // ARITH = 1), so the choice — and the timing it depends on — changes nothing but the frame time.
-    const bool cold = c->frames_since_reset < 3 && c->p.variant != SVGF_VARIANT_DIRECT;
-    bool crowded = false;
-    if (!cold && c->adaptive_moments && c->estimate_host && c->p.variant != SVGF_VARIANT_DIRECT && c->p.moments_radius == 3 && c->p.phi_normal != 0.0f && c->re > c->rb) {
-        const unsigned sample = *(volatile unsigned*)c->estimate_host;      // {waves that hold some young pixels: 12 bits, young pixels: 20 bits}, of one wave in 64
-        const double est = 64.0 * (double)(sample & 0xfffffu) / ((double)c->W * (double)(c->re - c->rb));
-        const unsigned appends = 64u * (sample >> 20);                      // what the list of such a frame takes (cap: svgf::kYoungAppendCap)
-        if (est > 0.08 || appends > svgf::kYoungAppendCap) c->dense_moments = true;
-        else if (est < 0.05 && appends < svgf::kYoungAppendCap / 4 * 3) c->dense_moments = false;
-        crowded = c->dense_moments;
-    }
+    bool cold = false, crowded = false;
+    choose_moments_kernel(c, &cold, &crowded);
     // (a crowded frame keeps every pixel's temporal colour: the streaming kernel reads its taps from one plane)
     const int sparse = c->p.steps >= 1 && !crowded;
-    c->dense_now = cold || crowded;                  // (the temporal launch of such a frame appends to no list)
-    c->cold_now = cold;                              // (... and of a cold one adds nothing to the sample)
     // The temporal launch also writes the filter buffer where history >= 4 (there FilterMoments is a copy), the
     // moments launch then only works on young pixels: same planes, 32 B/px less traffic in steady state.
     // ... and repacks what the wavelet iterations read of the G-buffer ({depth, ddepth, normal}: 16 B instead of 24 B of lines per

@@ -117,7 +117,8 @@ int join_side(svgf_ctx* c, hipStream_t onto);   // `onto` waits for the frame in
 int temporal_moments_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, void* colour_out, void* filter_out,
                           const svgf_gbuffer* cur, const svgf_gbuffer* prev, const uint8_t* hist_prev, uint8_t* hist_cur,
                           void* moments_cur, const void* moments_prev, int mrb, int mre, int feedback_follows, void* guide_out = nullptr,
-                          const void* guide_prev = nullptr);
+                          const void* guide_prev = nullptr, int dense = 0);
+void choose_moments_kernel(svgf_ctx* c, bool* cold, bool* crowded);   // frame / strip drivers, before the temporal launch of a frame (svgf_api.hip)
 int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration, const void* guide = nullptr);
 // iterations 0 and 1 in one launch on rows [c->rb, c->re) (iteration 1's; iteration 0 and the feedback store cover 4 more rows either side)
 int atrous_pair_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, const void* guide = nullptr);

@@ -470,8 +470,11 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
         void* guide = use_guide(c) ? c->guide : nullptr;      // as svgf_denoise_frame: the temporal launch repacks {depth, ddepth, normal} for the iterations
         const void* guide_prev = prev_guide_for(c, &cur[k], pv);   // the previous frame's guide plane stands in for its G-buffer (all held rows)
         c->guide_prev_valid = false;                               // until this frame has written its own (commit_guide below)
+        // which kernel serves the strip's young pixels (svgf_api.hip: every rank chooses for itself, the results do not depend on it)
+        bool cold = false, crowded = false;
+        choose_moments_kernel(c, &cold, &crowded);
         int rc = temporal_moments_impl(c, c->colour[1 - P], radiance[k], c->colour[P], c->filter[0], &cur[k], pv, c->hist[1 - P], c->hist[P],
-                                       c->moments[P], c->moments[1 - P], rm.a, rm.b, s->steps >= 1, guide, guide_prev);
+                                       c->moments[P], c->moments[1 - P], rm.a, rm.b, s->steps >= 1 && !crowded, guide, guide_prev, cold || crowded);
         // (the temporal launch also writes the guide texels of the rows the strip holds beyond the temporal rows: the a-trous halos
         // of the later iteration groups and the next frame's reprojection read them)
         if (rc != SVGF_OK) return sfail(s, rc, c->err);

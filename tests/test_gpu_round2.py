@@ -74,6 +74,42 @@ def test_native_strip_driver_over_rccl_loopback(G, loop_comm, plan, storage):
     drv.close()
 
 
+def test_native_strip_driver_on_crowded_frames(G, loop_comm):
+    """Every 8th column disoccluded in every frame from frame 3 on (12 % of the surface pixels young): each rank's sample says "crowded" two
+    frames later and the rank serves its strip's young pixels with the LDS-streaming kernel (choose_moments_kernel: every rank for itself).
+    Every frame still equals the single-context stage sequence bit for bit."""
+    import torch
+    from svgf_amd import filter as F
+    from svgf_amd import strips
+    W, H, world, N, storage = 512, 420, 3, 10, "f32"
+    fr = frames(W, H, 2, mv=(0.0, 0.0))
+    flipped = fr[0]["normal"].copy()
+    flipped.view(np.int16)[:, ::8, 0:3] ^= np.int16(-32768)
+    variants = [dict(fr[0]), dict(fr[0], normal=flipped)]                 # the two G-buffers the crowded frames alternate between
+    frame_of = lambda k: dict(variants[k % 2] if k >= 3 else variants[0], radiance=fr[k % 2]["radiance"])      # noqa: E731
+    params = F.Params(storage=storage, steps=5)
+    whole = G.HipPipeline(W, H, storage, steps=5)
+    side = torch.cuda.Stream(priority=-1)
+    drv = strips.NativeStrips(W, H, world, params, list(range(world)), [0] * world, streams=[side.cuda_stream] * world, comms=[loop_comm],
+                              plan="ghost", motion_reach=3, loopback=True)
+    torch.cuda.synchronize()
+    prev_in, prev_gb, crowded = None, None, []
+    for k in range(N):
+        f = frame_of(k)
+        gb = G.gb_dev(f)
+        want = whole.frame(f["radiance"], gb, prev_gb if prev_gb is not None else gb)
+        torch.cuda.synchronize()
+        cur_in = [_strip_inputs(G, f, lay, storage) for lay in drv.layouts]
+        outs = drv.frame([c[0] for c in cur_in], [c[1] for c in cur_in], [p[1] for p in prev_in] if prev_in else None)
+        drv.sync()
+        got = np.concatenate([G.host(drv.owned(r, o)) for r, o in enumerate(outs)], 0)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), f"frame {k}"
+        crowded.append([bool(drv.lib.svgf_adaptive_moments_state(drv.lib.svgf_strips_context(drv._h, r))) for r in range(world)])
+        prev_in, prev_gb = cur_in, gb
+    assert not any(crowded[3]) and all(crowded[-1]), crowded
+    drv.close()
+
+
 @pytest.mark.parametrize("plan", ["per-iteration", "grouped", "ghost"])
 def test_native_strip_driver_with_two_frames_in_flight(G, loop_comm, plan):
     """svgf_strips_set_frames_in_flight(2): iterations 1.. of a frame — their halo exchanges included — on a side stream of every
