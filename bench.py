@@ -550,19 +550,36 @@ def emit(line):
 
 
 # ------------------------------------------------------------------ launcher for N > 1 ---------
+def free_port():
+    """A rendezvous port nobody listens on, BELOW the kernel's ephemeral range (32768-60999 on Linux): a port handed out by bind(0) comes from
+    that range, where the local end of any outgoing connection of any process may take it between this test and the rendezvous (seen as one
+    failed N > 1 test in ~25 runs of the suite)."""
+    import random
+    import socket
+    rng = random.Random(os.getpid() ^ int(time.time() * 1e3))
+    for _ in range(200):
+        port = rng.randrange(20000, 32000)
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", port))
+                return port
+            except OSError:
+                continue
+    with socket.socket() as s:                   # (nothing free there: whatever the kernel offers)
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N rank processes (fresh interpreters, before anything in
     this process has touched the GPU), hand rank 0's JSON line through, fail if any rank fails."""
-    import socket
     import torch
     have = torch.cuda.device_count()          # does not initialise the GPU
     share = os.environ.get("SVGF_BENCH_SHARE_DEVICES") == "1"      # testing only: N ranks on fewer devices (process group: gloo, see main)
     if have < args.gpus and not (share and have >= 1):
         print(f"bench.py: --gpus {args.gpus} but only {have} device(s) are visible", file=sys.stderr)
         return 2
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % have if share else r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
@@ -608,10 +625,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:           # single process (--strips): any free port
-            import socket
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ["MASTER_PORT"] = str(free_port())
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         # SVGF_BENCH_SHARE_DEVICES=1 (testing the N > 1 flow on a box with fewer GPUs): RCCL refuses two ranks on one device, so the

@@ -512,8 +512,8 @@ def test_bench_refuses_a_silent_change_of_driver():
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "1080p", "--no-extra", "--no-one-gpu", "--prime-ms", "0", "--prime-frames", "0"],
                        env=env, capture_output=True, text=True, timeout=500)
-    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert "--driver python" in p.stderr
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")], (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+    assert "--driver python" in p.stderr, p.stderr[-2000:]
 
 
 def test_bench_strips_line_on_one_gpu(G):

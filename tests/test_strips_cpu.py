@@ -72,11 +72,8 @@ def test_virtual_ranks_bit_identical(oracle, plan, storage):
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    import bench
+    return bench.free_port()             # (below the ephemeral range: see there)
 
 
 def _gloo_worker(rank, world, port, W, H, N, plan, storage, q):
