@@ -98,7 +98,7 @@ int alloc_flags(svgf_ctx* c) {
     const size_t nmasks = (size_t)c->strip.rows * ((c->W + 63) / 64);
     hipError_t e = hipMalloc((void**)&c->young_masks, nmasks * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemsetAsync(c->young_masks, 0, nmasks * sizeof(unsigned long long), c->stream);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->young_list, std::min((size_t)c->strip.rows * c->W, svgf::kYoungListEntries) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->young_list, std::min((size_t)c->strip.rows * c->W, svgf::young_list_entries(c->strip.rows, c->W)) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&c->young_count, 2 * svgf::kYoungCounterStride * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemsetAsync(c->young_count, 0, 2 * svgf::kYoungCounterStride * sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) e = hipMalloc((void**)&c->nan_count, 2 * sizeof(unsigned));
@@ -257,7 +257,7 @@ int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, vo
                          c->p.depth_threshold, c->p.normal_threshold, c->p.history_base, c->p.mesh_id_test, passthrough_out,
                          passthrough_out ? c->young_masks : nullptr, passthrough_out && !c->dense_now ? c->young_list : nullptr,
                          passthrough_out ? c->young_count + c->young_phase * svgf::kYoungCounterStride : nullptr,
-                         passthrough_out ? c->young_count + (c->young_phase ^ 1) * svgf::kYoungCounterStride : nullptr,
+                         passthrough_out ? c->young_count + (c->young_phase ^ 1) * svgf::kYoungCounterStride : nullptr, svgf::young_append_cap(c->strip.rows, c->W),
                          sparse_colour, c->p.phi_normal > 0.0f, c->halo_violations,
                          std::max(c->vy0, c->strip.y0) - c->strip.y0, std::min(c->vy1, c->strip.y0 + c->strip.rows) - c->strip.y0, (uint4*)guide_out,
                          (const uint4*)guide_prev,
@@ -281,7 +281,7 @@ int moments_impl(svgf_ctx* c, const void* colour, void* out, const void* moments
     if (rc != SVGF_OK) return rc;
     svgf::MomentsArgs a{colour, out, moments, (const float4*)g->motion, (const uint2*)g->normal, hist,
                         c->p.phi_colour, c->p.phi_normal, c->p.moments_radius, cold_only, dense, sparse_colour,
-                        cold_only ? c->young_masks : nullptr, cold_only ? c->young_list : nullptr, cold_only ? c->young_count + c->young_phase * svgf::kYoungCounterStride : nullptr,
+                        cold_only ? c->young_masks : nullptr, cold_only ? c->young_list : nullptr, cold_only ? c->young_count + c->young_phase * svgf::kYoungCounterStride : nullptr, svgf::young_append_cap(c->strip.rows, c->W),
                         cold_only ? c->nan_list : nullptr, cold_only ? c->nan_count + c->young_phase : nullptr,
                         c->p.variant == SVGF_VARIANT_LDS_GENERAL};
     if (c->re <= c->rb) {
@@ -364,9 +364,9 @@ void choose_moments_kernel(svgf_ctx* c, bool* cold, bool* crowded) {
     if (!*cold && c->adaptive_moments && c->estimate_host && c->p.variant != SVGF_VARIANT_DIRECT && c->p.moments_radius == 3 && c->p.phi_normal != 0.0f && c->re > c->rb) {
         const unsigned sample = *(volatile unsigned*)c->estimate_host;      // {waves that hold some young pixels: 12 bits, young pixels: 20 bits}, of one wave in 64
         const double est = 64.0 * (double)(sample & 0xfffffu) / ((double)c->W * (double)(c->re - c->rb));
-        const unsigned appends = 64u * (sample >> 20);                      // what the list of such a frame takes (cap: svgf::kYoungAppendCap)
-        if (est > 0.08 || appends > svgf::kYoungAppendCap) c->dense_moments = true;
-        else if (est < 0.05 && appends < svgf::kYoungAppendCap / 4 * 3) c->dense_moments = false;
+        const unsigned appends = 64u * (sample >> 20), cap = svgf::young_append_cap(c->strip.rows, c->W);   // what the list of such a frame takes, and its cap
+        if (est > 0.08 || appends > cap) c->dense_moments = true;
+        else if (est < 0.05 && appends < cap / 4 * 3) c->dense_moments = false;
         *crowded = c->dense_moments;
     }
     c->dense_now = *cold || *crowded;               // (the temporal launch of such a frame appends to no list)

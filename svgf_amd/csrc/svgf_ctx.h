@@ -49,7 +49,7 @@ struct svgf_ctx {
     bool in_flight = false;                // a frame's tail is on `side` and `stream` has not been made to wait for it yet
     unsigned long long in_flight_capture = 0;   // ... and the stream capture that tail was recorded in (0: none; svgf.h, Stream capture)
     unsigned long long* young_masks = nullptr;   // scratch, temporal -> moments: per (row, 64-column segment) the lanes whose pixel (history < 4) needs the spatial estimate
-    uint32_t* young_list = nullptr;        // ... and the indices of the pixels of the partly young segments (svgf::kYoungListEntries)
+    uint32_t* young_list = nullptr;        // ... and the indices of the pixels of the partly young segments (svgf::young_list_entries)
     unsigned long long* young_count = nullptr;   // ... two {appends, pixels} counters used in turn (the temporal launch of a frame zeroes the next frame's)
     unsigned* nan_count = nullptr;         // two device counters of nan_list used in turn (the temporal launch of a frame zeroes the next frame's)
     unsigned* sample_count = nullptr;      // two device counters (128 B apart) used in turn: the sampled number of young pixels of a frame (TemporalArgs::sample_count)

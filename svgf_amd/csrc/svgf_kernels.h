@@ -11,13 +11,17 @@ struct Geo { int W, H, y0, rows, yb, ye; };
 // The list of pixels whose temporal result is not finite holds at most kNanListCap entries (more than that and the moments launch goes over
 // every pixel instead); its two counters are used in turn, frame by frame.
 constexpr unsigned kNanListCap = 1u << 16;
-// The young-pixel list takes at most kYoungAppendCap appends (one per wave that holds SOME young pixels; same-address atomics retire at ~11 ns each
-// on this part: the bench pan's 8 000 - 10 000 of them are 0.1 ms spread over a 0.19 ms launch — unseen —, 130 000 made it a 1.39 ms one).  A frame
-// with more such waves — thin geometry under motion: every wave holds a few young pixels — stops appending (a few thousand waves late: those already
-// past the test when the cap is reached), and the moments launch works from the per-segment lane masks instead.  Its counter is 64 bits:
-// {appends, pixels}.
-constexpr unsigned kYoungAppendCap = 16384;
-constexpr size_t kYoungListEntries = (size_t)kYoungAppendCap * 63;
+// The young-pixel list takes a bounded number of appends per frame (one per wave that holds SOME young pixels): same-address atomics retire at
+// ~11 ns each on this part, and what a temporal launch hides of them is proportional to its own length — the bench pan's 8 000 - 10 000 are
+// 0.1 ms spread over a 0.19 ms 4K launch, unseen; 130 000 made it a 1.39 ms one.  The cap is one eighth of the waves of the rows the context
+// holds (4K: 16 200).  A frame with more such waves — thin geometry under motion: every wave holds a few young pixels — stops appending (a few
+// thousand waves late: those already past the test when the cap is reached), and the moments launch works from the per-segment lane masks
+// instead.  The counter is 64 bits: {appends, pixels}.
+inline unsigned young_append_cap(int rows, int W) {
+    const long long waves = (long long)rows * ((W + 63) / 64);
+    return (unsigned)(waves / 8 > 1024 ? waves / 8 : 1024);
+}
+inline size_t young_list_entries(int rows, int W) { return (size_t)young_append_cap(rows, W) * 63; }
 // "The cap is reached" is a word of its own, 128 bytes behind its counter: a wave reads THAT before it appends — a load of the counter's own
 // line between the atomics makes each of them cost 50 instead of 11 ns (tools/ubench/atomic_one_address.hip), a load of a line nobody
 // writes is free.  A context holds two {counter, flag} pairs, kYoungCounterStride 64-bit words apart.
@@ -34,7 +38,8 @@ struct TemporalArgs {
                              // 64-column segment), stored by the wave that computes the segment ...
     uint32_t* young_list;    // ... and, for the waves that hold SOME young pixels (disocclusions are sparse: frame borders under a pan, silhouettes),
     unsigned long long* young_count;        // their local indices (row * W + x) appended to a list: one 64-bit atomic per wave on {appends, pixels}, at most
-    unsigned long long* young_count_next;   // kYoungAppendCap of them per frame (above).  The OTHER counter of the context's pair is zeroed by this launch.
+    unsigned long long* young_count_next;   // young_cap of them per frame (above).  The OTHER counter of the context's pair is zeroed by this launch.
+    unsigned young_cap;
     int sparse_colour;       // with passthrough_out and >= 1 a-trous iteration: colour_out is only stored where the iteration-0 feedback
                              // will not overwrite it or the moments estimate reads it (young pixels, depth-0 texels)
     int sky_zero;            // with passthrough_out: PhiNormal > 0, so a young pixel with an all-zero normal filters to exactly 0 (written here)
@@ -66,6 +71,7 @@ struct MomentsArgs {
     const unsigned long long* young_masks;   // with cold_only: TemporalArgs::young_masks / young_list / young_count of the same frame — only those pixels are visited
     const uint32_t* young_list;
     const unsigned long long* young_count;
+    unsigned young_cap;
     const uint32_t* nan_list;     // TemporalArgs::nan_list / nan_count of the same frame
     const unsigned* nan_count;
     int no_fastpath;              // SVGF_VARIANT_LDS_GENERAL: the LDS-streaming kernel without its uniform-normal form (bit-identical, slower)

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
     // mask; a wave that holds SOME young pixels also appends their indices to a list, one atomic per wave (disocclusions are sparse: frame
     // borders under a pan, silhouettes) — the list is dense in young pixels, so the moments launch spreads them evenly over its waves
     // however they are spread over the frame.  A wave whose 64 pixels are ALL young appends nothing (its mask says it all: after a reset every
-    // wave is one), and no wave appends once kYoungAppendCap have (svgf_kernels.h: the moments launch then works from the masks alone).
+    // wave is one), and no wave appends once young_cap have (svgf_kernels.h: the moments launch then works from the masks alone).
     if (a.young_masks) {
         const bool listed = young && !zero_young;
         const unsigned long long ym = __ballot(listed);
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
             unsigned base = ~0u;
             if (lane == first && __hip_atomic_load(a.young_count + kYoungFlagOffset, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) {
                 const unsigned long long old = atomicAdd(a.young_count, (1ull << 32) | (unsigned long long)__builtin_popcountll(ym));
-                if ((unsigned)(old >> 32) < kYoungAppendCap) base = (unsigned)old;       // (appends 0 .. cap-1 own their entries: < cap x 63 pixels)
+                if ((unsigned)(old >> 32) < a.young_cap) base = (unsigned)old;       // (appends 0 .. cap-1 own their entries: < cap x 63 pixels)
                 else __hip_atomic_store(a.young_count + kYoungFlagOffset, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             base = __shfl(base, first);
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a
     const int first = (g.yb - g.y0) * nseg, last = (g.ye - g.y0) * nseg;             // mask range of the launch rows
     if ((int)blockIdx.x >= scan_blocks) {
         const unsigned long long counted = *a.young_count;
-        if ((unsigned)(counted >> 32) < kYoungAppendCap) {
+        if ((unsigned)(counted >> 32) < a.young_cap) {
             const unsigned list_blocks = gridDim.x - (unsigned)scan_blocks, b = blockIdx.x - (unsigned)scan_blocks;
             const unsigned n = (unsigned)counted, ngroups = (n + 7u) / 8u;
             for (unsigned grp = b + list_blocks * (unsigned)w; grp < ngroups; grp += list_blocks * 4u) {
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a
         for (int base = first; base + bid < last; base += nslots * 256) {    // (uniform over the workgroup)
             const int sidx = base + t * nslots + bid;
             unsigned long long m = sidx < last ? a.young_masks[sidx] : 0ull;          // (requested together with the counter: one memory round)
-            const bool overflow = (unsigned)(*a.young_count >> 32) >= kYoungAppendCap;   // (uniform over the launch)
+            const bool overflow = (unsigned)(*a.young_count >> 32) >= a.young_cap;   // (uniform over the launch)
             if (!overflow) {
                 // the all-young segments of the slot; each of the slot's 4 F waves takes 8 / F octants of every one
                 const unsigned long long fm = __ballot(m == ~0ull);
