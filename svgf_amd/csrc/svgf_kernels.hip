@@ -505,7 +505,7 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long m, int r) {
 }
 
 template <int ST, int ARITH>
-__global__ __launch_bounds__(256) void moments_young_kernel(Geo g, MomentsArgs a, int scan_blocks) {
+__global__ __launch_bounds__(256, 3) void moments_young_kernel(Geo g, MomentsArgs a, int scan_blocks) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = threadIdx.x;
     __shared__ unsigned long long full[4];
     __shared__ unsigned long long smask[256];       // over the cap only: the slot's masks ...
