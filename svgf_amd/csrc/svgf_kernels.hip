@@ -479,17 +479,18 @@ __global__ __launch_bounds__(kBX* kBY) void moments3x3_shfl_kernel(Geo g, Moment
 
 // Steady state inside the frame driver: the temporal launch already copied every pixel with history >= 4 and told this launch where
 // the young ones are: one 64-bit lane mask per (row, 64-column segment), and the LIST of the pixels of the partly young segments.
-// All are served by moments_group8, eight pixels per wave-pass — a launch of a few thousand passes, bound by their latency: it wants them
-// spread over all resident waves, one each.
+// All are served by moments_group8, eight pixels per wave-pass — a launch of a few thousand passes (their gathering loads: the L1s' lookup
+// rate is its bound) that wants them spread over all resident waves, one each: 168 registers, three waves per SIMD (tests/test_kernel_budgets.py).
 //  * List workgroups: eight consecutive entries per pass, group g to wave g mod (waves).
 //  * Scan workgroups: 256 masks each (segment s belongs to scan slot s mod (scan_blocks / 2): a row of all-young segments — the rows that
 //    have just entered the frame under a vertical pan — spreads over as many slots); the segments whose mask is FULL are shared through LDS
 //    as four ballots, and the eight waves of the slot's TWO workgroups take one eighth of each.  Scan workgroups come first in the grid:
 //    theirs are the longer chains.
-//  * A frame whose list is over its cap (svgf_kernels.h; thin geometry under motion, or half the frame disoccluded): the list is ignored,
-//    a scan workgroup compacts the young pixels of ITS 256 masks into a list in LDS and its waves take eight entries per pass.
+//  * A frame whose list is over its cap (svgf_kernels.h; thin geometry under motion, or half the frame disoccluded — for the frame or two
+//    until the frame driver's sample sends such frames to the streaming kernel): the list is ignored, the slot's workgroups turn their 256
+//    masks into items {segment, eight of its young pixels} in LDS and their waves take the items in turn.
 // (Bench pan, ~28 000 listed pixels + ~300 all-young segments per 4K frame: 0.051 ms in round 2, 0.034 in round 3 (eight lanes per pixel,
-// two workgroups per slot), 0.028 now (the window loads of a pass in ONE memory round, not eight); nothing young: 0.007 ms.)
+// two workgroups per slot), 0.030 now (the window loads of a pass in ONE memory round, not eight); nothing young: 0.006 ms by the trace.)
 constexpr int kScanSplit = 2;
 
 // position of the r-th (0-based) set bit of m; r < popcount(m)
