@@ -303,7 +303,7 @@ int svgf_set_prev_guide(svgf_ctx* ctx, int enable);
  * over the young pixels alone (what they cost: 0.005 ms per 4K frame for none, 0.03 under a pan, 0.5 for 12 % of the frame, 1.6 for half of it) or the
  * LDS-streaming kernel over every pixel (0.21 ms whatever is young; always for the first three frames after a reset).  With enable = 1 (default)
  * the driver goes by a sample of the young pixels of a recent frame, which the temporal launch leaves in host-mapped memory (no synchronisation: it
- * is a few frames old): above 8 % of the frame — or with more waves holding young pixels than the young-pixel list takes appends from (one eighth of the frame's waves: 16 200 at 4K) — the
+ * is a few frames old): above 8 % of the frame — or with more waves holding young pixels than the young-pixel list takes appends from (a quarter of the frame's waves: 32 400 at 4K) — the
  * streaming kernel, back below 5 % (and three quarters of that).  Both evaluate the estimate on the same bits, so the choice
  * never shows in the results (finite input; around a NaN texel the two round the luminance term differently, both within the stated tolerance).
  * enable = 0: the young-pixel launch whenever the frame is not one of the first three.  The strip driver's contexts (svgf_strips_context) choose the

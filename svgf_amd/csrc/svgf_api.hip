@@ -98,7 +98,7 @@ int alloc_flags(svgf_ctx* c) {
     const size_t nmasks = (size_t)c->strip.rows * ((c->W + 63) / 64);
     hipError_t e = hipMalloc((void**)&c->young_masks, nmasks * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemsetAsync(c->young_masks, 0, nmasks * sizeof(unsigned long long), c->stream);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->young_list, std::min((size_t)c->strip.rows * c->W, svgf::young_list_entries(c->strip.rows, c->W)) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->young_list, svgf::young_list_entries(c->strip.rows, c->W) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&c->young_count, 2 * svgf::kYoungCounterStride * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemsetAsync(c->young_count, 0, 2 * svgf::kYoungCounterStride * sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) e = hipMalloc((void**)&c->nan_count, 2 * sizeof(unsigned));

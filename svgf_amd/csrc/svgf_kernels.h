@@ -11,21 +11,25 @@ struct Geo { int W, H, y0, rows, yb, ye; };
 // The list of pixels whose temporal result is not finite holds at most kNanListCap entries (more than that and the moments launch goes over
 // every pixel instead); its two counters are used in turn, frame by frame.
 constexpr unsigned kNanListCap = 1u << 16;
-// The young-pixel list takes a bounded number of appends per frame (one per wave that holds SOME young pixels): same-address atomics retire at
-// ~11 ns each on this part, and what a temporal launch hides of them is proportional to its own length — the bench pan's 8 000 - 10 000 are
-// 0.1 ms spread over a 0.19 ms 4K launch, unseen; 130 000 made it a 1.39 ms one.  The cap is one eighth of the waves of the rows the context
-// holds (4K: 16 200).  A frame with more such waves — thin geometry under motion: every wave holds a few young pixels — stops appending (a few
-// thousand waves late: those already past the test when the cap is reached), and the moments launch works from the per-segment lane masks
-// instead.  The counter is 64 bits: {appends, pixels}.
+// The young-pixel list takes a bounded number of appends per frame (one per wave that holds SOME young pixels).  Same-address atomics retire at
+// ~11 ns each on this part (tools/ubench/atomic_one_address.hip), one after the other: the bench pan's 8 000 - 10 000 such waves are 0.1 ms spread
+// over a 0.19 ms 4K launch — unseen — but its 4 500 at 1080p are 0.05 ms in a 0.043 ms launch, and a frame in which every wave holds a young pixel
+// made the 4K launch a 1.39 ms one.  So: the list is kYoungShards lists with a counter each on a line of its own (a workgroup's waves go to shard
+// (blockIdx.x + blockIdx.y) mod kYoungShards: a column and a row of such waves both spread over all of them), and each takes at most an eighth of
+// young_append_cap = a quarter of the waves of the rows the context holds (4K: 32 400).  A frame with more — thin geometry under motion — stops
+// appending (a few thousand waves late: those already past the test when a shard's cap is reached), and the moments launch works from the per-
+// segment lane masks instead.  A counter is 64 bits: {appends, pixels}.
+constexpr int kYoungShards = 8;
 inline unsigned young_append_cap(int rows, int W) {
     const long long waves = (long long)rows * ((W + 63) / 64);
-    return (unsigned)(waves / 8 > 1024 ? waves / 8 : 1024);
+    const long long cap = waves / 4 > 1024 ? waves / 4 : 1024;
+    return (unsigned)(cap / kYoungShards * kYoungShards);
 }
-inline size_t young_list_entries(int rows, int W) { return (size_t)young_append_cap(rows, W) * 63; }
-// "The cap is reached" is a word of its own, 128 bytes behind its counter: a wave reads THAT before it appends — a load of the counter's own
-// line between the atomics makes each of them cost 50 instead of 11 ns (tools/ubench/atomic_one_address.hip), a load of a line nobody
-// writes is free.  A context holds two {counter, flag} pairs, kYoungCounterStride 64-bit words apart.
-constexpr int kYoungFlagOffset = 16, kYoungCounterStride = 32;
+inline size_t young_list_entries(int rows, int W) { return (size_t)young_append_cap(rows, W) * 63; }   // shard s: entries [s, s + 1) x cap / kYoungShards x 63
+// "A cap is reached" is a word of its own: a wave reads THAT before it appends — a load of a counter's own line between the atomics makes each of
+// them cost 50 instead of 11 ns, a load of a line nobody writes is free.  A context holds two sets {kYoungShards counters, flag}, each word on a
+// 128-byte line of its own: counter s at s * kYoungLine, the flag at kYoungFlagOffset, the sets kYoungCounterStride 64-bit words apart.
+constexpr int kYoungLine = 16, kYoungFlagOffset = kYoungShards * kYoungLine, kYoungCounterStride = (kYoungShards + 1) * kYoungLine;
 
 struct TemporalArgs {
     const void* prev_colour; const void* radiance; void* colour_out;

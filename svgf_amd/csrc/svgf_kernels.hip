@@ -42,7 +42,9 @@ template <int ST>
 __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs a) {
     keep_nan_in_clamps();                                             // imageLoad / imageStore keep a NaN (svgf_device.h)
     if (a.young_masks && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) {
-        a.young_count_next[0] = 0ull; a.young_count_next[kYoungFlagOffset] = 0ull; a.nan_count_next[0] = 0u;
+#pragma unroll
+        for (int sh = 0; sh <= kYoungShards; sh++) a.young_count_next[sh * kYoungLine] = 0ull;                 // (the counters and the flag)
+        a.nan_count_next[0] = 0u;
         if (a.sample_count) {                       // last frame's sample is final: to the host (no answer awaited), and its counter starts again
             __hip_atomic_store(a.estimate_host, a.sample_prev[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             a.sample_prev[0] = 0u;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
     // mask; a wave that holds SOME young pixels also appends their indices to a list, one atomic per wave (disocclusions are sparse: frame
     // borders under a pan, silhouettes) — the list is dense in young pixels, so the moments launch spreads them evenly over its waves
     // however they are spread over the frame.  A wave whose 64 pixels are ALL young appends nothing (its mask says it all: after a reset every
-    // wave is one), and no wave appends once young_cap have (svgf_kernels.h: the moments launch then works from the masks alone).
+    // wave is one), and no wave appends once a shard of the list is full (svgf_kernels.h: the moments launch then works from the masks alone).
     if (a.young_masks) {
         const bool listed = young && !zero_young;
         const unsigned long long ym = __ballot(listed);
@@ -161,9 +163,10 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
         if (a.young_list && ym != 0ull && ym != ~0ull) {                 // (no list for a frame the streaming kernel will serve)
             const int lane = threadIdx.x, first = __builtin_ctzll(ym);
             unsigned base = ~0u;
+            const unsigned shard = (blockIdx.x + blockIdx.y) % kYoungShards, shard_cap = a.young_cap / kYoungShards;
             if (lane == first && __hip_atomic_load(a.young_count + kYoungFlagOffset, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) {
-                const unsigned long long old = atomicAdd(a.young_count, (1ull << 32) | (unsigned long long)__builtin_popcountll(ym));
-                if ((unsigned)(old >> 32) < a.young_cap) base = (unsigned)old;       // (appends 0 .. cap-1 own their entries: < cap x 63 pixels)
+                const unsigned long long old = atomicAdd(a.young_count + shard * kYoungLine, (1ull << 32) | (unsigned long long)__builtin_popcountll(ym));
+                if ((unsigned)(old >> 32) < shard_cap) base = shard * shard_cap * 63u + (unsigned)old;       // (appends 0 .. cap-1 own their entries: < cap x 63 pixels)
                 else __hip_atomic_store(a.young_count + kYoungFlagOffset, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             base = __shfl(base, first);
@@ -515,14 +518,24 @@ __global__ __launch_bounds__(256, 3) void moments_young_kernel(Geo g, MomentsArg
     const int nseg = (g.W + kBX - 1) / kBX;
     const int first = (g.yb - g.y0) * nseg, last = (g.ye - g.y0) * nseg;             // mask range of the launch rows
     if ((int)blockIdx.x >= scan_blocks) {
-        const unsigned long long counted = *a.young_count;
-        if ((unsigned)(counted >> 32) < a.young_cap) {
+        if (a.young_count[kYoungFlagOffset] == 0ull) {          // no shard over its cap: the lists are complete
             const unsigned list_blocks = gridDim.x - (unsigned)scan_blocks, b = blockIdx.x - (unsigned)scan_blocks;
-            const unsigned n = (unsigned)counted, ngroups = (n + 7u) / 8u;
-            for (unsigned grp = b + list_blocks * (unsigned)w; grp < ngroups; grp += list_blocks * 4u) {
-                const unsigned i = grp * 8u + ((unsigned)lane >> 3);
-                const bool valid = i < n;
-                moments_group8<ST, ARITH>(g, a, valid, valid ? a.young_list[i] : 0u);
+            // groups of eight entries, shard after shard: [first[s], first[s + 1])
+            unsigned n[kYoungShards], first_grp[kYoungShards + 1];
+            first_grp[0] = 0u;
+#pragma unroll
+            for (int sh = 0; sh < kYoungShards; sh++) { n[sh] = (unsigned)a.young_count[sh * kYoungLine]; first_grp[sh + 1] = first_grp[sh] + (n[sh] + 7u) / 8u; }
+            const unsigned region = a.young_cap / kYoungShards * 63u;
+            for (unsigned grp = b + list_blocks * (unsigned)w; grp < first_grp[kYoungShards]; grp += list_blocks * 4u) {     // (uniform over the wave)
+                unsigned sh = 0u;
+#pragma unroll
+                for (int q = 1; q < kYoungShards; q++) sh += grp >= first_grp[q] ? 1u : 0u;
+                unsigned f0 = 0u, ns = 0u;
+#pragma unroll
+                for (int q = 0; q < kYoungShards; q++) { if (sh == (unsigned)q) { f0 = first_grp[q]; ns = n[q]; } }
+                const unsigned i = (grp - f0) * 8u + ((unsigned)lane >> 3);
+                const bool valid = i < ns;
+                moments_group8<ST, ARITH>(g, a, valid, valid ? a.young_list[sh * region + i] : 0u);
             }
         }
     } else {
@@ -531,7 +544,7 @@ __global__ __launch_bounds__(256, 3) void moments_young_kernel(Geo g, MomentsArg
         for (int base = first; base + bid < last; base += nslots * 256) {    // (uniform over the workgroup)
             const int sidx = base + t * nslots + bid;
             unsigned long long m = sidx < last ? a.young_masks[sidx] : 0ull;          // (requested together with the counter: one memory round)
-            const bool overflow = (unsigned)(*a.young_count >> 32) >= a.young_cap;   // (uniform over the launch)
+            const bool overflow = a.young_count[kYoungFlagOffset] != 0ull;           // (uniform over the launch)
             if (!overflow) {
                 // the all-young segments of the slot; each of the slot's 4 F waves takes 8 / F octants of every one
                 const unsigned long long fm = __ballot(m == ~0ull);

@@ -264,7 +264,7 @@ def test_frame_driver_equals_stage_calls(G, storage):
 def test_frame_driver_when_every_wave_holds_young_pixels(G, period, storage):
     """Thin geometry under motion: every `period`-th column fails the reprojection test in every frame (the two G-buffers the frames
     alternate between disagree on its normals), so EVERY wave of the temporal launch holds young pixels — more waves than the young
-    list takes appends from (svgf_kernels.h: young_append_cap = one eighth of the waves).  The temporal launch stops appending and the moments launch
+    list takes appends from (svgf_kernels.h: young_append_cap = a quarter of the waves, an eighth of that per shard).  The temporal launch stops appending and the moments launch
     works from the per-segment masks: still the stage sequence's results, bit for bit."""
     from svgf_amd import filter as F
     W, H, N = 2048, 800, 6                                  # 32 x 800 = 25 600 waves, ~8 % of them sky
