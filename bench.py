@@ -704,6 +704,16 @@ def main():
                                           "Mpixels/s": round(W2 * H2 / (r2["ms_per_step"] * 1e-3) / 1e6, 1),
                                           "frac_of_8TBps": pass_block(W2, H2, storage, iters, r2["ms_per_step"])["frac_of_8TBps"],
                                           "atrous_avg_launch_ms": roof2["avg_launch_ms"] if roof2 else None, "atrous_roofline_frac": roof2["frac"] if roof2 else None}}
+            if args.frames_in_flight == 1 and not fuse and "pan" in motions:
+                # the bench pan at 1080p: the same few pixels per frame enter a frame a quarter the size (4 500 waves hold young pixels, of 32 400)
+                sc2p = Scene(W2, H2, device)
+                r2p = run_single(FramePool(sc2p, storage, "pan"), W2, H2, storage, iters, args.variant, max(args.steps, 20), args.warmup, device, windows=3,
+                                 prime=(min(args.prime_ms, 150.0), min(args.prime_frames, 200)))
+                _, st2p = roofline_block(W2, H2, storage, iters, r2p["stage_ms"], args.variant, r2p["fused"])
+                line["also"]["1920x1080"]["pan"] = {"mv": list(PAN_MV), "ms_per_step": round(r2p["ms_per_step"], 4), "Mpixels/s": round(W2 * H2 / (r2p["ms_per_step"] * 1e-3) / 1e6, 1),
+                                                    "temporal_ms": st2p["temporal+moments"]["temporal_ms"] if st2p else None,
+                                                    "moments_ms": st2p["temporal+moments"]["moments_ms"] if st2p else None}
+                del sc2p
             if args.frames_in_flight == 1 and not fuse:
                 line["also"]["1920x1080"]["hip_graph"] = run_graph_replay(FramePool(sc2, storage, "static"), W2, H2, storage, iters, args.variant, max(args.steps, 40), device,
                                                                           prime_ms=min(300.0, args.prime_ms))

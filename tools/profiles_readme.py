@@ -111,6 +111,8 @@ def main(tag):
                 notes.append(f"* also `seven_iterations` (steps 1..64, all LDS launches): {v['ms_per_step']} ms per frame; a-trous launch by step (ms): {v['atrous_launch_ms_by_step']}.")
             elif "ms_per_step" in v:
                 notes.append(f"* also `{k}`: {v['ms_per_step']} ms per frame, {v['Mpixels/s']} Mpixel/s, pass frac {v.get('frac_of_8TBps')}, à-trous launch {v.get('atrous_avg_launch_ms')} ms (frac {v.get('atrous_roofline_frac')}).")
+                if v.get("pan"):
+                    notes.append(f"* also `{k}.pan` ({v['pan']['mv']}): {v['pan']['ms_per_step']} ms per frame, temporal {v['pan']['temporal_ms']}, moments {v['pan']['moments_ms']} ms.")
                 g = v.get("hip_graph")
                 if g:
                     notes.append(f"* also `{k}.hip_graph` (four frames captured once and replayed, ms per frame): one frame in flight {g['calls_1_in_flight_ms']} by calls / {g['graph_1_in_flight_ms']} replayed; "
