@@ -57,3 +57,14 @@ def test_static_pool_ping_pongs_two_sets_of_planes(bench):
         assert a.data_ptr() != b.data_ptr() and torch.equal(a, b)
     assert float(c0.motion[..., :2].abs().max()) == 0.0
     assert bench.moved_bytes_full("f32", 5) == 130 + 5 * 48 + 16 and bench.alg_bytes_full("f32", 5) == 459 and bench.alg_bytes_full("f16", 5) == 323
+
+
+def test_rendezvous_port_is_below_the_ephemeral_range():
+    """bench.free_port: a port for the N > 1 rendezvous that no outgoing connection of another process can take in the meantime."""
+    import socket
+    import bench
+    for _ in range(5):
+        p = bench.free_port()
+        assert 20000 <= p < 32768
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", p))

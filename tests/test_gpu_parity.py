@@ -315,6 +315,12 @@ def test_adaptive_moments_switches_kernels_without_a_bit_changing(G, storage):
             res.append(G.host(d.Render(rad, gb_of(k), gb_of(k - 1) if k else None)))      # (G.host waits for the frame)
             if adaptive:
                 modes.append(d.adaptive_moments_state())
+                if k == 14:         # the sample the driver reads: one wave in 64 of a frame two calls ago, x 64 (svgf_adaptive_moments_sample)
+                    px, waves = d.adaptive_moments_sample()
+                    hist = G.host(d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong()))
+                    surface = fr[0]["motion"][..., 2] != 0
+                    young = int(((hist < 4) & surface).sum())
+                    assert 0.6 * young < px < 1.4 * young and waves > 0.5 * (H * W // 64), (px, waves, young)
         outs[adaptive] = res
         d.close()
     # frames 0-2 are young all over (the streaming kernel serves them whatever the sample says, and they add nothing to it), 9-15 crowded
