@@ -271,7 +271,8 @@ int svgf_flush(svgf_ctx* ctx);
  *     writes: the host refills them, normally by nodes of the same graph;
  *   - the first three frames after svgf_create / svgf_resize / svgf_reset_history cannot be captured (the first one allocates, all
  *     three run the cold-start moments kernel): under capture they are refused with SVGF_ERR_INVALID and record nothing — enqueue
- *     them directly; tunables, row ranges, debug mode and the switches are those in force at capture time;
+ *     them directly; tunables, row ranges, debug mode and the switches are those in force at capture time, and so is the kernel that serves the
+ *     young pixels (svgf_set_adaptive_moments: chosen per call from a sample of recent frames — a graph keeps the choice of the call it recorded);
  *   - with two frames in flight: svgf_flush before hipStreamBeginCapture (a frame enqueued before the capture cannot be joined inside
  *     it: refused) and again before hipStreamEndCapture (the side stream must be back on the captured one: HIP refuses to end a capture
  *     with unjoined work, and on ROCm 7.2 leaves its streams unusable afterwards);
