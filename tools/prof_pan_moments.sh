@@ -15,8 +15,9 @@ for sub in ("pmc1", "pmc2"):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % sub, recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0][-60:]
-            if "moments_young" in k or "temporal_kernel" in k:
+            name = r["Kernel_Name"]
+            k = "moments_young_kernel" if "moments_young" in name else "temporal_kernel" if "temporal_kernel" in name else None
+            if k:
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, c in agg.items():
         print(k, {n: round(sum(v) / len(v), 1) for n, v in c.items()}, "launches", len(next(iter(c.values()))))
