@@ -58,7 +58,7 @@
 extern "C" {
 #endif
 
-#define SVGF_ABI_VERSION 6
+#define SVGF_ABI_VERSION 7
 
 enum svgf_status {
     SVGF_OK = 0,
@@ -342,8 +342,8 @@ int svgf_timing_read(svgf_ctx* ctx, double* ms_sum, int* frames, int slots);   /
  * (App.cu:552-556) runs on every strip; rows a strip needs from its neighbours travel as RCCL send/recv groups over xGMI,
  * posted from a communication stream of the driver's own and tied to the filter stream by HIP events.  Results are
  * bit-identical to the single-GPU frame.  A driver holds the strips of the ranks of THIS process: one per process (one
- * process per GPU), several on several devices, or — for tests — several virtual ranks on one device sharing ONE
- * loop-back communicator (loopback != 0: every peer is communicator rank 0).  See svgf_amd/csrc/svgf_strip.hip.
+ * process per GPU), several on several devices, or — for tests — several virtual ranks on one device (svgf_strip_transport
+ * below).  See svgf_amd/csrc/svgf_strip.hip.
  * librccl is opened at run time (the one already in the process, else ROCm's; SVGF_RCCL_LIBRARY overrides). */
 enum svgf_halo_plan { SVGF_PLAN_AUTO = 0, SVGF_PLAN_GHOST = 1, SVGF_PLAN_GROUPED = 2, SVGF_PLAN_PER_ITERATION = 3 };
 typedef struct svgf_strips svgf_strips;
@@ -365,11 +365,46 @@ int svgf_rccl_unique_id(void* id128);
 int svgf_rccl_comm_init(void** comm, int world, int rank, const void* id128, int device);
 int svgf_rccl_comm_destroy(void* comm);
 int svgf_rccl_comm_count(void* comm, int* count);              /* ncclCommCount: the ranks RCCL itself reports for the communicator */
-/* ranks / devices / compute_streams (hipStream_t, NULL entries = the null stream) / comms (ncclComm_t; loopback: comms[0] only;
- * may be NULL when world == 1) describe the nlocal ranks of this process.  motion_reach = the largest |mv.y| (rows) the
+/* How the ranks of a driver reach their neighbours.
+ *   SVGF_TRANSPORT_RCCL           ncclSend / ncclRecv to the neighbour's rank of comms[k] — the product transport (one process per GPU, or one
+ *                                 process driving several devices with one communicator per device).
+ *   SVGF_TRANSPORT_RCCL_LOOPBACK  tests and the one-GPU simulation: ONE communicator of size 1 (comms[0]); every peer is its rank 0 and all virtual
+ *                                 ranks share one communication stream.  Exercises RCCL's groups and kernels, not the peer addressing.
+ *   SVGF_TRANSPORT_MAILBOX        tests: every rank of the partition lives in this process (nlocal == world, `comms` ignored) with a communication
+ *                                 stream of its own, addresses its neighbours by their real rank numbers — the code path of a multi-GPU run — and the
+ *                                 library matches each send to the receive its peer posted for it (posting order per {source, destination} pair,
+ *                                 same group: RCCL's rule) and turns the pair into a device-to-device copy on the receiver's stream.  A send nobody
+ *                                 receives, a receive nobody sends or a size mismatch — what deadlocks a real run — fails the frame with
+ *                                 SVGF_ERR_COMM.  Not a product transport: it cannot cross a process boundary. */
+enum svgf_strip_transport { SVGF_TRANSPORT_RCCL = 0, SVGF_TRANSPORT_RCCL_LOOPBACK = 1, SVGF_TRANSPORT_MAILBOX = 2 };
+/* ranks / devices / compute_streams (hipStream_t, NULL entries = the null stream) / comms (ncclComm_t; loop-back: comms[0] only;
+ * may be NULL when world == 1 or with the mailbox) describe the nlocal ranks of this process.  motion_reach = the largest |mv.y| (rows) the
  * temporal reprojection may need beyond what a strip computes itself; exceeding it is reported by svgf_strips_sync. */
 int svgf_strips_create(svgf_strips** out, int width, int height, int world, const svgf_params* params, int plan, int motion_reach,
-                       int nlocal, const int* ranks, const int* devices, void* const* compute_streams, void* const* comms, int loopback);
+                       int nlocal, const int* ranks, const int* devices, void* const* compute_streams, void* const* comms, int transport);
+/* The messages of ONE frame as rank `rank` posts them, in posting order (pure geometry, no device): what svgf_strips_frame hands to the
+ * transport.  exchange 0 = the frame's state for the next frame's reprojection (posted once iteration 0 has fed the colour back,
+ * waited for at the start of the next frame); exchange g >= 1 = the filter rows in front of iteration group g of the halo plan.
+ * Every send has its mirror among the peer's receives of the same exchange — same plane, same global rows, same bytes — in the same
+ * order per pair of ranks (tests/test_strips_cpu.py walks world = 2..8).  *count receives the number of messages; SVGF_ERR_INVALID
+ * if it exceeds `capacity` (the first `capacity` are written). */
+typedef struct svgf_strip_message {
+    int exchange;
+    int send;                 /* 1: this rank sends, 0: it receives */
+    int peer;                 /* the neighbour's rank */
+    int plane;                /* svgf_plane */
+    int row_begin, row_end;   /* global rows */
+    size_t bytes;
+} svgf_strip_message;
+int svgf_strips_messages(int width, int height, int rank, int world, int steps, int plan, int moments_radius, int motion_reach, int storage,
+                         svgf_strip_message* out, int capacity, int* count);
+/* SVGF_TRANSPORT_MAILBOX only, for the tests of the matching itself: the next send / receive rank `rank` posts is dropped, or its next
+ * receive posted with half its size — the defects of a schedule that a multi-GPU run would answer with a hang.  The frame that meets the
+ * defect fails with SVGF_ERR_COMM (the text names the ranks and the bytes) and the driver refuses further frames. */
+enum svgf_mailbox_fault { SVGF_FAULT_NONE = 0, SVGF_FAULT_DROP_SEND = 1, SVGF_FAULT_DROP_RECV = 2, SVGF_FAULT_SHORT_RECV = 3 };
+int svgf_strips_mailbox_fault(svgf_strips* s, int rank, int fault);
+/* SVGF_TRANSPORT_MAILBOX only: groups matched, copies enqueued and bytes copied so far (any pointer may be NULL). */
+int svgf_strips_transport_stats(const svgf_strips* s, unsigned long long* groups, unsigned long long* copies, unsigned long long* bytes);
 void svgf_strips_destroy(svgf_strips* s);
 const char* svgf_strips_last_error(const svgf_strips* s);
 svgf_ctx* svgf_strips_context(svgf_strips* s, int local_index);            /* the strip's context (state planes, svgf_get_size ...);

@@ -80,8 +80,25 @@ hipEvent_t take_event(svgf_ctx* c) {
     return e;
 }
 
+// Stream capture (svgf.h): 0 while the context's stream is not being captured, else a number that names the capture.
+int capture_of(svgf_ctx* c, unsigned long long* id) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long n = 0;
+    *id = 0;
+    if (!c->stream) return SVGF_OK;                 // the legacy default stream cannot be captured
+    SVGF_HIP(c, hipStreamGetCaptureInfo(c->stream, &st, &n));
+    if (st == hipStreamCaptureStatusInvalidated) return fail(c, SVGF_ERR_HIP, "the capture of the context's stream has been invalidated (hipStreamEndCapture will report it)");
+    if (st == hipStreamCaptureStatusActive) *id = n | (1ull << 63);
+    return SVGF_OK;
+}
+
 int alloc_flags(svgf_ctx* c) {
     if (c->young_masks && c->young_list && c->young_count && c->nan_count && c->nan_list && c->sample_count && c->estimate_host) return SVGF_OK;
+    // (svgf_temporal_moments under stream capture, first use of a context: the allocations below would invalidate the capture and their memsets
+    // would be recorded into the graph, zeroing the counters on every replay — refused like svgf_denoise_frame's first frames)
+    unsigned long long cap = 0;
+    if (int rc = capture_of(c, &cap); rc != SVGF_OK) return rc;
+    if (cap) return fail(c, SVGF_ERR_INVALID, "the context's stream is being captured and this call's first use of the context allocates its scratch: enqueue one call before the capture begins");
     // all or none: a failed allocation leaves nothing behind that a later call would mistake for a complete set
     auto drop = [&]() {
         if (c->young_masks) (void)hipFree(c->young_masks);
@@ -104,25 +121,13 @@ int alloc_flags(svgf_ctx* c) {
     if (e == hipSuccess) e = hipMalloc((void**)&c->nan_count, 2 * sizeof(unsigned));
     if (e == hipSuccess) e = hipMemsetAsync(c->nan_count, 0, 2 * sizeof(unsigned), c->stream);
     if (e == hipSuccess) e = hipMalloc((void**)&c->nan_list, (size_t)svgf::kNanListCap * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&c->sample_count, 64 * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMemsetAsync(c->sample_count, 0, 64 * sizeof(unsigned), c->stream);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->sample_count, 32 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(c->sample_count, 0, 32 * sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->estimate_host, 64, hipHostMallocMapped);
-    if (e == hipSuccess) { c->estimate_host[0] = 0u; c->dense_moments = false; }
+    if (e == hipSuccess) { c->estimate_host[0] = 0ull; c->dense_moments = false; }
     if (e != hipSuccess) { drop(); return hip_fail(c, e, "alloc_flags"); }
     c->young_phase = 0;
     c->young_pending = false;
-    return SVGF_OK;
-}
-
-// Stream capture (svgf.h): 0 while the context's stream is not being captured, else a number that names the capture.
-int capture_of(svgf_ctx* c, unsigned long long* id) {
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    unsigned long long n = 0;
-    *id = 0;
-    if (!c->stream) return SVGF_OK;                 // the legacy default stream cannot be captured
-    SVGF_HIP(c, hipStreamGetCaptureInfo(c->stream, &st, &n));
-    if (st == hipStreamCaptureStatusInvalidated) return fail(c, SVGF_ERR_HIP, "the capture of the context's stream has been invalidated (hipStreamEndCapture will report it)");
-    if (st == hipStreamCaptureStatusActive) *id = n | (1ull << 63);
     return SVGF_OK;
 }
 
@@ -264,7 +269,7 @@ int temporal_impl(svgf_ctx* c, const void* prev_colour, const void* radiance, vo
                          c->strip.y0, c->strip.y0 + c->strip.rows,       // the guide texels of every row held (a strip runs the stage on fewer)
                          passthrough_out ? c->nan_list : nullptr, passthrough_out ? c->nan_count + c->young_phase : nullptr,
                          passthrough_out ? c->nan_count + (c->young_phase ^ 1) : nullptr,
-                         passthrough_out ? c->sample_count + c->young_phase * 32 : nullptr, passthrough_out ? c->sample_count + (c->young_phase ^ 1) * 32 : nullptr,
+                         passthrough_out ? c->sample_count + c->young_phase * 16 : nullptr, passthrough_out ? c->sample_count + (c->young_phase ^ 1) * 16 : nullptr,
                          passthrough_out ? c->estimate_host : nullptr, c->cold_now, c->p.nan_policy == SVGF_NAN_ZERO};
     if (c->re <= c->rb) return SVGF_OK;             // nothing to launch: the young masks and the counters stay as they are
     SVGF_HIP(c, svgf::launch_temporal(geo_of(c), c->p.storage, a, c->stream));
@@ -359,12 +364,17 @@ bool can_fuse01(const svgf_ctx* c) {
 // the estimate on the same bits (moments_group8, ARITH = 1), so the choice — and the timing it depends on — changes nothing but the frame time; the
 // ranks of a strip driver choose each for itself.  Rows: [c->rb, c->re) as they are when this is called (the temporal rows).
 void choose_moments_kernel(svgf_ctx* c, bool* cold, bool* crowded) {
-    *cold = c->frames_since_reset < 3 && c->p.variant != SVGF_VARIANT_DIRECT;
+    // Only where launch_moments has a kernel that visits every pixel for a dense frame: the LDS-streaming one (the reference's radius, PhiNormal != 0)
+    // or the 3x3 shuffle kernel.  Any other setting keeps the young-pixel launch — which needs the temporal launch's LIST, and a cold or crowded
+    // frame's temporal launch appends to none (radius 0 / 2 or PhiNormal == 0 under the default variants lost the young pixels of the
+    // partly young segments of the first three frames).
+    const bool streams = c->p.variant != SVGF_VARIANT_DIRECT && ((c->p.moments_radius == 3 && c->p.phi_normal != 0.0f) || c->p.moments_radius == 1);
+    *cold = c->frames_since_reset < 3 && streams;
     *crowded = false;
-    if (!*cold && c->adaptive_moments && c->estimate_host && c->p.variant != SVGF_VARIANT_DIRECT && c->p.moments_radius == 3 && c->p.phi_normal != 0.0f && c->re > c->rb) {
-        const unsigned sample = *(volatile unsigned*)c->estimate_host;      // {waves that hold some young pixels: 12 bits, young pixels: 20 bits}, of one wave in 64
-        const double est = 64.0 * (double)(sample & 0xfffffu) / ((double)c->W * (double)(c->re - c->rb));
-        const unsigned appends = 64u * (sample >> 20), cap = svgf::young_append_cap(c->strip.rows, c->W);   // what the list of such a frame takes, and its cap
+    if (!*cold && c->adaptive_moments && c->estimate_host && streams && c->p.moments_radius == 3 && c->re > c->rb) {
+        const unsigned long long sample = *(volatile unsigned long long*)c->estimate_host;   // {waves that hold some young pixels: high word, young pixels: low word}, of one wave in 64
+        const double est = 64.0 * (double)(unsigned)sample / ((double)c->W * (double)(c->re - c->rb));
+        const unsigned long long appends = 64ull * (sample >> 32), cap = svgf::young_append_cap(c->strip.rows, c->W);   // what the list of such a frame takes, and its cap
         if (est > 0.08 || appends > cap) c->dense_moments = true;
         else if (est < 0.05 && appends < cap / 4 * 3) c->dense_moments = false;
         *crowded = c->dense_moments;
@@ -490,7 +500,7 @@ int svgf_resize_strip(svgf_ctx* c, int width, int height, const svgf_strip* stri
     if (c->halo_violations) { (void)hipFree(c->halo_violations); c->halo_violations = nullptr; }
     c->W = width; c->H = height; c->strip = *strip; c->rb = strip->own_begin; c->re = strip->own_end;
     c->vy0 = strip->y0; c->vy1 = strip->y0 + strip->rows;
-    c->pingpong = 0; c->frames_since_reset = 0; c->result_index = 0; c->filter_set = 0;
+    c->pingpong = 0; c->frames_since_reset = 0; c->result_index = 0; c->filter_set = 0; c->last_pair_alt = false;
     return SVGF_OK;
 }
 
@@ -560,9 +570,10 @@ int svgf_adaptive_moments_state(const svgf_ctx* c) { return c && c->dense_moment
 
 int svgf_adaptive_moments_sample(const svgf_ctx* c, unsigned* young_pixels, unsigned* appending_waves) {
     if (!c || !c->estimate_host) return SVGF_ERR_INVALID;
-    const unsigned sample = *(volatile unsigned*)c->estimate_host;
-    if (young_pixels) *young_pixels = 64u * (sample & 0xfffffu);
-    if (appending_waves) *appending_waves = 64u * (sample >> 20);
+    const unsigned long long sample = *(volatile unsigned long long*)c->estimate_host;
+    auto sat = [](unsigned long long v) { return v > 0xffffffffull ? 0xffffffffu : (unsigned)v; };
+    if (young_pixels) *young_pixels = sat(64ull * (sample & 0xffffffffull));
+    if (appending_waves) *appending_waves = sat(64ull * (sample >> 32));
     return SVGF_OK;
 }
 
@@ -631,9 +642,12 @@ int svgf_set_frames_in_flight(svgf_ctx* c, int frames) {
         // With one frame in flight every frame uses c->filter[], and svgf_state_plane(SVGF_PLANE_FILTER, ..) and the SVGF_DEBUG_ATROUS view
         // (which filters what the previous frame left in FilterBuffer, App.cu:611-620) index c->filter[] too: if the last frame used the
         // second pair, the pairs change names (the result pointer handed out stays valid: the planes themselves do not move).
-        if (c->filter_set == 0 && c->filter_alt[0] && c->filter_alt[1]) {      // filter_set is the pair the NEXT frame would use: the last one used the other
+        // (last_pair_alt is what the last FRAME wrote — not what filter_set implies: 2 -> 1 -> 2 -> 1 without a frame between the last two
+        // switches must not swap again)
+        if (c->last_pair_alt && c->filter_alt[0] && c->filter_alt[1]) {
             std::swap(c->filter[0], c->filter_alt[0]);
             std::swap(c->filter[1], c->filter_alt[1]);
+            c->last_pair_alt = false;
         }
         c->filter_set = 0;
     }
@@ -754,6 +768,7 @@ int svgf_denoise_frame(svgf_ctx* c, const void* radiance, const svgf_gbuffer* cu
     const int P = c->pingpong;
     // frames in flight: this frame's pair of filter planes (the previous frame's result sits in the other one until the call after this)
     void** const F = c->frames_in_flight > 1 && c->filter_set ? c->filter_alt : c->filter;
+    c->last_pair_alt = F == c->filter_alt;
     if (c->frames_in_flight > 1) c->filter_set ^= 1;
 
     svgf_ctx::FrameEvents fe;

@@ -46,14 +46,15 @@ struct svgf_ctx {
     hipEvent_t ev_first = nullptr, ev_done = nullptr;   // iteration 0 of the frame being enqueued is on `stream`; the last iteration of the frame in flight is on `side`
     void* filter_alt[2] = {nullptr, nullptr};
     int filter_set = 0;                    // which pair the NEXT frame uses (toggles per frame while frames_in_flight == 2)
+    bool last_pair_alt = false;            // the last frame wrote filter_alt[] (under its present name): what svgf_set_frames_in_flight(1) renames
     bool in_flight = false;                // a frame's tail is on `side` and `stream` has not been made to wait for it yet
     unsigned long long in_flight_capture = 0;   // ... and the stream capture that tail was recorded in (0: none; svgf.h, Stream capture)
     unsigned long long* young_masks = nullptr;   // scratch, temporal -> moments: per (row, 64-column segment) the lanes whose pixel (history < 4) needs the spatial estimate
     uint32_t* young_list = nullptr;        // ... and the indices of the pixels of the partly young segments (svgf::young_list_entries)
     unsigned long long* young_count = nullptr;   // ... two {appends, pixels} counters used in turn (the temporal launch of a frame zeroes the next frame's)
     unsigned* nan_count = nullptr;         // two device counters of nan_list used in turn (the temporal launch of a frame zeroes the next frame's)
-    unsigned* sample_count = nullptr;      // two device counters (128 B apart) used in turn: the sampled number of young pixels of a frame (TemporalArgs::sample_count)
-    unsigned* estimate_host = nullptr;     // host-mapped: the latest sample a temporal launch has published (read without synchronising: some frames old)
+    unsigned long long* sample_count = nullptr;   // two 64-bit device counters (128 B apart) used in turn: the sampled number of young pixels of a frame (TemporalArgs::sample_count)
+    unsigned long long* estimate_host = nullptr;    // host-mapped: the latest sample a temporal launch has published (read without synchronising: some frames old)
     bool adaptive_moments = true;          // svgf_set_adaptive_moments
     bool dense_moments = false;            // the frame driver's current choice (hysteresis)
     bool dense_now = false;                // the frame being enqueued is served by the streaming kernel (a cold or a crowded frame)

@@ -59,9 +59,9 @@ struct TemporalArgs {
     uint32_t* nan_list;          // with young_masks: the local indices of the pixels whose temporal colour / moments are NaN or inf, appended with one
     unsigned* nan_count;         // atomic per wave that holds any (none in a frame without a NaN); the moments launch redoes the zero-normal shortcut
     unsigned* nan_count_next;    // pixels around them.  The OTHER counter of the context's pair is zeroed by this launch for the next frame
-    unsigned* sample_count;      // with young_masks: every 64th wave (hashed) adds the number of its young pixels here, fire and forget — what the frame
-    unsigned* sample_prev;       // driver's choice between the young-pixel launch and the streaming kernel goes by (svgf_set_adaptive_moments).  This
-    unsigned* estimate_host;     // launch publishes the PREVIOUS frame's sum (sample_prev, then zeroed) in host-mapped memory; all three may be null
+    unsigned long long* sample_count;   // with young_masks: every 64th wave (hashed) adds the number of its young pixels here, fire and forget — what the frame
+    unsigned long long* sample_prev;      // driver's choice between the young-pixel launch and the streaming kernel goes by (svgf_set_adaptive_moments).  This
+    unsigned long long* estimate_host;    // launch publishes the PREVIOUS frame's sum (sample_prev, then zeroed) in host-mapped memory; all three may be null
     int sample_off;              // a frame after a reset (every pixel young by construction): publishes, but adds nothing — its sample would say "crowded"
                                  // two frames later, when nothing is
     int heal_nan;                // svgf_params::nan_policy == SVGF_NAN_ZERO: a NaN channel of the radiance / previous colour / previous moments reads as 0

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
         a.nan_count_next[0] = 0u;
         if (a.sample_count) {                       // last frame's sample is final: to the host (no answer awaited), and its counter starts again
             __hip_atomic_store(a.estimate_host, a.sample_prev[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            a.sample_prev[0] = 0u;
+            a.sample_prev[0] = 0ull;
         }
     }
     // The grid covers the compute rows [yb, ye) and, where a guide plane is written, the rows [guide_lo, guide_hi) around them (a strip
@@ -157,9 +157,10 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
         if (threadIdx.x == 0)                                             // (lane 0 is always inside the frame; lanes beyond W have left: their bits are 0)
             a.young_masks[(size_t)(y - g.y0) * ((g.W + kBX - 1) / kBX) + blockIdx.x] = ym;
         // one wave in 64 (hashed over segment and row: columns and rows of young pixels are sampled like anything else) reports how many it holds
-        // (low 20 bits: young pixels; high 12: waves that hold some but not 64 — the ones that append to the list)
+        // (low word: young pixels; high word: waves that hold some but not 64 — the ones that append to the list.  One 64-bit atomic: packed into
+        // 20 + 12 bits the wave field overflowed above 262 000 waves — an 8K frame has 518 000 — ADVICE r04)
         if (a.sample_count && !a.sample_off && ym != 0ull && threadIdx.x == 0 && (((unsigned)blockIdx.x * 29u + (unsigned)y * 13u) & 63u) == 0u)
-            (void)__hip_atomic_fetch_add(a.sample_count, (unsigned)__builtin_popcountll(ym) + (ym != ~0ull ? 1u << 20 : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(a.sample_count, (unsigned long long)__builtin_popcountll(ym) + (ym != ~0ull ? 1ull << 32 : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.young_list && ym != 0ull && ym != ~0ull) {                 // (no list for a frame the streaming kernel will serve)
             const int lane = threadIdx.x, first = __builtin_ctzll(ym);
             unsigned base = ~0u;

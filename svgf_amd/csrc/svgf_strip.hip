@@ -25,6 +25,16 @@
 //
 // RCCL is opened at run time (dlopen of the librccl the process already has — torch brings one — or of ROCm's): hosts that
 // never attach a strip driver do not need it.
+//
+// Transports.  The four calls an exchange is made of — group start, send, receive, group end — go through a table (Transport).  The
+// product transport is RCCL.  The second one, the MAILBOX, exists for tests: with every rank of the partition living in this process
+// (nlocal == world, one device or several) each rank keeps its own communication stream and addresses its neighbours by their REAL rank
+// numbers — the branch of post_exchange a multi-GPU run takes, which the loop-back communicator (every peer is rank 0, one shared
+// stream) never enters — and the mailbox matches every send to the receive its peer posted for it, in posting order per (source,
+// destination) pair and inside the same group: RCCL's matching rule.  A send without its receive, a receive without its send, or a pair
+// whose sizes differ is what would deadlock (or corrupt) a real run: the mailbox refuses the group with SVGF_ERR_COMM and says which.
+// A matched pair becomes a device-to-device copy on the RECEIVER's communication stream behind an event of the sender's, and the
+// sender's stream waits for the copy (a send is complete when its buffer may be reused).
 
 #include "svgf_ctx.h"
 
@@ -94,8 +104,14 @@ struct svgf_strip_plan_geo {
 
 struct svgf_strips {
     int W = 0, H = 0, world = 1, steps = 0, plan = SVGF_PLAN_AUTO, motion_reach = 0, moments_radius = 3, storage = SVGF_F32;
-    bool loopback = false;
-    bool broken = false;                   // an RCCL call failed inside a group: every later frame is refused
+    bool loopback = false;                 // SVGF_TRANSPORT_RCCL_LOOPBACK: one communicator of size 1, every peer is its rank 0, one shared communication stream
+    bool mailbox = false;                  // SVGF_TRANSPORT_MAILBOX (tests): sends and receives matched in this process (see the head of the file)
+    struct Posted { int rank, peer; char* buf; size_t bytes; };
+    std::vector<Posted> mb_sends, mb_recvs;   // the open group, in posting order
+    bool mb_open = false;
+    int mb_fault_rank = -1, mb_fault = 0;  // svgf_strips_mailbox_fault: the next message of that kind posted by that rank is dropped / resized (tests of the matching itself)
+    unsigned long long mb_groups = 0, mb_copies = 0, mb_bytes = 0;   // what the mailbox has matched so far (svgf_strips_transport_stats)
+    bool broken = false;                   // a transport call failed inside a group: every later frame is refused
     struct Local {
         int rank = 0, device = 0;
         svgf_ctx* ctx = nullptr;
@@ -109,6 +125,7 @@ struct svgf_strips {
         bool tail_pending = false;                            // ... which `compute` has not been made to wait for yet
         void* filter_alt[2] = {nullptr, nullptr};
         hipEvent_t ready = nullptr, halo_done = nullptr, state_done = nullptr;
+        hipEvent_t mb_ready = nullptr, mb_done = nullptr;      // mailbox: this rank's communication stream has reached the group / has received what the group sends it
         bool state_pending = false;
         // the host never runs more than kMaxAhead frames ahead of the device: frame f waits for the end of frame f - kMaxAhead.  With ~100
         // frames of launches, events and RCCL groups queued the device starts to starve (0.43 -> 0.6 ms per 8K/8 strip, tools/strip_sim.py)
@@ -171,8 +188,6 @@ bool make_geo(int W, int H, int rank, int world, int steps, int plan, int moment
 struct Rows { int a, b; };
 Rows grown(const svgf_strip_plan_geo& g, int H, int ext) { return Rows{std::max(0, g.own0 - ext), std::min(H, g.own1 + ext)}; }
 
-// One transfer of an exchange: rows [lo,hi) at distance from the boundary between rank `b` and `b + 1`, of one plane.
-struct Msg { int src, dst; size_t src_off, dst_off, bytes; int plane; };
 
 }  // namespace
 
@@ -188,20 +203,154 @@ size_t row_bytes(const svgf_strips* s, int plane) {
     }
 }
 
-// A send / receive failed between ncclGroupStart and ncclGroupEnd: close the group (whatever it returns) so that the thread's RCCL state
-// is not left half open, and mark the driver unusable — the events and transfers of this frame are in an unknown state.
-int group_failed(svgf_strips* s, const char* what, int e) {
-    (void)rccl()->GroupEnd();
-    s->broken = true;
-    return sfail(s, SVGF_ERR_COMM, std::string(what) + ": " + nccl_text(e) + " (the strip driver is unusable from here: destroy it)");
+// ------------------------------------------------------------------ what an exchange consists of ------------
+// The messages rank `rank` posts for ONE exchange, in posting order: for every plane, the rows at distance [held, h) from each of the strip's
+// two boundaries — towards the upper neighbour first (send, then receive), then towards the lower one.  Rows nearer than `held` the receiver has
+// computed itself (redundantly, bit-identically).  A pure function of the partition: svgf_strips_messages lists a frame's messages with it
+// (tests/test_strips_cpu.py pairs every send of every rank with its neighbour's receive), and post_exchange posts exactly these.
+//   rank b sends its rows [own1 - h, own1 - held) down and receives [own1 + held, own1 + h);  sends [own0 + held, own0 + h) up, receives [own0 - h, own0 - held)
+// Between one pair of ranks the sends of one side and the receives of the other come in the same plane order: RCCL matches them in posting order.
+struct MsgSpec { bool send; int peer; int plane, index; int g0, g1; };
+struct PlaneSpec { int plane, index, held; };
+
+void exchange_msgs(int H, int world, int rank, const std::vector<PlaneSpec>& planes, int h, std::vector<MsgSpec>& out) {
+    const int own0 = (int)((long long)H * rank / world), own1 = (int)((long long)H * (rank + 1) / world);
+    for (const PlaneSpec& pl : planes) {
+        if (h <= pl.held) continue;
+        if (rank > 0) {
+            out.push_back(MsgSpec{true, rank - 1, pl.plane, pl.index, own0 + pl.held, own0 + h});
+            out.push_back(MsgSpec{false, rank - 1, pl.plane, pl.index, own0 - h, own0 - pl.held});
+        }
+        if (rank + 1 < world) {
+            out.push_back(MsgSpec{true, rank + 1, pl.plane, pl.index, own1 - h, own1 - pl.held});
+            out.push_back(MsgSpec{false, rank + 1, pl.plane, pl.index, own1 + pl.held, own1 + h});
+        }
+    }
 }
 
-// Post ONE exchange for all local ranks: rows at distance [lo, h) from each strip boundary of the given planes.
-// planes[k] = {plane kind, index}; done_is_state selects which event the filter stream will wait for.
-int post_exchange(svgf_strips* s, const std::vector<std::pair<int, int>>& planes, const std::vector<int>& held, int h, bool is_state) {
+// the planes of the state exchange (posted once iteration 0 has written the feedback colour) — only rows a rank has NOT computed itself travel: it
+// holds the feedback colour ext_atrous[0] rows beyond its strip and moments / history ext_temporal rows beyond (bit-identical to the owner's)
+std::vector<PlaneSpec> state_planes(const svgf_strip_plan_geo& g, int steps, int P) {
+    const int colour_held = steps ? g.ext_atrous[0] : g.ext_temporal;
+    return {{SVGF_PLANE_COLOUR, P, colour_held}, {SVGF_PLANE_MOMENTS, P, g.ext_temporal}, {SVGF_PLANE_HISTORY, P, g.ext_temporal}};
+}
+
+// ------------------------------------------------------------------ transports ------------------------------
+struct Transport {
+    const char* name;
+    int (*group_start)(svgf_strips*);
+    int (*send)(svgf_strips*, svgf_strips::Local& from, const void* buf, size_t bytes, int peer);
+    int (*recv)(svgf_strips*, svgf_strips::Local& to, void* buf, size_t bytes, int peer);
+    int (*group_end)(svgf_strips*);      // SVGF_OK: every transfer of the group is enqueued on the communication streams of its two ends
+    void (*abandon)(svgf_strips*);       // a call between group_start and group_end failed: leave nothing half open
+};
+
+// -- RCCL: the product transport.  Loop-back: one communicator of size 1 — every peer is its rank 0.
+int rccl_group_start(svgf_strips* s) {
     Rccl* R = rccl();
     if (!R->Send) return sfail(s, SVGF_ERR_COMM, R->why.empty() ? "librccl not available" : R->why);
-    auto find_local = [&](int rank) -> svgf_strips::Local* { for (auto& l : s->local) if (l.rank == rank) return &l; return nullptr; };
+    SVGF_NCCL(s, R->GroupStart());
+    return SVGF_OK;
+}
+int rccl_send(svgf_strips* s, svgf_strips::Local& from, const void* buf, size_t bytes, int peer) {
+    if (int e = rccl()->Send(buf, bytes, ncclInt8, s->loopback ? 0 : peer, from.comm, from.comm_stream); e != ncclSuccess) return sfail(s, SVGF_ERR_COMM, "ncclSend: " + nccl_text(e));
+    return SVGF_OK;
+}
+int rccl_recv(svgf_strips* s, svgf_strips::Local& to, void* buf, size_t bytes, int peer) {
+    if (int e = rccl()->Recv(buf, bytes, ncclInt8, s->loopback ? 0 : peer, to.comm, to.comm_stream); e != ncclSuccess) return sfail(s, SVGF_ERR_COMM, "ncclRecv: " + nccl_text(e));
+    return SVGF_OK;
+}
+int rccl_group_end(svgf_strips* s) { SVGF_NCCL(s, rccl()->GroupEnd()); return SVGF_OK; }
+void rccl_abandon(svgf_strips*) { (void)rccl()->GroupEnd(); }      // (whatever it returns: the thread's RCCL state must not stay half open)
+const Transport kRccl{"rccl", rccl_group_start, rccl_send, rccl_recv, rccl_group_end, rccl_abandon};
+
+// -- mailbox: the test transport (head of the file)
+svgf_strips::Local* local_of(svgf_strips* s, int rank) { for (auto& l : s->local) if (l.rank == rank) return &l; return nullptr; }
+int mb_group_start(svgf_strips* s) {
+    if (s->mb_open) return sfail(s, SVGF_ERR_COMM, "mailbox: group started inside a group");
+    s->mb_sends.clear(); s->mb_recvs.clear();
+    s->mb_open = true;
+    return SVGF_OK;
+}
+int mb_post(svgf_strips* s, std::vector<svgf_strips::Posted>& box, int rank, const void* buf, size_t bytes, int peer, const char* what) {
+    if (!s->mb_open) return sfail(s, SVGF_ERR_COMM, std::string("mailbox: ") + what + " outside a group");
+    if (peer < 0 || peer >= s->world || peer == rank || !local_of(s, peer))
+        return sfail(s, SVGF_ERR_COMM, std::string("mailbox: rank ") + std::to_string(rank) + " posts a " + what + " whose peer " + std::to_string(peer) + " is not a rank of this driver");
+    if (s->mb_fault && s->mb_fault_rank == rank) {      // an injected defect of the schedule (svgf_strips_mailbox_fault): what group_end must catch
+        const bool is_send = &box == &s->mb_sends;
+        const int f = s->mb_fault;
+        if ((f == SVGF_FAULT_DROP_SEND && is_send) || (f == SVGF_FAULT_DROP_RECV && !is_send)) { s->mb_fault = 0; return SVGF_OK; }
+        if (f == SVGF_FAULT_SHORT_RECV && !is_send) { s->mb_fault = 0; bytes /= 2; }
+    }
+    box.push_back(svgf_strips::Posted{rank, peer, (char*)const_cast<void*>(buf), bytes});
+    return SVGF_OK;
+}
+int mb_send(svgf_strips* s, svgf_strips::Local& from, const void* buf, size_t bytes, int peer) { return mb_post(s, s->mb_sends, from.rank, buf, bytes, peer, "send"); }
+int mb_recv(svgf_strips* s, svgf_strips::Local& to, void* buf, size_t bytes, int peer) { return mb_post(s, s->mb_recvs, to.rank, buf, bytes, peer, "receive"); }
+int mb_group_end(svgf_strips* s) {
+    s->mb_open = false;
+    // match: the k-th send of (src -> dst) to the k-th receive dst posted with peer src
+    std::vector<int> taken(s->mb_recvs.size(), 0);
+    struct Pair { const svgf_strips::Posted* snd; const svgf_strips::Posted* rcv; };
+    std::vector<Pair> pairs;
+    for (const auto& snd : s->mb_sends) {
+        const svgf_strips::Posted* rcv = nullptr;
+        for (size_t k = 0; k < s->mb_recvs.size(); k++)
+            if (!taken[k] && s->mb_recvs[k].rank == snd.peer && s->mb_recvs[k].peer == snd.rank) { taken[k] = 1; rcv = &s->mb_recvs[k]; break; }
+        if (!rcv) return sfail(s, SVGF_ERR_COMM, "mailbox: rank " + std::to_string(snd.rank) + " sends " + std::to_string(snd.bytes) + " bytes to rank " + std::to_string(snd.peer) +
+                                                  ", which posts no receive for them in this group: a multi-GPU run would wait here for ever");
+        if (rcv->bytes != snd.bytes) return sfail(s, SVGF_ERR_COMM, "mailbox: rank " + std::to_string(snd.rank) + " sends " + std::to_string(snd.bytes) + " bytes to rank " + std::to_string(snd.peer) +
+                                                                    ", whose matching receive (posting order) expects " + std::to_string(rcv->bytes));
+        pairs.push_back(Pair{&snd, rcv});
+    }
+    for (size_t k = 0; k < s->mb_recvs.size(); k++)
+        if (!taken[k]) return sfail(s, SVGF_ERR_COMM, "mailbox: rank " + std::to_string(s->mb_recvs[k].rank) + " waits for " + std::to_string(s->mb_recvs[k].bytes) + " bytes from rank " +
+                                                      std::to_string(s->mb_recvs[k].peer) + ", which sends none in this group: a multi-GPU run would wait here for ever");
+    // every rank's communication stream has reached the group (post_exchange made it wait for the rows it sends and the rows it receives into)
+    for (auto& l : s->local) { DeviceGuard dg(l.device); SVGF_SHIP(s, hipEventRecord(l.mb_ready, l.comm_stream)); }
+    std::vector<char> receives(s->world, 0);
+    for (const Pair& p : pairs) {
+        svgf_strips::Local* src = local_of(s, p.snd->rank);
+        svgf_strips::Local* dst = local_of(s, p.rcv->rank);
+        DeviceGuard dg(dst->device);
+        SVGF_SHIP(s, hipStreamWaitEvent(dst->comm_stream, src->mb_ready, 0));
+        if (src->device == dst->device) SVGF_SHIP(s, hipMemcpyAsync(p.rcv->buf, p.snd->buf, p.snd->bytes, hipMemcpyDeviceToDevice, dst->comm_stream));
+        else SVGF_SHIP(s, hipMemcpyPeerAsync(p.rcv->buf, dst->device, p.snd->buf, src->device, p.snd->bytes, dst->comm_stream));
+        receives[dst->rank] = 1;
+        s->mb_copies++; s->mb_bytes += p.snd->bytes;
+    }
+    for (auto& l : s->local) if (receives[l.rank]) { DeviceGuard dg(l.device); SVGF_SHIP(s, hipEventRecord(l.mb_done, l.comm_stream)); }
+    // a send is complete when its buffer may be written again: the sender's stream waits for the copies out of it
+    for (auto& l : s->local) {
+        std::vector<char> waited(s->world, 0);
+        for (const Pair& p : pairs) {
+            if (p.snd->rank != l.rank || waited[p.rcv->rank]) continue;
+            waited[p.rcv->rank] = 1;
+            DeviceGuard dg(l.device);
+            SVGF_SHIP(s, hipStreamWaitEvent(l.comm_stream, local_of(s, p.rcv->rank)->mb_done, 0));
+        }
+    }
+    s->mb_groups++;
+    return SVGF_OK;
+}
+void mb_abandon(svgf_strips* s) { s->mb_open = false; s->mb_sends.clear(); s->mb_recvs.clear(); }
+const Transport kMailbox{"mailbox", mb_group_start, mb_send, mb_recv, mb_group_end, mb_abandon};
+
+const Transport& transport_of(const svgf_strips* s) { return s->mailbox ? kMailbox : kRccl; }
+
+// A call failed between group start and group end: close the group so that nothing is left half open, and mark the driver unusable — the
+// events and transfers of this frame are in an unknown state.
+int group_failed(svgf_strips* s, int rc) {
+    const std::string why = s->err;
+    transport_of(s).abandon(s);
+    s->broken = true;
+    return sfail(s, rc, why + " (the strip driver is unusable from here: destroy it)");
+}
+
+// Post ONE exchange for all local ranks: for every plane of `planes` the rows at distance [held, h) from each strip boundary (exchange_msgs).
+// is_state selects which event the filter stream will wait for.
+int post_exchange(svgf_strips* s, const std::vector<PlaneSpec>& planes, int h, bool is_state) {
+    const Transport& T = transport_of(s);
     // The transfers of a rank start when its filter stream has produced the rows it sends and is done with the halo rows it
     // receives into.  Loop-back: every virtual rank shares one communication stream, which then waits for all of them.
     for (auto& l : s->local) {
@@ -213,35 +362,20 @@ int post_exchange(svgf_strips* s, const std::vector<std::pair<int, int>>& planes
         if (!s->loopback) SVGF_SHIP(s, hipStreamWaitEvent(l.comm_stream, l.ready, 0));
         else if (&l == &s->local[0]) for (auto& m : s->local) SVGF_SHIP(s, hipStreamWaitEvent(l.comm_stream, m.ready, 0));
     }
-    SVGF_NCCL(s, R->GroupStart());
-    for (size_t k = 0; k < planes.size(); k++) {
-        const int lo = held[k];
-        if (h <= lo) continue;
-        const size_t rb = row_bytes(s, planes[k].first);
-        for (int b = 0; b + 1 < s->world; b++) {
-            svgf_strips::Local* up = find_local(b);
-            svgf_strips::Local* dn = find_local(b + 1);
-            // message 1: rank b's bottom rows [own1-h, own1-lo) -> rank b+1's halo rows of the same global index
-            // message 2: rank b+1's top rows [own0+lo, own0+h) -> rank b's halo
-            for (int dir = 0; dir < 2; dir++) {
-                svgf_strips::Local* src = dir == 0 ? up : dn;
-                svgf_strips::Local* dst = dir == 0 ? dn : up;
-                const int src_rank = dir == 0 ? b : b + 1, dst_rank = dir == 0 ? b + 1 : b;
-                // global rows of the message, from the owner's geometry (own ranges are a pure function of (H, world, rank))
-                const int o0 = (int)((long long)s->H * src_rank / s->world), o1 = (int)((long long)s->H * (src_rank + 1) / s->world);
-                const int g0 = dir == 0 ? o1 - h : o0 + lo, g1 = dir == 0 ? o1 - lo : o0 + h;
-                if (src) {
-                    char* base = (char*)svgf_state_plane(src->ctx, planes[k].first, planes[k].second);
-                    if (int e = R->Send(base + (size_t)(g0 - src->g.y0) * rb, (size_t)(g1 - g0) * rb, ncclInt8, s->loopback ? 0 : dst_rank, src->comm, src->comm_stream); e != ncclSuccess) return group_failed(s, "ncclSend", e);
-                }
-                if (dst) {
-                    char* base = (char*)svgf_state_plane(dst->ctx, planes[k].first, planes[k].second);
-                    if (int e = R->Recv(base + (size_t)(g0 - dst->g.y0) * rb, (size_t)(g1 - g0) * rb, ncclInt8, s->loopback ? 0 : src_rank, dst->comm, dst->comm_stream); e != ncclSuccess) return group_failed(s, "ncclRecv", e);
-                }
-            }
+    if (int rc = T.group_start(s); rc != SVGF_OK) return rc;
+    std::vector<MsgSpec> msgs;
+    for (auto& l : s->local) {
+        msgs.clear();
+        exchange_msgs(s->H, s->world, l.rank, planes, h, msgs);
+        for (const MsgSpec& m : msgs) {
+            const size_t rb = row_bytes(s, m.plane);
+            char* base = (char*)svgf_state_plane(l.ctx, m.plane, m.index) + (size_t)(m.g0 - l.g.y0) * rb;
+            const size_t bytes = (size_t)(m.g1 - m.g0) * rb;
+            const int rc = m.send ? T.send(s, l, base, bytes, m.peer) : T.recv(s, l, base, bytes, m.peer);
+            if (rc != SVGF_OK) return group_failed(s, rc);
         }
     }
-    SVGF_NCCL(s, R->GroupEnd());
+    if (int rc = T.group_end(s); rc != SVGF_OK) { s->broken = true; return rc; }
     for (auto& l : s->local) {
         DeviceGuard dg(l.device);
         SVGF_SHIP(s, hipEventRecord(is_state ? l.state_done : l.halo_done, l.comm_stream));
@@ -347,16 +481,66 @@ int svgf_strips_plan(int width, int height, int rank, int world, int steps, int 
     return SVGF_OK;
 }
 
+// A frame's messages as rank `rank` posts them (exchange 0: the state, posted after iteration 0; exchange g >= 1: the filter rows in front of
+// iteration group g), in posting order.  Pure geometry — no device needed.
+int svgf_strips_messages(int width, int height, int rank, int world, int steps, int plan, int moments_radius, int motion_reach, int storage,
+                         svgf_strip_message* out, int capacity, int* count) {
+    if (!count || (capacity > 0 && !out) || (storage != SVGF_F32 && storage != SVGF_F16)) return SVGF_ERR_INVALID;
+    svgf_strip_layout lay;
+    int rc = svgf_strips_plan(width, height, rank, world, steps, plan, moments_radius, motion_reach, &lay);
+    if (rc != SVGF_OK) return rc;
+    svgf_strip_plan_geo g;
+    make_geo(width, height, rank, world, steps, lay.plan, moments_radius, motion_reach, g);
+    svgf_strips dims;
+    dims.W = width; dims.storage = storage;
+    int n = 0;
+    auto emit = [&](int exchange, const std::vector<PlaneSpec>& planes, int h) {
+        std::vector<MsgSpec> msgs;
+        exchange_msgs(height, world, rank, planes, h, msgs);
+        for (const MsgSpec& m : msgs) {
+            if (n < capacity) out[n] = svgf_strip_message{exchange, m.send ? 1 : 0, m.peer, m.plane, m.g0, m.g1, (size_t)(m.g1 - m.g0) * row_bytes(&dims, m.plane)};
+            n++;
+        }
+    };
+    if (world > 1) {
+        emit(0, state_planes(g, steps, 0), g.halo_state);
+        for (size_t gi = 1; gi < g.groups.size(); gi++) emit((int)gi, {{SVGF_PLANE_FILTER, 0, 0}}, g.halo_group[gi]);
+    }
+    *count = n;
+    return n <= capacity ? SVGF_OK : SVGF_ERR_INVALID;
+}
+
+int svgf_strips_transport_stats(const svgf_strips* s, unsigned long long* groups, unsigned long long* copies, unsigned long long* bytes) {
+    if (!s || !s->mailbox) return SVGF_ERR_INVALID;
+    if (groups) *groups = s->mb_groups;
+    if (copies) *copies = s->mb_copies;
+    if (bytes) *bytes = s->mb_bytes;
+    return SVGF_OK;
+}
+
+int svgf_strips_mailbox_fault(svgf_strips* s, int rank, int fault) {
+    if (!s || !s->mailbox || rank < 0 || rank >= s->world || fault < 0 || fault > SVGF_FAULT_SHORT_RECV) return SVGF_ERR_INVALID;
+    s->mb_fault_rank = rank; s->mb_fault = fault;
+    return SVGF_OK;
+}
+
 int svgf_strips_create(svgf_strips** out, int width, int height, int world, const svgf_params* params, int plan, int motion_reach,
-                       int nlocal, const int* ranks, const int* devices, void* const* compute_streams, void* const* comms, int loopback) {
+                       int nlocal, const int* ranks, const int* devices, void* const* compute_streams, void* const* comms, int transport) {
     if (!out) return SVGF_ERR_INVALID;
     *out = nullptr;
     if (!params || nlocal < 1 || !ranks || !devices || world < 1 || nlocal > world) return SVGF_ERR_INVALID;
-    if (world > 1 && !comms) return SVGF_ERR_INVALID;
+    if (transport < SVGF_TRANSPORT_RCCL || transport > SVGF_TRANSPORT_MAILBOX) return SVGF_ERR_INVALID;
+    if (world > 1 && !comms && transport != SVGF_TRANSPORT_MAILBOX) return SVGF_ERR_INVALID;
+    if (transport == SVGF_TRANSPORT_MAILBOX) {           // every rank of the partition lives here, once
+        if (nlocal != world) return SVGF_ERR_INVALID;
+        std::vector<char> seen(world, 0);
+        for (int k = 0; k < nlocal; k++) { if (ranks[k] < 0 || ranks[k] >= world || seen[ranks[k]]) return SVGF_ERR_INVALID; seen[ranks[k]] = 1; }
+    }
     std::unique_ptr<svgf_strips> s(new (std::nothrow) svgf_strips());
     if (!s) return SVGF_ERR_ALLOC;
     s->W = width; s->H = height; s->world = world; s->steps = params->steps; s->motion_reach = motion_reach;
-    s->moments_radius = params->moments_radius; s->storage = params->storage; s->loopback = loopback != 0;
+    s->moments_radius = params->moments_radius; s->storage = params->storage;
+    s->loopback = transport == SVGF_TRANSPORT_RCCL_LOOPBACK; s->mailbox = transport == SVGF_TRANSPORT_MAILBOX;
     svgf_strip_layout lay;
     int rc = svgf_strips_plan(width, height, ranks[0], world, params->steps, plan, params->moments_radius, motion_reach, &lay);
     if (rc != SVGF_OK) return rc;
@@ -370,7 +554,7 @@ int svgf_strips_create(svgf_strips** out, int width, int height, int world, cons
         make_geo(width, height, l.rank, world, params->steps, s->plan, params->moments_radius, motion_reach, l.g);
         l.compute = compute_streams ? (hipStream_t)compute_streams[k] : nullptr;
         l.cur = l.compute;
-        l.comm = comms ? (ncclComm_t)comms[s->loopback ? 0 : k] : nullptr;
+        l.comm = comms && !s->mailbox ? (ncclComm_t)comms[s->loopback ? 0 : k] : nullptr;
         svgf_strip st{l.g.y0, l.g.y1 - l.g.y0, l.g.own0, l.g.own1};
         rc = svgf_create_strip(&l.ctx, width, height, &st, params, l.device, l.compute);
         if (rc != SVGF_OK) { cleanup(); return rc; }
@@ -385,6 +569,8 @@ int svgf_strips_create(svgf_strips** out, int width, int height, int world, cons
         if (e == hipSuccess) e = hipEventCreateWithFlags(&l.ready, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&l.halo_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&l.state_done, hipEventDisableTiming);
+        if (e == hipSuccess && s->mailbox) e = hipEventCreateWithFlags(&l.mb_ready, hipEventDisableTiming);
+        if (e == hipSuccess && s->mailbox) e = hipEventCreateWithFlags(&l.mb_done, hipEventDisableTiming);
         if (e != hipSuccess) { cleanup(); return SVGF_ERR_HIP; }
     }
     *out = s.release();
@@ -407,6 +593,8 @@ void svgf_strips_destroy(svgf_strips* s) {
         if (l.ready) (void)hipEventDestroy(l.ready);
         if (l.halo_done) (void)hipEventDestroy(l.halo_done);
         if (l.state_done) (void)hipEventDestroy(l.state_done);
+        if (l.mb_ready) (void)hipEventDestroy(l.mb_ready);
+        if (l.mb_done) (void)hipEventDestroy(l.mb_done);
         if (l.own_comm_stream && l.comm_stream) (void)hipStreamDestroy(l.comm_stream);
     }
     delete s;
@@ -483,10 +671,7 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
         if (s->world <= 1) return SVGF_OK;
         const svgf_strip_plan_geo& g = s->local[0].g;
         const int P = s->local[0].ctx->pingpong;           // all local contexts advance together
-        const int colour_held = s->steps ? g.ext_atrous[0] : g.ext_temporal;
-        // only rows a rank has NOT computed itself travel: it holds the feedback colour ext_atrous[0] rows beyond its strip and
-        // moments / history ext_temporal rows beyond (bit-identical to the owner's)
-        return post_exchange(s, {{SVGF_PLANE_COLOUR, P}, {SVGF_PLANE_MOMENTS, P}, {SVGF_PLANE_HISTORY, P}}, {colour_held, g.ext_temporal, g.ext_temporal}, g.halo_state, true);
+        return post_exchange(s, state_planes(g, s->steps, P), g.halo_state, true);
     };
     // Two frames in flight: everything the NEXT frame's temporal launch reads is written once iteration 0 has stored the feedback colour and
     // the state exchange is posted; the remaining iterations (their exchanges included) go to the side stream.  Only when they read nothing
@@ -542,7 +727,7 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
                 if (rc != SVGF_OK) return rc;
                 q++;
                 if (q + 1 == groups[gi].size() && gi + 1 < groups.size() && s->world > 1) {      // (a group of exactly {0, 1}: its output travels whole)
-                    rc = post_exchange(s, {{SVGF_PLANE_FILTER, pp[0]}}, {0}, s->local[0].g.halo_group[gi + 1], false);
+                    rc = post_exchange(s, {{SVGF_PLANE_FILTER, pp[0], 0}}, s->local[0].g.halo_group[gi + 1], false);
                     if (rc != SVGF_OK) return rc;
                     posted = true;
                 }
@@ -573,7 +758,7 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
                 if (rc != SVGF_OK) return rc;
             }
             if (feeds_exchange) {
-                int rc = post_exchange(s, {{SVGF_PLANE_FILTER, 1 - pp[0]}}, {0}, h, false);
+                int rc = post_exchange(s, {{SVGF_PLANE_FILTER, 1 - pp[0], 0}}, h, false);
                 if (rc != SVGF_OK) return rc;
                 posted = true;
             }

@@ -31,9 +31,10 @@ EXPORTS = [
     "svgf_import_gbuffer_pitched", "svgf_import_gbuffer_array", "svgf_export_to_array",
     "svgf_strips_plan", "svgf_rccl_unique_id", "svgf_rccl_comm_init", "svgf_rccl_comm_destroy", "svgf_rccl_comm_count", "svgf_strips_create", "svgf_strips_destroy",
     "svgf_strips_last_error", "svgf_strips_context", "svgf_strips_layout", "svgf_strips_frame", "svgf_strips_sync",
-    "svgf_strips_timing_enable", "svgf_strips_timing_read", "svgf_strips_set_frames_in_flight",
+    "svgf_strips_timing_enable", "svgf_strips_timing_read", "svgf_strips_set_frames_in_flight", "svgf_strips_messages", "svgf_strips_transport_stats", "svgf_strips_mailbox_fault",
 ]
-ABI_VERSION = 6
+ABI_VERSION = 7
+TRANSPORT = {"rccl": 0, "rccl-loopback": 1, "mailbox": 2}
 DEBUG_MODE = {"final": 0, "temporal": 1, "atrous": 2}
 HALO_PLAN = {"auto": 0, "ghost": 1, "grouped": 2, "per-iteration": 3}
 HALO_PLAN_NAME = {v: k for k, v in HALO_PLAN.items()}
@@ -52,6 +53,10 @@ class ParamsC(C.Structure):
     _fields_ = [("steps", C.c_int), ("depth_threshold", C.c_float), ("normal_threshold", C.c_float),
                 ("history_base", C.c_int), ("phi_colour", C.c_float), ("phi_normal", C.c_float),
                 ("moments_radius", C.c_int), ("storage", C.c_int), ("mesh_id_test", C.c_int), ("variant", C.c_int), ("nan_policy", C.c_int)]
+
+
+class StripMessageC(C.Structure):
+    _fields_ = [("exchange", C.c_int), ("send", C.c_int), ("peer", C.c_int), ("plane", C.c_int), ("row_begin", C.c_int), ("row_end", C.c_int), ("bytes", C.c_size_t)]
 
 
 class CameraC(C.Structure):
@@ -177,6 +182,9 @@ def load_library():
     lib.svgf_rccl_comm_destroy.argtypes = [vp]
     lib.svgf_rccl_comm_count.argtypes = [vp, C.POINTER(ip)]
     lib.svgf_strips_create.argtypes = [C.POINTER(vp), ip, ip, ip, C.POINTER(ParamsC), ip, ip, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(vp), C.POINTER(vp), ip]
+    lib.svgf_strips_messages.argtypes = [ip, ip, ip, ip, ip, ip, ip, ip, ip, C.POINTER(StripMessageC), ip, C.POINTER(ip)]
+    lib.svgf_strips_transport_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    lib.svgf_strips_mailbox_fault.argtypes = [vp, ip, ip]
     lib.svgf_strips_destroy.argtypes = [vp]
     lib.svgf_strips_destroy.restype = None
     lib.svgf_strips_last_error.argtypes = [vp]

@@ -406,6 +406,20 @@ def strips_plan(W, H, rank, world, steps, plan="auto", moments_radius=3, motion_
                 ext_temporal=lay.ext_temporal, halo_state=lay.halo_state, halo_max=lay.halo_max)
 
 
+def strip_messages(W, H, rank, world, steps, plan="auto", moments_radius=3, motion_reach=0, storage="f32"):
+    """svgf_strips_messages -> the messages of one frame as `rank` posts them: list of dicts (exchange, send, peer, plane, rows, bytes)."""
+    import ctypes as C
+    from . import filter as F
+    lib = F.load_library()
+    cap = 64
+    buf = (F.StripMessageC * cap)()
+    n = C.c_int()
+    rc = lib.svgf_strips_messages(W, H, rank, world, steps, F.HALO_PLAN[plan], moments_radius, motion_reach, F.STORAGE[storage], buf, cap, C.byref(n))
+    if rc != 0:
+        raise ValueError(f"svgf_strips_messages: {lib.svgf_status_string(rc).decode()}")
+    return [dict(exchange=m.exchange, send=bool(m.send), peer=m.peer, plane=m.plane, rows=(m.row_begin, m.row_end), bytes=m.bytes) for m in buf[:n.value]]
+
+
 def rccl_comm(world, rank, device_index, group=None):
     """An ncclComm_t for the C++ strip driver: rank 0 draws the unique id (svgf_rccl_unique_id), torch.distributed carries its
     128 bytes to the other ranks — the only thing Python does for the exchange — and every rank joins (svgf_rccl_comm_init)."""
@@ -434,7 +448,9 @@ class NativeStrips:
     """The C++ strip driver of the library (svgf_strips_*, svgf_amd/csrc/svgf_strip.hip): the stage sequence of every local
     strip, the RCCL groups, the communication stream and the events all live in C++; Python hands over device pointers."""
 
-    def __init__(self, W, H, world, params, ranks, devices, streams=None, comms=None, plan="auto", motion_reach=0, loopback=False):
+    def __init__(self, W, H, world, params, ranks, devices, streams=None, comms=None, plan="auto", motion_reach=0, loopback=False, transport=None):
+        """transport: "rccl" (default; one communicator per local rank), "rccl-loopback" (= loopback=True: ONE communicator of size 1), or
+        "mailbox" (tests: every rank local, real peer addressing, sends matched to receives inside the library — include/svgf.h)."""
         import ctypes as C
         import torch
         from . import filter as F
@@ -447,10 +463,12 @@ class NativeStrips:
         pc = params.to_c()
         r_arr, d_arr = (C.c_int * n)(*ranks), (C.c_int * n)(*devices)
         s_arr = (C.c_void_p * n)(*[(s if s is not None else None) for s in (streams or [None] * n)])
-        ncomm = 1 if loopback else n
-        c_arr = (C.c_void_p * ncomm)(*[(c.value if hasattr(c, "value") else c) for c in comms]) if comms else None
+        transport = transport or ("rccl-loopback" if loopback else "rccl")
+        self.transport = transport
+        ncomm = 1 if transport == "rccl-loopback" else n
+        c_arr = (C.c_void_p * ncomm)(*[(c.value if hasattr(c, "value") else c) for c in comms]) if comms and transport != "mailbox" else None
         h = C.c_void_p()
-        rc = self.lib.svgf_strips_create(C.byref(h), W, H, world, C.byref(pc), F.HALO_PLAN[plan], motion_reach, n, r_arr, d_arr, s_arr, c_arr, int(loopback))
+        rc = self.lib.svgf_strips_create(C.byref(h), W, H, world, C.byref(pc), F.HALO_PLAN[plan], motion_reach, n, r_arr, d_arr, s_arr, c_arr, F.TRANSPORT[transport])
         if rc != 0:
             raise F.SvgfError(f"svgf_strips_create: {self.lib.svgf_status_string(rc).decode()}")
         self._h = h
@@ -516,6 +534,13 @@ class NativeStrips:
         """Iterations 0 and 1 as one launch on every local strip (where the halo plan keeps them in one group)."""
         for k in range(self.n):
             self._check(self.lib.svgf_set_iteration_fusion(self.lib.svgf_strips_context(self._h, k), 1 if enable else 0))
+
+    def transport_stats(self):
+        """mailbox transport: (groups matched, copies enqueued, bytes copied) so far."""
+        C = self.C
+        g, c, b = C.c_ulonglong(), C.c_ulonglong(), C.c_ulonglong()
+        self._check(self.lib.svgf_strips_transport_stats(self._h, C.byref(g), C.byref(c), C.byref(b)))
+        return g.value, c.value, b.value
 
     def owned(self, k, t):
         lay = self.layouts[k]

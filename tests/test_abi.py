@@ -23,7 +23,7 @@ def test_header_symbols_all_exported():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/svgf.h but not exported"
     assert sorted(F.EXPORTS) == syms
-    assert lib.svgf_abi_version() == F.ABI_VERSION == 6
+    assert lib.svgf_abi_version() == F.ABI_VERSION == 7
 
 
 def test_default_params_match_reference_defaults():
@@ -89,6 +89,54 @@ def test_strip_plan_matches_python_geometry():
                             assert lay["plan"] == (g.plan if isinstance(g.plan, str) else plan)
                             n += 1
     assert n > 500
+
+
+def test_every_posted_send_has_its_mirror_receive_on_the_neighbour():
+    """svgf_strips_messages is what svgf_strips_frame hands to its transport (svgf_strip.hip: exchange_msgs).  For world = 2..8, every plan,
+    both storages, frame sizes with uneven strips and several motion reaches: within every exchange, the sends of rank a to rank b and the
+    receives rank b posts with peer a are the SAME sequence of (plane, global rows, bytes) — RCCL matches the sends and receives of a pair
+    of ranks in posting order, so an unmatched or mis-ordered message is a deadlock (or rows in the wrong place) on a real node.  Also: peers
+    are direct neighbours, a rank receives only rows outside its own strip and inside what it holds, sends only rows it owns."""
+    from svgf_amd import strips
+    cases = 0
+    for (W, H) in ((7680, 4320), (3840, 2160), (640, 1003), (96, 700)):
+        for world in range(2, 9):
+            for steps in (0, 1, 3, 5):
+                for plan in ("ghost", "grouped", "per-iteration", "auto"):
+                    for mr, reach in ((3, 4), (1, 0), (3, 9)):
+                        for storage in ("f32", "f16"):
+                            try:
+                                lays = [strips.strips_plan(W, H, r, world, steps, plan, mr, reach) for r in range(world)]
+                            except ValueError:
+                                with pytest.raises(ValueError):
+                                    strips.strip_messages(W, H, 0, world, steps, plan, mr, reach, storage)
+                                continue
+                            msgs = [strips.strip_messages(W, H, r, world, steps, plan, mr, reach, storage) for r in range(world)]
+                            nex = 1 + max(0, len(lays[0]["halo_group"]) - 1)
+                            # (no iteration and no motion reach: every state row a rank needs it has computed itself — nothing travels)
+                            state = steps > 0 or reach > 0
+                            assert {m["exchange"] for r in range(world) for m in msgs[r]} == set(range(0 if state else 1, nex)), (W, H, world, steps, plan)
+                            for ex in range(nex):
+                                for a in range(world):
+                                    for b in (a - 1, a + 1):
+                                        if not 0 <= b < world:
+                                            assert not [m for m in msgs[a] if m["peer"] == b]
+                                            continue
+                                        sent = [(m["plane"], m["rows"], m["bytes"]) for m in msgs[a] if m["exchange"] == ex and m["send"] and m["peer"] == b]
+                                        recv = [(m["plane"], m["rows"], m["bytes"]) for m in msgs[b] if m["exchange"] == ex and not m["send"] and m["peer"] == a]
+                                        assert sent == recv and (sent or (ex == 0 and not state)), (W, H, world, steps, plan, ex, a, b, sent, recv)
+                            for r in range(world):
+                                own, y0, y1 = lays[r]["own"], lays[r]["y0"], lays[r]["y1"]
+                                for m in msgs[r]:
+                                    assert abs(m["peer"] - r) == 1
+                                    lo, hi = m["rows"]
+                                    assert lo < hi and m["bytes"] == (hi - lo) * W * {0: 16, 1: 8, 2: 16, 3: 1}[m["plane"]] // ((2 if m["plane"] != 3 else 1) if storage == "f16" else 1)
+                                    if m["send"]:
+                                        assert own[0] <= lo and hi <= own[1], (r, m, own)
+                                    else:
+                                        assert y0 <= lo and hi <= y1 and (hi <= own[0] or lo >= own[1]), (r, m, own, y0, y1)
+                            cases += 1
+    assert cases > 1000
 
 
 def test_strip_driver_refuses_without_gpu_or_bad_arguments():

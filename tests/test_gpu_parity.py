@@ -355,6 +355,38 @@ def test_frame_driver_fusions_hold_for_any_parameters(G, params):
         assert np.array_equal(G.host(d.state_plane(F.PLANE_MOMENTS, 1 - d.pingpong())).view(np.uint8), hip.taps["mom"].view(np.uint8))
 
 
+@pytest.mark.parametrize("params", [
+    dict(steps=3, moments_radius=0), dict(steps=3, moments_radius=2), dict(steps=3, phi_normal=0.0), dict(steps=2, moments_radius=1),
+    dict(steps=3, moments_radius=2, variant="lds"),
+])
+def test_frame_driver_first_frames_under_the_default_variants(G, params):
+    """in the first three frames after a reset the frame driver called every frame "cold" under variant auto / lds —
+    its temporal launch then appends to no young list — while launch_moments only has an every-pixel kernel for the reference's radius
+    with PhiNormal != 0 (LDS streaming) and for radius 1 (wave shuffles).  With radius 0 / 2 or PhiNormal == 0 the young-pixel launch
+    ran without its list: the young pixels of partly young 64-column segments (sky silhouettes; the right-most segment when W % 64 != 0)
+    kept stale filter_out texels.  W = 203 (W % 64 = 11), a scene with sky, a reset in mid-sequence; bitwise against the stage calls."""
+    from svgf_amd import filter as F
+    W, H, N = 203, 77, 9
+    fr = frames(W, H, N, mv=(-2.5, 1.5))
+    p = dict(variant="auto")
+    p.update(params)
+    for storage in ("f32", "f16"):
+        hip = G.HipPipeline(W, H, storage, **p)
+        d = F.Denoiser(W, H, F.Params(storage=storage, **p))
+        gbs = [G.gb_dev(f) for f in fr]
+        for k in range(N):
+            if k == 5:                                   # a reset in mid-sequence: three more cold frames, on planes that hold stale data
+                d.reset_history()
+                for t in hip.colour + hip.mom + hip.hist:
+                    t.zero_()
+                hip.filt[0].fill_(0.25)                  # (the stage calls overwrite every texel; the driver's planes are zeroed by the reset)
+            kp = max(k - 1, 0)
+            a = hip.frame(fr[k]["radiance"], gbs[k], gbs[kp])
+            b = G.host(d.Render(G.dev(fr[k]["radiance"].astype(G.NPDT[storage])), gbs[k], gbs[kp] if k else None))
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (storage, k)
+        assert np.array_equal(G.host(d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong())), hip.taps["hist"])
+
+
 @pytest.mark.parametrize("storage", ["f32", "f16"])
 def test_temporal_moments_fused_equals_stage_calls(G, storage):
     """svgf_temporal_moments (caller-owned planes; the strip runner's path) == svgf_temporal + svgf_moments, bitwise,

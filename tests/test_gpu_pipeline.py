@@ -159,6 +159,11 @@ def test_filter_plane_and_debug_view_after_switching_back_to_one_frame(G):
         two.set_frames_in_flight(1)
         idx = 4 & 1                                      # steps = 4: the result is in FilterBuffer[0] (no odd-N copy, App. B #12)
         assert np.array_equal(G.host(two.state_plane(F.PLANE_FILTER, idx)).view(np.uint8), G.host(r1).view(np.uint8)), nflight
+        # ... and a second 2 -> 1 switch WITHOUT a frame in between must not rename the pairs again (the switch used to infer
+        # "the last frame used the second pair" from the toggle, which also reads that way when no frame ran since the last switch)
+        two.set_frames_in_flight(2)
+        two.set_frames_in_flight(1)
+        assert np.array_equal(G.host(two.state_plane(F.PLANE_FILTER, idx)).view(np.uint8), G.host(r1).view(np.uint8)), (nflight, "2 -> 1 -> 2 -> 1")
         one.set_debug_mode("atrous"); two.set_debug_mode("atrous")
         k = nflight
         a = one.Render(G.dev(seq[k]["radiance"]), gbs[k], gbs[k - 1])
