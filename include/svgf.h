@@ -42,8 +42,24 @@
  *    svgf_atrous, svgf_atrous_pair, svgf_denoise_frame and the strip driver reproduce exactly that (tests/test_gpu_nonfinite.py: NaN
  *    masks identical to the oracle's, finite values within the stage tolerances): a host that wants its NaNs healed must clean the
  *    radiance before the temporal stage — the reference does not, and neither does this library.  svgf_taa likewise: a NaN texel goes
- *    through glm's min / max position by position (Filter.cuh:330-338) and the NaN test of :351 writes the pixel black.  Not covered:
- *    NaN / inf in the G-buffer planes (depth, normal, motion).
+ *    through glm's min / max position by position (Filter.cuh:330-338) and the NaN test of :351 writes the pixel black.
+ *  - Non-finite / out-of-range G-buffer texels: what the reference's binary does, reproduced (tests/test_gpu_gbuffer_nonfinite.py):
+ *        motion   `Coord + ivec2(MotionVector)` (Filter.cuh:232) is a float -> int conversion toward zero that SATURATES and turns a NaN
+ *                 into 0, added to the pixel coordinate with wrap-around: a NaN motion reprojects the pixel onto itself; +-inf and anything
+ *                 beyond +-2^31 pixels lands outside the frame and is rejected (:235).  The instance ID of mesh_id_test = 1 converts the same way.
+ *        depth    only 0 is the sentinel (:204; -0 too): a negative or denormal depth is a number, a depth of exactly 1e30 reads like the
+ *                 sentinel.  A NaN depth fails no test — `abs(dz) > DepthThreshold` is false, the reprojection is ACCEPTED (:242) — and drops
+ *                 out of every weight it enters: `max(weightZ, 0.0)` is CUDA's fmax (:424).
+ *        ddepth   `max(ddepth, 1e-6f)` / `max(ddepth, 1e-8)` are fmaxf / fmax (:563,461): a NaN or negative derivative gives the floor.
+ *        normal   a NaN normal fails no test either (`dot < NormalThreshold` is false: ACCEPTED, :252) and has weight 0 in the filters
+ *                 (saturate(NaN) = 0, :419); a zero-length normal is rejected and has weight 0.
+ *    Not reproduced: a depth derivative of +inf (or beyond ~1e22 / step) on a sky texel — see "Sky" above.
+ *  - Bit-identity next to a NaN.  The streaming a-trous kernel redoes, the reference's way, exactly the pixels whose fast result held a NaN;
+ *    every other pixel keeps its bits, so strips and row ranges stay bit-identical to the whole frame with NaN texels present (colour or
+ *    G-buffer).  Two places still round a FINITE pixel next to a NaN texel differently depending on how the work is cut (both within the stated
+ *    tolerance): the LDS-streaming moments kernel (the first three frames after a reset, crowded frames: a workgroup that has staged a
+ *    non-finite texel evaluates all its pixels in the exact form) and the pair launch svgf_atrous_pair (its second pass takes the exact form
+ *    for the whole band).
  *  - Strips: a context may hold only rows [y0, y0+rows) of a WxH frame (multi-GPU row strips);
  *    "inside the frame" tests always use the global frame, so strip results are bit-identical
  *    to the whole-frame result as long as the halo rows hold valid data.

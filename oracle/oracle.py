@@ -14,7 +14,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsvgf_oracle.so")
-_lib = None
+# the envelope build (Makefile: fp64 islands in fp32, FMA contraction on): flavour="fp32fma".  Never the checker — see svgf_oracle.cpp, wide_t
+_ENV_PATH = os.path.join(_HERE, "libsvgf_oracle_fp32fma.so")
+_libs = {}
 
 STORAGE = {"f32": 0, "f16": 1}
 _CDT = {"f32": np.float32, "f16": np.float16}
@@ -25,21 +27,44 @@ DEFAULTS = dict(steps=3, depth_threshold=0.8, normal_threshold=0.9, history_base
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "svgf_oracle.cpp")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libsvgf_oracle.so"], stdout=subprocess.DEVNULL)
+    stale = lambda p: not os.path.exists(p) or os.path.getmtime(p) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "Makefile")))   # noqa: E731
+    if force or stale(_LIB_PATH) or stale(_ENV_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 
-def lib():
-    global _lib
-    if _lib is None:
+_flavour = "oracle"
+
+
+def lib(flavour=None):
+    """flavour None: the library the module-level stage functions currently run on (the oracle, unless inside `using("fp32fma")`)."""
+    flavour = flavour or _flavour
+    if flavour not in _libs:
         build()
-        _lib = C.CDLL(_LIB_PATH)
-        _lib.svgf_oracle_f2h.restype = C.c_uint16
-        _lib.svgf_oracle_f2h.argtypes = [C.c_float]
-        _lib.svgf_oracle_h2f.restype = C.c_float
-        _lib.svgf_oracle_h2f.argtypes = [C.c_uint16]
-    return _lib
+        L = C.CDLL({"oracle": _LIB_PATH, "fp32fma": _ENV_PATH}[flavour])
+        L.svgf_oracle_f2h.restype = C.c_uint16
+        L.svgf_oracle_f2h.argtypes = [C.c_float]
+        L.svgf_oracle_h2f.restype = C.c_float
+        L.svgf_oracle_h2f.argtypes = [C.c_uint16]
+        _libs[flavour] = L
+    return _libs[flavour]
+
+
+class using:
+    """with oracle.using("fp32fma"): ... — the stage functions and Pipeline.frame run on the envelope build inside the block."""
+
+    def __init__(self, flavour):
+        self.flavour = flavour
+
+    def __enter__(self):
+        global _flavour
+        self.prev, _flavour = _flavour, self.flavour
+        return self
+
+    def __exit__(self, *exc):
+        global _flavour
+        _flavour = self.prev
+        return False
 
 
 def _p(a):

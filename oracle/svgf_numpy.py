@@ -44,6 +44,20 @@ def _dot(a, b):
     return (a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]) + a[..., 2] * b[..., 2]
 
 
+def _cvt_rzi_s32(a):
+    """PTX cvt.rzi.s32.f32 — what int(x) / ivec2(vec2) compile to on the device (Filter.cuh:232,245-246): toward zero, saturating, NaN -> 0;
+    returned as int64 so that the caller's two's-complement add can be written out (_add_wrap)."""
+    with np.errstate(all="ignore"):
+        t = np.trunc(a.astype(np.float64))
+    t = np.where(np.isnan(t), 0.0, np.clip(t, -2147483648.0, 2147483647.0))
+    return t.astype(np.int64)
+
+
+def _add_wrap(a, b):
+    """int32 + int32 with wrap-around (int64 in, int64 out)."""
+    return ((a + b + 2**31) % 2**32) - 2**31
+
+
 def _weight(zc, zp, phi_d, nc, npix, phi_n, lc, lp, phi_l):      # A.5
     with np.errstate(all="ignore"):
         d = _clamp01(_dot(nc, npix))
@@ -64,8 +78,8 @@ def temporal(prev_colour, cur, gb_cur, gb_prev, hist_prev, mom_prev, *, depth_th
     c = _clamp01(_ld(cur))[..., :3]
     Y, X = np.mgrid[0:H, 0:W]
     mv = gb_cur["motion"][..., :2]
-    qx = X + np.trunc(mv[..., 0]).astype(np.int64)
-    qy = Y + np.trunc(mv[..., 1]).astype(np.int64)
+    qx = _add_wrap(X.astype(np.int64), _cvt_rzi_s32(mv[..., 0]))
+    qy = _add_wrap(Y.astype(np.int64), _cvt_rzi_s32(mv[..., 1]))
     inb = (qx >= 0) & (qx < W) & (qy >= 0) & (qy < H)
     qxc, qyc = np.clip(qx, 0, W - 1), np.clip(qy, 0, H - 1)
     zc, _ = _depth(gb_cur["motion"])
@@ -74,12 +88,13 @@ def temporal(prev_colour, cur, gb_cur, gb_prev, hist_prev, mom_prev, *, depth_th
     with np.errstate(all="ignore"):
         ok = inb & ~(np.abs(zp - zc) > f32(depth_threshold))
     if mesh_id_test:
-        idc = gb_cur["uv"][..., 3].view(np.float16).astype(np.float32).astype(np.int32)
-        idp = gb_prev["uv"][..., 3].view(np.float16).astype(np.float32).astype(np.int32)[qyc, qxc]
+        idc = _cvt_rzi_s32(gb_cur["uv"][..., 3].view(np.float16).astype(np.float32))
+        idp = _cvt_rzi_s32(gb_prev["uv"][..., 3].view(np.float16).astype(np.float32))[qyc, qxc]
         ok &= idc == idp
     nc = _normal(gb_cur["normal"])
     npv = _normal(gb_prev["normal"])[qyc, qxc]
-    ok &= ~(_dot(nc, npv) < f32(normal_threshold))
+    with np.errstate(all="ignore"):
+        ok &= ~(_dot(nc, npv) < f32(normal_threshold))
 
     cp = np.where(ok[..., None], _clamp01(_ld(prev_colour))[qyc, qxc][..., :3], f32(0))
     mp = np.where(ok[..., None], _ld(mom_prev)[qyc, qxc], f32(0))
@@ -107,7 +122,7 @@ def moments(colour, mom, gb, hist, *, phi_colour, phi_normal, radius=3):
     zc, dzc = _depth(gb["motion"])
     nc = _normal(gb["normal"])
     lc = _lum(craw)
-    phi_d = (np.maximum(dzc.astype(np.float64), 1e-8) * 3.0).astype(np.float32)
+    phi_d = (np.fmax(dzc.astype(np.float64), 1e-8) * 3.0).astype(np.float32)      # :461 max(float, double) = fmax: a NaN ddepth gives 1e-8
     Y, X = np.mgrid[0:H, 0:W]
     sw = np.zeros((H, W), np.float32)
     sc = np.zeros((H, W, 3), np.float32)
@@ -125,7 +140,7 @@ def moments(colour, mom, gb, hist, *, phi_colour, phi_normal, radius=3):
             sw = np.where(inside, sw + w, sw)
             sc = np.where(inside[..., None], sc + cpix[..., :3] * w[..., None], sc)
             sm = np.where(inside[..., None], sm + mraw[pyc, pxc] * w[..., None], sm)
-    sw = np.maximum(sw, f32(1e-6))
+    sw = np.fmax(sw, f32(1e-6))
     C = sc / sw[..., None]
     M = sm / sw[..., None]
     var = M[..., 1] - M[..., 0] * M[..., 0]
@@ -152,7 +167,7 @@ def atrous(src, gb, *, step, phi_colour, phi_normal):
     sky = zc == SKY_Z
     # :562 max(0.0, eps + variance): the double literal selects CUDA's fmax, which drops a NaN variance (phi_l = 0: only equal luminances pass)
     phi_l = (np.float64(f32(phi_colour)) * np.sqrt(np.fmax(0.0, (f32(1e-10) + var).astype(np.float64)))).astype(np.float32)
-    phi_d = np.maximum(dzc, f32(1e-6)) * f32(step)
+    phi_d = np.fmax(dzc, f32(1e-6)) * f32(step)                                      # :563 max(float, float) = fmaxf
     Y, X = np.mgrid[0:H, 0:W]
     S = np.ones((H, W), np.float32)
     acc = c.copy()

@@ -28,6 +28,17 @@
 
 namespace {
 
+// The reference's fp64 islands are evaluated in `wide_t`.  The oracle proper keeps them (double).  A SECOND build of this
+// file — libsvgf_oracle_fp32fma.so: -DSVGF_ORACLE_ALL_FP32 -ffp-contract=fast -mfma — evaluates them in fp32 and lets the compiler contract
+// a*b+c into FMAs, as nvcc's default does to Filter.cuh:393-398,498-499,608: a second "correct" implementation of the same source.  The
+// distance between the two, free-running on the same frames, is the envelope inside which the HIP path must sit (tests/test_gpu_parity.py,
+// profiles/r05_parity_report.json: VERDICT r04 #4).
+#ifdef SVGF_ORACLE_ALL_FP32
+typedef float wide_t;
+#else
+typedef double wide_t;
+#endif
+
 struct Geo { int W, H, y0, rows, yb, ye; };
 
 // ---------------------------------------------------------------- storage ----
@@ -111,6 +122,17 @@ inline void get_depth(const float* motion, size_t idx, float& z, float& dz) {
 inline void get_normal(const uint16_t* normal, size_t idx, float* n) {
     n[0] = h2f(normal[4 * idx]); n[1] = h2f(normal[4 * idx + 1]); n[2] = h2f(normal[4 * idx + 2]);
 }
+// int(x) / ivec2(vec2) on the device (Filter.cuh:232 `Coord + ivec2(MotionVector)`; the instance ID of :245-246) is PTX cvt.rzi.s32.f32:
+// round toward zero, out-of-range values SATURATE, NaN converts to 0.  (A C++ cast of such a value is undefined — x86's cvttss2si
+// returns INT_MIN for all of them, which is not what the reference's binary does: VERDICT r04.)  The sum with the pixel coordinate is a
+// two's-complement add: INT_MAX + x wraps negative, so every saturated motion lands outside the frame and is rejected (:235).
+inline int cvt_rzi_s32(float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return -2147483647 - 1;
+    return (int)f;
+}
+inline int add_wrap(int a, int b) { return (int)((uint32_t)a + (uint32_t)b); }
 inline float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }  // glm::dot
 // CalculateLuminance (Filter.cuh:260-263)
 inline float luminance(const float* c) { return 0.2126f * c[0] + 0.7152f * c[1] + 0.0722f * c[2]; }
@@ -126,7 +148,7 @@ inline float compute_weight(float zc, float zp, float phi_depth, const float* nc
     const float wn = std::pow(d, phi_normal);                           // powf
     const float wz = (phi_depth == 0) ? 0.0f : std::fabs(zc - zp) / phi_depth;
     const float wl = std::fabs(lc - lp) / phi_illum;
-    const double e = std::exp(0.0 - std::fmax((double)wl, 0.0) - std::fmax((double)wz, 0.0)) * (double)wn;
+    const wide_t e = std::exp((wide_t)0.0 - std::fmax((wide_t)wl, (wide_t)0.0) - std::fmax((wide_t)wz, (wide_t)0.0)) * (wide_t)wn;
     return (float)e;
 }
 
@@ -161,14 +183,14 @@ void temporal(const Geo& g, const void* prev_colour, const void* cur_in, void* c
                 int h = 1; float alpha;                                           // :372
                 bool ok = false;
                 const float mvx = motion_c[4 * idx], mvy = motion_c[4 * idx + 1]; // :230-231
-                const int qx = x + (int)mvx, qy = y + (int)mvy;                   // :232 (trunc toward 0)
+                const int qx = add_wrap(x, cvt_rzi_s32(mvx)), qy = add_wrap(y, cvt_rzi_s32(mvy));   // :232 (toward 0, saturating, NaN -> 0)
                 if (qx >= 0 && qx < g.W && qy >= 0 && qy < g.H) {                 // :235
                     const size_t q = (size_t)(qy - g.y0) * g.W + qx;
                     float zc, dzc, zp, dzp;
                     get_depth(motion_c, idx, zc, dzc); get_depth(motion_p, q, zp, dzp);   // :239-240
                     ok = !(std::fabs(zp - zc) > depth_thr);                       // :242
                     if (ok && mesh_id_test) {                                     // :245-247
-                        const int idc = (int)h2f(uv_c[4 * idx + 3]), idp = (int)h2f(uv_p[4 * q + 3]);
+                        const int idc = cvt_rzi_s32(h2f(uv_c[4 * idx + 3])), idp = cvt_rzi_s32(h2f(uv_p[4 * q + 3]));
                         ok = (idc == idp);
                     }
                     if (ok) {                                                     // :250-252
@@ -182,7 +204,7 @@ void temporal(const Geo& g, const void* prev_colour, const void* cur_in, void* c
                         T::ld2(mom_prev, q, mp);
                     }
                 }
-                if (ok) { h = std::min(history_base, h + 1); alpha = (float)(1.0 / (double)h); }   // :380-381
+                if (ok) { h = std::min(history_base, h + 1); alpha = (float)((wide_t)1.0 / (wide_t)h); }   // :380-381
                 else    { alpha = 1.0f; h = 1; }                                                   // :385-386
                 float m[2]; m[0] = luminance(c); m[1] = m[0] * m[0];              // :391-392
                 m[0] = mixf(mp[0], m[0], alpha); m[1] = mixf(mp[1], m[1], alpha); // :393
@@ -213,7 +235,7 @@ void moments(const Geo& g, const void* colour, void* out, const void* mom, const
                     float zc, dzc; get_depth(motion, idx, zc, dzc);               // :453
                     float nc[3]; get_normal(normal, idx, nc);                     // :459
                     const float phi_l = phi_colour;                               // :460
-                    const float phi_d = (float)(std::max((double)dzc, 1e-8) * 3.0);   // :461
+                    const float phi_d = (float)(std::fmax((wide_t)dzc, (wide_t)1e-8) * (wide_t)3.0);  // :461 (CUDA's max(float, double) is fmax: a NaN ddepth gives 1e-8)
                     for (int yy = -radius; yy <= radius; yy++)
                         for (int xx = -radius; xx <= radius; xx++) {              // :467-469
                             const int px = x + xx, py = y + yy;
@@ -230,11 +252,11 @@ void moments(const Geo& g, const void* colour, void* out, const void* mom, const
                             sc[0] += cpix[0] * w; sc[1] += cpix[1] * w; sc[2] += cpix[2] * w;   // :498
                             sm[0] += mpix[0] * w; sm[1] += mpix[1] * w;           // :499
                         }
-                    sw = std::max(sw, 1e-6f);                                     // :505
+                    sw = std::fmax(sw, 1e-6f);                                    // :505 (fmaxf)
                     float o[4] = {sc[0] / sw, sc[1] / sw, sc[2] / sw, 0};         // :507
                     sm[0] /= sw; sm[1] /= sw;                                     // :508
                     float var = sm[1] - sm[0] * sm[0];                            // :511
-                    var = (float)((double)var * (4.0 / (double)h));               // :514
+                    var = (float)((wide_t)var * ((wide_t)4.0 / (wide_t)h));               // :514
                     o[3] = var;
                     T::st4(out, idx, o);                                          // :516 unclamped
                 } else {
@@ -262,8 +284,8 @@ void atrous(const Geo& g, const void* in, void* out, void* feedback, const float
                 if (zc == 1e30f) { T::st4(out, idx, c); continue; }               // :554-558 (no feedback)
                 float nc[3]; get_normal(normal, idx, nc);                         // :560
                 const float eps = 1e-10f;
-                const float phi_l = (float)((double)phi_colour * std::sqrt(std::max(0.0, (double)(eps + var))));  // :562
-                const float phi_d = std::max(dzc, 1e-6f) * (float)step;           // :563
+                const float phi_l = (float)((wide_t)phi_colour * std::sqrt(std::max((wide_t)0.0, (wide_t)(eps + var))));  // :562
+                const float phi_d = std::fmax(dzc, 1e-6f) * (float)step;          // :563 (CUDA's max(float, float) is fmaxf: a NaN ddepth gives 1e-6)
                 float sw = 1.0f;                                                  // :567
                 float s[4] = {c[0], c[1], c[2], c[3]};                            // :568
                 for (int yy = -2; yy <= 2; yy++)

@@ -145,7 +145,7 @@ __device__ __forceinline__ bool fused_band(const Geo& g, const AtrousArgs& a, ch
         auto step = [&](int k, Staged& cs, Staged& fs) __attribute__((always_inline)) {
             const bool active = k < K0, more = k + 1 < K0;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            bool sky = true;
+            bool sky = true, redo = true;
             if (active) {
                 if (k + PD < K0 && !(SVGF_FUSED_DIAG & 4)) fetch(j0 + 2 * (k + PD - 1), fs);
                 int rowbase[5];
@@ -156,7 +156,10 @@ __device__ __forceinline__ bool fused_band(const Geo& g, const AtrousArgs& a, ch
                 sky = c.sky;
                 const bool wave_has_surface = !(SVGF_FUSED_DIAG & 1) && wave_any(!sky);
                 const bool uniform = !EXACT && !a.no_fastpath && !wave_any(lane < 2 * kFRA && flagA[lane < 2 * kFRA ? lane : 0] != 0u);
-                o = filter_px<1, TD, kFRA * kFWA * 8, EXACT>(rows_from_index(aA, aL, rowbase), c, phi_n, wave_has_surface, uniform);
+                // (EXACT: the exact form for every pixel of the second pass — the one-launch-per-iteration kernel keeps the first pass's value of the finite
+                // ones (filter_px), which costs a second set of taps this kernel has no registers for.  Around a NaN texel the pair launch therefore rounds
+                // as the exact form does: within the stage tolerance, not bit-identical to two launches there)
+                o = filter_px<1, TD, kFRA * kFWA * 8, EXACT, false>(rows_from_index(aA, aL, rowbase), c, phi_n, wave_has_surface, uniform);
                 if constexpr (!EXACT) nan_out |= lanes_where(__builtin_isunordered(o.x, o.w));
                 // ring B record: the texel iteration 1 would load from the plane iteration 0 stores (:618 unclamped, in the storage type;
                 // :586 imageLoad clamps — a NaN stays NaN, svgf_device.h)
@@ -187,10 +190,10 @@ __device__ __forceinline__ bool fused_band(const Geo& g, const AtrousArgs& a, ch
                     const __amdgpu_buffer_rsrc_t rs_fb = __builtin_amdgcn_make_buffer_rsrc(a.feedback ? a.feedback : a.out, 0, a.feedback ? (int)(npx * CB) : 0, 0x00020000);
                     if constexpr (ST == 0) {
                         const u32x4 raw = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
-                        __builtin_amdgcn_raw_buffer_store_b128(raw, rs_fb, sky ? kOob : vo_fb, srow * CB, 0);       // :619-622 (not for sky)
+                        __builtin_amdgcn_raw_buffer_store_b128(raw, rs_fb, sky || (EXACT && !redo) ? kOob : vo_fb, srow * CB, 0);       // :619-622 (not for sky)
                     } else {
                         const u32x2 raw = {pack_h2(o.x, o.y), pack_h2(o.z, o.w)};
-                        __builtin_amdgcn_raw_buffer_store_b64(raw, rs_fb, sky ? kOob : vo_fb, srow * CB, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(raw, rs_fb, sky || (EXACT && !redo) ? kOob : vo_fb, srow * CB, 0);
                     }
                 }
             }
@@ -212,6 +215,7 @@ __device__ __forceinline__ bool fused_band(const Geo& g, const AtrousArgs& a, ch
         for (int k = 0; k <= K0; k++) {
             const bool active = k >= kFLag;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool redo = true;                                      // EXACT: only the texels whose first-pass result held a NaN are stored again (filter_px)
             if (active) {
                 int rowbase[5];
 #pragma unroll
@@ -220,7 +224,7 @@ __device__ __forceinline__ bool fused_band(const Geo& g, const AtrousArgs& a, ch
                 const TapCentre c = centre_setup<2>(bA[ci], bL[ci], bN[ci], bD[ci], inv_phi_c);
                 const bool wave_has_surface = !(SVGF_FUSED_DIAG & 2) && wave_any(!c.sky);
                 const bool uniform = !EXACT && !a.no_fastpath && !wave_any(lane < 2 * kFRB && flagB[lane < 2 * kFRB ? lane : 0] != 0u);
-                o = filter_px<2, TD, kFRB * kFT0 * 8, EXACT>(rows_from_index(bA, bL, rowbase), c, phi_n, wave_has_surface, uniform);
+                o = filter_px<2, TD, kFRB * kFT0 * 8, EXACT, false>(rows_from_index(bA, bL, rowbase), c, phi_n, wave_has_surface, uniform);
                 if constexpr (!EXACT) nan_out |= lanes_where(__builtin_isunordered(o.x, o.w));
             }
             lds_barrier();
@@ -229,12 +233,13 @@ __device__ __forceinline__ bool fused_band(const Geo& g, const AtrousArgs& a, ch
                 if (j < j1 && !((SVGF_FUSED_DIAG & 8) && o.x != 12345.678f)) {                                      // scalar
                     const int srow = (g.yb + j - g.y0) * g.W;
                     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(npx * CB), 0x00020000);
+                    const unsigned so_c = EXACT && !redo ? kOob : vo_c;
                     if constexpr (ST == 0) {
                         const u32x4 raw = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
-                        __builtin_amdgcn_raw_buffer_store_b128(raw, rs_out, vo_c, srow * CB, 0);                    // :618
+                        __builtin_amdgcn_raw_buffer_store_b128(raw, rs_out, so_c, srow * CB, 0);                    // :618
                     } else {
                         const u32x2 raw = {pack_h2(o.x, o.y), pack_h2(o.z, o.w)};
-                        __builtin_amdgcn_raw_buffer_store_b64(raw, rs_out, vo_c, srow * CB, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(raw, rs_out, so_c, srow * CB, 0);
                     }
                 }
                 slotB += 2; if (slotB >= kFRB) slotB -= kFRB;

@@ -180,7 +180,8 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
         const bool sky = c.sky;
         const bool wave_has_surface = wave_any(!sky);
         const bool uniform = !EXACT && !a.no_fastpath && !wave_any(lane < kRing * 8 && lds_load(L.flag(0) + 4 * (lane < kRing * 8 ? lane : 0)) != 0u);
-        const float4 o = filter_px<S, kTapDepth, NOFF, EXACT>(rows, c, phi_n, wave_has_surface, uniform, &ref_base);
+        bool redo = true;                          // EXACT: this lane's first-pass result held a NaN — only those texels are stored again
+        const float4 o = filter_px<S, kTapDepth, NOFF, EXACT>(rows, c, phi_n, wave_has_surface, uniform, &ref_base, EXACT ? &redo : nullptr);
         if constexpr (!EXACT) nan_out |= lanes_where(__builtin_isunordered(o.x, o.w));
 
         // Output values now, their stores AFTER the ring refill: hipcc's vmcnt bookkeeping cannot tell that the rows committed
@@ -197,14 +198,15 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
             const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(npx * CB), 0x00020000);
             const __amdgpu_buffer_rsrc_t rs_fb = __builtin_amdgcn_make_buffer_rsrc(a.feedback ? a.feedback : a.out, 0, a.feedback ? (int)(npx * CB) : 0, 0x00020000);
             // columns outside the frame carry the out-of-range offset: the store is dropped by the range check
+            const unsigned so_c = EXACT && !redo ? kOob : vo_c;                                             // (EXACT = false: vo_c, a constant)
             if constexpr (ST == 0) {
                 const u32x4 raw = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
-                __builtin_amdgcn_raw_buffer_store_b128(raw, rs_out, vo_c, srow * CB, 0);                   // :618
-                __builtin_amdgcn_raw_buffer_store_b128(raw, rs_fb, sky ? kOob : vo_c, srow * CB, 0);       // :619-622 (not for sky)
+                __builtin_amdgcn_raw_buffer_store_b128(raw, rs_out, so_c, srow * CB, 0);                   // :618
+                __builtin_amdgcn_raw_buffer_store_b128(raw, rs_fb, sky ? kOob : so_c, srow * CB, 0);       // :619-622 (not for sky)
             } else {
                 const u32x2 raw = {pack_h2(o.x, o.y), pack_h2(o.z, o.w)};
-                __builtin_amdgcn_raw_buffer_store_b64(raw, rs_out, vo_c, srow * CB, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(raw, rs_fb, sky ? kOob : vo_c, srow * CB, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(raw, rs_out, so_c, srow * CB, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(raw, rs_fb, sky ? kOob : so_c, srow * CB, 0);
             }
         }
     }

@@ -69,8 +69,9 @@ __device__ __forceinline__ UniBase uni_base(uint32_t n01, float nz, float phi_n)
 // MODE: kTapsGeneral, kTapsUniform (the uniform-normal path), or kTapsNaN — the general path in the form that treats a NaN the way
 // the reference does (a band that is run again because a NaN showed in its output, svgf_atrous_lds.h): a NaN luminance
 // difference counts as 0 — `max(weightLillum, 0.0)` in :424 is CUDA's fmax, which drops the NaN — so the weight stays finite and the
-// NaN reaches the sums only through the channels that hold it (:608); saturate(n.n') of a NaN is 0.  The other two paths fold
-// |dl| / phi_l into one FMA of the exponent, which makes the weight — and with it all four channels — NaN.
+// NaN reaches the sums only through the channels that hold it (:608); a NaN depth difference (a NaN depth in the G-buffer, or inf - inf)
+// counts as 0 the same way (`max(weightZ, 0.0)`, :424); saturate(n.n') of a NaN is 0 (:419).  The other two paths fold
+// |dl| / phi_l and |dz| / phi_z into FMAs of the exponent, which makes the weight — and with it all four channels — NaN.
 constexpr int kTapsGeneral = 0, kTapsUniform = 1, kTapsNaN = 2;
 template <int CS, int D, int MODE, int NOFF>
 __device__ __forceinline__ void taps24(const TapRows& rows, const TapCentre& c, float phi_n, float& sw, f32x2& srg, f32x2& sbv, const UniBase* shared_base) {
@@ -113,7 +114,8 @@ __device__ __forceinline__ void taps24(const TapRows& rows, const TapCentre& c, 
         }
         if constexpr (MODE == kTapsNaN) e -= fmaxf(fabsf(dlz.x) * c.il, 0.0f);          // fmax(NaN, 0) = 0, :424
         else e = fmaf(-fabsf(dlz.x), c.il, e);
-        e = fmaf(-fabsf(dlz.y), c.iz[len_class(xx, yy)], e);
+        if constexpr (MODE == kTapsNaN) e -= fmaxf(fabsf(dlz.y) * c.iz[len_class(xx, yy)], 0.0f);   // fmax(NaN, 0) = 0, :424
+        else e = fmaf(-fabsf(dlz.y), c.iz[len_class(xx, yy)], e);
         const float w = hw_exp2(e);
         const f32x2 ww = {w, w * w};                                                     // weights of (b, variance): :604-608
         sw += w;                                                                         // :607
@@ -124,21 +126,53 @@ __device__ __forceinline__ void taps24(const TapRows& rows, const TapCentre& c, 
 }
 
 // One pixel: taps + normalisation (:554-558,567-568,615).  `wave_has_surface` (a wave whose centres are all sky has nothing to
-// filter) and `uniform` are wave-uniform.  EXACT: the band is run again because a NaN showed in its output (svgf_atrous_lds.h).
-template <int CS, int D, int NOFF, bool EXACT = false>
-__device__ __forceinline__ float4 filter_px(const TapRows& rows, const TapCentre& c, float phi_n, bool wave_has_surface, bool uniform, const UniBase* shared_base = nullptr) {
+// filter) and `uniform` are wave-uniform.
+//
+// EXACT: the band is run again because a NaN showed in its output (svgf_atrous_lds.h).  In the second pass a pixel takes the exact form's
+// value only if its FAST result holds a NaN — the test that sent the band here (general taps: the uniform form computes the same bits);
+// a pixel whose window is finite keeps its first-pass bits whichever workgroup, band or strip it falls into next to a NaN (ADVICE r04:
+// the whole band used to take the exact form's rounding of the luminance term, and strips / row ranges then differed from the whole frame
+// in the last bit around a NaN texel).  Two ways to say that: *fast_bad receives the per-lane test and the exact value is returned for EVERY
+// lane — the caller stores only where the test holds, the other texels are in memory from the first pass (no register kept across the
+// second set of taps: the streaming kernel has none to spare) — or, with fast_bad == nullptr, the merged value is returned (the pair
+// launch, whose iteration-0 result goes into an LDS ring, not to memory).
+// KEEP_FAST = false (the pair launch, which has no register for a second set of taps either): the exact form for every pixel of the second pass,
+// as in round 4 — around a NaN texel its finite pixels then round as the exact form does (within the stage tolerance).
+template <int CS, int D, int NOFF, bool EXACT = false, bool KEEP_FAST = true>
+__device__ __forceinline__ float4 filter_px(const TapRows& rows, const TapCentre& c, float phi_n, bool wave_has_surface, bool uniform, const UniBase* shared_base = nullptr,
+                                            bool* fast_bad = nullptr) {
     float sw = 1.0f;                                                                     // :567
     f32x2 srg = {c.A.x, c.A.y}, sbv = {c.A.z, c.A.w};                                    // :568
-    if (wave_has_surface) {
-        if constexpr (EXACT) {
+    if constexpr (EXACT && !KEEP_FAST) {
+        if (wave_has_surface) {
             taps24<CS, D, kTapsNaN, NOFF>(rows, c, phi_n, sw, srg, sbv, nullptr);
-            // a sky centre is copied (:554-558): its taps' weights are exactly 0, but 0 x NaN is not
-            if (c.sky) { sw = 1.0f; srg = (f32x2){c.A.x, c.A.y}; sbv = (f32x2){c.A.z, c.A.w}; }
-        } else if (uniform) taps24<CS, D, kTapsUniform, NOFF>(rows, c, phi_n, sw, srg, sbv, shared_base);
+            if (c.sky) { sw = 1.0f; srg = (f32x2){c.A.x, c.A.y}; sbv = (f32x2){c.A.z, c.A.w}; }      // copied (:554-558): weights exactly 0, but 0 x NaN is not
+        }
+        const float inv = hw_rcp(sw);
+        return make_float4(srg.x * inv, srg.y * inv, sbv.x * inv, sbv.y * (inv * inv));
+    }
+    if (wave_has_surface) {
+        if (!EXACT && uniform) taps24<CS, D, kTapsUniform, NOFF>(rows, c, phi_n, sw, srg, sbv, shared_base);
         else taps24<CS, D, kTapsGeneral, NOFF>(rows, c, phi_n, sw, srg, sbv, nullptr);
     }
     const float inv = hw_rcp(sw);                                                        // sw >= 1 (a sky centre: exactly 1, and the sums are its colour)
-    return make_float4(srg.x * inv, srg.y * inv, sbv.x * inv, sbv.y * (inv * inv));      // :615
+    const float4 o = make_float4(srg.x * inv, srg.y * inv, sbv.x * inv, sbv.y * (inv * inv));  // :615
+    if constexpr (!EXACT) return o;
+    else {
+        const bool bad = __builtin_isunordered(o.x, o.w);
+        if (fast_bad) *fast_bad = bad;
+        float sw2 = 1.0f;
+        f32x2 srg2 = {c.A.x, c.A.y}, sbv2 = {c.A.z, c.A.w};
+        if (wave_has_surface && (fast_bad || wave_any(bad))) {
+            taps24<CS, D, kTapsNaN, NOFF>(rows, c, phi_n, sw2, srg2, sbv2, nullptr);
+            // a sky centre is copied (:554-558): its taps' weights are exactly 0, but 0 x NaN is not
+            if (c.sky) { sw2 = 1.0f; srg2 = (f32x2){c.A.x, c.A.y}; sbv2 = (f32x2){c.A.z, c.A.w}; }
+        }
+        const float inv2 = hw_rcp(sw2);
+        const float4 o2 = make_float4(srg2.x * inv2, srg2.y * inv2, sbv2.x * inv2, sbv2.y * (inv2 * inv2));
+        if (fast_bad) return o2;
+        return bad ? o2 : o;
+    }
 }
 
 }  // namespace

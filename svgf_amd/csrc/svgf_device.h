@@ -74,6 +74,12 @@ __device__ __forceinline__ float3 normal_of(uint2 n) {
 __device__ __forceinline__ uint4 guide_texel(float4 motion, uint2 normal, uint2 uv) {
     return make_uint4(__float_as_uint(motion.z), __float_as_uint(motion.w), normal.x, (normal.y & 0xffffu) | (uv.y & 0xffff0000u));
 }
+// int(x) / ivec2(vec2) of CUDA (Filter.cuh:232: `Coord + ivec2(MotionVector)`; the instance ID of :245-246) is cvt.rzi.s32.f32: truncation toward
+// zero, out-of-range values SATURATE to INT_MIN / INT_MAX and a NaN converts to 0.  v_cvt_i32_f32 does exactly that — but a C++ cast of an
+// out-of-range float is undefined behaviour, which the compiler may exploit; the instruction is therefore written out.  The sum with the pixel
+// coordinate wraps (two's complement): every motion beyond +-2^31 pixels lands outside the frame and is rejected (:235); a NaN motion is 0.
+__device__ __forceinline__ int cvt_rzi_sat(float f) { int r; asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f)); return r; }
+__device__ __forceinline__ int add_wrap(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
 // glm::dot order; exact (no contraction) — used by threshold tests
 __device__ __forceinline__ float dot3_exact(float3 a, float3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ float dot3_fma(float3 a, float3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
@@ -105,7 +111,8 @@ __device__ __forceinline__ float edge_weight(float dl_abs, float il, float dz_ab
     const float d = clamp01(ndot != ndot ? 0.0f : ndot);              // saturate(): NaN -> 0 (explicitly: some callers run with keep_nan_in_clamps())
     const float ln = (phi_n == 0.0f) ? 0.0f : phi_n * hw_log2(d);
     const float wl = fmaxf(dl_abs * il, 0.0f);                        // NaN (0*inf at phi_l = 0) -> 0 like fmax() in :424
-    const float e = fmaf(-kLog2e, wl + dz_abs * iz, ln);
+    const float wz = fmaxf(dz_abs * iz, 0.0f);                        // NaN (a NaN depth in the G-buffer, inf - inf) -> 0 likewise
+    const float e = fmaf(-kLog2e, wl + wz, ln);
     return hw_exp2(e);
 }
 

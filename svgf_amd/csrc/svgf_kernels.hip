@@ -64,9 +64,9 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
     }
 
     const float4 mc = a.motion_c[idx];
-    const int qx = x + (int)mc.x, qy = y + (int)mc.y;                 // :232, truncation toward zero
+    const int qx = add_wrap(x, cvt_rzi_sat(mc.x)), qy = add_wrap(y, cvt_rzi_sat(mc.y));   // :232, CUDA's float -> int: toward zero, saturating, NaN -> 0
     bool ok = qx >= 0 && qx < g.W && qy >= 0 && qy < g.H;             // :235
-    const int ql = qy - g.y0;
+    const int ql = add_wrap(qy, -g.y0);                               // (only used when `ok`: qy is inside the frame then)
     // Strip guard: never read outside the local planes.  A reprojection that lands inside the FRAME but outside the rows
     // this strip holds would silently turn into a rejection (history reset) and the strip would no longer equal the whole
     // frame: it is counted, and the host reports SVGF_ERR_HALO at its next synchronising call (svgf_sync).
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kBX* kBY) void temporal_kernel(Geo g, TemporalArgs 
     depth_of(mp, zp, dzp);
     ok = ok && !(fabsf(zp - zc) > a.depth_thr);                       // :242
     if (a.mesh_id_test) {                                             // :245-247 (intended test)
-        const int idc = (int)unpack_h2(uc_raw.y).y, idp = (int)unpack_h2(up_raw.y).y;
+        const int idc = cvt_rzi_sat(unpack_h2(uc_raw.y).y), idp = cvt_rzi_sat(unpack_h2(up_raw.y).y);
         ok = ok && idc == idp;
     }
     ok = ok && !(dot3_exact(normal_of(nc_raw), normal_of(np_raw)) < a.normal_thr);   // :252
@@ -353,7 +353,9 @@ __device__ __forceinline__ void moments_group8(const Geo& g, const MomentsArgs& 
             float e = hw_log2(d) * a.phi_normal;
             const float dl = lum_exact(t0[r], t1[r], t2[r]) - lc;
             if (dl == dl) e = fmaf(-fabsf(dl), il1, e);               // a NaN luminance: max(|dl| / phi_l, 0.0) is CUDA's fmax, which drops it (:424)
-            if (l2 != 0) e = fmaf(-fabsf(zp - zc), l2 == 1 ? izb1 : izb1 * km, e);
+            const float dz = fabsf(zp - zc), izk = l2 == 1 ? izb1 : izb1 * km;
+            const float pz = dz * izk;
+            if (l2 != 0 && pz == pz) e = fmaf(-dz, izk, e);          // a NaN depth term (NaN depth, inf - inf, inf x 0): max(|dz| / phi_z, 0.0) drops it likewise (:424)
             tw[r] = hw_exp2(e);
         }
         okbits |= ok[r] ? 1u << r : 0u;

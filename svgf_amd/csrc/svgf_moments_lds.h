@@ -13,7 +13,7 @@
 //            record, run no v_dot2 / v_log: 9 vector instructions per tap instead of 13.  Same expressions on the same bits as the
 //            general form: bit-identical;
 //   general  n.n' per tap;
-//   exact    a texel of the ring holds a NaN or inf (colour or moments): the luminance term is evaluated the way the reference does —
+//   exact    a texel of the ring holds a NaN or inf (colour, moments, depth or normal): the luminance and depth terms are evaluated the way the reference does —
 //            max(|dl| / phi_l, 0.0) is CUDA's fmax, which drops a NaN (:424), so the weight stays finite and the NaN reaches the sums
 //            through the channels that hold it (:498-499) — and a zero-normal centre takes no shortcut (its weights are exactly 0,
 //            and 0 x NaN is NaN).
@@ -76,7 +76,10 @@ __device__ __forceinline__ void moments_taps49(const f32x4* recA, const f32x2* r
         }
         if constexpr (MODE == kTapsNaN) e -= fmaxf(fabsf(L.x - c.lc) * c.il, 0.0f);      // fmax(NaN, 0) = 0, :424
         else e = fmaf(-fabsf(L.x - c.lc), c.il, e);
-        if (xx != 0 || yy != 0) e = fmaf(-fabsf(L.y - c.zc), c.iz[len_class7(xx, yy)], e);   // phiDepth == 0 -> wZ = 0 at the centre, :420
+        if (xx != 0 || yy != 0) {                                                        // phiDepth == 0 -> wZ = 0 at the centre, :420
+            if constexpr (MODE == kTapsNaN) e -= fmaxf(fabsf(L.y - c.zc) * c.iz[len_class7(xx, yy)], 0.0f);   // fmax(NaN, 0) = 0, :424 (a NaN depth)
+            else e = fmaf(-fabsf(L.y - c.zc), c.iz[len_class7(xx, yy)], e);
+        }
         const float w = hw_exp2(e);
         s.sw += w;                                                                       // :497-499
         s.srg = __builtin_elementwise_fma((f32x2){w, w}, (f32x2){A.x, A.y}, s.srg);
@@ -155,7 +158,10 @@ __global__ __launch_bounds__(kMTX* kRS, 4) void moments_lds_kernel(Geo g, Moment
         recL[at] = (f32x2){lum, z};
         recN[at] = (f32x2){__uint_as_float(p.n.x), unpack_h2(p.n.y).x};
         recC[at] = m.y;
-        bad = bad | !(fabsf(lum + (m.x + m.y)) < __builtin_inff());                 // (an overflowing sum of finite values: the exact form, needlessly)
+        // ... or its depth is NaN / inf, or a component of its normal is (half exponent 31): the general form would turn the weight NaN where the
+        // reference drops the term (`max(weightZ, 0.0)`, :424) or reads saturate(NaN) as 0 (:419)
+        bad = bad | !(fabsf(fmaf(z, 0.0f, lum + (m.x + m.y))) < __builtin_inff());  // (an overflowing sum of finite values: the exact form, needlessly)
+        bad = bad | ((((p.n.x & 0x7c007c00u) + 0x04000400u) & 0x80008000u) != 0u) | ((p.n.y & 0x7c00u) == 0x7c00u);
         return (p.n.x != ref01) | ((p.n.y & 0xffffu) != refz);
     };
     auto commit = [&](int sl, const Staged& st) __attribute__((always_inline)) {

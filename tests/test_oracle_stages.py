@@ -405,3 +405,80 @@ def test_taa_nonfinite_matches_numpy(oracle, storage):
         np.testing.assert_allclose(got, want, rtol=2e-6, atol=3e-7)
     else:
         assert half_ulp_diff(got, want).max() <= 1
+
+
+def test_nonfinite_gbuffer_matches_numpy_and_known_answers(oracle):
+    """NaN / inf / out-of-range texels in the G-buffer planes.  The C++ oracle and the independent NumPy restatement agree on
+    poisoned G-buffers (temporal bit-exact incl. history; moments and a-trous: identical NaN masks, values to fp32 round-off), and the reference's
+    semantics are pinned by hand: a NaN motion reprojects onto the pixel itself (cvt.rzi: NaN -> 0) and is accepted; +-inf / +-1e20 / 3e9 motions
+    saturate, wrap with the pixel coordinate and are rejected; a NaN depth or a NaN normal ACCEPTS the reprojection (Filter.cuh:242,252: the
+    comparisons are false); a zero-length normal rejects it; NaN instance IDs compare as 0."""
+    from tests.gbuffer_poison import poison_gbuffer
+    W, H = 96, 64
+    rng = np.random.default_rng(5)
+    f0, f1 = synth.make_frame(W, H, 3, mv=(1.0, -2.0)), synth.make_frame(W, H, 4, mv=(1.0, -2.0))
+    p0, _ = poison_gbuffer(rng, f0, per_value=2)
+    p1, placed = poison_gbuffer(rng, f1, per_value=2)
+    for storage in ("f32", "f16"):
+        dt = CDT[storage]
+        prev = rng.uniform(0, 1, (H, W, 4)).astype(dt)
+        mom_prev = rng.uniform(0, 1, (H, W, 2)).astype(dt)
+        hist_prev = rng.integers(0, 30, (H, W)).astype(np.uint8)
+        cur = f1["radiance"].astype(dt)
+        for mesh in (0, 1):
+            out = np.zeros_like(cur); hist = np.zeros((H, W), np.uint8); mom = np.zeros((H, W, 2), dt)
+            oracle.temporal(W, H, storage, prev, cur, out, gbuf(p1), gbuf(p0), hist_prev, hist, mom, mom_prev, depth_threshold=0.8, normal_threshold=0.9,
+                            history_base=24, mesh_id_test=mesh)
+            n_out, n_hist, n_mom = snp.temporal(prev, cur, gbuf(p1), gbuf(p0), hist_prev, mom_prev, depth_threshold=0.8, normal_threshold=0.9,
+                                                history_base=24, mesh_id_test=mesh)
+            assert np.array_equal(hist, n_hist), (storage, mesh)
+            assert np.array_equal(out.view(np.uint8), n_out.view(np.uint8)) and np.array_equal(mom.view(np.uint8), n_mom.view(np.uint8))
+        # moments / a-trous on the poisoned current G-buffer
+        col = rng.uniform(0, 1, (H, W, 4)).astype(dt)
+        hist_y = rng.integers(1, 8, (H, W)).astype(np.uint8)
+        want = np.zeros_like(col)
+        oracle.moments(W, H, storage, col, want, mom_prev, gbuf(p1), hist_y, phi_colour=10.0, phi_normal=128.0)
+        got = snp.moments(col, mom_prev, gbuf(p1), hist_y, phi_colour=10.0, phi_normal=128.0)
+        assert np.array_equal(np.isnan(want.astype(np.float32)), np.isnan(got.astype(np.float32)))
+        assert np.allclose(want.astype(np.float64), got.astype(np.float64), rtol=2e-3 if storage == "f16" else 1e-5, atol=2e-3 if storage == "f16" else 1e-6, equal_nan=True)
+        for step in (1, 4):
+            want = np.zeros_like(col)
+            oracle.atrous(W, H, storage, col, want, None, gbuf(p1), step=step, phi_colour=10.0, phi_normal=128.0, iteration=1)
+            got, _ = snp.atrous(col, gbuf(p1), step=step, phi_colour=10.0, phi_normal=128.0)
+            assert np.isfinite(want.astype(np.float32)).all(), "a finite colour plane stays finite whatever the G-buffer holds"
+            assert np.allclose(want.astype(np.float64), got.astype(np.float64), rtol=2e-3 if storage == "f16" else 1e-5, atol=2e-3 if storage == "f16" else 1e-6)
+    # ---- known answers, one texel at a time (static camera, identical G-buffers, history 7 everywhere: an accepted pixel gets history 8, a rejected one 1)
+    f = synth.make_frame(W, H, 0)
+    surf = np.argwhere(f["region"] == synth.QUAD_A)
+    y, x = (int(v) for v in surf[len(surf) // 2])
+    cur = f["radiance"].astype(np.float32)
+    prev = np.full((H, W, 4), 0.5, np.float32); mom_prev = np.full((H, W, 2), 0.25, np.float32); hist_prev = np.full((H, W), 7, np.uint8)
+
+    def hist_at(gc, gp):
+        out = np.zeros_like(cur); hist = np.zeros((H, W), np.uint8); mom = np.zeros((H, W, 2), np.float32)
+        oracle.temporal(W, H, "f32", prev, cur, out, gc, gp, hist_prev, hist, mom, mom_prev, depth_threshold=0.8, normal_threshold=0.9, history_base=24, mesh_id_test=1)
+        return int(hist[y, x])
+
+    def edited(plane, ch, value):
+        g = {k: v.copy() for k, v in gbuf(f).items()}
+        g[plane][y, x, ch] = value
+        return g
+    assert hist_at(gbuf(f), gbuf(f)) == 8
+    with np.errstate(all="ignore"):
+        for ch in (0, 1):
+            assert hist_at(edited("motion", ch, np.float32(np.nan)), gbuf(f)) == 8, "a NaN motion converts to 0: the pixel reprojects onto itself"
+            for v in (np.inf, -np.inf, 1e20, -1e20, 3e9, -3e9):
+                assert hist_at(edited("motion", ch, np.float32(v)), gbuf(f)) == 1, f"motion {v} saturates and leaves the frame"
+        assert hist_at(edited("motion", 2, np.float32(np.nan)), gbuf(f)) == 8, "NaN depth (current): abs(NaN) > threshold is false"
+        assert hist_at(gbuf(f), edited("motion", 2, np.float32(np.nan))) == 8, "NaN depth (previous)"
+        assert hist_at(edited("motion", 2, np.float32(-3.0)), gbuf(f)) == 1, "a negative depth is a number: 7 units from the previous one"
+        assert hist_at(edited("motion", 2, np.float32(-3.0)), edited("motion", 2, np.float32(-3.0))) == 8
+        assert hist_at(edited("motion", 2, np.float32(1e-40)), edited("motion", 2, np.float32(1e-40))) == 8, "a denormal depth is not the sentinel"
+        assert hist_at(edited("motion", 2, np.float32(1e-40)), edited("motion", 2, np.float32(0.0))) == 1, "... the previous texel reads as 1e30"
+        assert hist_at(edited("motion", 2, np.float32(1e30)), edited("motion", 2, np.float32(0.0))) == 8, "1e30 and the sentinel are the same depth here"
+        assert hist_at(edited("normal", 0, np.uint16(0x7e00)), gbuf(f)) == 8, "NaN normal: dot < threshold is false"
+        g0 = edited("normal", 0, np.uint16(0)); g0["normal"][y, x, :3] = 0
+        assert hist_at(g0, gbuf(f)) == 1, "zero-length normal: dot = 0 < 0.9"
+        assert hist_at(edited("uv", 3, np.uint16(0x7e00)), gbuf(f)) == 1, "instance ID NaN -> 0 against the quad's 1"
+        assert hist_at(edited("uv", 3, np.uint16(0x7e00)), edited("uv", 3, np.uint16(0))) == 8
+        assert hist_at(edited("uv", 3, np.uint16(0x7c00)), edited("uv", 3, np.uint16(0x7c00))) == 8, "inf -> INT_MAX on both sides"
