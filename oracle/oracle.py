@@ -41,7 +41,8 @@ def lib(flavour=None):
     flavour = flavour or _flavour
     if flavour not in _libs:
         build()
-        L = C.CDLL({"oracle": _LIB_PATH, "fp32fma": _ENV_PATH}[flavour])
+        L = C.CDLL({"oracle": _LIB_PATH, "fp32fma": _ENV_PATH, "fp32": os.path.join(_HERE, "libsvgf_oracle_fp32.so"),
+                    "fma": os.path.join(_HERE, "libsvgf_oracle_fma.so"), "fused": os.path.join(_HERE, "libsvgf_oracle_fused.so")}[flavour])
         L.svgf_oracle_f2h.restype = C.c_uint16
         L.svgf_oracle_f2h.argtypes = [C.c_float]
         L.svgf_oracle_h2f.restype = C.c_float

@@ -145,6 +145,16 @@ inline float compute_weight(float zc, float zp, float phi_depth, const float* nc
                             float phi_normal, float lc, float lp, float phi_illum) {
     float d = clamp01(dot3(nc, np));
     if (!(d == d)) d = 0.0f;                                            // saturate(): NaN -> 0
+#ifdef SVGF_ORACLE_FUSED_EXPONENT
+    // Envelope build "fused" only (Makefile): the weight as ONE exp2 of a fused fp32 exponent, the divisions as multiplications by reciprocals —
+    // the formulation of the HIP kernels (svgf_device.h: edge_weight), evaluated with libm.  A third correct reading of :407-427, like nvcc -use_fast_math.
+    {
+        const float ln = (phi_normal == 0.0f) ? 0.0f : phi_normal * std::log2(d);
+        const float wz1 = (phi_depth == 0) ? 0.0f : std::fabs(zc - zp) * (1.0f / phi_depth);
+        const float wl1 = std::fabs(lc - lp) * (1.0f / phi_illum);
+        return std::exp2(ln - (std::fmax(wl1, 0.0f) + std::fmax(wz1, 0.0f)) * 1.4426950408889634f);
+    }
+#endif
     const float wn = std::pow(d, phi_normal);                           // powf
     const float wz = (phi_depth == 0) ? 0.0f : std::fabs(zc - zp) / phi_depth;
     const float wl = std::fabs(lc - lp) / phi_illum;

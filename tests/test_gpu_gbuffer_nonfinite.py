@@ -11,7 +11,7 @@ import pytest
 
 from svgf_amd import synth
 from tests.gbuffer_poison import poison_gbuffer
-from tests.helpers import CDT, frames, gbuf
+from tests.helpers import CDT, frames, free_running_bounds, free_running_envelope, gbuf
 from tests.test_gpu_nonfinite import assert_close_with_nan, assert_same_bits_or_nan
 
 pytestmark = pytest.mark.gpu
@@ -151,9 +151,12 @@ def test_free_running_sequence_with_poisoned_gbuffers(G, oracle, storage, mv, va
     d = F.Denoiser(W, H, F.Params(storage=storage, steps=5, variant=variant))
     d.set_prev_guide(True)
     gbs = [G.gb_dev(f) for f in fr]
-    tight = 2e-5 if storage == "f32" else 1e-3
-    loose = 5e-4 if storage == "f32" else 2e-2
-    frac = 1e-3 if storage == "f32" else 2e-3
+    # bounds: those of the clean sequences (tests/helpers.py:FREE_RUNNING) with twice the maximum — a texel whose NaN depth drops the depth term
+    # of its weights blends across edges, where the ill-conditioned luminance term (phi_l = 1e-4 at zero variance) is all that is left — and, for
+    # the cases the clean sequences sit inside it, the envelope of THESE frames (two correct CPU builds of the reference's source)
+    b = free_running_bounds(storage, mv)
+    tight, loose, frac = b["tight"], 2 * b["loose"], b["frac"]
+    worst = 0.0
     for k in range(N):
         kp = max(k - 1, 0)
         want = ref.frame(fr[k]["radiance"], gbuf(fr[k]), gbuf(fr[kp])).astype(np.float64)
@@ -161,8 +164,13 @@ def test_free_running_sequence_with_poisoned_gbuffers(G, oracle, storage, mv, va
         assert np.array_equal(G.host(d.state_plane(F.PLANE_HISTORY, 1 - d.pingpong())), ref.taps["hist"]), f"frame {k}: history"
         assert np.isfinite(want).all() and np.isfinite(got).all(), f"frame {k}"
         err = np.abs(got - want)[..., :3]
+        worst = max(worst, float(err.max()))
         assert err.max() <= loose, f"frame {k}: max colour error {err.max():.3e}"
         assert (err > tight + 1e-5 * np.abs(want[..., :3])).mean() <= frac, f"frame {k}"
+    env = free_running_envelope(oracle, fr, storage)
+    assert env["mask_mismatches"] == 0
+    if b["inside_envelope"]:
+        assert worst <= env["max_abs"], f"HIP-vs-oracle {worst:.3e} is outside oracle-vs-oracle' {env['max_abs']:.3e}"
 
 
 @pytest.mark.parametrize("variant", ["direct", "auto"])

@@ -9,7 +9,7 @@ import pytest
 
 from svgf_amd import synth
 from tests.conftest import ROOT
-from tests.helpers import CDT, frames, gbuf
+from tests.helpers import CDT, frames, free_running_envelope, gbuf
 
 pytestmark = pytest.mark.gpu
 
@@ -453,12 +453,32 @@ def test_parity_report(G, oracle):
         rep = {n: {"max_abs": a["max_abs"], "mean_abs": a["sum"] / a["n"]} for n, a in acc.items()}
         rep["mask_mismatches"] = mask_mismatch
         report["stages"][storage] = rep
+        # The envelope: the same 8 frames free-running through two CORRECT CPU builds of the reference's source — the oracle and its
+        # all-fp32 + FMA-contraction build — against the device's distance from the oracle, for both cameras.
+        for mv in ((-2.5, 1.5), (0.0, 0.0)):
+            frs = fr if mv[0] else frames(W, H, N, mv=mv)
+            env = {fl: free_running_envelope(oracle, frs, storage, flavour=fl) for fl in ("fp32", "fp32fma", "fused")}
+            refm = oracle.Pipeline(W, H, storage, steps=5, nthreads=8)
+            hipm = G.HipPipeline(W, H, storage, steps=5)
+            gbm = gbs if mv[0] else [G.gb_dev(f) for f in frs]
+            worst, tight = 0.0, (2e-5 if storage == "f32" else 1e-3)
+            worst_frac = 0.0
+            for k in range(N):
+                kp = max(k - 1, 0)
+                w_ = refm.frame(frs[k]["radiance"], gbuf(frs[k]), gbuf(frs[kp])).astype(np.float64)
+                g_ = hipm.frame(frs[k]["radiance"], gbm[k], gbm[kp]).astype(np.float64)
+                e_ = np.abs(g_ - w_)[..., :3]
+                worst = max(worst, float(e_.max()))
+                worst_frac = max(worst_frac, float((e_ > tight + 1e-5 * np.abs(w_[..., :3])).mean()))
+            report.setdefault("envelope", {})[f"{storage} mv={list(mv)}"] = {
+                "hip_vs_oracle": {"max_abs": worst, "frac_beyond_tight": worst_frac},
+                "oracle_vs_build": env, "hip_inside_fp32fma_envelope": bool(worst <= env["fp32fma"]["max_abs"])}
         assert mask_mismatch == 0
         assert rep["temporal_colour"]["max_abs"] == 0.0 and rep["temporal_moments"]["max_abs"] == 0.0          # bit-exact stage
         lim = 2e-5 + 1e-5 if storage == "f32" else 1e-3
         for i in range(5):
             assert rep[f"atrous_step{1 << i}_colour"]["max_abs"] <= lim, (storage, i)
-        assert rep["free_running_colour"]["max_abs"] <= (5e-4 if storage == "f32" else 2e-2)
+        assert rep["free_running_colour"]["max_abs"] <= (5e-4 if storage == "f32" else 5e-3)
     # (written before the guard below: a run that trips it still leaves its numbers to be looked at — and, if the change is meant, committed)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "parity_report.json"), "w") as f:
