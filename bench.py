@@ -68,7 +68,6 @@ def parse():
     ap.add_argument("--variant", default="auto")
     ap.add_argument("--halo-plan", default="auto")
     ap.add_argument("--motion", choices=["static", "pan", "both"], default="both", help="N = 1: which camera motions are timed (value = static)")
-    ap.add_argument("--driver", choices=["native", "python"], default="native", help="N > 1: the C++ strip driver of the library, or svgf_amd/strips.py")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (pan, 1080p, fp16, cold frames)")
     ap.add_argument("--strips", action="store_true", help="run the strip driver even at N=1 (exercises the N>1 code path)")
@@ -628,8 +627,8 @@ def main():
             os.environ["MASTER_PORT"] = str(free_port())
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        # SVGF_BENCH_SHARE_DEVICES=1 (testing the N > 1 flow on a box with fewer GPUs): RCCL refuses two ranks on one device, so the
-        # process group is gloo and the strip schedule runs through the Python driver
+        # SVGF_BENCH_SHARE_DEVICES=1 (tests: rank processes sharing a device): torch's process group over gloo.  RCCL itself refuses two
+        # ranks on one device, so such a job ends in bench_strips with a non-zero exit code — there is no other driver to fall back to
         if os.environ.get("SVGF_BENCH_SHARE_DEVICES") == "1":
             dist.init_process_group("gloo")
         else:
@@ -797,7 +796,7 @@ def main():
     W, H = WORKLOADS[wl]
     try:
         res = strips.bench_strips(W, H, storage, iters, args.variant, args.steps, args.warmup, device, plan=args.halo_plan,
-                                  make_inputs=make_inputs, prime_frames=PRIME_FRAMES, driver=args.driver,
+                                  make_inputs=make_inputs, prime_frames=PRIME_FRAMES,
                                   plans=() if args.no_extra else ("per-iteration", "grouped"), pan_mv=None if args.no_extra else STRIP_PAN_MV,
                                   one_gpu_reference=not args.no_one_gpu, busy=(args.prime_ms, args.prime_frames))
     except Exception as e:  # noqa: BLE001

@@ -438,6 +438,12 @@ int svgf_strips_sync(svgf_strips* s);
  * those — and stays valid until call f + 2 (frames alternate between two pairs of filter planes); cur[k] is not read after the call has
  * returned (a frame whose iterations would read it — the direct kernel — keeps its tail on the compute stream).  Default 1. */
 int svgf_strips_set_frames_in_flight(svgf_strips* s, int frames);
+/* Edge rows first (default 1).  The iteration in front of a halo exchange produces the rows its neighbours wait for FIRST.  With enable = 1 that is
+ * ONE launch: its first workgroups compute the two edge ranges, the last of them to finish writes a sequence number into device memory, the
+ * communication stream waits for that word (hipStreamWaitValue64) and starts the exchange while the interior tiles of the same launch still run.
+ * enable = 0 (and any iteration the direct kernel runs, and devices without stream memory operations): round 4's schedule — two edge launches,
+ * an event, the exchange, an interior launch.  Same bits either way. */
+int svgf_strips_set_edge_first(svgf_strips* s, int enable);
 /* HIP events around the a-trous launches of the first local rank on every n-th frame (0 = off); read: launches, their summed
  * ms, the pixels they covered in all iterations and in iteration 0 (for the roofline's algorithmic bytes). */
 int svgf_strips_timing_enable(svgf_strips* s, int every);

@@ -336,6 +336,28 @@ int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const sv
     return SVGF_OK;
 }
 
+// One iteration over up to three row ranges in ONE launch, the first `nfirst` ranges produced first and signalled (svgf_kernels.h: AtrousRanges;
+// the strip driver's edge rows, svgf_strip.hip).  The caller has checked atrous_ranges_ok().
+bool atrous_ranges_ok(const svgf_ctx* c, int step) {
+    svgf::AtrousArgs a{};
+    a.step = step; a.phi_normal = c->p.phi_normal;
+    return svgf::atrous_ranges_available(c->p.variant, a);
+}
+int atrous_ranges_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration, const void* guide, const svgf::AtrousRanges& r) {
+    if (!in || !out) return fail(c, SVGF_ERR_INVALID, "svgf_atrous: null plane");
+    if (in == out || in == feedback) return fail(c, SVGF_ERR_INVALID, "svgf_atrous: in-place filtering is a race");
+    int rc = check_gbuf(c, g, false, "svgf_atrous");
+    if (rc != SVGF_OK) return rc;
+    const int rb = c->rb, re = c->re;
+    for (int k = 0; k < r.n && rc == SVGF_OK; k++) { c->rb = r.yb[k]; c->re = r.ye[k]; rc = check_halo(c, 2 * step, "svgf_atrous"); }
+    c->rb = rb; c->re = re;
+    if (rc != SVGF_OK) return rc;
+    svgf::AtrousArgs a{in, out, iteration == 0 ? feedback : nullptr, (const float4*)g->motion, (const uint2*)g->normal,
+                       step, c->p.phi_colour, c->p.phi_normal, (const uint4*)guide, c->p.variant == SVGF_VARIANT_LDS_GENERAL};
+    SVGF_HIP(c, svgf::launch_atrous_ranges(geo_of(c), c->p.storage, a, r, c->stream));
+    return SVGF_OK;
+}
+
 // Iterations 0 and 1 of application::WaveletFilter's loop (App.cu:497-507: steps 1 and 2) as ONE launch: iteration 0's rows never
 // leave the chip except as the feedback plane (svgf_atrous_fused.h).  `out` receives iteration 1's result on rows [rb, re).
 int atrous_pair_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, const void* guide) {

@@ -1,6 +1,6 @@
 // svgf_atrous_lds.h — one iteration of the wavelet filter (filter::FilterKernel, Filter.cuh:527-624) as an LDS-streaming kernel
-// for CDNA4, steps 1..16.  (tools/variants/atrous_lds_instrumented.h is this kernel with its measurement switches and stamps;
-// -DSVGF_DIAG builds compile that one instead.)
+// for CDNA4, steps 1..64.  (Rounds 2-4 kept an instrumented twin of this kernel and three alternative kernels under tools/variants/ for the
+// ablations of DESIGN.md 3.3; their results live in profiles/r02_* .. r04_*, the code left the tree in round 5.)
 //
 // The reference gathers 25 taps x 3 textures per pixel.  For step S a pixel only ever reads pixels of its own row residue
 // (y mod S), so a workgroup (4 waves) owns ONE residue of a band of rows and a 128-column block and STREAMS DOWN the band: a ring
@@ -42,7 +42,8 @@ template <int S, int TX> struct AtrousLds {
     static constexpr int NOFF = kRing * WL * 8;                         // bytes from a pixel's {luminance, depth} record to its normal record
     __device__ __forceinline__ uint32_t flag(int i) const { return l() + 2 * NOFF + 4 * i; }
     __device__ __forceinline__ uint32_t nref(int i) const { return flag(kRing * 8 + i); }
-    static constexpr size_t bytes = (size_t)kRing * WL * kRecBytes + (kRing * 8 + 3) * sizeof(uint32_t);
+    // nref(3): the waves that have finished; nref(4..11): what the end of a signalling workgroup needs (stashed by thread 0 at the start)
+    static constexpr size_t bytes = (size_t)kRing * WL * kRecBytes + (kRing * 8 + 12) * sizeof(uint32_t);
 };
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ uint32_t lds_load(uint32_t addr) { return *(const lds_u32*)(uintptr_t)addr; }
@@ -213,8 +214,17 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
     return nan_out != 0ull;
 }
 
+// What the kernel knows of its row ranges.  One range (every launch but the strip driver's): rows [g.yb, g.ye).  Several (AtrousRanges): the
+// first `first_blocks` workgroup ids serve the first ranges' `first_tiles` tiles (XCD-aware order of their own), the others the last range.
+struct RangePlan {
+    int nranges, nfirst;
+    int yb[3], ye[3], band[3], nbands[3], tiles_end[3];      // tiles_end: cumulative over the first ranges; [nranges - 1]: the last range's own count
+    int first_blocks, first_tiles, xgroup_first, xgroup;
+    unsigned long long* signal; unsigned* arrivals; unsigned long long value;
+};
+
 template <int ST, int S, int TX>
-__global__ __launch_bounds__(TX * kRS, atrous_waves(S)) void atrous_lds_kernel(Geo g, AtrousArgs a, int band_rows, int nbands, int xgroup, int xrot) {
+__global__ __launch_bounds__(TX * kRS, atrous_waves(S)) void atrous_lds_kernel(Geo g, AtrousArgs a, RangePlan rp) {
     keep_nan_in_clamps();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AtrousLds<S, TX> L{lds_addr(smem)};
@@ -223,51 +233,118 @@ __global__ __launch_bounds__(TX * kRS, atrous_waves(S)) void atrous_lds_kernel(G
     // residue; of the six direction patterns tried for them, only "step 8 backwards too" measured better than all forwards (-1.5 to
     // -3 % for that launch, -0.7 % for step 16 after it; steps 2 and 4 backwards are 1-4 % slower: profiles/r03_small_experiments.txt)
     const int xtiles = (g.W + TX - 1) / TX;
-    const int ntiles = xtiles * nbands * S;
-    int v = xcd_tile(xgroup, xrot);
-    if (v >= ntiles) return;                       // padding of the last groups
-    if (S == 1 || S == 8) v = ntiles - 1 - v;
+    const bool first = (int)blockIdx.x < rp.first_blocks;         // (scalar) a tile of the ranges that signal
+    // (the range's numbers are SELECTED, never indexed: a run-time index into a by-value argument makes the compiler copy it to scratch)
+    int v, r = rp.nranges - 1;
+    auto pick3 = [&](int f0, int f1, int f2) { return r == 0 ? f0 : r == 1 ? f1 : f2; };
+#define pick(f) pick3(rp.f[0], rp.f[1], rp.f[2])
+    if (first) {
+        v = xcd_tile_of((int)blockIdx.x, rp.xgroup_first, 3);
+        if (v >= rp.first_tiles) return;                          // padding
+        r = 0;
+        if (rp.nfirst > 1 && v >= rp.tiles_end[0]) { r = 1; v -= rp.tiles_end[0]; }
+    } else {
+        const int ntiles = pick(tiles_end);
+        v = xcd_tile_of((int)blockIdx.x - rp.first_blocks, rp.xgroup, 3);
+        if (v >= ntiles) return;                                  // padding of the last groups
+        if (S == 1 || S == 8) v = ntiles - 1 - v;
+    }
+    const int yb = pick(yb), nrows = pick(ye) - yb, nbands = pick(nbands), band_rows = pick(band);
+#undef pick
     const int x0 = (v % xtiles) * TX;
     const int band = (v / xtiles) % nbands;
-    const int rv = v / (xtiles * nbands);          // row residue (relative to g.yb) this workgroup owns
-    const int nrows = g.ye - g.yb;
+    const int rv = v / (xtiles * nbands);          // row residue (relative to yb) this workgroup owns
     const int nj = (nrows - rv + S - 1) / S;       // decimated rows of this residue
     const int j0 = band * band_rows;
-    if (j0 >= nj) return;
-    const int j1 = min(nj, j0 + band_rows);
-    const int ybase = g.yb + rv;                   // global row of decimated index j: ybase + S*j
-
-    if (threadIdx.x == 0) lds_store(L.nref(2), 0u);    // (ordered before the waves' stores below by the band's barriers)
-    const bool nan_wave = atrous_band<ST, S, TX, false>(g, a, L, x0, j0, j1, ybase);
-    if (nan_wave && (threadIdx.x & 63) == 0) lds_store(L.nref(2), 1u);
-    __syncthreads();
-    if (lds_load(L.nref(2)) == 0u) return;         // every frame without a NaN
-    __syncthreads();                               // (the band's prologue writes the flag words again)
-    (void)atrous_band<ST, S, TX, true>(g, a, L, x0, j0, j1, ybase);
+    if (threadIdx.x == 0) {                        // (ordered before the waves' stores below by the band's barriers)
+        lds_store(L.nref(2), 0u); lds_store(L.nref(3), 0u);
+        // what the end of the workgroup needs to signal, kept in LDS: in scalar registers through the band it spilled the product loop's
+        // (the kernel sits at its SGPR and VGPR limits; tests/test_kernel_budgets.py)
+        lds_store(L.nref(4), first ? 1u : 0u);
+        if (first) {
+            lds_store(L.nref(5), (uint32_t)(uintptr_t)rp.arrivals); lds_store(L.nref(6), (uint32_t)((uintptr_t)rp.arrivals >> 32));
+            lds_store(L.nref(7), (uint32_t)(uintptr_t)rp.signal); lds_store(L.nref(8), (uint32_t)((uintptr_t)rp.signal >> 32));
+            lds_store(L.nref(9), (uint32_t)rp.value); lds_store(L.nref(10), (uint32_t)(rp.value >> 32));
+            lds_store(L.nref(11), (uint32_t)rp.first_tiles);
+        }
+    }
+    if (j0 >= nj) __syncthreads();
+    else {
+        const int j1 = min(nj, j0 + band_rows);
+        const int ybase = yb + rv;                 // global row of decimated index j: ybase + S*j
+        const bool nan_wave = atrous_band<ST, S, TX, false>(g, a, L, x0, j0, j1, ybase);
+        if (nan_wave && (threadIdx.x & 63) == 0) lds_store(L.nref(2), 1u);
+        __syncthreads();
+        if (lds_load(L.nref(2)) != 0u) {           // (no frame without a NaN gets here)
+            __syncthreads();                       // (the band's prologue writes the flag words again)
+            (void)atrous_band<ST, S, TX, true>(g, a, L, x0, j0, j1, ybase);
+        }
+    }
+    // The rows a neighbour waits for: every wave's stores are made visible (release: vmcnt(0) + L2 write-back) and the wave counts itself in
+    // LDS; the last wave counts the workgroup in device memory, and the last workgroup publishes the value the communication stream waits
+    // for (hipStreamWaitValue64).  No thread index, no argument is used here: they would have to live through the band.
+    if (lds_load(L.nref(4)) != 0u) {
+        __threadfence();
+        const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (lane == 0 && __hip_atomic_fetch_add((lds_u32*)(uintptr_t)L.nref(3), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u == (unsigned)(TX * kRS / 64)) {
+            unsigned* arrivals = (unsigned*)((uintptr_t)lds_load(L.nref(5)) | ((uintptr_t)lds_load(L.nref(6)) << 32));
+            const unsigned n = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (n + 1u == lds_load(L.nref(11))) {
+                unsigned long long* signal = (unsigned long long*)((uintptr_t)lds_load(L.nref(7)) | ((uintptr_t)lds_load(L.nref(8)) << 32));
+                __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(signal, (unsigned long long)lds_load(L.nref(9)) | ((unsigned long long)lds_load(L.nref(10)) << 32), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
-template <int ST, int S, int TX>
-hipError_t launch_atrous_lds_tx(const Geo& g, const AtrousArgs& a, hipStream_t s) {
-    constexpr size_t lds = AtrousLds<S, TX>::bytes;
-    static std::atomic<unsigned long long> attr_done{0};
-    if (hipError_t e = allow_dynamic_lds(atrous_lds_kernel<ST, S, TX>, lds, attr_done); e != hipSuccess) return e;
-    // Bands are sized so that (x tiles) x (S residues) x (bands) is FOUR times the resident slots of the chip (LDS: 160 KiB per CU;
-    // registers: atrous_waves(S) waves per SIMD): workgroups that take a fast path (all sky, uniform normals) make room for others
-    // instead of idling until the slowest one of a single round finishes (A/B on one device: 2x -3..5 %, 4x another -1.5 %, 6x worse).
-    constexpr int per_cu_lds = (int)((160 * 1024) / lds), per_cu_waves = atrous_waves(S) * 4 / (TX * kRS / 64);      // workgroups of TX * kRS / 64 waves
-    constexpr int per_cu = per_cu_lds < per_cu_waves ? per_cu_lds : per_cu_waves;
-    const int nrows = g.ye - g.yb;
+// bands of one range: (x tiles) x (S residues) x (bands) is kAtrousOversubscribe times the resident slots of the chip (LDS: 160 KiB per CU;
+// registers: atrous_waves(S) waves per SIMD): workgroups that take a fast path (all sky, uniform normals) make room for others
+// instead of idling until the slowest one of a single round finishes (A/B on one device: 2x -3..5 %, 4x another -1.5 %, 6x worse).
+template <int S, int TX>
+inline void cut_bands(int nrows, int xtiles, size_t lds, int& band, int& nbands) {
+    const int per_cu_lds = (int)((160 * 1024) / lds), per_cu_waves = atrous_waves(S) * 4 / (TX * kRS / 64);      // workgroups of TX * kRS / 64 waves
+    const int per_cu = per_cu_lds < per_cu_waves ? per_cu_lds : per_cu_waves;
     const int njmax = (nrows + S - 1) / S;
-    const int xtiles = (g.W + TX - 1) / TX;
-    int nbands = per_cu * num_cus() * kAtrousOversubscribe / (xtiles * S);
+    nbands = per_cu * num_cus() * kAtrousOversubscribe / (xtiles * S);
     if (nbands < 1) nbands = 1;
-    int band = (njmax + nbands - 1) / nbands;
+    band = (njmax + nbands - 1) / nbands;
     if (band < kAtrousMinBand) band = kAtrousMinBand;
     band = (band + kRS - 1) / kRS * kRS;
     nbands = (njmax + band - 1) / band;
-    int xgroup;
-    const dim3 grid = xcd_grid(xtiles * nbands * S, S <= 2 ? 16 : (S == 16 ? 2 : 1), xgroup);     // groups per XCD: A/B per step on one device (4K)
-    atrous_lds_kernel<ST, S, TX><<<grid, dim3(TX * kRS), lds, s>>>(g, a, band, nbands, xgroup, 3);
+}
+
+template <int ST, int S, int TX>
+hipError_t launch_atrous_lds_tx(const Geo& g, const AtrousArgs& a, hipStream_t s, const AtrousRanges* ranges = nullptr) {
+    constexpr size_t lds = AtrousLds<S, TX>::bytes;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (hipError_t e = allow_dynamic_lds(atrous_lds_kernel<ST, S, TX>, lds, attr_done); e != hipSuccess) return e;
+    const int xtiles = (g.W + TX - 1) / TX;
+    RangePlan rp{};
+    if (!ranges) { rp.nranges = 1; rp.nfirst = 0; rp.yb[0] = g.yb; rp.ye[0] = g.ye; }
+    else {
+        rp.nranges = ranges->n; rp.nfirst = ranges->nfirst;
+        for (int r = 0; r < ranges->n; r++) { rp.yb[r] = ranges->yb[r]; rp.ye[r] = ranges->ye[r]; }
+        rp.signal = ranges->signal; rp.arrivals = ranges->arrivals; rp.value = ranges->value;
+    }
+    if (rp.nranges < 1 || rp.nranges > 3 || rp.nfirst < 0 || rp.nfirst > 2 || rp.nfirst >= rp.nranges + (rp.nfirst ? 1 : 0)) return hipErrorInvalidValue;
+    int total_first = 0;
+    for (int r = 0; r < rp.nranges; r++) {
+        cut_bands<S, TX>(rp.ye[r] - rp.yb[r], xtiles, lds, rp.band[r], rp.nbands[r]);
+        const int nt = rp.ye[r] > rp.yb[r] ? xtiles * rp.nbands[r] * S : 0;
+        if (r < rp.nfirst) { total_first += nt; rp.tiles_end[r] = total_first; } else rp.tiles_end[r] = nt;
+    }
+    const bool has_last = rp.nranges > rp.nfirst;                      // (a launch may consist of first ranges only)
+    const int last_tiles = has_last ? rp.tiles_end[rp.nranges - 1] : 0;
+    rp.first_tiles = total_first;
+    unsigned blocks = 0;
+    if (total_first > 0) { const dim3 gf = xcd_grid(total_first, 1, rp.xgroup_first); rp.first_blocks = (int)gf.x; blocks += gf.x; }
+    else { rp.first_blocks = 0; rp.xgroup_first = 1; }
+    if (!has_last) { rp.nranges += 1; rp.yb[rp.nranges - 1] = rp.ye[rp.nranges - 1] = 0; rp.band[rp.nranges - 1] = kAtrousMinBand; rp.nbands[rp.nranges - 1] = 1; rp.tiles_end[rp.nranges - 1] = 0; rp.xgroup = 1; }
+    if (last_tiles > 0) { const dim3 gl = xcd_grid(last_tiles, S <= 2 ? 16 : (S == 16 ? 2 : 1), rp.xgroup); blocks += gl.x; }     // groups per XCD: A/B per step on one device (4K)
+    else rp.xgroup = 1;
+    if (!blocks) return hipSuccess;
+    atrous_lds_kernel<ST, S, TX><<<dim3(blocks), dim3(TX * kRS), lds, s>>>(g, a, rp);
     return hipGetLastError();
 }
 
@@ -275,18 +352,18 @@ hipError_t launch_atrous_lds_tx(const Geo& g, const AtrousArgs& a, hipStream_t s
 // where they cut twice as many tiles in x and so allow bands twice as tall: parity-green and 3-5 % SLOWER at 1080p, on an 8K/8 strip
 // and at 4K, profiles/r04_small_experiments.txt block 6.)
 template <int ST, int S>
-hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s) { return launch_atrous_lds_tx<ST, S, kTX>(g, a, s); }
+hipError_t launch_atrous_lds(const Geo& g, const AtrousArgs& a, hipStream_t s, const AtrousRanges* r) { return launch_atrous_lds_tx<ST, S, kTX>(g, a, s, r); }
 
 template <int ST>
-hipError_t launch_atrous_lds_step(const Geo& g, const AtrousArgs& a, hipStream_t s) {
+hipError_t launch_atrous_lds_step(const Geo& g, const AtrousArgs& a, hipStream_t s, const AtrousRanges* r = nullptr) {
     switch (a.step) {
-        case 1: return launch_atrous_lds<ST, 1>(g, a, s);
-        case 2: return launch_atrous_lds<ST, 2>(g, a, s);
-        case 4: return launch_atrous_lds<ST, 4>(g, a, s);
-        case 8: return launch_atrous_lds<ST, 8>(g, a, s);
-        case 16: return launch_atrous_lds<ST, 16>(g, a, s);
-        case 32: return launch_atrous_lds<ST, 32>(g, a, s);
-        case 64: return launch_atrous_lds<ST, 64>(g, a, s);
+        case 1: return launch_atrous_lds<ST, 1>(g, a, s, r);
+        case 2: return launch_atrous_lds<ST, 2>(g, a, s, r);
+        case 4: return launch_atrous_lds<ST, 4>(g, a, s, r);
+        case 8: return launch_atrous_lds<ST, 8>(g, a, s, r);
+        case 16: return launch_atrous_lds<ST, 16>(g, a, s, r);
+        case 32: return launch_atrous_lds<ST, 32>(g, a, s, r);
+        case 64: return launch_atrous_lds<ST, 64>(g, a, s, r);
         default: return hipErrorInvalidValue;
     }
 }

@@ -121,6 +121,9 @@ int temporal_moments_impl(svgf_ctx* c, const void* prev_colour, const void* radi
                           const void* guide_prev = nullptr, int dense = 0);
 void choose_moments_kernel(svgf_ctx* c, bool* cold, bool* crowded);   // frame / strip drivers, before the temporal launch of a frame (svgf_api.hip)
 int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration, const void* guide = nullptr);
+// one iteration over several row ranges in one launch, the first ranges signalled (the strip driver's edge rows; svgf_kernels.h: AtrousRanges)
+bool atrous_ranges_ok(const svgf_ctx* c, int step);
+int atrous_ranges_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration, const void* guide, const svgf::AtrousRanges& r);
 // iterations 0 and 1 in one launch on rows [c->rb, c->re) (iteration 1's; iteration 0 and the feedback store cover 4 more rows either side)
 int atrous_pair_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, const void* guide = nullptr);
 bool can_fuse01(const svgf_ctx* c);     // the drivers run iterations 0 and 1 as one launch

@@ -256,11 +256,12 @@ __device__ __forceinline__ float dot2_h2(uint32_t a, uint32_t b) {
 // texel comes from memory twice.  Tiles are numbered with x fastest, cut into groups of `xgroup` consecutive tiles, and group k
 // goes to XCD k % 8 (rotated by `xrot` per round, so that an XCD's groups come from different parts of the frame): neighbours
 // inside a group run on one XCD at about the same time and share their halos in its L2.  -> tile number, or >= ntiles (padding).
-__device__ __forceinline__ int xcd_tile(int xgroup, int xrot) {
-    const int wid = blockIdx.x >> 3;               // index among the workgroups of this XCD
+__device__ __forceinline__ int xcd_tile_of(int bid, int xgroup, int xrot) {      // bid: the workgroup's index (a multiple of 8 may have been taken off)
+    const int wid = bid >> 3;                      // index among the workgroups of this XCD
     const int round = wid / xgroup;                // the XCD's round-th group
-    return (round * kXcds + ((blockIdx.x + xrot * round) & (kXcds - 1))) * xgroup + wid % xgroup;
+    return (round * kXcds + ((bid + xrot * round) & (kXcds - 1))) * xgroup + wid % xgroup;
 }
+__device__ __forceinline__ int xcd_tile(int xgroup, int xrot) { return xcd_tile_of((int)blockIdx.x, xgroup, xrot); }
 inline dim3 xcd_grid(int ntiles, int xm, int& xgroup) {      // xm groups per XCD
     xgroup = (ntiles + kXcds * xm - 1) / (kXcds * xm);
     if (xgroup < 1) xgroup = 1;

@@ -86,10 +86,24 @@ struct AtrousArgs {
     const uint4* guide;          // TemporalArgs::guide_out of the same frame (LDS kernel only; motion / normal are then not read), or null
     int no_fastpath;             // SVGF_VARIANT_LDS_GENERAL: every wave takes the general tap path (bit-identical, slower)
 };
+// Strip driver: ONE launch over up to three row ranges of an iteration, the first `nfirst` of them — the rows a neighbour rank waits for —
+// produced by the launch's first workgroups; the last of those to finish publishes `value` in `signal` (device memory), which the
+// communication stream waits for with hipStreamWaitValue64: the halo exchange starts while the interior tiles of the same launch still
+// run.  (Round 4 launched the two edge ranges and the interior separately: three launches' ramp and tail per iteration.)  Every range is
+// cut into bands by itself, so a pixel's result is what a launch over its range alone would give: bit-identical.
+struct AtrousRanges {
+    int n, nfirst;               // ranges; how many of them come first and signal
+    int yb[3], ye[3];            // global rows
+    unsigned long long* signal;  // 8 bytes, written once per launch by the last of the first ranges' workgroups (release, system scope) ...
+    unsigned* arrivals;          // ... counted here (left at 0)
+    unsigned long long value;
+};
 
 hipError_t launch_temporal(const Geo& g, int storage, const TemporalArgs& a, hipStream_t s);
 hipError_t launch_moments(const Geo& g, int storage, const MomentsArgs& a, bool direct, hipStream_t s);
 hipError_t launch_atrous(const Geo& g, int storage, int variant, const AtrousArgs& a, hipStream_t s);
+bool atrous_ranges_available(int variant, const AtrousArgs& a);     // the LDS-streaming kernel serves this step (else: one launch_atrous per range)
+hipError_t launch_atrous_ranges(const Geo& g, int storage, const AtrousArgs& a, const AtrousRanges& r, hipStream_t s);   // g.yb / g.ye are not used
 // iterations 0 and 1 (steps 1 and 2) in ONE launch: `in` -> `out` is iteration 1's result, `feedback` iteration 0's (written on the launch rows
 // and 4 rows beyond inside the frame); the launch rows [yb, ye) are iteration 1's and the planes hold 6 rows around them
 bool atrous_fused_available(int variant, const AtrousArgs& a);

@@ -20,13 +20,8 @@
 #include <cstdlib>
 #include <type_traits>
 
-// The streaming a-trous kernels live in headers of their own (shared tap code: svgf_atrous_taps.h).  -DSVGF_DIAG twins of the
-// library (tools/) swap the product kernel for its instrumented round-2 form; nothing else in this file is conditional.
-#ifdef SVGF_DIAG
-#include "../../tools/variants/atrous_lds_instrumented.h"
-#else
+// The streaming a-trous kernels live in headers of their own (shared tap code: svgf_atrous_taps.h).
 #include "svgf_atrous_lds.h"
-#endif
 #include "svgf_atrous_fused.h"
 #include "svgf_moments_lds.h"
 
@@ -941,6 +936,15 @@ hipError_t launch_atrous(const Geo& g, int storage, int variant, const AtrousArg
     if (storage == 0) atrous_direct_kernel<0><<<grid, block, 0, s>>>(g, a);
     else atrous_direct_kernel<1><<<grid, block, 0, s>>>(g, a);
     return hipGetLastError();
+}
+
+// The strip driver's one-launch iteration (AtrousRanges, svgf_kernels.h): LDS-streaming kernel only.
+bool atrous_ranges_available(int variant, const AtrousArgs& a) {
+    const bool lds_ok = a.step == 1 || a.step == 2 || a.step == 4 || a.step == 8 || a.step == 16 || a.step == 32 || a.step == 64;
+    return variant != 1 /* SVGF_VARIANT_DIRECT */ && lds_ok && a.phi_normal != 0.0f;
+}
+hipError_t launch_atrous_ranges(const Geo& g, int storage, const AtrousArgs& a, const AtrousRanges& r, hipStream_t s) {
+    return storage == 0 ? launch_atrous_lds_step<0>(g, a, s, &r) : launch_atrous_lds_step<1>(g, a, s, &r);
 }
 
 // Iterations 0 and 1 (steps 1 and 2) in one launch (svgf_atrous_fused.h); Geo's launch rows are iteration 1's.

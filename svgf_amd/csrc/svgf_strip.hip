@@ -126,6 +126,12 @@ struct svgf_strips {
         void* filter_alt[2] = {nullptr, nullptr};
         hipEvent_t ready = nullptr, halo_done = nullptr, state_done = nullptr;
         hipEvent_t mb_ready = nullptr, mb_done = nullptr;      // mailbox: this rank's communication stream has reached the group / has received what the group sends it
+        // edge rows first (svgf_strips_set_edge_first): the iteration in front of an exchange is ONE launch whose first workgroups produce the rows the
+        // neighbours wait for; the last of them writes edge_value into edge_signal[0] (device memory; the arrival counter sits 128 B behind it) and
+        // the communication stream waits for that word (hipStreamWaitValue64) instead of for an event behind two extra launches
+        unsigned long long* edge_signal = nullptr;
+        unsigned long long edge_value = 0;
+        bool edge_pending = false;                             // the launch just enqueued signals: the next exchange waits for edge_value
         bool state_pending = false;
         // the host never runs more than kMaxAhead frames ahead of the device: frame f waits for the end of frame f - kMaxAhead.  With ~100
         // frames of launches, events and RCCL groups queued the device starts to starve (0.43 -> 0.6 ms per 8K/8 strip, tools/strip_sim.py)
@@ -139,6 +145,7 @@ struct svgf_strips {
     std::vector<Local> local;
     int timing_every = 0, timing_base = 0, frame_no = 0;       // timed: frames timing_base, timing_base + every, ...
     int frames_in_flight = 1;
+    bool edge_first = true;                // svgf_strips_set_edge_first
     double t_ms = 0, t_px_iter = 0, t_px_fb = 0;
     int t_launches = 0;
     std::string err;
@@ -357,23 +364,48 @@ int post_exchange(svgf_strips* s, const std::vector<PlaneSpec>& planes, int h, b
         DeviceGuard dg(l.device);
         SVGF_SHIP(s, hipEventRecord(l.ready, l.cur));
     }
+    // (edge rows first: the rows a rank sends are final when the first workgroups of the launch it has just enqueued have signalled — the
+    // communication stream waits for that word, not for the launch; everything enqueued BEFORE that launch is complete by then, stream order)
+    auto wait_for = [&](svgf_strips::Local& on, svgf_strips::Local& of) -> int {
+        if (of.edge_pending) SVGF_SHIP(s, hipStreamWaitValue64(on.comm_stream, of.edge_signal, of.edge_value, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
+        else SVGF_SHIP(s, hipStreamWaitEvent(on.comm_stream, of.ready, 0));
+        return SVGF_OK;
+    };
     for (auto& l : s->local) {
         DeviceGuard dg(l.device);
-        if (!s->loopback) SVGF_SHIP(s, hipStreamWaitEvent(l.comm_stream, l.ready, 0));
-        else if (&l == &s->local[0]) for (auto& m : s->local) SVGF_SHIP(s, hipStreamWaitEvent(l.comm_stream, m.ready, 0));
+        if (!s->loopback) { if (int rc = wait_for(l, l); rc != SVGF_OK) return rc; }
+        else if (&l == &s->local[0]) for (auto& m : s->local) { if (int rc = wait_for(l, m); rc != SVGF_OK) return rc; }
     }
+    for (auto& l : s->local) l.edge_pending = false;
     if (int rc = T.group_start(s); rc != SVGF_OK) return rc;
+    struct Post { svgf_strips::Local* l; MsgSpec m; };
+    std::vector<Post> posts;
     std::vector<MsgSpec> msgs;
     for (auto& l : s->local) {
         msgs.clear();
         exchange_msgs(s->H, s->world, l.rank, planes, h, msgs);
-        for (const MsgSpec& m : msgs) {
-            const size_t rb = row_bytes(s, m.plane);
-            char* base = (char*)svgf_state_plane(l.ctx, m.plane, m.index) + (size_t)(m.g0 - l.g.y0) * rb;
-            const size_t bytes = (size_t)(m.g1 - m.g0) * rb;
-            const int rc = m.send ? T.send(s, l, base, bytes, m.peer) : T.recv(s, l, base, bytes, m.peer);
-            if (rc != SVGF_OK) return group_failed(s, rc);
-        }
+        for (const MsgSpec& m : msgs) posts.push_back(Post{&l, m});
+    }
+    if (s->loopback) {
+        // ONE communicator whose only peer is itself: RCCL matches ALL sends to ALL receives in posting order, so the sends and the receives are
+        // each posted in the order of the messages they belong to, (source rank, destination rank), planes in plan order within a pair.  (With real
+        // peers — RCCL or the mailbox — only the order within a pair of ranks matters, and exchange_msgs keeps that the same on both sides.)
+        auto src_of = [](const Post& p) { return p.m.send ? p.l->rank : p.m.peer; };
+        auto dst_of = [](const Post& p) { return p.m.send ? p.m.peer : p.l->rank; };
+        std::stable_sort(posts.begin(), posts.end(), [&](const Post& a, const Post& b) {
+            if (a.m.send != b.m.send) return a.m.send && !b.m.send;
+            if (src_of(a) != src_of(b)) return src_of(a) < src_of(b);
+            return dst_of(a) < dst_of(b);
+        });
+    }
+    for (const Post& p : posts) {
+        const MsgSpec& m = p.m;
+        svgf_strips::Local& l = *p.l;
+        const size_t rb = row_bytes(s, m.plane);
+        char* base = (char*)svgf_state_plane(l.ctx, m.plane, m.index) + (size_t)(m.g0 - l.g.y0) * rb;
+        const size_t bytes = (size_t)(m.g1 - m.g0) * rb;
+        const int rc = m.send ? T.send(s, l, base, bytes, m.peer) : T.recv(s, l, base, bytes, m.peer);
+        if (rc != SVGF_OK) return group_failed(s, rc);
     }
     if (int rc = T.group_end(s); rc != SVGF_OK) { s->broken = true; return rc; }
     for (auto& l : s->local) {
@@ -392,7 +424,8 @@ int wait_exchange(svgf_strips* s, svgf_strips::Local& l, bool is_state) {
 }
 
 // pair: iterations 0 and 1 in one launch on `rows` (iteration 1's; iteration 0 and the feedback store cover 4 rows more either side)
-int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src, int dst, int P, const svgf_gbuffer* cur, int i, bool pair = false) {
+// inner != nullptr: ONE launch over the two edge ranges [rows.a, inner->a), [inner->b, rows.b) — produced first and signalled — and the interior *inner
+int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src, int dst, int P, const svgf_gbuffer* cur, int i, bool pair = false, const Rows* inner = nullptr) {
     if (rows.b <= rows.a) return SVGF_OK;
     svgf_ctx* c = l.ctx;
     DeviceGuard dg(l.device);
@@ -405,8 +438,18 @@ int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src
         if (hipError_t e = hipEventRecord(e0, l.cur); e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return sfail(s, SVGF_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e)); }
     }
     const void* guide = use_guide(c) ? c->guide : nullptr;
-    int rc = pair ? atrous_pair_impl(c, c->filter[src], c->filter[dst], c->colour[P], cur, guide)
-                  : atrous_impl(c, c->filter[src], c->filter[dst], i == 0 ? c->colour[P] : nullptr, cur, 1 << i, i, guide);
+    int rc = SVGF_OK;
+    if (inner) {
+        svgf::AtrousRanges r{};
+        auto add = [&](int a, int b) { if (b > a) { r.yb[r.n] = a; r.ye[r.n] = b; r.n++; } };
+        add(rows.a, inner->a); add(inner->b, rows.b);
+        r.nfirst = r.n;
+        add(inner->a, inner->b);
+        r.signal = l.edge_signal; r.arrivals = (unsigned*)(l.edge_signal + 16); r.value = ++l.edge_value;
+        rc = atrous_ranges_impl(c, c->filter[src], c->filter[dst], i == 0 ? c->colour[P] : nullptr, cur, 1 << i, i, guide, r);
+        if (rc == SVGF_OK) l.edge_pending = r.nfirst > 0;
+    } else rc = pair ? atrous_pair_impl(c, c->filter[src], c->filter[dst], c->colour[P], cur, guide)
+                     : atrous_impl(c, c->filter[src], c->filter[dst], i == 0 ? c->colour[P] : nullptr, cur, 1 << i, i, guide);
     if (rc != SVGF_OK) {
         if (timed) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
         return sfail(s, rc, c->err);
@@ -569,6 +612,14 @@ int svgf_strips_create(svgf_strips** out, int width, int height, int world, cons
         if (e == hipSuccess) e = hipEventCreateWithFlags(&l.ready, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&l.halo_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&l.state_done, hipEventDisableTiming);
+        if (e == hipSuccess && world > 1) {
+            int can = 0;
+            // (a part or runtime without stream memory operations keeps round 4's three launches per exchanging iteration)
+            if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, l.device) == hipSuccess && can) {
+                e = hipMalloc((void**)&l.edge_signal, 256);
+                if (e == hipSuccess) e = hipMemset(l.edge_signal, 0, 256);
+            }
+        }
         if (e == hipSuccess && s->mailbox) e = hipEventCreateWithFlags(&l.mb_ready, hipEventDisableTiming);
         if (e == hipSuccess && s->mailbox) e = hipEventCreateWithFlags(&l.mb_done, hipEventDisableTiming);
         if (e != hipSuccess) { cleanup(); return SVGF_ERR_HIP; }
@@ -593,6 +644,7 @@ void svgf_strips_destroy(svgf_strips* s) {
         if (l.ready) (void)hipEventDestroy(l.ready);
         if (l.halo_done) (void)hipEventDestroy(l.halo_done);
         if (l.state_done) (void)hipEventDestroy(l.state_done);
+        if (l.edge_signal) (void)hipFree(l.edge_signal);
         if (l.mb_ready) (void)hipEventDestroy(l.mb_ready);
         if (l.mb_done) (void)hipEventDestroy(l.mb_done);
         if (l.own_comm_stream && l.comm_stream) (void)hipStreamDestroy(l.comm_stream);
@@ -747,16 +799,22 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
                     if (hi <= lo) split = false;         // a strip shorter than its two edges: one launch, the exchange behind it
                 }
             }
+            // edge rows first, in ONE launch (round 5): the launch's first workgroups produce the two edge ranges and signal, the interior follows
+            // in the same launch — instead of two edge launches, the exchange's event, and an interior launch (three launches' ramp and tail)
+            bool one_launch = split && s->edge_first;
+            for (int k = 0; k < n && one_launch; k++) one_launch = atrous_ranges_ok(s->local[k].ctx, 1 << i) && s->local[k].edge_signal != nullptr;
             for (int k = 0; k < n; k++) {
                 auto& l = s->local[k];
                 const Rows rows = grown(l.g, s->H, l.g.ext_atrous[i]);
                 int rc = SVGF_OK;
-                if (split) {
+                if (one_launch) rc = launch_atrous_rows(s, l, rows, pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], i, false, &inner[k]);
+                else if (split) {
                     rc = launch_atrous_rows(s, l, Rows{rows.a, inner[k].a}, pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], i);
                     if (rc == SVGF_OK) rc = launch_atrous_rows(s, l, Rows{inner[k].b, rows.b}, pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], i);
                 } else rc = launch_atrous_rows(s, l, rows, pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], i);
                 if (rc != SVGF_OK) return rc;
             }
+            if (one_launch) split = false;            // (the interior is part of that launch)
             if (feeds_exchange) {
                 int rc = post_exchange(s, {{SVGF_PLANE_FILTER, 1 - pp[0], 0}}, h, false);
                 if (rc != SVGF_OK) return rc;
@@ -827,6 +885,12 @@ int svgf_strips_set_frames_in_flight(svgf_strips* s, int frames) {
         }
     }
     s->frames_in_flight = frames;
+    return SVGF_OK;
+}
+
+int svgf_strips_set_edge_first(svgf_strips* s, int enable) {
+    if (!s) return SVGF_ERR_INVALID;
+    s->edge_first = enable != 0;
     return SVGF_OK;
 }
 

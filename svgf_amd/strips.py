@@ -1,24 +1,24 @@
-"""Row-strip execution of the SVGF pass across the GPUs of one node.
+"""Row strips across the GPUs of one node: Python's share of it.
 
-The reference is single-GPU (no NCCL/MPI anywhere in src/); this is the build's only parallel strategy: the
-frame is cut into `world` contiguous row strips, one process per GPU, and the strips exchange HALO ROWS with
-their two neighbours through torch.distributed point-to-point ops (backend "nccl" = RCCL over xGMI on MI355X,
-"gloo" in the CPU tests).  There is no collective in the data path: every stage is a bounded-reach gather, so
-strip results are bit-identical to the single-GPU frame.
+The product path is C++: `svgf_strips_*` in svgf_amd/csrc/svgf_strip.hip runs the stage sequence of every strip, posts the halo
+exchanges as RCCL send/recv groups and ties them to the filter stream.  This module holds
+  * the bindings of that driver (`NativeStrips`, `strips_plan`, `strip_messages`) and the rank bootstrap (`rccl_comm`: the 128-byte
+    unique id travels over torch.distributed — the only thing Python does for an exchange);
+  * `bench_strips`, bench.py's N > 1 leg;
+  * a Python restatement of the driver's SCHEDULE (`Geometry`, `StripRunner`, `LocalComm`, `DistComm`) that runs on any stage
+    backend.  It is NOT the product and no GPU path uses it: tests/test_strips_cpu.py drives it with oracle stages over gloo (world
+    size 2) and in lock step, which checks the halo plan's arithmetic — what must travel when for the strips to equal the whole
+    frame — independently of the C++ code; `svgf_strips_plan` / `svgf_strips_messages` are checked against it (tests/test_abi.py).
 
-Halo plan.  À-trous iteration i reaches 2*2^i rows.  A plan groups the iterations; a group's input halo
-(the sum of its iterations' reaches) is exchanged once, before the group, and inside the group iteration i is
-computed on `ext_i` extra rows each side (redundantly with the neighbour, bit-identically) so that the next
-iteration of the group finds its halo locally:
+Halo plan.  À-trous iteration i reaches 2*2^i rows.  A plan groups the iterations; a group's input halo (the sum of its iterations'
+reaches) is exchanged once, before the group, and inside the group iteration i is computed on `ext_i` extra rows each side
+(redundantly with the neighbour, bit-identically) so that the next iteration of the group finds its halo locally:
     "per-iteration"  [[0],[1],[2],[3],[4]]   one exchange before every iteration  (the literal north-star scheme)
-    "grouped"        [[0,1,2],[3,4]]         2 à-trous exchanges per frame, <3 % redundant work   (default)
+    "grouped"        [[0,1,2],[3,4]]         2 à-trous exchanges per frame, <3 % redundant work
     "ghost"          [[0,1,2,3,4]]           no exchange between iterations, 62 ghost rows each side
-The temporal and moments stages are computed redundantly on the first group's halo, so a frame needs ONE more
-exchange: its state (colour feedback, moments, history) on the rows the next frame's reprojection can reach.
-That state is final once iteration 0 has written the feedback colour, so it is posted right there and waited
-for at the start of the NEXT frame: the transfer runs beside iterations 1.. of the frame that produced it.
-The à-trous exchanges are posted before the rows that do not depend on them are computed (interior/boundary
-split), so those transfers overlap the interior kernels.
+The temporal and moments stages are computed redundantly on the first group's halo, so a frame needs ONE more exchange: its state
+(colour feedback, moments, history) on the rows the next frame's reprojection can reach.  That state is final once iteration 0 has
+written the feedback colour, so it is posted right there and waited for at the start of the NEXT frame.
 """
 from __future__ import annotations
 
@@ -179,57 +179,6 @@ class LocalComm:
                 for t, p in recvs:
                     t.copy_(parent.box[(p, rank, n)].pop(0))
         return _C()
-
-
-class HipStages:
-    """The three stages on a strip through the C ABI (libsvgf_mi355x.so)."""
-
-    def __init__(self, geo: Geometry, params, device):
-        from . import filter as F
-        self.F, self.geo = F, geo
-        self.d = F.Denoiser(geo.W, geo.H, params, device=device.index or 0, strip=(geo.y0, geo.y1 - geo.y0, geo.own[0], geo.own[1]))
-        # previous-frame state is only kept up to date own +- halo_state rows; the planes hold more (the a-trous halos)
-        self.d.set_valid_rows(max(geo.y0, geo.own[0] - geo.halo_state), min(geo.y1, geo.own[1] + geo.halo_state))
-        self.device = device
-        self.timing, self.events = False, []
-
-    def gbuffer(self, motion, normal, uv):
-        return self.F.GBuffer(motion, normal, uv)
-
-    def temporal(self, rows, prev_colour, radiance, colour_out, gb_cur, gb_prev, hist_prev, hist_cur, mom_cur, mom_prev):
-        self.d.set_rows(*rows)
-        self.d.TemporalFilter(prev_colour, radiance, colour_out, gb_cur, gb_prev, hist_prev, hist_cur, mom_cur, mom_prev)
-
-    def moments(self, rows, colour, out, mom, gb, hist):
-        self.d.set_rows(*rows)
-        self.d.FilterMoments(colour, out, mom, gb, hist)
-
-    def temporal_moments(self, rows_t, rows_m, prev_colour, radiance, colour_out, filter_out, gb_cur, gb_prev, hist_prev, hist_cur, mom_cur, mom_prev,
-                         feedback_follows=False):
-        """Both stages with the steady-state moments copy fused into the temporal launch (svgf_temporal_moments)."""
-        self.d.set_rows(*rows_t)
-        self.d.TemporalMoments(prev_colour, radiance, colour_out, filter_out, gb_cur, gb_prev, hist_prev, hist_cur, mom_cur, mom_prev, rows_m,
-                               feedback_follows=feedback_follows)
-
-    def atrous(self, rows, src, dst, feedback, gb, step, iteration):
-        self.d.set_rows(*rows)
-        if self.timing:                              # HIP events on the stream the kernel is launched on (torch's current one)
-            import torch
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            self.d.FilterKernel(src, dst, feedback, gb, step, iteration)
-            e1.record()
-            self.events.append((e0, e1, (rows[1] - rows[0]) * self.geo.W, iteration))
-        else:
-            self.d.FilterKernel(src, dst, feedback, gb, step, iteration)
-
-    def atrous_timing(self, bytes_iter, bytes_feedback):
-        """-> (launches, total ms, total algorithmic bytes) of the a-trous launches recorded while self.timing was set."""
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.events)
-        by = sum(px * (bytes_iter + (bytes_feedback if it == 0 else 0)) for _, _, px, it in self.events)
-        n = len(self.events)
-        self.events = []
-        return n, ms, by
 
 
 class StripRunner:
@@ -530,6 +479,10 @@ class NativeStrips:
         a frame's result is ordered on the compute stream two calls later, or by sync())."""
         self._check(self.lib.svgf_strips_set_frames_in_flight(self._h, int(frames)), "svgf_strips_set_frames_in_flight")
 
+    def set_edge_first(self, enable=True):
+        """svgf_strips_set_edge_first: the iteration in front of an exchange as ONE launch whose first workgroups produce the edge rows and signal (default on)."""
+        self._check(self.lib.svgf_strips_set_edge_first(self._h, 1 if enable else 0))
+
     def set_iteration_fusion(self, enable=True):
         """Iterations 0 and 1 as one launch on every local strip (where the halo plan keeps them in one group)."""
         for k in range(self.n):
@@ -602,43 +555,6 @@ class _NativeRunner:
         self.drv.close()
 
 
-class _PythonRunner:
-    """The same schedule through svgf_amd/strips.py (StripRunner + torch.distributed point-to-point ops)."""
-    name = "python (svgf_amd/strips.py)"
-
-    def __init__(self, W, H, world, rank, params, device, stream, comm, plan, motion_reach):
-        geo = Geometry.make(W, H, rank, world, params.steps, plan=plan, moments_radius=params.moments_radius, motion_reach=motion_reach)
-        self.stages = HipStages(geo, params, device)
-        self.runner = StripRunner(geo, self.stages, DistComm(device=device), storage=params.storage, device=device)
-        self.lay = dict(plan=geo.plan, y0=geo.y0, y1=geo.y1, own=geo.own)
-        self._on = False
-
-    def frame(self, rad, cur, prev):
-        return self.runner.frame(rad, cur, prev)
-
-    def owned(self, t):
-        return self.runner.owned(t)
-
-    def timing(self, on):
-        self._on = bool(on)
-        if not on:
-            self.stages.timing = False
-
-    def frame_timing(self, k):
-        self.stages.timing = self._on and (k % 4) == 0     # a-trous launches of every 4th timed frame between HIP events
-
-    def sync(self):
-        self.runner.flush()
-        self.stages.d.sync()
-
-    def atrous_timing(self, bytes_iter, bytes_feedback):
-        return self.stages.atrous_timing(bytes_iter, bytes_feedback)
-
-    def close(self):
-        self.runner.flush()
-        self.stages.d.close()
-
-
 def _strip_pan_frames(W, H, storage, device, mv, y0, y1):
     """Two consecutive frames of a camera pan (rows [y0, y1)), walked forth and back: frame n shows canvas n & 1; walking back, a
     frame's predecessor is the other one with the motion vector negated (bench.py's FramePool, pool of 2).
@@ -660,14 +576,14 @@ def _strip_pan_frames(W, H, storage, device, mv, y0, y1):
     return rads, gbs
 
 
-def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, make_inputs, prime_frames, driver="native", motion_reach=None,
+def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, make_inputs, prime_frames, motion_reach=None,
                  plans=("per-iteration", "grouped"), pan_mv=(1.5, -3.5), one_gpu_reference=True, busy=(400.0, 600)):
     """bench.py's N > 1 leg: this rank's strip of a W x H frame; every measurement is `steps` frames between barriers, MAX over ranks.
     Measured: the headline plan (`plan`, static camera), the other halo plans (BASELINE config #4 names "per-iteration"), a camera
     pan whose state exchange really carries moments and history (motion reach >= 3), and — on rank 0 alone, before the strips —
     the whole frame on one GPU, which is what the strip-parallel speed-up is relative to.
-    driver = "native": the C++ strip driver of the library (RCCL groups posted from C++); a rank that cannot bring it up makes every
-    rank raise (bench.py exits non-zero): the Python twin of the schedule runs only when asked for (driver = "python")."""
+    The driver is the C++ strip driver of the library (RCCL groups posted from C++); a rank that cannot bring its communicator up makes
+    every rank raise (bench.py exits non-zero): there is nothing else to fall back to."""
     import math
     import time
     import torch
@@ -735,7 +651,7 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
         motion_reach = int(math.ceil(float(mvy.item())))
 
     comm, rccl_ranks = None, None
-    if driver == "native" and world > 1:
+    if world > 1:
         # every rank brings the communicator up; if any rank cannot, ALL stop (no silent change of what is measured)
         err = ""
         try:
@@ -746,9 +662,9 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
         bad = torch.tensor([0 if comm is not None else 1], device=device, dtype=torch.int32)
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         if int(bad.item()):
-            raise F.SvgfError(f"rank {rank}: the C++ strip driver's RCCL communicator is unavailable on some rank ({err or 'see the other ranks'}); "
-                              "rerun with --driver python to measure the Python twin of the schedule instead")
-    Runner = _NativeRunner if driver == "native" else _PythonRunner
+            raise F.SvgfError(f"rank {rank}: the C++ strip driver's RCCL communicator is unavailable on some rank ({err or 'see the other ranks'}): "
+                              "nothing is measured (RCCL wants one device per rank)")
+    Runner = _NativeRunner
 
     def measure(plan_name, reach, frame_of, keep_timing=False):
         """One driver under one plan: prime, then `steps` frames between barriers.  frame_of(n) -> (radiance, cur, prev) of THIS layout."""

@@ -469,127 +469,6 @@ def test_strips_bitwise_equal_whole_frame(G, variant):
         assert np.array_equal(G.host(o)[yb - y0:ye - y0], want[yb:ye]), (yb, ye)
 
 
-@pytest.mark.parametrize("plan", ["per-iteration", "grouped", "ghost"])
-@pytest.mark.parametrize("storage", ["f32", "f16"])
-def test_strip_runner_virtual_ranks(G, plan, storage):
-    """The multi-GPU strip runner with 3 virtual ranks on ONE device (device-to-device copies stand in for the
-    RCCL send/recv): every frame of a panning sequence must equal the single-context result bit for bit."""
-    import torch
-    from svgf_amd import filter as F
-    from svgf_amd import strips
-    W, H, world, N = 320, 420, 3, 4
-    mv = (1.0, -2.5)
-    fr = frames(W, H, N, mv=mv)
-    params = F.Params(storage=storage, steps=5)
-    whole = G.HipPipeline(W, H, storage, steps=5)          # the same stage calls the strips make, on the whole frame
-    dev = torch.device("cuda:0")
-    lc = strips.LocalComm()
-    geos = [strips.Geometry.make(W, H, r, world, 5, plan=plan, motion_reach=3) for r in range(world)]
-    runners = [strips.StripRunner(g, strips.HipStages(g, params, dev), lc.for_rank(g.rank), storage=storage, device=dev) for g in geos]
-    gbs = [G.gb_dev(f) for f in fr]
-
-    def local_gb(f, g):
-        return F.GBuffer(*(G.dev(np.ascontiguousarray(f[k][g.y0:g.y1])) for k in ("motion", "normal", "uv")))
-    for k in range(N):
-        kp = max(k - 1, 0)
-        want = whole.frame(fr[k]["radiance"], gbs[k], gbs[kp])
-        inputs = [(G.dev(np.ascontiguousarray(fr[k]["radiance"][g.y0:g.y1].astype(G.NPDT[storage]))), local_gb(fr[k], g), local_gb(fr[kp], g))
-                  for g in geos]
-        outs = strips.run_virtual(runners, inputs)
-        got = np.concatenate([G.host(r.owned(o)) for r, o in zip(runners, outs)], 0)
-        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), f"plan {plan}: frame {k}"
-    hist = np.concatenate([G.host(r.owned(r.hist[r.P ^ 1])) for r in runners], 0)
-    assert np.array_equal(hist, whole.taps["hist"])
-
-
-class _RcclLoopComm:
-    """Virtual ranks in one process whose halo traffic really goes through RCCL: the sends and receives every rank posted
-    for one exchange become ONE batch_isend_irecv with this (only) rank as peer, issued through strips.DistComm — so its
-    post-stream / event logic and RCCL's kernels are what moves the rows.  RCCL matches the sends and receives of a peer
-    pair in posting order; the batch lists, for each receive, the matching send right next to it."""
-
-    def __init__(self, device):
-        from svgf_amd import strips
-        self.comm = strips.DistComm(device=device)
-        self.posted = {}                                     # seq -> {rank: (sends, recvs)}
-        self.handles = {}
-
-    def for_rank(self, rank):
-        parent = self
-
-        class _C:
-            seq = 0
-
-            def start(self, sends, recvs):
-                n = self.seq
-                self.seq += 1
-                parent.posted.setdefault(n, {})[rank] = (list(sends), list(recvs))
-                return n
-
-            def finish(self, n):
-                if n not in parent.handles:                  # the first rank to wait issues the whole exchange
-                    ranks = parent.posted[n]
-                    pend = {r: list(sr[0]) for r, sr in ranks.items()}
-                    s_all, r_all = [], []
-                    for r, (_, recvs) in sorted(ranks.items()):
-                        for t, p in recvs:
-                            k = next(i for i, (_, dst) in enumerate(pend[p]) if dst == r)
-                            src, _ = pend[p].pop(k)
-                            assert src.shape == t.shape
-                            r_all.append((t, 0))
-                            s_all.append((src, 0))
-                    assert all(not v for v in pend.values())
-                    parent.handles[n] = parent.comm.start(s_all, r_all)
-                    parent.comm.finish(parent.handles[n])
-        return _C()
-
-
-@pytest.mark.parametrize("plan", ["ghost", "grouped"])
-def test_strip_runner_over_rccl_loopback(G, plan):
-    """As test_strip_runner_virtual_ranks, but the halo rows travel through RCCL send/recv batches (peer = this rank) posted by
-    strips.DistComm from its own stream, with the filter kernels on a high-priority stream as in bench.py."""
-    import os
-    import torch
-    import torch.distributed as dist
-    from svgf_amd import filter as F
-    from svgf_amd import strips
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29577")
-    dev = torch.device("cuda:0")
-    created = not dist.is_initialized()
-    if created:
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    side = torch.cuda.Stream(device=dev, priority=-1)
-    try:
-        with torch.cuda.stream(side):
-            W, H, world, N, storage = 320, 420, 3, 4, "f32"
-            fr = frames(W, H, N, mv=(1.0, -2.5))
-            params = F.Params(storage=storage, steps=5)
-            whole = G.HipPipeline(W, H, storage, steps=5)
-            lc = _RcclLoopComm(dev)
-            geos = [strips.Geometry.make(W, H, r, world, 5, plan=plan, motion_reach=3) for r in range(world)]
-            runners = [strips.StripRunner(g, strips.HipStages(g, params, dev), lc.for_rank(g.rank), storage=storage, device=dev) for g in geos]
-            gbs = [G.gb_dev(f) for f in fr]
-
-            def local_gb(f, g):
-                return F.GBuffer(*(G.dev(np.ascontiguousarray(f[k][g.y0:g.y1])) for k in ("motion", "normal", "uv")))
-            for k in range(N):
-                kp = max(k - 1, 0)
-                want = whole.frame(fr[k]["radiance"], gbs[k], gbs[kp])
-                inputs = [(G.dev(np.ascontiguousarray(fr[k]["radiance"][g.y0:g.y1].astype(G.NPDT[storage]))), local_gb(fr[k], g), local_gb(fr[kp], g))
-                          for g in geos]
-                outs = strips.run_virtual(runners, inputs)
-                torch.cuda.synchronize()
-                got = np.concatenate([G.host(r.owned(o)) for r, o in zip(runners, outs)], 0)
-                assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), f"plan {plan}: frame {k}"
-            for r in runners:
-                r.flush()
-    finally:
-        torch.cuda.synchronize()
-        if created:
-            dist.destroy_process_group()
-
-
 def test_abi_errors(G):
     from svgf_amd import filter as F
     W, H = 64, 48

@@ -41,7 +41,7 @@ def _expected_traffic(W, H, world, steps, plan, reach, storage, radius=3):
     return len({m["exchange"] for m in msgs}), len(sends), sum(m["bytes"] for m in sends)
 
 
-def _run_sequence(G, W, H, world, plan, storage, fr, reach, params=None, own_streams=True):
+def _run_sequence(G, W, H, world, plan, storage, fr, reach, params=None, own_streams=True, edge_first=True):
     """N frames of `fr` through the mailbox driver and through the single-context stage calls; asserts bitwise equality of every frame,
     of the final history and moments, and that the transport matched exactly the messages svgf_strips_messages lists."""
     import torch
@@ -54,6 +54,7 @@ def _run_sequence(G, W, H, world, plan, storage, fr, reach, params=None, own_str
     streams = [torch.cuda.Stream(priority=-1) for _ in range(world)] if own_streams else None     # a compute stream per rank, as in a real run
     drv = strips.NativeStrips(W, H, world, P, list(range(world)), [0] * world, streams=[s.cuda_stream for s in streams] if streams else None,
                               plan=plan, motion_reach=reach, transport="mailbox")
+    drv.set_edge_first(edge_first)
     gbs = [G.gb_dev(f) for f in fr]
     torch.cuda.synchronize()
     prev_in = None
@@ -85,6 +86,24 @@ def test_real_peer_addressing_small_worlds(G, world, plan, storage):
     state exchange carries colour, moments AND history rows that the next frame's reprojection really reads."""
     W, H = 320, 420
     _run_sequence(G, W, H, world, plan, storage, frames(W, H, 4, mv=(1.0, -3.5)), reach=4)
+
+
+@pytest.mark.parametrize("plan", ["grouped", "per-iteration"])
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_three_launches_per_exchanging_iteration_still_give_the_same_bits(G, plan, storage):
+    """svgf_strips_set_edge_first(0): round 4's schedule — two edge launches, the exchange behind an event, an interior launch — stays behind the
+    ABI (devices without stream memory operations, iterations the direct kernel runs).  The default — ONE launch whose first workgroups
+    produce the edge rows and write the word the communication stream waits for — is what every other test of this file runs."""
+    W, H = 320, 420
+    _run_sequence(G, W, H, 3, plan, storage, frames(W, H, 4, mv=(1.0, -3.5)), reach=4, edge_first=False)
+
+
+def test_edge_rows_first_on_odd_sizes_and_seven_iterations(G):
+    """W % 128 != 0 (a last x tile that is mostly outside the frame), strips of unequal height (H % world != 0), seven iterations (steps 32 and 64:
+    edge ranges of 128 / 256 rows... as far as the strips allow: the plan keeps them per iteration) — every exchanging iteration a single launch
+    over {top edge, bottom edge, interior} with bands cut per range."""
+    W, H = 333, 1621
+    _run_sequence(G, W, H, 3, "per-iteration", "f32", frames(W, H, 3, mv=(-1.0, 2.5)), reach=3, params=dict(steps=7))
 
 
 @pytest.mark.parametrize("plan,storage", [("ghost", "f32"), ("grouped", "f16"), ("per-iteration", "f32"), ("per-iteration", "f16"), ("grouped", "f32"), ("ghost", "f16")])
