@@ -76,8 +76,9 @@ def parse():
     ap.add_argument("--frames-in-flight", type=int, choices=[1, 2], default=1,
                     help="2: svgf_set_frames_in_flight(2) - iterations 1.. of a frame on a side stream beside the next frame's temporal launch (bit-identical results; "
                          "a frame's result is ordered on the stream one call later)")
-    ap.add_argument("--no-prev-guide", action="store_true", help="leave svgf_set_prev_guide off (the ABI's default): the reprojection test reads the three planes of the "
-                                                                 "previous G-buffer instead of the guide plane the previous frame kept (+16 B/px)")
+    ap.add_argument("--prev-guide", action="store_true", help="svgf_set_prev_guide(1) for the headline run (an opt-in of the ABI: the host vouches that the previous "
+                                                             "G-buffer's planes are last frame's current ones, untouched; the reprojection test then reads the kept 16-B guide "
+                                                             "plane instead of three planes, 32 B/px).  Default: off, the ABI's default; the opt-in is reported as also.prev_guide_on")
     ap.add_argument("--prime-ms", type=float, default=400.0, help="untimed load before the first timed frame: at least this long ...")
     ap.add_argument("--prime-frames", type=int, default=600, help="... and at least this many frames, --warmup included (DESIGN.md 6: the post-idle clock ramp and the "
                                                                    "one-off stall of a process's first ~4 000 stream operations belong in front of the timed region; 0 / 0 for smoke runs)")
@@ -90,11 +91,17 @@ def alg_bytes_full(storage, iters):
     return b["temporal"] + b["moments"] + iters * b["atrous_iter"] + (b["atrous_feedback"] if iters > 0 else 0)
 
 
-def moved_bytes_full(storage, iters, fused=False):
+def moved_temporal(storage, prev_guide):
+    """MOVED_BYTES counts 16 B/px at the reprojected address: the kept guide plane (svgf_set_prev_guide).  The ABI's default reads the previous
+    G-buffer's three planes there: 32 B/px."""
+    return MOVED_BYTES[storage]["temporal_moments"] + (0 if prev_guide else 16)
+
+
+def moved_bytes_full(storage, iters, fused=False, prev_guide=False):
     b = MOVED_BYTES[storage]
     if fused and iters >= 2:        # the pair launch reads colour + guide once and writes the feedback plane and iteration 1's result
-        return b["temporal_moments"] + (iters - 2) * b["atrous_iter"] + 4 * (16 if storage == "f32" else 8)
-    return b["temporal_moments"] + iters * b["atrous_iter"] + (b["atrous_feedback"] if iters > 0 else 0)
+        return moved_temporal(storage, prev_guide) + (iters - 2) * b["atrous_iter"] + 4 * (16 if storage == "f32" else 8)
+    return moved_temporal(storage, prev_guide) + iters * b["atrous_iter"] + (b["atrous_feedback"] if iters > 0 else 0)
 
 
 # ------------------------------------------------------------------ inputs ---------------------
@@ -188,7 +195,7 @@ class FramePool:
 
 
 # ------------------------------------------------------------------ single GPU -----------------
-def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, device, cold_frames=0, fuse=False, windows=5, in_flight=1, prime=(400.0, 600), prev_guide=True, adaptive=True):
+def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, device, cold_frames=0, fuse=False, windows=5, in_flight=1, prime=(400.0, 600), prev_guide=False, adaptive=True):
     """-> dict(ms_per_step = median over `windows` timed windows of `steps` frames each (sync, K frames, sync), windows_ms, stage_ms[list],
     ms_no_events: one more window without the per-stage HIP events, ...)."""
     import torch
@@ -197,7 +204,7 @@ def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, de
     d.set_iteration_fusion(fuse)
     d.set_frames_in_flight(in_flight)
     d.set_adaptive_moments(adaptive)
-    d.set_prev_guide(prev_guide)   # the pools hand over last frame's current G-buffer, untouched, as `prev` (tests/test_bench_inputs.py): the precondition of svgf_set_prev_guide
+    d.set_prev_guide(prev_guide)   # default off = the ABI's default.  (On: the pools do hand over last frame's current G-buffer, untouched, as `prev` — tests/test_bench_inputs.py — the precondition of svgf_set_prev_guide)
     n = 0
     for _ in range(PRIME_FRAMES + warmup):
         d.Render(*pool.frame(n))
@@ -413,7 +420,7 @@ def measured_traffic(W, H, storage, kernel):
         return None, None
 
 
-def roofline_block(W, H, storage, iters, stage_ms, variant="auto", fused=False):
+def roofline_block(W, H, storage, iters, stage_ms, variant="auto", fused=False, prev_guide=False):
     """Roofline of the dominant kernel (the LDS-streaming a-trous kernel: `iters` launches per frame, or iters - 2 next to the pair launch)
     + per-stage table."""
     b, mv = ALG_BYTES[storage], MOVED_BYTES[storage]
@@ -444,8 +451,8 @@ def roofline_block(W, H, storage, iters, stage_ms, variant="auto", fused=False):
     tm = stage_ms[0] + stage_ms[1]
     tt, _ = measured_traffic(W, H, storage, "temporal_bytes_per_launch")
     stages = {"temporal+moments": {"ms": round(tm, 5), "temporal_ms": round(stage_ms[0], 5), "moments_ms": round(stage_ms[1], 5),
-                                   "algorithmic_B_per_px": b["temporal"] + b["moments"], "moved_B_per_px": mv["temporal_moments"],
-                                   "algorithmic_equivalent_GBps": rate(b["temporal"] + b["moments"], tm), "moved_GBps": rate(mv["temporal_moments"], tm),
+                                   "algorithmic_B_per_px": b["temporal"] + b["moments"], "moved_B_per_px": moved_temporal(storage, prev_guide),
+                                   "algorithmic_equivalent_GBps": rate(b["temporal"] + b["moments"], tm), "moved_GBps": rate(moved_temporal(storage, prev_guide), tm),
                                    "measured_hbm_bytes": tt}}
     if fused:
         px, mpx = 2 * b["atrous_iter"] + b["atrous_feedback"], 4 * (16 if storage == "f32" else 8)      # colour + guide in, feedback + result out
@@ -460,8 +467,8 @@ def roofline_block(W, H, storage, iters, stage_ms, variant="auto", fused=False):
     return roof, stages
 
 
-def pass_block(W, H, storage, iters, ms, fused=False):
-    alg, mov = alg_bytes_full(storage, iters), moved_bytes_full(storage, iters, fused)
+def pass_block(W, H, storage, iters, ms, fused=False, prev_guide=False):
+    alg, mov = alg_bytes_full(storage, iters), moved_bytes_full(storage, iters, fused, prev_guide)
     g = lambda bpp: bpp * W * H / (ms * 1e-3) / 1e9   # noqa: E731
     return {"algorithmic_bytes_per_px": alg, "algorithmic_equivalent_GBps": round(g(alg), 1), "frac_of_8TBps": round(g(alg) / HBM_PEAK_GBPS, 4),
             "frac_of_6.29TBps_copy": round(g(alg) / 6290.0, 4),
@@ -646,12 +653,12 @@ def main():
         for m in motions:
             res[m] = run_single(FramePool(scene, storage, m), W, H, storage, iters, args.variant, args.steps, args.warmup, device,
                                 cold_frames=5 if (m == "static" and not args.no_extra) else 0, fuse=fuse, windows=args.windows, in_flight=args.frames_in_flight, prime=(args.prime_ms, args.prime_frames),
-                                prev_guide=not args.no_prev_guide)
+                                prev_guide=args.prev_guide)
         head = motions[0]
         r = res[head]
         ms = r["ms_per_step"]
         value = W * H / (ms * 1e-3) / 1e6
-        roof, stages = roofline_block(W, H, storage, iters, r["stage_ms"], args.variant, r["fused"])
+        roof, stages = roofline_block(W, H, storage, iters, r["stage_ms"], args.variant, r["fused"], args.prev_guide)
         line = {
             "metric": METRIC, "value": round(value, 1),
             "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
@@ -662,12 +669,12 @@ def main():
                                    f"G-buffer in distinct planes (ping-ponged), 1-spp noise, seed 0x5356474600000001",
                        "width": W, "height": H, "storage": storage, "atrous_iterations": iters, "variant": args.variant, "motion": head,
                        "iterations_0_and_1_in_one_launch": r["fused"], "frames_in_flight": r["in_flight"],
-                       "prev_guide": "off (the ABI's default: the previous G-buffer's three planes are read)" if args.no_prev_guide else
-                                     "on (svgf_set_prev_guide, opt-in: the previous G-buffer's planes are last frame's current ones, not rewritten in between - as in the "
-                                     "reference, App.cu:374; also.prev_guide_off is the same run with the ABI's default)"},
+                       "prev_guide": "off (ABI default): the reprojection test reads the previous G-buffer's three planes; also.prev_guide_on is the same run with the opt-in" if not args.prev_guide else
+                                     "on (svgf_set_prev_guide, an opt-in of the ABI: the host vouches that the previous G-buffer's planes are last frame's current ones, "
+                                     "not rewritten in between - as in the reference, App.cu:374)"},
             **timing_fields(r),
             "roofline": roof,
-            "pass_roofline": pass_block(W, H, storage, iters, ms, r["fused"]),
+            "pass_roofline": pass_block(W, H, storage, iters, ms, r["fused"], args.prev_guide),
             "stages": stages,
             "stages_note": "stage times from HIP events recorded by the library on its launch stream, on every 4th timed frame; svgf_denoise_frame folds "
                            "the steady-state moments copy into the temporal launch and the moments slot only re-filters the young pixels the temporal launch listed, "
@@ -724,20 +731,27 @@ def main():
                                                  "Mpixels/s": round(W * H / (r3["ms_per_step"] * 1e-3) / 1e6, 1),
                                                  "frac_of_8TBps": pass_block(W, H, "f16", iters, r3["ms_per_step"])["frac_of_8TBps"],
                                                  "atrous_avg_launch_ms": roof3["avg_launch_ms"] if roof3 else None,
-                                                 "atrous_roofline_frac": roof3["frac"] if roof3 else None}
-        if not args.no_extra and not args.no_prev_guide and wl == "4k":
-            # the ABI's default: svgf_set_prev_guide off (the host has not vouched for the previous G-buffer's planes)
-            r6 = run_single(FramePool(scene, storage, "static"), W, H, storage, iters, args.variant, max(args.steps, 20), args.warmup, device, fuse=fuse, windows=args.windows, prime=(args.prime_ms, args.prime_frames), prev_guide=False)
-            roof6, st6 = roofline_block(W, H, storage, iters, r6["stage_ms"], args.variant, r6["fused"])
-            line.setdefault("also", {})["prev_guide_off"] = {
+                                                 "atrous_roofline_frac": roof3["frac"] if roof3 else None,
+                                                 "roofline_secondary": roof3.get("secondary") if roof3 else None,
+                                                 # BASELINE.md's own 60 % line for configs[4] (323 B/px at 0.60 x 8 TB/s): where the number is, so is the miss
+                                                 "target_ms": 0.558, "target_met": bool(r3["ms_per_step"] <= 0.558), "bound": "valu",
+                                                 "why": "fp16 storage halves the colour bytes and none of the arithmetic: the a-trous launches run the same ~290 vector "
+                                                        "instructions per pixel on 40 instead of 56 B/px and are bound by vector issue (valu_busy, DESIGN.md 3.3), the temporal "
+                                                        "launch already moves its bytes at the part's copy rate"}
+        if not args.no_extra and not args.prev_guide and wl == "4k":
+            # the opt-in: svgf_set_prev_guide on (the host vouches for the previous G-buffer's planes; the pools do leave them alone)
+            r6 = run_single(FramePool(scene, storage, "static"), W, H, storage, iters, args.variant, max(args.steps, 20), args.warmup, device, fuse=fuse, windows=args.windows, prime=(args.prime_ms, args.prime_frames), prev_guide=True)
+            roof6, st6 = roofline_block(W, H, storage, iters, r6["stage_ms"], args.variant, r6["fused"], True)
+            line.setdefault("also", {})["prev_guide_on"] = {
                 "ms_per_step": round(r6["ms_per_step"], 4), "ms_per_step_min": round(min(r6["windows_ms"]), 4), "ms_per_step_max": round(max(r6["windows_ms"]), 4),
-                "Mpixels/s": round(W * H / (r6["ms_per_step"] * 1e-3) / 1e6, 1), "frac_of_8TBps": pass_block(W, H, storage, iters, r6["ms_per_step"])["frac_of_8TBps"],
+                "Mpixels/s": round(W * H / (r6["ms_per_step"] * 1e-3) / 1e6, 1), "frac_of_8TBps": pass_block(W, H, storage, iters, r6["ms_per_step"], False, True)["frac_of_8TBps"],
                 "temporal_ms": st6["temporal+moments"]["temporal_ms"] if st6 else None,
-                "note": "the ABI's default configuration: the reprojection test reads motion / normal / uv of the previous G-buffer (32 B/px) instead of the kept guide plane (16 B/px)"}
+                "note": "svgf_set_prev_guide(ctx, 1), an opt-in: the reprojection test reads the guide plane the previous frame kept (16 B/px) instead of motion / normal / uv of "
+                        "the previous G-buffer (32 B/px); rounds 2-4 quoted this configuration as the headline"}
         if not args.no_extra and wl == "4k" and iters == 5:
             # the GUI's range is 0-10 iterations (GUI.cpp:988), step = 1 << i (App.cu:502): steps 32 and 64 run through the LDS kernel too
             r7 = run_single(FramePool(scene, storage, "static"), W, H, storage, 7, args.variant, max(args.steps, 20), args.warmup, device, fuse=fuse, windows=3, prime=(args.prime_ms, args.prime_frames),
-                            prev_guide=not args.no_prev_guide)
+                            prev_guide=args.prev_guide)
             line.setdefault("also", {})["seven_iterations"] = {"ms_per_step": round(r7["ms_per_step"], 4), "Mpixels/s": round(W * H / (r7["ms_per_step"] * 1e-3) / 1e6, 1),
                                                                "atrous_launch_ms_by_step": {str(1 << i): round(r7["stage_ms"][2 + i], 5) for i in range(7)},
                                                                "note": "temporal + moments + 7 a-trous iterations (steps 1..64), all LDS-streaming launches"}

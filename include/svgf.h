@@ -56,10 +56,10 @@
  *    Not reproduced: a depth derivative of +inf (or beyond ~1e22 / step) on a sky texel — see "Sky" above.
  *  - Bit-identity next to a NaN.  The streaming a-trous kernel redoes, the reference's way, exactly the pixels whose fast result held a NaN;
  *    every other pixel keeps its bits, so strips and row ranges stay bit-identical to the whole frame with NaN texels present (colour or
- *    G-buffer).  Two places still round a FINITE pixel next to a NaN texel differently depending on how the work is cut (both within the stated
- *    tolerance): the LDS-streaming moments kernel (the first three frames after a reset, crowded frames: a workgroup that has staged a
- *    non-finite texel evaluates all its pixels in the exact form) and the pair launch svgf_atrous_pair (its second pass takes the exact form
- *    for the whole band).
+ *    G-buffer); the LDS-streaming moments kernel (the first three frames after a reset, crowded frames) does the same.  What still depends on
+ *    the path taken (within the stated tolerance): a pixel whose 7x7 WINDOW holds a non-finite texel is rounded differently by the streaming
+ *    moments kernel and by the young-pixel launch (svgf_set_adaptive_moments; svgf_moments against the frame driver), and the pair launch
+ *    svgf_atrous_pair takes the exact form for every pixel of a band that holds a NaN.
  *  - Strips: a context may hold only rows [y0, y0+rows) of a WxH frame (multi-GPU row strips);
  *    "inside the frame" tests always use the global frame, so strip results are bit-identical
  *    to the whole-frame result as long as the halo rows hold valid data.

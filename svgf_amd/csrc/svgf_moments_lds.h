@@ -13,7 +13,8 @@
 //            record, run no v_dot2 / v_log: 9 vector instructions per tap instead of 13.  Same expressions on the same bits as the
 //            general form: bit-identical;
 //   general  n.n' per tap;
-//   exact    a texel of the ring holds a NaN or inf (colour, moments, depth or normal): the luminance and depth terms are evaluated the way the reference does —
+//   exact    a texel of the ring holds a NaN or inf (colour, moments, depth or normal) AND the pixel's sums came out NaN in the general form: the pixel is
+//            evaluated again with the luminance and depth terms the way the reference has them —
 //            max(|dl| / phi_l, 0.0) is CUDA's fmax, which drops a NaN (:424), so the weight stays finite and the NaN reaches the sums
 //            through the channels that hold it (:498-499) — and a zero-normal centre takes no shortcut (its weights are exactly 0,
 //            and 0 x NaN is NaN).
@@ -228,9 +229,19 @@ __global__ __launch_bounds__(kMTX* kRS, 4) void moments_lds_kernel(Geo g, Moment
         const bool zero_normal = !exact && ((c.nc01 & 0x7fff7fffu) == 0u) && (c.ncz == 0.0f);
         const bool need = (h < 4.0f) && !zero_normal && (j + rg < j1);
         if (wave_any(need)) {
-            if (exact) moments_taps49<kTapsNaN>(recA, recL, recN, recC, rowbase, c, phi_n, e0, s);
-            else if (uniform) moments_taps49<kTapsUniform>(recA, recL, recN, recC, rowbase, c, phi_n, e0, s);
+            if (uniform) moments_taps49<kTapsUniform>(recA, recL, recN, recC, rowbase, c, phi_n, e0, s);
             else moments_taps49<kTapsGeneral>(recA, recL, recN, recC, rowbase, c, phi_n, e0, s);
+            if (exact) {
+                // A workgroup that has staged a non-finite texel: the pixels whose sums came out NaN — every pixel with a NaN (or inf - inf, 0 x inf)
+                // in its window, and no other — are evaluated again the reference's way; the others keep the bits every other workgroup would
+                // give them, however the frame is cut into tiles, bands or strips (round 4 took the exact form for the whole workgroup).
+                const bool redo = need && (__builtin_isunordered(s.sw, s.sm2) | __builtin_isunordered(s.srg.x, s.srg.y) | __builtin_isunordered(s.sbm.x, s.sbm.y));
+                if (wave_any(redo)) {
+                    MomSums s2{0.0f, 0.0f, {0.f, 0.f}, {0.f, 0.f}};
+                    moments_taps49<kTapsNaN>(recA, recL, recN, recC, rowbase, c, phi_n, e0, s2);
+                    if (redo) s = s2;
+                }
+            }
         }
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f * (4.0f / h));
         if (!zero_normal) {

@@ -195,20 +195,22 @@ def test_frame_driver_with_poisoned_gbuffers_equals_stage_calls(G, variant):
 @pytest.mark.parametrize("plan", ["per-iteration", "ghost"])
 def test_strip_driver_with_poisoned_gbuffers_equals_the_whole_frame(G, plan):
     """Three ranks with real peer addressing (the mailbox transport), a pan with motion reach 3, poisoned G-buffers: every frame equals the
-    single-context stage sequence BIT FOR BIT.  (A saturated motion vector lands outside the FRAME, so it is a rejection on every rank and
-    never a halo violation; a NaN depth makes the streaming a-trous kernel redo pixels — only those whose fast result held a NaN, so the
-    finite ones do not depend on how the strips cut the bands.)"""
+    single-context FRAME DRIVER's BIT FOR BIT.  (A saturated motion vector lands outside the FRAME, so it is a rejection on every rank and
+    never a halo violation; a NaN depth makes the streaming kernels redo pixels — only those whose fast result held a NaN, so the finite ones
+    do not depend on how the strips cut tiles and bands.  Against the frame driver, not the stage calls: svgf_moments serves every pixel with
+    the streaming kernel, the drivers serve steady-state young pixels with the young-pixel launch, and the two round a pixel whose WINDOW holds
+    a NaN differently — include/svgf.h, "Bit-identity next to a NaN".)"""
     import torch
     from svgf_amd import filter as F
     from svgf_amd import strips
     W, H, world, N, storage = 320, 420, 3, 6, "f32"
     fr = _poisoned_sequence(W, H, N, (1.0, -2.5), 171, which=(1, 2, 4))
-    whole = G.HipPipeline(W, H, storage, steps=5)
+    whole = F.Denoiser(W, H, F.Params(storage=storage, steps=5))
     drv = strips.NativeStrips(W, H, world, F.Params(storage=storage, steps=5), list(range(world)), [0] * world, plan=plan, motion_reach=3, transport="mailbox")
     gbs = [G.gb_dev(f) for f in fr]
     prev_in = None
     for k in range(N):
-        want = whole.frame(fr[k]["radiance"], gbs[k], gbs[max(k - 1, 0)])
+        want = G.host(whole.Render(G.dev(fr[k]["radiance"]), gbs[k], gbs[k - 1] if k else None))
         torch.cuda.synchronize()
         cur_in = []
         for lay in drv.layouts:
