@@ -60,8 +60,11 @@ __device__ __forceinline__ void lds_store(uint32_t addr, uint32_t v) { *(lds_u32
 // every channel, or (a NaN variance only) in the variance channel — and costs the product path ONE compare per output.  The
 // kernel then runs the band again with EXACT = true: the general taps in the form that evaluates the luminance term as the
 // reference does (taps24<.., kTapsNaN>) and a select for the sky centres.  A workgroup whose texels are all finite never gets there.
+// WT: the band's stores are written THROUGH to memory (sc0 sc1) — the ranges that signal (RangePlan): their rows are read by another kernel (RCCL's) while
+// this launch is still running, and making them visible with release fences instead means an L2 write-back per workgroup (measured: the one-launch
+// iteration 0.17 ms SLOWER per frame than three launches, profiles/r05_strip_sim_*.txt)
 template <int ST, int S, int TX, bool EXACT>
-__device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, const AtrousLds<S, TX>& L, int x0, int j0, int j1, int ybase) {
+__device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, const AtrousLds<S, TX>& L, int x0, int j0, int j1, int ybase, bool wt = false) {
     constexpr int WL = TX + 4 * S;                 // staged columns per ring row
     constexpr int CB = ST == 0 ? 16 : 8;           // bytes per colour texel
     constexpr int NH = 4 * S;                      // halo pixels per ring row.  Steps 1-16: all staged by wave 0 of the row group (lanes
@@ -200,14 +203,25 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
             const __amdgpu_buffer_rsrc_t rs_fb = __builtin_amdgcn_make_buffer_rsrc(a.feedback ? a.feedback : a.out, 0, a.feedback ? (int)(npx * CB) : 0, 0x00020000);
             // columns outside the frame carry the out-of-range offset: the store is dropped by the range check
             const unsigned so_c = EXACT && !redo ? kOob : vo_c;                                             // (EXACT = false: vo_c, a constant)
+            constexpr int kWT = 1 | 16;                                                                     // sc0 | sc1: system-scope write-through
             if constexpr (ST == 0) {
                 const u32x4 raw = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
-                __builtin_amdgcn_raw_buffer_store_b128(raw, rs_out, so_c, srow * CB, 0);                   // :618
-                __builtin_amdgcn_raw_buffer_store_b128(raw, rs_fb, sky ? kOob : so_c, srow * CB, 0);       // :619-622 (not for sky)
+                if (wt) {                                                                                   // (scalar)
+                    __builtin_amdgcn_raw_buffer_store_b128(raw, rs_out, so_c, srow * CB, kWT);
+                    __builtin_amdgcn_raw_buffer_store_b128(raw, rs_fb, sky ? kOob : so_c, srow * CB, kWT);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(raw, rs_out, so_c, srow * CB, 0);               // :618
+                    __builtin_amdgcn_raw_buffer_store_b128(raw, rs_fb, sky ? kOob : so_c, srow * CB, 0);   // :619-622 (not for sky)
+                }
             } else {
                 const u32x2 raw = {pack_h2(o.x, o.y), pack_h2(o.z, o.w)};
-                __builtin_amdgcn_raw_buffer_store_b64(raw, rs_out, so_c, srow * CB, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(raw, rs_fb, sky ? kOob : so_c, srow * CB, 0);
+                if (wt) {
+                    __builtin_amdgcn_raw_buffer_store_b64(raw, rs_out, so_c, srow * CB, kWT);
+                    __builtin_amdgcn_raw_buffer_store_b64(raw, rs_fb, sky ? kOob : so_c, srow * CB, kWT);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b64(raw, rs_out, so_c, srow * CB, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(raw, rs_fb, sky ? kOob : so_c, srow * CB, 0);
+                }
             }
         }
     }
@@ -272,27 +286,29 @@ __global__ __launch_bounds__(TX * kRS, atrous_waves(S)) void atrous_lds_kernel(G
     else {
         const int j1 = min(nj, j0 + band_rows);
         const int ybase = yb + rv;                 // global row of decimated index j: ybase + S*j
-        const bool nan_wave = atrous_band<ST, S, TX, false>(g, a, L, x0, j0, j1, ybase);
+        const bool nan_wave = atrous_band<ST, S, TX, false>(g, a, L, x0, j0, j1, ybase, first);
         if (nan_wave && (threadIdx.x & 63) == 0) lds_store(L.nref(2), 1u);
         __syncthreads();
         if (lds_load(L.nref(2)) != 0u) {           // (no frame without a NaN gets here)
             __syncthreads();                       // (the band's prologue writes the flag words again)
-            (void)atrous_band<ST, S, TX, true>(g, a, L, x0, j0, j1, ybase);
+            (void)atrous_band<ST, S, TX, true>(g, a, L, x0, j0, j1, ybase, lds_load(L.nref(4)) != 0u);
         }
     }
     // The rows a neighbour waits for: every wave's stores are made visible (release: vmcnt(0) + L2 write-back) and the wave counts itself in
     // LDS; the last wave counts the workgroup in device memory, and the last workgroup publishes the value the communication stream waits
     // for (hipStreamWaitValue64).  No thread index, no argument is used here: they would have to live through the band.
     if (lds_load(L.nref(4)) != 0u) {
-        __threadfence();
+        // this wave's stores were written through (atrous_band, WT): once they have been acknowledged they are in memory — no release fence, which
+        // on this part is a write-back of the XCD's whole L2, per workgroup, under the interior tiles' feet
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        if (lane == 0 && __hip_atomic_fetch_add((lds_u32*)(uintptr_t)L.nref(3), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u == (unsigned)(TX * kRS / 64)) {
+        if (lane == 0 && __hip_atomic_fetch_add((lds_u32*)(uintptr_t)L.nref(3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u == (unsigned)(TX * kRS / 64)) {
             unsigned* arrivals = (unsigned*)((uintptr_t)lds_load(L.nref(5)) | ((uintptr_t)lds_load(L.nref(6)) << 32));
-            const unsigned n = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned n = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (n + 1u == lds_load(L.nref(11))) {
                 unsigned long long* signal = (unsigned long long*)((uintptr_t)lds_load(L.nref(7)) | ((uintptr_t)lds_load(L.nref(8)) << 32));
                 __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(signal, (unsigned long long)lds_load(L.nref(9)) | ((unsigned long long)lds_load(L.nref(10)) << 32), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(signal, (unsigned long long)lds_load(L.nref(9)) | ((unsigned long long)lds_load(L.nref(10)) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
