@@ -129,9 +129,13 @@ struct svgf_strips {
         // edge rows first (svgf_strips_set_edge_first): the iteration in front of an exchange is ONE launch whose first workgroups produce the rows the
         // neighbours wait for; the last of them writes edge_value into edge_signal[0] (device memory; the arrival counter sits 128 B behind it) and
         // the communication stream waits for that word (hipStreamWaitValue64) instead of for an event behind two extra launches
+        // Two slots, 256 B apart: launches on the filter stream use slot 0, launches on the side stream (two frames in flight: a frame's tail) slot 1 —
+        // the two streams run CONCURRENTLY, and a word (or an arrival counter) shared between them is written out of order: the wait for the
+        // smaller sequence number passes early and the one for the larger never (round 5's first version hung exactly there).
         unsigned long long* edge_signal = nullptr;
-        unsigned long long edge_value = 0;
-        bool edge_pending = false;                             // the launch just enqueued signals: the next exchange waits for edge_value
+        unsigned long long edge_value[2] = {0, 0};
+        int edge_slot = 0;                                     // the slot of the launch just enqueued
+        bool edge_pending = false;                             // the launch just enqueued signals: the next exchange waits for edge_value[edge_slot]
         bool state_pending = false;
         // the host never runs more than kMaxAhead frames ahead of the device: frame f waits for the end of frame f - kMaxAhead.  With ~100
         // frames of launches, events and RCCL groups queued the device starts to starve (0.43 -> 0.6 ms per 8K/8 strip, tools/strip_sim.py)
@@ -367,7 +371,7 @@ int post_exchange(svgf_strips* s, const std::vector<PlaneSpec>& planes, int h, b
     // (edge rows first: the rows a rank sends are final when the first workgroups of the launch it has just enqueued have signalled — the
     // communication stream waits for that word, not for the launch; everything enqueued BEFORE that launch is complete by then, stream order)
     auto wait_for = [&](svgf_strips::Local& on, svgf_strips::Local& of) -> int {
-        if (of.edge_pending) SVGF_SHIP(s, hipStreamWaitValue64(on.comm_stream, of.edge_signal, of.edge_value, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
+        if (of.edge_pending) SVGF_SHIP(s, hipStreamWaitValue64(on.comm_stream, of.edge_signal + 32 * of.edge_slot, of.edge_value[of.edge_slot], hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
         else SVGF_SHIP(s, hipStreamWaitEvent(on.comm_stream, of.ready, 0));
         return SVGF_OK;
     };
@@ -445,9 +449,10 @@ int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src
         add(rows.a, inner->a); add(inner->b, rows.b);
         r.nfirst = r.n;
         add(inner->a, inner->b);
-        r.signal = l.edge_signal; r.arrivals = (unsigned*)(l.edge_signal + 16); r.value = ++l.edge_value;
+        const int slot = l.cur == l.compute ? 0 : 1;
+        r.signal = l.edge_signal + 32 * slot; r.arrivals = (unsigned*)(l.edge_signal + 32 * slot + 16); r.value = ++l.edge_value[slot];
         rc = atrous_ranges_impl(c, c->filter[src], c->filter[dst], i == 0 ? c->colour[P] : nullptr, cur, 1 << i, i, guide, r);
-        if (rc == SVGF_OK) l.edge_pending = r.nfirst > 0;
+        if (rc == SVGF_OK) { l.edge_pending = r.nfirst > 0; l.edge_slot = slot; }
     } else rc = pair ? atrous_pair_impl(c, c->filter[src], c->filter[dst], c->colour[P], cur, guide)
                      : atrous_impl(c, c->filter[src], c->filter[dst], i == 0 ? c->colour[P] : nullptr, cur, 1 << i, i, guide);
     if (rc != SVGF_OK) {
@@ -608,7 +613,15 @@ int svgf_strips_create(svgf_strips** out, int width, int height, int world, cons
         DeviceGuard dg(l.device);
         hipError_t e = hipSuccess;
         if (s->loopback && k > 0) l.comm_stream = s->local[0].comm_stream;     // one communicator: one stream for its groups
-        else { e = hipStreamCreateWithFlags(&l.comm_stream, hipStreamNonBlocking); l.own_comm_stream = true; }
+        else {
+            // at the highest priority: the exchange's kernels are a few workgroups that must find a slot while an a-trous launch, oversubscribed four
+            // times, is being dispatched — behind a filter stream of higher priority they start when that grid has drained, i.e. when the transfer
+            // should long be over (the exchange is then exposed in front of the next iteration)
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            e = hipStreamCreateWithPriority(&l.comm_stream, hipStreamNonBlocking, greatest);
+            l.own_comm_stream = true;
+        }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&l.ready, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&l.halo_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&l.state_done, hipEventDisableTiming);
@@ -616,8 +629,8 @@ int svgf_strips_create(svgf_strips** out, int width, int height, int world, cons
             int can = 0;
             // (a part or runtime without stream memory operations keeps round 4's three launches per exchanging iteration)
             if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, l.device) == hipSuccess && can) {
-                e = hipMalloc((void**)&l.edge_signal, 256);
-                if (e == hipSuccess) e = hipMemset(l.edge_signal, 0, 256);
+                e = hipMalloc((void**)&l.edge_signal, 512);
+                if (e == hipSuccess) e = hipMemset(l.edge_signal, 0, 512);
             }
         }
         if (e == hipSuccess && s->mailbox) e = hipEventCreateWithFlags(&l.mb_ready, hipEventDisableTiming);
