@@ -566,6 +566,38 @@ int svgf_strips_transport_stats(const svgf_strips* s, unsigned long long* groups
     return SVGF_OK;
 }
 
+// A stream for the FILTER launches of a strip driver that leaves `reserve_pairs_per_xcd` pairs of compute units of every XCD alone
+// (hipExtStreamCreateWithCUMask).  Why: an a-trous launch oversubscribes every CU four times over, and whenever one of its workgroups retires
+// the dispatcher hands the freed registers and LDS to the next one — the exchange's RCCL kernel (one workgroup of 256 threads with 132
+// registers per thread and 20 KB of LDS on this stack: more than one retiring filter workgroup frees) never finds a CU, whatever the priority of
+// its stream, until the filter launch has drained.  Measured (profiles/r05_rccl_selfcopy.txt, r05_probe_cu_mask.txt): a loop-back group takes
+// 15-23 us on an idle device and 75-150 us beside the filter launches; with 8 CUs kept free, 28 us.  The mask of this part: 32 bits per XCD, XCD
+// after XCD; the two bits of a pair enable the pair together (clearing one of them changes nothing), so whole pairs are cleared — the same in every
+// XCD, because the dispatcher deals workgroups to the XCDs in turn and an XCD with fewer CUs than the others would be the launch's straggler.
+int svgf_stream_create_reserving(void** stream, int device, int reserve_pairs_per_xcd) {
+    if (!stream || reserve_pairs_per_xcd < 0) return SVGF_ERR_INVALID;
+    *stream = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SVGF_ERR_NO_DEVICE;
+    DeviceGuard dg(device);
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) return SVGF_ERR_HIP;
+    constexpr int kXcdCount = 8;
+    const int per_xcd = ncu / kXcdCount;
+    if (ncu % kXcdCount != 0 || per_xcd % 2 != 0 || 2 * reserve_pairs_per_xcd >= per_xcd) return SVGF_ERR_INVALID;
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    for (int i = 0; i < ncu; i++) if (i % per_xcd >= 2 * reserve_pairs_per_xcd) mask[i / 32] |= 1u << (i % 32);
+    hipStream_t st = nullptr;
+    if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); return SVGF_ERR_HIP; }
+    *stream = st;
+    return SVGF_OK;
+}
+
+int svgf_stream_destroy(void* stream) {
+    if (!stream) return SVGF_ERR_INVALID;
+    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? SVGF_OK : SVGF_ERR_HIP;
+}
+
 int svgf_strips_mailbox_fault(svgf_strips* s, int rank, int fault) {
     if (!s || !s->mailbox || rank < 0 || rank >= s->world || fault < 0 || fault > SVGF_FAULT_SHORT_RECV) return SVGF_ERR_INVALID;
     s->mb_fault_rank = rank; s->mb_fault = fault;

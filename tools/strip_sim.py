@@ -33,6 +33,7 @@ ap.add_argument("--storage", default="f32")
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--in-flight", type=int, default=1, help="svgf_strips_set_frames_in_flight")
+ap.add_argument("--reserve", type=int, default=0, help="svgf_stream_create_reserving: CU pairs per XCD the filter stream leaves to the exchange's kernels")
 ap.add_argument("--no-whole", action="store_true", help="skip the whole frame on this GPU")
 ap.add_argument("--warm-ms", type=float, default=400.0, help="untimed frames for at least this long before anything is timed (DESIGN.md 6)")
 ap.add_argument("--warm-frames", type=int, default=600, help="... and at least this many")
@@ -51,7 +52,10 @@ os.environ.setdefault("RANK", "0")
 os.environ.setdefault("WORLD_SIZE", "1")
 dist.init_process_group("nccl", device_id=dev)
 
-side = torch.cuda.Stream(device=dev, priority=-1)          # a hardware queue of its own: RCCL's kernels run beside the filter kernels
+if args.reserve:
+    side, side_handle = strips.reserving_stream(0, args.reserve)
+else:
+    side = torch.cuda.Stream(device=dev, priority=-1)          # a hardware queue of its own: RCCL's kernels run beside the filter kernels
 torch.cuda.set_stream(side)
 params = F.Params(storage=args.storage, steps=5)
 
@@ -222,7 +226,7 @@ for c in configs:
     ms = med(c.ms)
     own = c.geo.own[1] - c.geo.own[0]
     scale = f", {args.world} GPUs = x{whole_ms / ms:.2f} of one" if whole_ms else ""
-    print(f"{W}x{H} strip {args.rank}/{args.world} ({own} rows, held {c.geo.y1 - c.geo.y0}), plan {c.name}{', two frames in flight' if args.in_flight == 2 else ''}: "
+    print(f"{W}x{H} strip {args.rank}/{args.world} ({own} rows, held {c.geo.y1 - c.geo.y0}), plan {c.name}{', two frames in flight' if args.in_flight == 2 else ''}{f', filter stream off {16 * args.reserve} CUs' if args.reserve else ''}: "
           f"{ms:.4f} ms/frame (rounds: {' '.join(f'{v:.4f}' for v in c.ms)}; host enqueue {med(c.host):.4f} ms){scale}")
     extra = wire_model(c, ms)
     print(f"  with wire: {ms + extra:.4f} ms/frame" + (f" = x{whole_ms / (ms + extra):.2f}" if whole_ms else ""))
