@@ -443,7 +443,7 @@ int svgf_strips_set_frames_in_flight(svgf_strips* s, int frames);
  *     ranges (written through to memory); the last of them writes a sequence number into device memory, the communication stream waits for that word
  *     (hipStreamWaitValue64) and starts the exchange while the interior tiles of the same launch still run.
  *   - The iteration BEHIND the exchange is enqueued at once: one resident round of its workgroups works on rows that read nothing of the halo, then
- *     its edge workgroups poll the word the communication stream writes behind the exchange, read their rows past the caches
+ *     its edge workgroups poll the word the communication stream writes behind the exchange (hipStreamWriteValue64), read their rows past the caches
  *     and go on; the rest of the interior follows.  Beside a filter launch that oversubscribes the chip an exchange's kernel only completes when the
  *     launch drains, and a stream-level wait behind it costs exchange -> event -> barrier -> launch with nothing running: ~20 us per iteration.
  *     A workgroup that polls for ~50 ms gives up and svgf_strips_sync reports SVGF_ERR_COMM (the device never hangs on a lost exchange).

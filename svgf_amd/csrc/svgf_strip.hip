@@ -92,13 +92,6 @@ Rccl* rccl() {
 
 }  // namespace
 
-// "the exchange in front of it has completed": the word the first workgroups of a consuming launch poll (launch_atrous_rows, `waits`), written by
-// ONE thread on the communication stream behind the exchange.  (hipStreamWriteValue64 is what this is — and on ROCm 7.0 it costs the HOST 0.5 ms per
-// call: four exchanges per frame made the per-iteration plan 3.5 ms per frame, host-bound.)
-__global__ void publish_kernel(unsigned long long* word, unsigned long long value) {
-    __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 // ------------------------------------------------------------------ the driver -----------------------------
 constexpr int kMaxAhead = 32;
 
@@ -425,10 +418,7 @@ int post_exchange(svgf_strips* s, const std::vector<PlaneSpec>& planes, int h, b
     for (auto& l : s->local) {
         DeviceGuard dg(l.device);
         // filter rows: the consumer may be a launch that is already running (launch_atrous_rows, `wait`): it polls this word
-        if (!is_state && l.edge_signal) {
-            publish_kernel<<<1, 1, 0, l.comm_stream>>>(l.edge_signal + 64, ++l.halo_seq);
-            SVGF_SHIP(s, hipGetLastError());
-        }
+        if (!is_state && l.edge_signal) SVGF_SHIP(s, hipStreamWriteValue64(l.comm_stream, l.edge_signal + 64, ++l.halo_seq, 0));
         SVGF_SHIP(s, hipEventRecord(is_state ? l.state_done : l.halo_done, l.comm_stream));
         if (is_state) l.state_pending = true;
     }
