@@ -438,17 +438,11 @@ int svgf_strips_sync(svgf_strips* s);
  * those — and stays valid until call f + 2 (frames alternate between two pairs of filter planes); cur[k] is not read after the call has
  * returned (a frame whose iterations would read it — the direct kernel — keeps its tail on the compute stream).  Default 1. */
 int svgf_strips_set_frames_in_flight(svgf_strips* s, int frames);
-/* Edge rows first (default 1): no stream ever waits for an exchange between two iterations.
- *   - The iteration in FRONT of an exchange produces the rows its neighbours wait for first: ONE launch whose first workgroups compute the two edge
- *     ranges (written through to memory); the last of them writes a sequence number into device memory, the communication stream waits for that word
- *     (hipStreamWaitValue64) and starts the exchange while the interior tiles of the same launch still run.
- *   - The iteration BEHIND the exchange is enqueued at once: one resident round of its workgroups works on rows that read nothing of the halo, then
- *     its edge workgroups poll the word the communication stream writes behind the exchange (hipStreamWriteValue64), read their rows past the caches
- *     and go on; the rest of the interior follows.  Beside a filter launch that oversubscribes the chip an exchange's kernel only completes when the
- *     launch drains, and a stream-level wait behind it costs exchange -> event -> barrier -> launch with nothing running: ~20 us per iteration.
- *     A workgroup that polls for ~50 ms gives up and svgf_strips_sync reports SVGF_ERR_COMM (the device never hangs on a lost exchange).
+/* Edge rows first (default 1).  The iteration in front of a halo exchange produces the rows its neighbours wait for FIRST.  With enable = 1 that is
+ * ONE launch: its first workgroups compute the two edge ranges, the last of them to finish writes a sequence number into device memory, the
+ * communication stream waits for that word (hipStreamWaitValue64) and starts the exchange while the interior tiles of the same launch still run.
  * enable = 0 (and any iteration the direct kernel runs, and devices without stream memory operations): round 4's schedule — two edge launches,
- * an event, the exchange, an interior launch; an event wait in front of the next iteration.  Same bits either way. */
+ * an event, the exchange, an interior launch.  Same bits either way. */
 int svgf_strips_set_edge_first(svgf_strips* s, int enable);
 /* Room for the exchange.  A filter launch oversubscribes every compute unit several times over; the kernels of a halo exchange (RCCL's send / receive
  * workgroups, 132 registers per thread and 20 KB of LDS each on ROCm 7) then wait until the launch has drained, whatever the priority of their stream:

@@ -60,10 +60,9 @@ __device__ __forceinline__ void lds_store(uint32_t addr, uint32_t v) { *(lds_u32
 // every channel, or (a NaN variance only) in the variance channel — and costs the product path ONE compare per output.  The
 // kernel then runs the band again with EXACT = true: the general taps in the form that evaluates the luminance term as the
 // reference does (taps24<.., kTapsNaN>) and a select for the sky centres.  A workgroup whose texels are all finite never gets there.
-// wt (the first ranges of a RangePlan): the band's stores are written THROUGH to memory (sc0 sc1) — their rows are read by another kernel (RCCL's) while
+// WT: the band's stores are written THROUGH to memory (sc0 sc1) — the ranges that signal (RangePlan): their rows are read by another kernel (RCCL's) while
 // this launch is still running, and making them visible with release fences instead means an L2 write-back per workgroup (measured: the one-launch
-// iteration 0.17 ms SLOWER per frame than three launches, profiles/r05_strip_sim_*.txt) — and its colour rows are read past the caches: some of them
-// were delivered by another kernel after this one had started
+// iteration 0.17 ms SLOWER per frame than three launches, profiles/r05_strip_sim_*.txt)
 template <int ST, int S, int TX, bool EXACT>
 __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, const AtrousLds<S, TX>& L, int x0, int j0, int j1, int ybase, bool wt = false) {
     constexpr int WL = TX + 4 * S;                 // staged columns per ring row
@@ -119,10 +118,10 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
         const bool rok = y >= 0 && y < g.H && yl >= 0 && yl < g.rows;
         const int srow = rok ? yl * g.W : 0;
         const PlaneRsrc rs = plane_rsrc(a, npx, CB, gs.n_shift, rok);
-        raw_load<ST, true>(st.o, rs, vo_c, vo_m, vo_n, srow, gs.n_shift, gs.m_off, wt);
+        raw_load<ST, true>(st.o, rs, vo_c, vo_m, vo_n, srow, gs.n_shift, gs.m_off);
         if (halo_wave) {
 #pragma unroll
-            for (int p = 0; p < HP; p++) raw_load<ST, false>(st.h[p], rs, vh_c[p], vh_m[p], vh_n[p], srow, gs.n_shift, gs.m_off, wt);
+            for (int p = 0; p < HP; p++) raw_load<ST, false>(st.h[p], rs, vh_c[p], vh_m[p], vh_n[p], srow, gs.n_shift, gs.m_off);
         }
     };
     uint32_t ref01 = 0, refz = 0;
@@ -234,9 +233,8 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
 struct RangePlan {
     int nranges, nfirst;
     int yb[3], ye[3], band[3], nbands[3], tiles_end[3];      // tiles_end: cumulative over the first ranges; [nranges - 1]: the last range's own count
-    int pre_blocks, first_blocks, first_tiles, xgroup_first, xgroup;      // workgroup ids: [0, pre) last range, [pre, pre + first) first ranges, the rest last range again
+    int first_blocks, first_tiles, xgroup_first, xgroup;
     unsigned long long* signal; unsigned* arrivals; unsigned long long value;
-    const unsigned long long* wait; unsigned long long wait_value; unsigned* wait_timeouts;
 };
 
 template <int ST, int S, int TX>
@@ -249,31 +247,19 @@ __global__ __launch_bounds__(TX * kRS, atrous_waves(S)) void atrous_lds_kernel(G
     // residue; of the six direction patterns tried for them, only "step 8 backwards too" measured better than all forwards (-1.5 to
     // -3 % for that launch, -0.7 % for step 16 after it; steps 2 and 4 backwards are 1-4 % slower: profiles/r03_small_experiments.txt)
     const int xtiles = (g.W + TX - 1) / TX;
-    const bool first = (int)blockIdx.x >= rp.pre_blocks && (int)blockIdx.x < rp.pre_blocks + rp.first_blocks;         // (scalar) a tile of the first ranges
+    const bool first = (int)blockIdx.x < rp.first_blocks;         // (scalar) a tile of the ranges that signal
     // (the range's numbers are SELECTED, never indexed: a run-time index into a by-value argument makes the compiler copy it to scratch)
     int v, r = rp.nranges - 1;
     auto pick3 = [&](int f0, int f1, int f2) { return r == 0 ? f0 : r == 1 ? f1 : f2; };
 #define pick(f) pick3(rp.f[0], rp.f[1], rp.f[2])
     if (first) {
-        v = xcd_tile_of((int)blockIdx.x - rp.pre_blocks, rp.xgroup_first, 3);
+        v = xcd_tile_of((int)blockIdx.x, rp.xgroup_first, 3);
         if (v >= rp.first_tiles) return;                          // padding
         r = 0;
         if (rp.nfirst > 1 && v >= rp.tiles_end[0]) { r = 1; v -= rp.tiles_end[0]; }
-        if (rp.wait) {
-            // this workgroup's input rows are the ones an exchange delivers: wait for the word the communication stream writes behind it.  Bounded (~50 ms of
-            // the 100 MHz wall clock): an exchange that never completes must not hang the device — the workgroup goes on with what is there and says so
-            if (threadIdx.x == 0) {
-                const long long t0 = wall_clock64();
-                while (__hip_atomic_load(rp.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < rp.wait_value) {
-                    __builtin_amdgcn_s_sleep(32);
-                    if (wall_clock64() - t0 > 5000000ll) { atomicAdd(rp.wait_timeouts, 1u); break; }
-                }
-            }
-            __syncthreads();
-        }
     } else {
         const int ntiles = pick(tiles_end);
-        v = xcd_tile_of((int)blockIdx.x - ((int)blockIdx.x < rp.pre_blocks ? 0 : rp.first_blocks), rp.xgroup, 3);
+        v = xcd_tile_of((int)blockIdx.x - rp.first_blocks, rp.xgroup, 3);
         if (v >= ntiles) return;                                  // padding of the last groups
         if (S == 1 || S == 8) v = ntiles - 1 - v;
     }
@@ -288,8 +274,8 @@ __global__ __launch_bounds__(TX * kRS, atrous_waves(S)) void atrous_lds_kernel(G
         lds_store(L.nref(2), 0u); lds_store(L.nref(3), 0u);
         // what the end of the workgroup needs to signal, kept in LDS: in scalar registers through the band it spilled the product loop's
         // (the kernel sits at its SGPR and VGPR limits; tests/test_kernel_budgets.py)
-        lds_store(L.nref(4), first ? (rp.signal ? 3u : 1u) : 0u);      // bit 0: a first range (write-through stores, coherent loads); bit 1: it signals
-        if (first && rp.signal) {
+        lds_store(L.nref(4), first ? 1u : 0u);
+        if (first) {
             lds_store(L.nref(5), (uint32_t)(uintptr_t)rp.arrivals); lds_store(L.nref(6), (uint32_t)((uintptr_t)rp.arrivals >> 32));
             lds_store(L.nref(7), (uint32_t)(uintptr_t)rp.signal); lds_store(L.nref(8), (uint32_t)((uintptr_t)rp.signal >> 32));
             lds_store(L.nref(9), (uint32_t)rp.value); lds_store(L.nref(10), (uint32_t)(rp.value >> 32));
@@ -311,7 +297,7 @@ __global__ __launch_bounds__(TX * kRS, atrous_waves(S)) void atrous_lds_kernel(G
     // The rows a neighbour waits for: every wave's stores are made visible (release: vmcnt(0) + L2 write-back) and the wave counts itself in
     // LDS; the last wave counts the workgroup in device memory, and the last workgroup publishes the value the communication stream waits
     // for (hipStreamWaitValue64).  No thread index, no argument is used here: they would have to live through the band.
-    if ((lds_load(L.nref(4)) & 2u) != 0u) {
+    if (lds_load(L.nref(4)) != 0u) {
         // this wave's stores were written through (atrous_band, WT): once they have been acknowledged they are in memory — no release fence, which
         // on this part is a write-back of the XCD's whole L2, per workgroup, under the interior tiles' feet
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -356,9 +342,8 @@ hipError_t launch_atrous_lds_tx(const Geo& g, const AtrousArgs& a, hipStream_t s
         rp.nranges = ranges->n; rp.nfirst = ranges->nfirst;
         for (int r = 0; r < ranges->n; r++) { rp.yb[r] = ranges->yb[r]; rp.ye[r] = ranges->ye[r]; }
         rp.signal = ranges->signal; rp.arrivals = ranges->arrivals; rp.value = ranges->value;
-        rp.wait = ranges->wait; rp.wait_value = ranges->wait_value; rp.wait_timeouts = ranges->wait_timeouts;
     }
-    if (rp.nranges < 1 || rp.nranges > 3 || rp.nfirst < 0 || rp.nfirst > 2 || rp.nfirst > rp.nranges) return hipErrorInvalidValue;
+    if (rp.nranges < 1 || rp.nranges > 3 || rp.nfirst < 0 || rp.nfirst > 2 || rp.nfirst >= rp.nranges + (rp.nfirst ? 1 : 0)) return hipErrorInvalidValue;
     int total_first = 0;
     for (int r = 0; r < rp.nranges; r++) {
         cut_bands<S, TX>(rp.ye[r] - rp.yb[r], xtiles, lds, rp.band[r], rp.nbands[r]);
@@ -372,19 +357,8 @@ hipError_t launch_atrous_lds_tx(const Geo& g, const AtrousArgs& a, hipStream_t s
     if (total_first > 0) { const dim3 gf = xcd_grid(total_first, 1, rp.xgroup_first); rp.first_blocks = (int)gf.x; blocks += gf.x; }
     else { rp.first_blocks = 0; rp.xgroup_first = 1; }
     if (!has_last) { rp.nranges += 1; rp.yb[rp.nranges - 1] = rp.ye[rp.nranges - 1] = 0; rp.band[rp.nranges - 1] = kAtrousMinBand; rp.nbands[rp.nranges - 1] = 1; rp.tiles_end[rp.nranges - 1] = 0; rp.xgroup = 1; }
-    unsigned last_blocks = 0;
-    if (last_tiles > 0) { const dim3 gl = xcd_grid(last_tiles, S <= 2 ? 16 : (S == 16 ? 2 : 1), rp.xgroup); last_blocks = gl.x; blocks += gl.x; }     // groups per XCD: A/B per step on one device (4K)
+    if (last_tiles > 0) { const dim3 gl = xcd_grid(last_tiles, S <= 2 ? 16 : (S == 16 ? 2 : 1), rp.xgroup); blocks += gl.x; }     // groups per XCD: A/B per step on one device (4K)
     else rp.xgroup = 1;
-    // `pre`: one resident round of the last range in front of the first ranges (whole groups of the XCD-aware order: the tile numbering stays a bijection)
-    rp.pre_blocks = 0;
-    if (ranges && ranges->wait && ranges->pre && total_first > 0 && last_blocks > 0) {
-        constexpr int per_cu_lds = (int)((160 * 1024) / lds), per_cu_waves = atrous_waves(S) * 4 / (TX * kRS / 64);
-        const unsigned round = (unsigned)((per_cu_lds < per_cu_waves ? per_cu_lds : per_cu_waves) * num_cus());
-        const unsigned unit = (unsigned)(kXcds * rp.xgroup);
-        unsigned pre = (round + unit - 1) / unit * unit;
-        if (pre > last_blocks) pre = last_blocks;
-        rp.pre_blocks = (int)pre;
-    }
     if (!blocks) return hipSuccess;
     atrous_lds_kernel<ST, S, TX><<<dim3(blocks), dim3(TX * kRS), lds, s>>>(g, a, rp);
     return hipGetLastError();

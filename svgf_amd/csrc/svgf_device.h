@@ -165,15 +165,10 @@ __device__ __forceinline__ PlaneRsrc plane_rsrc(const AtrousArgs& a, unsigned np
 // voff_*: the lane's constant byte offsets into the colour, depth and normal planes (voff_m WITHOUT the position of {depth, ddepth}
 // inside the 16-byte texel, m_off: it travels in the scalar offset, so that with fp32 storage voff_m IS voff_c — one register less in
 // a loop that has none to spare); srow: the row's scalar element offset yl*W.
-// coherent (scalar): the colour texel is fetched past the caches (sc0 sc1) — rows another kernel (the exchange's) wrote while THIS kernel was already running
 template <int ST, bool DZ>
-__device__ __forceinline__ void raw_load(RawPx<ST, DZ>& r, const PlaneRsrc& rs, unsigned voff_c, unsigned voff_m, unsigned voff_n, int srow, unsigned n_shift, unsigned m_off, bool coherent = false) {
+__device__ __forceinline__ void raw_load(RawPx<ST, DZ>& r, const PlaneRsrc& rs, unsigned voff_c, unsigned voff_m, unsigned voff_n, int srow, unsigned n_shift, unsigned m_off) {
     constexpr int cb = ST == 0 ? 16 : 8;
-    constexpr int kCoherent = 1 | 16;
-    if (coherent) {
-        if constexpr (ST == 0) r.c = __builtin_amdgcn_raw_buffer_load_b128(rs.colour, voff_c, srow * cb, kCoherent);
-        else r.c = __builtin_amdgcn_raw_buffer_load_b64(rs.colour, voff_c, srow * cb, kCoherent);
-    } else if constexpr (ST == 0) r.c = __builtin_amdgcn_raw_buffer_load_b128(rs.colour, voff_c, srow * cb, 0);
+    if constexpr (ST == 0) r.c = __builtin_amdgcn_raw_buffer_load_b128(rs.colour, voff_c, srow * cb, 0);
     else r.c = __builtin_amdgcn_raw_buffer_load_b64(rs.colour, voff_c, srow * cb, 0);
     if constexpr (DZ) r.zd = __builtin_amdgcn_raw_buffer_load_b64(rs.motion, voff_m, srow * 16 + (int)m_off, 0);      // {depth, ddepth}
     else r.zd = __builtin_amdgcn_raw_buffer_load_b32(rs.motion, voff_m, srow * 16 + (int)m_off, 0);                   // depth

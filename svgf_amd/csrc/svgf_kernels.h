@@ -91,22 +91,12 @@ struct AtrousArgs {
 // communication stream waits for with hipStreamWaitValue64: the halo exchange starts while the interior tiles of the same launch still
 // run.  (Round 4 launched the two edge ranges and the interior separately: three launches' ramp and tail per iteration.)  Every range is
 // cut into bands by itself, so a pixel's result is what a launch over its range alone would give: bit-identical.
-// The same first ranges may also be the rows whose INPUT another kernel is still delivering (the halo rows of the exchange in front of this iteration):
-// with `wait` set the launch is enqueued WITHOUT a stream-level wait for that exchange; its first `pre` round of workgroups works on the last range (rows
-// that read nothing of the halo), then the first ranges' workgroups start — each one polls `wait` until it holds `wait_value` (the communication stream
-// writes it behind the exchange, hipStreamWriteValue64), reads its colour rows past the caches, and goes on; the rest of the last range follows.  A
-// stream-level wait costs the chain exchange -> event -> barrier packet -> launch (14 us here) after an exchange that, beside a filter launch, only
-// completes when that launch drains (profiles/r05_strip_trace_*.txt): ~20 us per iteration with nothing running.
 struct AtrousRanges {
-    int n, nfirst;               // ranges; how many of them come first (and signal, if `signal`)
+    int n, nfirst;               // ranges; how many of them come first and signal
     int yb[3], ye[3];            // global rows
-    unsigned long long* signal;  // 8 bytes, written once per launch by the last of the first ranges' workgroups ... (null: nobody waits for these rows)
+    unsigned long long* signal;  // 8 bytes, written once per launch by the last of the first ranges' workgroups (release, system scope) ...
     unsigned* arrivals;          // ... counted here (left at 0)
     unsigned long long value;
-    const unsigned long long* wait;   // null, or the word the first ranges' workgroups poll before they start
-    unsigned long long wait_value;
-    unsigned* wait_timeouts;     // counts workgroups that gave up after ~50 ms (the exchange never completed): the results are then wrong, the driver reports it
-    int pre;                     // with `wait`: 1 = one resident round of the last range's workgroups is dispatched in front of the first ranges'
 };
 
 hipError_t launch_temporal(const Geo& g, int storage, const TemporalArgs& a, hipStream_t s);

@@ -132,9 +132,6 @@ struct svgf_strips {
         // Two slots, 256 B apart: launches on the filter stream use slot 0, launches on the side stream (two frames in flight: a frame's tail) slot 1 —
         // the two streams run CONCURRENTLY, and a word (or an arrival counter) shared between them is written out of order: the wait for the
         // smaller sequence number passes early and the one for the larger never (round 5's first version hung exactly there).
-        // [+512 B]: the word the communication stream writes behind every exchange of filter rows (hipStreamWriteValue64: halo_seq), polled by the
-        // first workgroups of the launch that consumes those rows; [+640 B]: how many of them gave up waiting (svgf_strips_sync reports it)
-        unsigned long long halo_seq = 0;
         unsigned long long* edge_signal = nullptr;
         unsigned long long edge_value[2] = {0, 0};
         int edge_slot = 0;                                     // the slot of the launch just enqueued
@@ -417,8 +414,6 @@ int post_exchange(svgf_strips* s, const std::vector<PlaneSpec>& planes, int h, b
     if (int rc = T.group_end(s); rc != SVGF_OK) { s->broken = true; return rc; }
     for (auto& l : s->local) {
         DeviceGuard dg(l.device);
-        // filter rows: the consumer may be a launch that is already running (launch_atrous_rows, `wait`): it polls this word
-        if (!is_state && l.edge_signal) SVGF_SHIP(s, hipStreamWriteValue64(l.comm_stream, l.edge_signal + 64, ++l.halo_seq, 0));
         SVGF_SHIP(s, hipEventRecord(is_state ? l.state_done : l.halo_done, l.comm_stream));
         if (is_state) l.state_pending = true;
     }
@@ -433,11 +428,8 @@ int wait_exchange(svgf_strips* s, svgf_strips::Local& l, bool is_state) {
 }
 
 // pair: iterations 0 and 1 in one launch on `rows` (iteration 1's; iteration 0 and the feedback store cover 4 rows more either side)
-// inner != nullptr: ONE launch over the two edge ranges [rows.a, inner->a), [inner->b, rows.b) — produced first — and the interior *inner.  signals: the
-// edge rows feed an exchange (the last edge workgroup writes the word the communication stream waits for); waits: the edge rows READ what the exchange posted
-// last delivers — the launch is enqueued without a stream-level wait and its edge workgroups poll the word written behind that exchange
-int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src, int dst, int P, const svgf_gbuffer* cur, int i, bool pair = false, const Rows* inner = nullptr,
-                       bool signals = true, bool waits = false) {
+// inner != nullptr: ONE launch over the two edge ranges [rows.a, inner->a), [inner->b, rows.b) — produced first and signalled — and the interior *inner
+int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src, int dst, int P, const svgf_gbuffer* cur, int i, bool pair = false, const Rows* inner = nullptr) {
     if (rows.b <= rows.a) return SVGF_OK;
     svgf_ctx* c = l.ctx;
     DeviceGuard dg(l.device);
@@ -458,10 +450,9 @@ int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src
         r.nfirst = r.n;
         add(inner->a, inner->b);
         const int slot = l.cur == l.compute ? 0 : 1;
-        if (signals) { r.signal = l.edge_signal + 32 * slot; r.arrivals = (unsigned*)(l.edge_signal + 32 * slot + 16); r.value = ++l.edge_value[slot]; }
-        if (waits) { r.wait = l.edge_signal + 64; r.wait_value = l.halo_seq; r.wait_timeouts = (unsigned*)(l.edge_signal + 80); r.pre = 1; }
+        r.signal = l.edge_signal + 32 * slot; r.arrivals = (unsigned*)(l.edge_signal + 32 * slot + 16); r.value = ++l.edge_value[slot];
         rc = atrous_ranges_impl(c, c->filter[src], c->filter[dst], i == 0 ? c->colour[P] : nullptr, cur, 1 << i, i, guide, r);
-        if (rc == SVGF_OK && signals) { l.edge_pending = r.nfirst > 0; l.edge_slot = slot; }
+        if (rc == SVGF_OK) { l.edge_pending = r.nfirst > 0; l.edge_slot = slot; }
     } else rc = pair ? atrous_pair_impl(c, c->filter[src], c->filter[dst], c->colour[P], cur, guide)
                      : atrous_impl(c, c->filter[src], c->filter[dst], i == 0 ? c->colour[P] : nullptr, cur, 1 << i, i, guide);
     if (rc != SVGF_OK) {
@@ -670,8 +661,8 @@ int svgf_strips_create(svgf_strips** out, int width, int height, int world, cons
             int can = 0;
             // (a part or runtime without stream memory operations keeps round 4's three launches per exchanging iteration)
             if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, l.device) == hipSuccess && can) {
-                e = hipMalloc((void**)&l.edge_signal, 1024);
-                if (e == hipSuccess) e = hipMemset(l.edge_signal, 0, 1024);
+                e = hipMalloc((void**)&l.edge_signal, 512);
+                if (e == hipSuccess) e = hipMemset(l.edge_signal, 0, 512);
             }
         }
         if (e == hipSuccess && s->mailbox) e = hipEventCreateWithFlags(&l.mb_ready, hipEventDisableTiming);
@@ -815,15 +806,10 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
     for (size_t gi = 0; gi < groups.size(); gi++) {
         for (size_t q = 0; q < groups[gi].size(); q++) {
             const int i = groups[gi][q];
-            // The first iteration of a group reads the rows the exchange posted last delivers.  With edge rows first (svgf_strips_set_edge_first, the
-            // LDS-streaming kernel) it does NOT wait for them at stream level: it is enqueued at once, works on rows that read nothing of the halo, and its
-            // edge workgroups poll the word the communication stream writes behind the exchange (launch_atrous_rows: `waits`).  Otherwise: an event wait.
-            const bool needs_halo = q == 0 && posted;
-            bool waits_in_kernel = needs_halo && s->edge_first && !(i == 0 && q + 1 < groups[gi].size() && groups[gi][q + 1] == 1 && can_fuse01(s->local[0].ctx));
-            for (int k = 0; k < n && waits_in_kernel; k++) waits_in_kernel = atrous_ranges_ok(s->local[k].ctx, 1 << i) && s->local[k].edge_signal != nullptr;
-            if (needs_halo && !waits_in_kernel)
+            if (q == 0 && posted) {
                 for (int k = 0; k < n; k++) { int rc = wait_exchange(s, s->local[k], false); if (rc != SVGF_OK) return rc; }
-            posted = false;
+                posted = false;
+            }
             // iterations 0 and 1 of one group: ONE launch on iteration 1's rows (svgf_atrous_pair); iteration 0 runs on 4 rows more
             // either side — grown(ext_atrous[0]) exactly — inside it
             if (i == 0 && q + 1 < groups[gi].size() && groups[gi][q + 1] == 1 && can_fuse01(s->local[0].ctx)) {
@@ -846,25 +832,17 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
             }
             const bool feeds_exchange = q + 1 == groups[gi].size() && gi + 1 < groups.size() && s->world > 1;
             const int h = feeds_exchange ? s->local[0].g.halo_group[gi + 1] : 0;
-            // Edge rows: inside the strip, the rows within `depth` of a boundary with a neighbour — the rows the neighbours will need (h) and, for an iteration
-            // that polls for its halo, the rows whose taps reach into it (2 x step) — plus every row it computes beyond the strip
-            const int depth = std::max(h, waits_in_kernel ? 2 << i : 0);
             std::vector<Rows> inner(n, Rows{0, 0});
-            bool split = feeds_exchange || waits_in_kernel;
-            if (split) {
-                for (int k = 0; k < n; k++) {
+            bool split = feeds_exchange;
+            if (feeds_exchange) {
+                for (int k = 0; k < n; k++) {            // the rows the neighbours will need (the last iteration of a group runs on the owned rows)
                     auto& l = s->local[k];
                     const Rows rows = grown(l.g, s->H, l.g.ext_atrous[i]);
-                    const int lo = l.rank == 0 ? rows.a : std::min(rows.b, l.g.own0 + depth);
-                    const int hi = l.rank == s->world - 1 ? rows.b : std::max(rows.a, l.g.own1 - depth);
+                    const int lo = l.rank == 0 ? rows.a : std::min(rows.b, l.g.own0 + h);
+                    const int hi = l.rank == s->world - 1 ? rows.b : std::max(rows.a, l.g.own1 - h);
                     inner[k] = Rows{lo, std::max(lo, hi)};
                     if (hi <= lo) split = false;         // a strip shorter than its two edges: one launch, the exchange behind it
                 }
-            }
-            if (waits_in_kernel && !split) {             // (no interior to run beside the wait: the event after all)
-                for (int k = 0; k < n; k++) { int rc = wait_exchange(s, s->local[k], false); if (rc != SVGF_OK) return rc; }
-                waits_in_kernel = false;
-                split = false;
             }
             // edge rows first, in ONE launch (round 5): the launch's first workgroups produce the two edge ranges and signal, the interior follows
             // in the same launch — instead of two edge launches, the exchange's event, and an interior launch (three launches' ramp and tail)
@@ -874,7 +852,7 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
                 auto& l = s->local[k];
                 const Rows rows = grown(l.g, s->H, l.g.ext_atrous[i]);
                 int rc = SVGF_OK;
-                if (one_launch) rc = launch_atrous_rows(s, l, rows, pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], i, false, &inner[k], feeds_exchange, waits_in_kernel);
+                if (one_launch) rc = launch_atrous_rows(s, l, rows, pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], i, false, &inner[k]);
                 else if (split) {
                     rc = launch_atrous_rows(s, l, Rows{rows.a, inner[k].a}, pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], i);
                     if (rc == SVGF_OK) rc = launch_atrous_rows(s, l, Rows{inner[k].b, rows.b}, pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], i);
@@ -977,16 +955,6 @@ int svgf_strips_sync(svgf_strips* s) {
         if (l.side) SVGF_SHIP(s, hipStreamSynchronize(l.side));
         SVGF_SHIP(s, hipStreamSynchronize(l.comm_stream));
         total += n;
-        if (l.edge_signal) {                  // workgroups that polled for their halo rows and gave up (launch_atrous_rows, `waits`)
-            unsigned gave_up = 0;
-            SVGF_SHIP(s, hipMemcpy(&gave_up, (const unsigned*)(l.edge_signal + 80), sizeof(gave_up), hipMemcpyDeviceToHost));
-            if (gave_up) {
-                SVGF_SHIP(s, hipMemset((unsigned*)(l.edge_signal + 80), 0, sizeof(unsigned)));
-                s->broken = true;
-                return sfail(s, SVGF_ERR_COMM, "rank " + std::to_string(l.rank) + ": " + std::to_string(gave_up) + " workgroup(s) waited ~50 ms for halo rows that never arrived "
-                                                "(an exchange did not complete): the frames since the last sync are wrong; destroy this driver");
-            }
-        }
     }
     if (total) return sfail(s, SVGF_ERR_HALO, "temporal stage: " + std::to_string(total) + " reprojection(s) reached beyond the state halo (motion_reach = " +
                                               std::to_string(s->motion_reach) + " rows): the strips differ from the whole frame there");
