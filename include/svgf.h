@@ -444,15 +444,6 @@ int svgf_strips_set_frames_in_flight(svgf_strips* s, int frames);
  * enable = 0 (and any iteration the direct kernel runs, and devices without stream memory operations): round 4's schedule — two edge launches,
  * an event, the exchange, an interior launch.  Same bits either way. */
 int svgf_strips_set_edge_first(svgf_strips* s, int enable);
-/* Room for the exchange.  A filter launch oversubscribes every compute unit several times over; the kernels of a halo exchange (RCCL's send / receive
- * workgroups, 132 registers per thread and 20 KB of LDS each on ROCm 7) then wait until the launch has drained, whatever the priority of their stream:
- * the transfer that should run BESIDE the iteration runs behind it.  svgf_stream_create_reserving returns a HIP stream (hipStream_t) whose launches stay
- * off `reserve_pairs_per_xcd` pairs of compute units in every XCD (hipExtStreamCreateWithCUMask); handed to svgf_strips_create as a rank's compute
- * stream it costs the filter 1/16 of the chip per pair and lets the exchange start when it is posted.  Worth it where exchanges sit between iterations
- * (plans grouped / per-iteration: measured -12 % per 8K/8 strip frame); not for the ghost plan, whose only exchange has four iterations to hide behind.
- * Destroy it with svgf_stream_destroy after the driver. */
-int svgf_stream_create_reserving(void** stream, int device, int reserve_pairs_per_xcd);
-int svgf_stream_destroy(void* stream);
 /* HIP events around the a-trous launches of the first local rank on every n-th frame (0 = off); read: launches, their summed
  * ms, the pixels they covered in all iterations and in iteration 0 (for the roofline's algorithmic bytes). */
 int svgf_strips_timing_enable(svgf_strips* s, int every);

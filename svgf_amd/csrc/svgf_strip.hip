@@ -360,13 +360,16 @@ int group_failed(svgf_strips* s, int rc) {
 
 // Post ONE exchange for all local ranks: for every plane of `planes` the rows at distance [held, h) from each strip boundary (exchange_msgs).
 // is_state selects which event the filter stream will wait for.
-int post_exchange(svgf_strips* s, const std::vector<PlaneSpec>& planes, int h, bool is_state) {
+// in_order: the rows this exchange carries were final before the exchange posted last started (the communication stream runs in order: nothing to wait for)
+int post_exchange(svgf_strips* s, const std::vector<PlaneSpec>& planes, int h, bool is_state, bool in_order = false) {
     const Transport& T = transport_of(s);
     // The transfers of a rank start when its filter stream has produced the rows it sends and is done with the halo rows it
     // receives into.  Loop-back: every virtual rank shares one communication stream, which then waits for all of them.
+    // (An event record is a barrier packet on the filter stream — ~6 us between two launches that would otherwise run back to back,
+    // profiles/r05_strip_trace_*.txt: it is only recorded where something will wait for it.)
     for (auto& l : s->local) {
         DeviceGuard dg(l.device);
-        SVGF_SHIP(s, hipEventRecord(l.ready, l.cur));
+        if (!in_order && !l.edge_pending) SVGF_SHIP(s, hipEventRecord(l.ready, l.cur));
     }
     // (edge rows first: the rows a rank sends are final when the first workgroups of the launch it has just enqueued have signalled — the
     // communication stream waits for that word, not for the launch; everything enqueued BEFORE that launch is complete by then, stream order)
@@ -375,7 +378,7 @@ int post_exchange(svgf_strips* s, const std::vector<PlaneSpec>& planes, int h, b
         else SVGF_SHIP(s, hipStreamWaitEvent(on.comm_stream, of.ready, 0));
         return SVGF_OK;
     };
-    for (auto& l : s->local) {
+    if (!in_order) for (auto& l : s->local) {
         DeviceGuard dg(l.device);
         if (!s->loopback) { if (int rc = wait_for(l, l); rc != SVGF_OK) return rc; }
         else if (&l == &s->local[0]) for (auto& m : s->local) { if (int rc = wait_for(l, m); rc != SVGF_OK) return rc; }
@@ -429,7 +432,8 @@ int wait_exchange(svgf_strips* s, svgf_strips::Local& l, bool is_state) {
 
 // pair: iterations 0 and 1 in one launch on `rows` (iteration 1's; iteration 0 and the feedback store cover 4 rows more either side)
 // inner != nullptr: ONE launch over the two edge ranges [rows.a, inner->a), [inner->b, rows.b) — produced first and signalled — and the interior *inner
-int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src, int dst, int P, const svgf_gbuffer* cur, int i, bool pair = false, const Rows* inner = nullptr) {
+int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src, int dst, int P, const svgf_gbuffer* cur, int i, bool pair = false, const Rows* inner = nullptr,
+                       const Rows* left_out = nullptr) {
     if (rows.b <= rows.a) return SVGF_OK;
     svgf_ctx* c = l.ctx;
     DeviceGuard dg(l.device);
@@ -446,7 +450,7 @@ int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src
     if (inner) {
         svgf::AtrousRanges r{};
         auto add = [&](int a, int b) { if (b > a) { r.yb[r.n] = a; r.ye[r.n] = b; r.n++; } };
-        add(rows.a, inner->a); add(inner->b, rows.b);
+        add(rows.a, inner->a); add(left_out ? left_out->b : inner->b, rows.b);        // (left_out: interior rows [inner->b, left_out->b) go into the NEXT launch)
         r.nfirst = r.n;
         add(inner->a, inner->b);
         const int slot = l.cur == l.compute ? 0 : 1;
@@ -564,38 +568,6 @@ int svgf_strips_transport_stats(const svgf_strips* s, unsigned long long* groups
     if (copies) *copies = s->mb_copies;
     if (bytes) *bytes = s->mb_bytes;
     return SVGF_OK;
-}
-
-// A stream for the FILTER launches of a strip driver that leaves `reserve_pairs_per_xcd` pairs of compute units of every XCD alone
-// (hipExtStreamCreateWithCUMask).  Why: an a-trous launch oversubscribes every CU four times over, and whenever one of its workgroups retires
-// the dispatcher hands the freed registers and LDS to the next one — the exchange's RCCL kernel (one workgroup of 256 threads with 132
-// registers per thread and 20 KB of LDS on this stack: more than one retiring filter workgroup frees) never finds a CU, whatever the priority of
-// its stream, until the filter launch has drained.  Measured (profiles/r05_rccl_selfcopy.txt, r05_probe_cu_mask.txt): a loop-back group takes
-// 15-23 us on an idle device and 75-150 us beside the filter launches; with 8 CUs kept free, 28 us.  The mask of this part: 32 bits per XCD, XCD
-// after XCD; the two bits of a pair enable the pair together (clearing one of them changes nothing), so whole pairs are cleared — the same in every
-// XCD, because the dispatcher deals workgroups to the XCDs in turn and an XCD with fewer CUs than the others would be the launch's straggler.
-int svgf_stream_create_reserving(void** stream, int device, int reserve_pairs_per_xcd) {
-    if (!stream || reserve_pairs_per_xcd < 0) return SVGF_ERR_INVALID;
-    *stream = nullptr;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SVGF_ERR_NO_DEVICE;
-    DeviceGuard dg(device);
-    int ncu = 0;
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) return SVGF_ERR_HIP;
-    constexpr int kXcdCount = 8;
-    const int per_xcd = ncu / kXcdCount;
-    if (ncu % kXcdCount != 0 || per_xcd % 2 != 0 || 2 * reserve_pairs_per_xcd >= per_xcd) return SVGF_ERR_INVALID;
-    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-    for (int i = 0; i < ncu; i++) if (i % per_xcd >= 2 * reserve_pairs_per_xcd) mask[i / 32] |= 1u << (i % 32);
-    hipStream_t st = nullptr;
-    if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); return SVGF_ERR_HIP; }
-    *stream = st;
-    return SVGF_OK;
-}
-
-int svgf_stream_destroy(void* stream) {
-    if (!stream) return SVGF_ERR_INVALID;
-    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? SVGF_OK : SVGF_ERR_HIP;
 }
 
 int svgf_strips_mailbox_fault(svgf_strips* s, int rank, int fault) {
@@ -764,11 +736,21 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
         // of the later iteration groups and the next frame's reprojection read them)
         if (rc != SVGF_OK) return sfail(s, rc, c->err);
     }
-    auto post_state = [&]() -> int {
+    // The state exchange: final once iteration 0 has written the feedback colour, needed by the NEXT frame's temporal launch.  The communication stream
+    // runs in order, so it is posted BEHIND the frame's last exchange of filter rows (in front of them it delayed the exchange the next iteration
+    // waits for: 23 us of idle filter stream in the trace) — and needs no wait of its own there: an exchange posted for an iteration >= 1 started
+    // after rows of that iteration were done, i.e. after iteration 0.  A frame without such an exchange posts it right behind iteration 0.
+    int last_feed = -1;
+    {
+        const auto& gr = s->local[0].g.groups;
+        for (size_t gi = 0; gi + 1 < gr.size(); gi++) last_feed = gr[gi].back();
+        if (s->world <= 1) last_feed = -1;
+    }
+    auto post_state = [&](bool in_order) -> int {
         if (s->world <= 1) return SVGF_OK;
         const svgf_strip_plan_geo& g = s->local[0].g;
         const int P = s->local[0].ctx->pingpong;           // all local contexts advance together
-        return post_exchange(s, state_planes(g, s->steps, P), g.halo_state, true);
+        return post_exchange(s, state_planes(g, s->steps, P), g.halo_state, true, in_order);
     };
     // Two frames in flight: everything the NEXT frame's temporal launch reads is written once iteration 0 has stored the feedback colour and
     // the state exchange is posted; the remaining iterations (their exchanges included) go to the side stream.  Only when they read nothing
@@ -819,12 +801,13 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
                     if (rc != SVGF_OK) return rc;
                     pp[k] ^= 1;
                 }
-                int rc = post_state();
+                int rc = last_feed < 1 ? post_state(false) : SVGF_OK;
                 if (rc == SVGF_OK) rc = go_aside();
                 if (rc != SVGF_OK) return rc;
                 q++;
                 if (q + 1 == groups[gi].size() && gi + 1 < groups.size() && s->world > 1) {      // (a group of exactly {0, 1}: its output travels whole)
                     rc = post_exchange(s, {{SVGF_PLANE_FILTER, pp[0], 0}}, s->local[0].g.halo_group[gi + 1], false);
+                    if (rc == SVGF_OK && last_feed == 1) rc = post_state(true);
                     if (rc != SVGF_OK) return rc;
                     posted = true;
                 }
@@ -846,24 +829,42 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
             }
             // edge rows first, in ONE launch (round 5): the launch's first workgroups produce the two edge ranges and signal, the interior follows
             // in the same launch — instead of two edge launches, the exchange's event, and an interior launch (three launches' ramp and tail)
+            std::vector<Rows> rest(n, Rows{0, 0});
             bool one_launch = split && s->edge_first;
             for (int k = 0; k < n && one_launch; k++) one_launch = atrous_ranges_ok(s->local[k].ctx, 1 << i) && s->local[k].edge_signal != nullptr;
             for (int k = 0; k < n; k++) {
                 auto& l = s->local[k];
                 const Rows rows = grown(l.g, s->H, l.g.ext_atrous[i]);
                 int rc = SVGF_OK;
-                if (one_launch) rc = launch_atrous_rows(s, l, rows, pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], i, false, &inner[k]);
+                if (one_launch) {
+                    // ... and only the first third of the interior: the rest is a launch of its own BEHIND the exchange's post.  An exchange's kernel
+                    // (one RCCL workgroup: 132 registers per thread, 20 KB of LDS) finds no room beside a launch that oversubscribes every CU — whenever a
+                    // filter workgroup retires, the next one takes its place — and so completed when the iteration drained, with the next iteration
+                    // waiting behind it: ~20 us of idle filter stream per exchange (profiles/r05_strip_trace_*.txt).  At the boundary between the two
+                    // launches the chip drains for a moment, the exchange gets its CU, and it has the second launch to finish in.
+                    constexpr int kHeadPercent = 33;      // (20 / 33 / 50 measure the same within 1 %, 66 leaves the exchange too little time)
+                    rest[k] = Rows{inner[k].a + (int)((long long)(inner[k].b - inner[k].a) * kHeadPercent / 100), inner[k].b};
+                    const Rows head{inner[k].a, rest[k].a};
+                    rc = launch_atrous_rows(s, l, rows, pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], i, false, &head, &rest[k]);
+                }
                 else if (split) {
                     rc = launch_atrous_rows(s, l, Rows{rows.a, inner[k].a}, pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], i);
                     if (rc == SVGF_OK) rc = launch_atrous_rows(s, l, Rows{inner[k].b, rows.b}, pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], i);
                 } else rc = launch_atrous_rows(s, l, rows, pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], i);
                 if (rc != SVGF_OK) return rc;
             }
-            if (one_launch) split = false;            // (the interior is part of that launch)
             if (feeds_exchange) {
                 int rc = post_exchange(s, {{SVGF_PLANE_FILTER, 1 - pp[0], 0}}, h, false);
+                if (rc == SVGF_OK && i == last_feed && i >= 1) rc = post_state(true);
                 if (rc != SVGF_OK) return rc;
                 posted = true;
+            }
+            if (one_launch) {
+                split = false;                        // (the interior is part of that launch — and of the one behind it)
+                for (int k = 0; k < n; k++) {
+                    int rc = launch_atrous_rows(s, s->local[k], rest[k], pp[k], 1 - pp[k], s->local[k].ctx->pingpong, &cur[k], i);
+                    if (rc != SVGF_OK) return rc;
+                }
             }
             if (split) for (int k = 0; k < n; k++) {
                 auto& l = s->local[k];
@@ -872,13 +873,13 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
             }
             for (int k = 0; k < n; k++) pp[k] ^= 1;
             if (i == 0) {                             // this frame's state is final once iteration 0 has written the feedback colour
-                int rc = post_state();
+                int rc = last_feed < 1 ? post_state(false) : SVGF_OK;
                 if (rc == SVGF_OK) rc = go_aside();
                 if (rc != SVGF_OK) return rc;
             }
         }
     }
-    if (!s->steps) { int rc = post_state(); if (rc != SVGF_OK) return rc; }
+    if (!s->steps) { int rc = post_state(false); if (rc != SVGF_OK) return rc; }
     for (int k = 0; k < n; k++) {
         auto& l = s->local[k];
         svgf_ctx* c = l.ctx;

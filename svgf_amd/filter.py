@@ -31,7 +31,7 @@ EXPORTS = [
     "svgf_import_gbuffer_pitched", "svgf_import_gbuffer_array", "svgf_export_to_array",
     "svgf_strips_plan", "svgf_rccl_unique_id", "svgf_rccl_comm_init", "svgf_rccl_comm_destroy", "svgf_rccl_comm_count", "svgf_strips_create", "svgf_strips_destroy",
     "svgf_strips_last_error", "svgf_strips_context", "svgf_strips_layout", "svgf_strips_frame", "svgf_strips_sync",
-    "svgf_strips_timing_enable", "svgf_strips_timing_read", "svgf_strips_set_frames_in_flight", "svgf_strips_messages", "svgf_strips_transport_stats", "svgf_strips_mailbox_fault", "svgf_strips_set_edge_first", "svgf_stream_create_reserving", "svgf_stream_destroy",
+    "svgf_strips_timing_enable", "svgf_strips_timing_read", "svgf_strips_set_frames_in_flight", "svgf_strips_messages", "svgf_strips_transport_stats", "svgf_strips_mailbox_fault", "svgf_strips_set_edge_first",
 ]
 ABI_VERSION = 7
 TRANSPORT = {"rccl": 0, "rccl-loopback": 1, "mailbox": 2}
@@ -186,8 +186,6 @@ def load_library():
     lib.svgf_strips_transport_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.svgf_strips_mailbox_fault.argtypes = [vp, ip, ip]
     lib.svgf_strips_set_edge_first.argtypes = [vp, ip]
-    lib.svgf_stream_create_reserving.argtypes = [C.POINTER(vp), ip, ip]
-    lib.svgf_stream_destroy.argtypes = [vp]
     lib.svgf_strips_destroy.argtypes = [vp]
     lib.svgf_strips_destroy.restype = None
     lib.svgf_strips_last_error.argtypes = [vp]

@@ -369,19 +369,6 @@ def strip_messages(W, H, rank, world, steps, plan="auto", moments_radius=3, moti
     return [dict(exchange=m.exchange, send=bool(m.send), peer=m.peer, plane=m.plane, rows=(m.row_begin, m.row_end), bytes=m.bytes) for m in buf[:n.value]]
 
 
-def reserving_stream(device_index, reserve_pairs_per_xcd=1):
-    """svgf_stream_create_reserving -> (torch.cuda.ExternalStream, raw handle): a compute stream for a strip driver whose launches leave
-    `reserve_pairs_per_xcd` pairs of compute units per XCD to the exchange's kernels.  Destroy the handle with svgf_stream_destroy after the driver."""
-    import ctypes as C
-    import torch
-    from . import filter as F
-    h = C.c_void_p()
-    rc = F.load_library().svgf_stream_create_reserving(C.byref(h), device_index, reserve_pairs_per_xcd)
-    if rc != 0:
-        raise F.SvgfError(f"svgf_stream_create_reserving: {F.load_library().svgf_status_string(rc).decode()}")
-    return torch.cuda.ExternalStream(h.value, device=torch.device("cuda", device_index)), h
-
-
 def rccl_comm(world, rank, device_index, group=None):
     """An ncclComm_t for the C++ strip driver: rank 0 draws the unique id (svgf_rccl_unique_id), torch.distributed carries its
     128 bytes to the other ranks — the only thing Python does for the exchange — and every rank joins (svgf_rccl_comm_init)."""

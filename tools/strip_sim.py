@@ -3,8 +3,8 @@
 The geometry is that of rank `--rank` of `--world` strips of a WxH frame through the C++ strip driver (svgf_strips_frame); the halo
 exchanges are real RCCL send/recv groups whose peer is this very rank (a loop-back communicator), so a strip's number holds its kernels
 (ghost rows, edge tiles), the host's enqueue cost and RCCL's launches — everything but the xGMI wire time, which the wire model below
-adds from the bytes per boundary.  Every (plan, edge-first) configuration and the whole frame are timed in ROUNDS, interleaved, in one
-process on one device (devices of the pool differ by +-4 %): medians over the rounds.
+adds from the bytes per boundary.  Every (plan, edge-first) configuration and the whole frame are timed in one process on one device (devices of
+the pool differ by +-4 %), one configuration after the other: medians of `--rounds` windows.
 
     python tools/strip_sim.py [--workload 8k] [--world 8] [--rank 3] [--plans ghost,grouped,per-iteration] [--edge-first both|0|1] [--rounds 3]
 """
@@ -33,7 +33,6 @@ ap.add_argument("--storage", default="f32")
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--in-flight", type=int, default=1, help="svgf_strips_set_frames_in_flight")
-ap.add_argument("--reserve", type=int, default=0, help="svgf_stream_create_reserving: CU pairs per XCD the filter stream leaves to the exchange's kernels")
 ap.add_argument("--no-whole", action="store_true", help="skip the whole frame on this GPU")
 ap.add_argument("--warm-ms", type=float, default=400.0, help="untimed frames for at least this long before anything is timed (DESIGN.md 6)")
 ap.add_argument("--warm-frames", type=int, default=600, help="... and at least this many")
@@ -52,10 +51,7 @@ os.environ.setdefault("RANK", "0")
 os.environ.setdefault("WORLD_SIZE", "1")
 dist.init_process_group("nccl", device_id=dev)
 
-if args.reserve:
-    side, side_handle = strips.reserving_stream(0, args.reserve)
-else:
-    side = torch.cuda.Stream(device=dev, priority=-1)          # a hardware queue of its own: RCCL's kernels run beside the filter kernels
+side = torch.cuda.Stream(device=dev, priority=-1)          # a hardware queue of its own: RCCL's kernels run beside the filter kernels
 torch.cuda.set_stream(side)
 params = F.Params(storage=args.storage, steps=5)
 
@@ -142,18 +138,35 @@ def timed(c, steps, per_frame=False):
 
 
 edge = {"both": (True, False), "1": (True,), "0": (False,)}[args.edge_first]
-configs = [Config(pl, e) for pl in args.plans.split(",") for e in edge if e or len(strips.PLANS[pl](5)) > 1]
-allc = ([] if args.no_whole else [Whole()]) + configs
-for c in allc:
-    warm(c, args.warm_ms, args.warm_frames)
-for r in range(args.rounds):
-    for c in allc:
-        warm(c, 60.0, 40)                      # back at load after the other configurations' turn
-        timed(c, args.steps if not isinstance(c, Whole) else max(20, args.steps // 4), per_frame=args.per_frame and r == 0 and c is configs[0])
+todo = [(pl, e) for pl in args.plans.split(",") for e in edge if e or len(strips.PLANS[pl](5)) > 1]
 med = lambda v: statistics.median(v)           # noqa: E731
-whole_ms = None if args.no_whole else med(allc[0].ms)
-if whole_ms:
-    print(f"{W}x{H} {args.storage} whole frame on one GPU: {whole_ms:.4f} ms/frame (rounds: {' '.join(f'{v:.4f}' for v in allc[0].ms)}); an ideal 1/{args.world}: {whole_ms / args.world:.4f} ms")
+# The configurations run ONE AFTER THE OTHER, each created, primed, timed (`rounds` windows) and destroyed before the next: several strip drivers
+# alive at once and taking turns measured up to twice as slow (RCCL ties a communicator to the stream it was last used on, and the drivers'
+# communication streams interfere).  The whole frame is timed before the first and after the last of them: the drift of the box across the call.
+whole = None if args.no_whole else Whole()
+if whole:
+    warm(whole, args.warm_ms, args.warm_frames)
+    for r in range(args.rounds):
+        timed(whole, max(20, args.steps // 4))
+configs = []
+for pl, e in todo:
+    c = Config(pl, e)
+    warm(c, args.warm_ms, args.warm_frames)
+    for r in range(args.rounds):
+        timed(c, args.steps, per_frame=args.per_frame and r == 0 and not configs)
+    c.drv.sync()
+    c.drv.close()
+    F.load_library().svgf_rccl_comm_destroy(c.comm)
+    c.drv = None
+    del c.gbs, c.rads
+    configs.append(c)
+whole_ms = None
+if whole:
+    warm(whole, 100.0, 40)
+    for r in range(args.rounds):
+        timed(whole, max(20, args.steps // 4))
+    whole_ms = med(whole.ms)
+    print(f"{W}x{H} {args.storage} whole frame on one GPU: {whole_ms:.4f} ms/frame (windows before and after the strips: {' '.join(f'{v:.4f}' for v in whole.ms)}); an ideal 1/{args.world}: {whole_ms / args.world:.4f} ms")
 
 
 def rccl_group_latency_us(n=200):
@@ -226,12 +239,8 @@ for c in configs:
     ms = med(c.ms)
     own = c.geo.own[1] - c.geo.own[0]
     scale = f", {args.world} GPUs = x{whole_ms / ms:.2f} of one" if whole_ms else ""
-    print(f"{W}x{H} strip {args.rank}/{args.world} ({own} rows, held {c.geo.y1 - c.geo.y0}), plan {c.name}{', two frames in flight' if args.in_flight == 2 else ''}{f', filter stream off {16 * args.reserve} CUs' if args.reserve else ''}: "
+    print(f"{W}x{H} strip {args.rank}/{args.world} ({own} rows, held {c.geo.y1 - c.geo.y0}), plan {c.name}{', two frames in flight' if args.in_flight == 2 else ''}: "
           f"{ms:.4f} ms/frame (rounds: {' '.join(f'{v:.4f}' for v in c.ms)}; host enqueue {med(c.host):.4f} ms){scale}")
     extra = wire_model(c, ms)
     print(f"  with wire: {ms + extra:.4f} ms/frame" + (f" = x{whole_ms / (ms + extra):.2f}" if whole_ms else ""))
-for c in configs:
-    c.drv.sync()
-    c.drv.close()
-    F.load_library().svgf_rccl_comm_destroy(c.comm)
 dist.destroy_process_group()
