@@ -156,6 +156,31 @@ class Scene:
         return out if storage == "f32" else out.to(torch.float16)
 
 
+class UpsampledScene:
+    """A static 2W x 2H scene made on the device from a W x H Scene: the same geometry sampled at twice the rate (every G-buffer texel becomes a 2 x 2
+    block, the depth derivative per pixel halves), fresh 1-spp noise per pixel.  For `also.7680x4320` of the default run: synth.make_scene takes
+    ~30 s of host time per 8K canvas, this takes none.  (`bench.py --workload 8k` times the 8K scene of svgf_amd/synth.py itself.)"""
+
+    def __init__(self, scene, nmasks=2):
+        import torch
+        self.W, self.H, self.device = 2 * scene.W, 2 * scene.H, scene.device
+        w = scene.window(0)
+        up = lambda t: t.repeat_interleave(2, 0).repeat_interleave(2, 1).contiguous()      # noqa: E731
+        up16 = lambda t: up(t.view(torch.int16)).view(torch.uint16)                       # noqa: E731 (no uint16 gather in torch)
+        mo = up(w["motion"])
+        mo[..., :2] = 0.0
+        mo[..., 3] *= 0.5
+        self._w = {"motion": mo, "normal": up16(w["normal"]), "uv": up16(w["uv"]), "base": up(w["base"])}
+        g = torch.Generator(device=self.device)
+        g.manual_seed(0x53564746)
+        self.hit = [torch.rand((self.H, self.W), generator=g, device=self.device) < 0.25 for _ in range(nmasks)]
+
+    def window(self, f):
+        return {n: t.clone() if n == "motion" else t for n, t in self._w.items()}
+
+    radiance = Scene.radiance
+
+
 class FramePool:
     """frame(n) -> (radiance, cur G-buffer, prev G-buffer) of the n-th frame of a sequence; everything lives in HBM."""
 
@@ -738,6 +763,21 @@ def main():
                                                  "why": "fp16 storage halves the colour bytes and none of the arithmetic: the a-trous launches run the same ~290 vector "
                                                         "instructions per pixel on 40 instead of 56 B/px and are bound by vector issue (valu_busy, DESIGN.md 3.3), the temporal "
                                                         "launch already moves its bytes at the part's copy rate"}
+        if not args.no_extra and wl == "4k" and storage == "f32":
+            # BASELINE configs[3]'s frame on ONE GPU: the denominator of every strip-scaling figure
+            sc8 = UpsampledScene(scene)
+            r8 = run_single(FramePool(sc8, storage, "static"), sc8.W, sc8.H, storage, iters, args.variant, max(args.steps, 20), args.warmup, device, fuse=fuse, windows=3,
+                            prime=(min(args.prime_ms, 300.0), min(args.prime_frames, 200)), prev_guide=args.prev_guide)
+            roof8, _ = roofline_block(sc8.W, sc8.H, storage, iters, r8["stage_ms"], args.variant, r8["fused"], args.prev_guide)
+            line.setdefault("also", {})["7680x4320"] = {
+                "ms_per_step": round(r8["ms_per_step"], 4), "ms_per_step_min": round(min(r8["windows_ms"]), 4), "ms_per_step_max": round(max(r8["windows_ms"]), 4),
+                "Mpixels/s": round(sc8.W * sc8.H / (r8["ms_per_step"] * 1e-3) / 1e6, 1),
+                "pass_roofline": {k: v for k, v in pass_block(sc8.W, sc8.H, storage, iters, r8["ms_per_step"], r8["fused"], args.prev_guide).items() if k != "note"},
+                "atrous_avg_launch_ms": roof8["avg_launch_ms"] if roof8 else None, "atrous_roofline_frac": roof8["frac"] if roof8 else None,
+                "scene": "the 4K scene's G-buffer at twice the sampling rate (2 x 2 texel blocks, ddepth halved), fresh 1-spp noise per 8K pixel, made on the device; "
+                         "`bench.py --workload 8k` times svgf_amd/synth.py's own 8K scene (profiles/r05_bench_8k_f32.json)",
+                "note": "7680x4320 through svgf_denoise_frame on one GPU: what the strip-parallel speed-up at N GPUs is relative to (configs[3])"}
+            del sc8
         if not args.no_extra and not args.prev_guide and wl == "4k":
             # the opt-in: svgf_set_prev_guide on (the host vouches for the previous G-buffer's planes; the pools do leave them alone)
             r6 = run_single(FramePool(scene, storage, "static"), W, H, storage, iters, args.variant, max(args.steps, 20), args.warmup, device, fuse=fuse, windows=args.windows, prime=(args.prime_ms, args.prime_frames), prev_guide=True)

@@ -529,7 +529,7 @@ class _NativeRunner:
 
     def __init__(self, W, H, world, rank, params, device, stream, comm, plan, motion_reach):
         self.drv = NativeStrips(W, H, world, params, [rank], [device.index or 0], streams=[stream], comms=[comm] if comm else None, plan=plan, motion_reach=motion_reach)
-        self.drv.set_prev_guide(True)             # bench inputs: the previous G-buffer IS last frame's current one, untouched (tests/test_bench_inputs.py)
+        # (svgf_set_prev_guide stays off: the ABI's default is what the N > 1 line reports, like the N = 1 headline)
         self.lay = self.drv.layouts[0]
 
     def frame(self, rad, cur, prev):
@@ -610,7 +610,6 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
             gb_w, rads_w = make_inputs(W, H, storage, device, nframes=2)
             gb2 = F.GBuffer(gb_w.motion.clone(), gb_w.normal.clone(), gb_w.uv.clone())
             d = F.Denoiser(W, H, params, device=device.index or 0, stream=side.cuda_stream)
-            d.set_prev_guide(True)
             gbp = [gb_w, gb2]
             n = 0
             # primed like the strips it is compared with (`busy`: at least that many ms AND frames of untimed load: the post-idle clock ramp

@@ -81,7 +81,7 @@ class Config:
         # six drivers taking turns on ONE loop-back communicator measured 0.74 ms of host time per frame instead of 0.36)
         self.comm = strips.rccl_comm(1, 0, 0)
         self.drv = strips.NativeStrips(W, H, args.world, params, [args.rank], [0], streams=[side.cuda_stream], comms=[self.comm], plan=geo.plan, motion_reach=4, loopback=True)
-        self.drv.set_prev_guide(True)          # the previous G-buffer IS last frame's current one, untouched
+        # (svgf_set_prev_guide stays off, as in bench.py: the ABI default on both sides of every ratio)
         self.drv.set_frames_in_flight(args.in_flight)
         self.drv.set_edge_first(edge_first)
         self.k = 0
@@ -101,7 +101,7 @@ class Whole:
         gb, self.rads = bench.make_inputs(W, H, args.storage, dev, nframes=2)
         self.gbs = [gb, F.GBuffer(gb.motion.clone(), gb.normal.clone(), gb.uv.clone())]
         self.d = F.Denoiser(W, H, params, device=0, stream=side.cuda_stream)
-        self.d.set_prev_guide(True)
+        # (svgf_set_prev_guide off: see Config)
         self.k = 0
         self.ms, self.host = [], []
 
