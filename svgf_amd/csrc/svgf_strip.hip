@@ -93,7 +93,7 @@ Rccl* rccl() {
 }  // namespace
 
 // ------------------------------------------------------------------ the driver -----------------------------
-constexpr int kMaxAhead = 32;
+constexpr int kMaxAhead = 32, kAheadStride = 4;      // the host runs at most kMaxAhead (+ kAheadStride) frames ahead of the device
 
 struct svgf_strip_plan_geo {
     int own0 = 0, own1 = 0;
@@ -695,7 +695,8 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
         if (!radiance[k]) return sfail(s, SVGF_ERR_INVALID, "svgf_strips_frame: null radiance");
         l.cur = l.compute; c->stream = l.compute;      // (a frame that failed behind its go_aside leaves them on the side stream)
         if (l.frame_done.empty()) l.frame_done.assign(kMaxAhead, nullptr);
-        if (hipEvent_t old = l.frame_done[s->frame_no % kMaxAhead]) SVGF_SHIP(s, hipEventSynchronize(old));   // the end of frame f - kMaxAhead
+        // the end of frame f - kMaxAhead (an event record is a barrier packet on the filter stream, ~6 us with nothing running: every kAheadStride-th frame carries one)
+        if (s->frame_no % kAheadStride == 0) if (hipEvent_t old = l.frame_done[(s->frame_no / kAheadStride) % (kMaxAhead / kAheadStride)]) SVGF_SHIP(s, hipEventSynchronize(old));
         int rc0 = alloc_state(c);                 // svgf_denoise_frame's lazy allocation (exact size, zeroed)
         if (rc0 == SVGF_OK) rc0 = alloc_flags(c);
         if (rc0 != SVGF_OK) return sfail(s, rc0, c->err);
@@ -814,10 +815,13 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
                 continue;
             }
             const bool feeds_exchange = q + 1 == groups[gi].size() && gi + 1 < groups.size() && s->world > 1;
-            const int h = feeds_exchange ? s->local[0].g.halo_group[gi + 1] : 0;
+            // iteration 0 of a frame whose STATE exchange is posted right behind it (no exchange of filter rows later in the frame: the ghost plan): the rows
+            // the state exchange carries — within halo_state of the boundaries — are produced first and signalled like the rows of any other exchange
+            const bool feeds_state = i == 0 && last_feed < 1 && s->world > 1 && !feeds_exchange && s->edge_first;
+            const int h = feeds_exchange ? s->local[0].g.halo_group[gi + 1] : feeds_state ? s->local[0].g.halo_state : 0;
             std::vector<Rows> inner(n, Rows{0, 0});
-            bool split = feeds_exchange;
-            if (feeds_exchange) {
+            bool split = feeds_exchange || feeds_state;
+            if (split) {
                 for (int k = 0; k < n; k++) {            // the rows the neighbours will need (the last iteration of a group runs on the owned rows)
                     auto& l = s->local[k];
                     const Rows rows = grown(l.g, s->H, l.g.ext_atrous[i]);
@@ -844,6 +848,7 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
                     // launches the chip drains for a moment, the exchange gets its CU, and it has the second launch to finish in.
                     constexpr int kHeadPercent = 33;      // (20 / 33 / 50 measure the same within 1 %, 66 leaves the exchange too little time)
                     rest[k] = Rows{inner[k].a + (int)((long long)(inner[k].b - inner[k].a) * kHeadPercent / 100), inner[k].b};
+                    if (feeds_state) rest[k] = Rows{inner[k].b, inner[k].b};      // (nobody waits for the state exchange before the next frame: one launch)
                     const Rows head{inner[k].a, rest[k].a};
                     rc = launch_atrous_rows(s, l, rows, pp[k], 1 - pp[k], l.ctx->pingpong, &cur[k], i, false, &head, &rest[k]);
                 }
@@ -885,9 +890,11 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
         svgf_ctx* c = l.ctx;
         {
             DeviceGuard dg(l.device);
-            hipEvent_t& done = l.frame_done[s->frame_no % kMaxAhead];
-            if (!done) SVGF_SHIP(s, hipEventCreateWithFlags(&done, hipEventDisableTiming));
-            SVGF_SHIP(s, hipEventRecord(done, l.cur));
+            if (s->frame_no % kAheadStride == 0) {
+                hipEvent_t& done = l.frame_done[(s->frame_no / kAheadStride) % (kMaxAhead / kAheadStride)];
+                if (!done) SVGF_SHIP(s, hipEventCreateWithFlags(&done, hipEventDisableTiming));
+                SVGF_SHIP(s, hipEventRecord(done, l.cur));
+            }
             if (l.cur != l.compute) {             // the end of this frame's tail on the side stream
                 SVGF_SHIP(s, hipEventRecord(l.ev_tail, l.cur));
                 l.tail_pending = true;
