@@ -1,7 +1,7 @@
 #!/bin/bash
 # After `gpurun -- tools/final_round.sh <tag>`: copy what was measured into profiles/ (run here, in the container), then
 # `python3 tools/profiles_readme.py <tag>` regenerates that round's section of profiles/README.md FROM the copied files.
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/$TAG
 RN=$(echo $TAG | sed 's/^r0*//')

@@ -61,7 +61,12 @@ def main(tag):
         (f"{tag}_kernel_stats_4k_f32.csv", f"the raw `*_kernel_stats.csv` of the SAME trace run `{tag}_rocprofv3_summary_4k_f32.txt` was condensed from"),
         (f"{tag}_bench_under_rocprofv3_4k_f32.json", "the bench line that traced run printed itself (the library's HIP events under the tracer)"),
         ("hbm_traffic.json", "HBM bytes per launch from this round's PMC passes (`tools/make_traffic.py`), stamped with the hash of the kernel sources; `bench.py` attaches it (`roofline.traffic`, `traffic_source`) only when the sources it runs hash to the same value"),
-        (f"{tag}_strip_sim_8k_over_8.txt", "`tools/strip_sim.py --driver native`, plans ghost / grouped / per-iteration: the middle strip of an 8K/8 partition with loop-back RCCL groups"),
+        (f"{tag}_strip_sim_8k_over_8.txt", "`tools/strip_sim.py`, plans ghost / grouped / per-iteration (round 5: each with edge rows first and with round 4's three launches, and the whole 8K frame on the same GPU in the same call): the middle strip of an 8K/8 partition with loop-back RCCL groups"),
+        (f"{tag}_strip_trace_per-iteration_three_launches.txt, _one_launch.txt, _two_launches.txt, {tag}_strip_trace_ghost.txt", "`tools/strip_trace.py`: a strip frame as the device ran it (rocprofv3 kernel trace of `strip_sim.py`): timeline of one frame, mean kernel durations, mean gap between consecutive filter kernels — round 4's schedule, edge rows first in one launch, and with the interior in two launches"),
+        (f"{tag}_rccl_selfcopy.txt", "`tools/rccl_selfcopy.py`: one loop-back halo exchange (2 sends + 2 receives, 4 KB - 3.9 MB) on an idle device and beside filter launches, communication stream at normal / highest priority"),
+        (f"{tag}_probe_wait_value.txt, {tag}_probe_cu_mask.txt, {tag}_probe_rccl_two_ranks_one_gpu.txt", "`tools/ubench/wait_value.hip`, `tools/ubench/cu_mask.hip`, `tools/probe_rccl_one_gpu.py`: stream memory operations against a running kernel; CU masks; two RCCL ranks on one device (refused)"),
+        (f"{tag}_strip_sim_reserved_cus.txt", "`strip_sim.py` with the filter stream kept off one CU pair per XCD (`hipExtStreamCreateWithCUMask`): slower for every plan (the helper left the ABI)"),
+        (f"{tag}_parity_envelope.json", "`tools/parity_envelope.py` (CPU): the oracle against its fp32 / fma / fp32fma / fused builds, free-running on the parity frames"),
         (f"{tag}_fused_pair_ablations.txt", "iterations 0 + 1 as one launch: A/B against two launches, its knobs, what it is made of; the fp16 half-record experiment"),
         (f"{tag}_small_experiments.txt", "the `tools/abn.sh` / `tools/strip_ab.sh` blocks of the round (interleaved A/B of prebuilt twins on one device)"),
         (f"{tag}_cold_frames.txt", "`tools/cold_frames.py`: per-frame stage times over the cold -> steady transition (fp32, fp16)"),
@@ -154,6 +159,13 @@ def main(tag):
             m = re.search(r"plan (\S+), .*?: ([0-9.]+) ms/frame \(host enqueue ([0-9.]+) ms\)", ln)
             if m:
                 notes.append(f"* `{tag}_strip_sim_8k_over_8.txt`: middle strip of 8K/8, plan {m.group(1)}: {m.group(2)} ms per frame (host enqueue {m.group(3)} ms).")
+            m = re.search(r"plan ([^:]+): ([0-9.]+) ms/frame \(rounds: [^;]*; host enqueue ([0-9.]+) ms\)(?:, (\d+) GPUs = x([0-9.]+) of one)?", ln)
+            if m:
+                notes.append(f"* `{tag}_strip_sim_8k_over_8.txt`: middle strip of 8K/8, plan {m.group(1)}: **{m.group(2)} ms** per frame (host enqueue {m.group(3)} ms)" +
+                             (f" = **{m.group(5)}x** for {m.group(4)} GPUs against the whole frame of the same call." if m.group(5) else "."))
+            m = re.search(r"whole frame on one GPU: ([0-9.]+) ms/frame", ln)
+            if m:
+                notes.append(f"* `{tag}_strip_sim_8k_over_8.txt`: the whole 8K frame on the same GPU in the same call: {m.group(1)} ms.")
     section = [f"<!-- {tag}:begin -->", f"## Round {int(tag[1:])}  (generated by `tools/profiles_readme.py {tag}` from the files it names)", "", "| file | what |", "|---|---|"] + rows + \
               ["", "Numbers read out of those files", ""] + notes + [f"<!-- {tag}:end -->", ""]
     path = os.path.join(P, "README.md")
@@ -166,4 +178,4 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r04")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r05")
