@@ -1,8 +1,8 @@
 """TEST-ONLY stage backend for svgf_amd.strips.StripRunner: the CPU oracle on torch CPU tensors.
 
-The product's only stage backend is strips.HipStages (HIP kernels through the C ABI).  This class lives under
-tests/ so that the strip scheduling, halo plans and torch.distributed plumbing can be exercised with gloo on
-machines without a GPU; it is never imported by svgf_amd/."""
+The product's strip driver is C++ (svgf_amd/csrc/svgf_strip.hip); StripRunner is a Python restatement of its schedule that runs on any
+stage backend.  This one lives under tests/ so that the halo plans and the torch.distributed plumbing can be exercised with gloo on machines
+without a GPU; it is never imported by svgf_amd/."""
 from __future__ import annotations
 
 from oracle import oracle as orc

@@ -98,6 +98,13 @@ def test_three_launches_per_exchanging_iteration_still_give_the_same_bits(G, pla
     _run_sequence(G, W, H, 3, plan, storage, frames(W, H, 4, mv=(1.0, -3.5)), reach=4, edge_first=False)
 
 
+def test_strips_no_taller_than_their_two_edges(G):
+    """64-row strips under the per-iteration plan: at step 16 the two 32-row edge ranges ARE the strip — no interior to split off: that iteration is one
+    plain launch with the exchange behind an event (the `hi <= lo` branch of the schedule), the others run edge rows first."""
+    W, H = 256, 192
+    _run_sequence(G, W, H, 3, "per-iteration", "f32", frames(W, H, 3, mv=(1.0, -1.5)), reach=2)
+
+
 def test_edge_rows_first_on_odd_sizes_and_seven_iterations(G):
     """W % 128 != 0 (a last x tile that is mostly outside the frame), strips of unequal height (H % world != 0), seven iterations (steps 32 and 64:
     edge ranges of 128 / 256 rows... as far as the strips allow: the plan keeps them per iteration) — every exchanging iteration a single launch

@@ -1,6 +1,10 @@
-"""Multi-GPU row-strip path on CPU: geometry/plan arithmetic, lock-step virtual ranks, and a real world_size-2
-torch.distributed run over gloo.  Stage compute comes from the test-only OracleStages backend, so every strip
-result can be demanded bit-identical to the whole-frame oracle pipeline."""
+"""The halo plan's arithmetic on CPU: geometry, lock-step virtual ranks, and a real world_size-2 torch.distributed run over gloo.
+
+What runs here is the PYTHON restatement of the strip schedule (svgf_amd/strips.py: Geometry, StripRunner, LocalComm / DistComm) with the CPU
+oracle as its stage backend (tests/oracle_stages.py) — NOT the product driver.  The product's strip driver is C++ (svgf_amd/csrc/svgf_strip.hip)
+and is tested on the GPU, with real peer addressing, in tests/test_gpu_strips_mailbox.py; its geometry and its message lists are checked against
+this restatement without a GPU in tests/test_abi.py.  What these tests establish is that the plan itself is right: which rows must travel when
+for N strips to equal the whole frame bit for bit — over a real process group (world size 2), for every plan."""
 import os
 import socket
 
@@ -99,6 +103,7 @@ def _gloo_worker(rank, world, port, W, H, N, plan, storage, q):
 
 @pytest.mark.parametrize("plan", ["per-iteration", "grouped", "ghost"])
 def test_gloo_world2_bit_identical(oracle, plan):
+    """Two processes, torch.distributed over gloo, the Python schedule with oracle stages (see the module docstring: not the product driver)."""
     import torch.multiprocessing as mp
     W, H, N, world, storage = 64, 200, 3, 2, "f32"
     frs = [synth.make_frame(W, H, f, mv=(1.0, -2.5)) for f in range(N)]
