@@ -466,7 +466,8 @@ int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src
     if (timed) {
         if (hipError_t e = hipEventRecord(e1, l.cur); e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return sfail(s, SVGF_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e)); }
         l.tev.push_back(e0); l.tev.push_back(e1);
-        l.tbytes_px.push_back((double)(rows.b - rows.a) * s->W);
+        // (rows of the interior that were left to the NEXT launch are that launch's: left_out)
+        l.tbytes_px.push_back((double)((rows.b - rows.a) - (inner && left_out ? left_out->b - left_out->a : 0)) * s->W);
         l.titer.push_back(pair ? -1 : i);
     }
     return SVGF_OK;
