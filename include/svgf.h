@@ -439,10 +439,14 @@ int svgf_strips_sync(svgf_strips* s);
  * returned (a frame whose iterations would read it — the direct kernel — keeps its tail on the compute stream).  Default 1. */
 int svgf_strips_set_frames_in_flight(svgf_strips* s, int frames);
 /* Edge rows first (default 1).  The iteration in front of a halo exchange produces the rows its neighbours wait for FIRST.  With enable = 1 that is
- * ONE launch: its first workgroups compute the two edge ranges, the last of them to finish writes a sequence number into device memory, the
- * communication stream waits for that word (hipStreamWaitValue64) and starts the exchange while the interior tiles of the same launch still run.
- * enable = 0 (and any iteration the direct kernel runs, and devices without stream memory operations): round 4's schedule — two edge launches,
- * an event, the exchange, an interior launch.  Same bits either way. */
+ * ONE launch over {the two edge ranges, the first third of the interior}: its first workgroups compute the edge ranges (written through to memory), the
+ * last of them to finish writes a sequence number into device memory, and the communication stream — created at the highest priority — waits for
+ * that word (hipStreamWaitValue64) and posts the exchange while the interior still runs; the rest of the interior is a second launch, so that the
+ * exchange's kernel finds a compute unit at the boundary between the two (beside a launch that oversubscribes every CU it does not, whatever its
+ * priority) and is done when the next iteration wants its rows.  The frame's state exchange is posted behind its last exchange of filter rows, and no
+ * event is recorded on the filter stream that nothing waits for.  Measured on an 8K/8 strip: the per-iteration plan -14 %, grouped -5 % per frame
+ * (DESIGN.md 5).  enable = 0 (and any iteration the direct kernel runs, and devices without stream memory operations,
+ * hipDeviceAttributeCanUseStreamWaitValue): round 4's schedule — two edge launches, an event, the exchange, an interior launch.  Same bits either way. */
 int svgf_strips_set_edge_first(svgf_strips* s, int enable);
 /* HIP events around the a-trous launches of the first local rank on every n-th frame (0 = off); read: launches, their summed
  * ms, the pixels they covered in all iterations and in iteration 0 (for the roofline's algorithmic bytes). */
