@@ -77,7 +77,7 @@ class Config:
             rads = [take(r) for r in rads]
         self.gbs = [gb, F.GBuffer(gb.motion.clone(), gb.normal.clone(), gb.uv.clone())]      # current / previous G-buffer in distinct planes
         self.rads = rads
-        # (a communicator of its own: RCCL ties a communicator to the stream it was last used on and pays for every change of it on the host —
+        # (a communicator of its own; a guess at the cause of what was measured — RCCL pays on the host for every change of the stream a communicator is used on —
         # six drivers taking turns on ONE loop-back communicator measured 0.74 ms of host time per frame instead of 0.36)
         self.comm = strips.rccl_comm(1, 0, 0)
         self.drv = strips.NativeStrips(W, H, args.world, params, [args.rank], [0], streams=[side.cuda_stream], comms=[self.comm], plan=geo.plan, motion_reach=4, loopback=True)
@@ -141,8 +141,7 @@ edge = {"both": (True, False), "1": (True,), "0": (False,)}[args.edge_first]
 todo = [(pl, e) for pl in args.plans.split(",") for e in edge if e or len(strips.PLANS[pl](5)) > 1]
 med = lambda v: statistics.median(v)           # noqa: E731
 # The configurations run ONE AFTER THE OTHER, each created, primed, timed (`rounds` windows) and destroyed before the next: several strip drivers
-# alive at once and taking turns measured up to twice as slow (RCCL ties a communicator to the stream it was last used on, and the drivers'
-# communication streams interfere).  The whole frame is timed before the first and after the last of them: the drift of the box across the call.
+# alive at once and taking turns measured up to twice as slow, host-bound (profiles/r05_small_experiments.txt block 1; the cause was not pursued).  The whole frame is timed before the first and after the last of them: the drift of the box across the call.
 whole = None if args.no_whole else Whole()
 if whole:
     warm(whole, args.warm_ms, args.warm_frames)
