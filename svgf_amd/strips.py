@@ -711,10 +711,11 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
         res = dict(ms_per_step=max_over_ranks((t1 - t0) * 1e3 / steps), plan=lay["plan"], rows_per_rank=lay["own"][1] - lay["own"][0],
                    rows_held=lay["y1"] - lay["y0"], host_ms=round(host * 1e3 / steps, 4), motion_reach=reach)
         if keep_timing:
-            res["atrous_timing"] = run.atrous_timing
-            res["_keep"] = run
-        else:
-            run.close()
+            # read now and close: a second strip driver alive beside the one being timed (the other plans below) is not something the figures
+            # of either should depend on (tools/strip_sim.py measured drivers taking turns in one process up to twice as slow)
+            nl, ms_l, px_all, px0 = run.drv.timing_read()
+            res["atrous_timing"] = lambda bytes_iter, bytes_feedback: (nl, ms_l, px_all * bytes_iter + px0 * bytes_feedback)
+        run.close()
         return res
 
     def static_frames(lay):
