@@ -878,6 +878,8 @@ def main():
         for name, r in res["other_plans"].items():
             plans[name] = {"ms_per_step": round(r["ms_per_step"], 4), "Mpixels/s": mpx(r["ms_per_step"]), "rows_held_per_rank": r["rows_held"],
                            "host_enqueue_ms_per_frame": r["host_ms"], "speedup_vs_one_gpu": round(one / r["ms_per_step"], 3) if one else None}
+            if "ms_per_step_three_launches" in r:
+                plans[name]["ms_per_step_three_launches"] = round(r["ms_per_step_three_launches"], 4)
         pan = res["pan"]
         if pan:
             pan = dict(pan, ms_per_step=round(pan["ms_per_step"], 4), **{"Mpixels/s": mpx(pan["ms_per_step"])})
@@ -896,7 +898,8 @@ def main():
             "speedup_vs_one_gpu": round(one / ms, 3) if one else None,
             "halo_plans": plans,
             "halo_plans_note": "per-iteration = BASELINE.json configs[3]'s 'RCCL halo exchange per a-trous iter' (1 state + 4 exchanges per frame); grouped: 1 + 1; "
-                               "ghost (what `auto` resolves to while the strips are taller than the 69-row halo): the state exchange only, iterations recomputed on ghost rows",
+                               "ghost (what `auto` resolves to while the strips are taller than the 69-row halo): the state exchange only, iterations recomputed on ghost rows; "
+                               "ms_per_step_three_launches: the same plan with svgf_strips_set_edge_first(0), round 4's three launches per exchanging iteration",
             "pan": pan,
             "pan_note": "a camera pan whose state exchange carries moments and history rows as well as colour (motion reach >= 3); value / ms_per_step are the static camera",
             "rccl_ranks": res["rccl_ranks"],

@@ -665,10 +665,13 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
                               "nothing is measured (RCCL wants one device per rank)")
     Runner = _NativeRunner
 
-    def measure(plan_name, reach, frame_of, keep_timing=False):
-        """One driver under one plan: prime, then `steps` frames between barriers.  frame_of(n) -> (radiance, cur, prev) of THIS layout."""
+    def measure(plan_name, reach, frame_of, keep_timing=False, edge_first=True):
+        """One driver under one plan: prime, then `steps` frames between barriers.  frame_of(n) -> (radiance, cur, prev) of THIS layout.
+        edge_first=False: round 4's schedule (three launches per exchanging iteration, svgf_strips_set_edge_first(0)), for comparison."""
         lay = strips_plan(W, H, rank, world, iters, plan=plan_name, moments_radius=params.moments_radius, motion_reach=reach)
         run = Runner(W, H, world, rank, params, device, side.cuda_stream, comm, lay["plan"], reach)
+        if not edge_first:
+            run.drv.set_edge_first(False)
         get = frame_of(lay)
         n = 0
         dist.barrier()                           # the ranks enter the untimed frames together ...
@@ -733,6 +736,9 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
             continue
         r = measure(pl, motion_reach, static_frames)
         others[pl] = {k: r[k] for k in ("ms_per_step", "rows_held", "host_ms")}
+        if pl != "ghost":
+            # the same plan under round 4's schedule: on real links this pair of numbers is what the edge-rows-first launch is worth
+            others[pl]["ms_per_step_three_launches"] = measure(pl, motion_reach, static_frames, edge_first=False)["ms_per_step"]
 
     pan = None
     if pan_mv is not None:
