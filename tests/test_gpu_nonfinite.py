@@ -5,7 +5,10 @@ The reference's imageLoad / imageStore clamp with glm::clamp = min(max(x, 0), 1)
 `mix` (:398), reaches the wavelet sums channel by channel (:608 — the weight itself stays finite, because
 `max(weightLillum, 0.0)` in :424 is CUDA's fmax, which drops a NaN), and turns the zero-weight sums of sky texels
 into NaN (0 x NaN, :498-499).  A 1-spp path tracer does produce such texels.  The oracle restates exactly that; the HIP
-kernels must reproduce it: same NaN positions, finite values within the stage tolerances (tests/gpu_helpers.py:TOL)."""
+kernels must reproduce it: same NaN positions, finite values within the stage tolerances (tests/gpu_helpers.py:TOL).
+
+Non-finite and out-of-range G-BUFFER texels (motion, depth, normal, ddepth; include/svgf.h "Non-finite / out-of-range G-buffer texels")
+have their own file: tests/test_gpu_gbuffer_nonfinite.py (temporal mask-exact, moments, a-trous LDS + direct, frame and strip drivers)."""
 import numpy as np
 import pytest
 
