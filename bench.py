@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (pan, 1080p, fp16, cold frames)")
     ap.add_argument("--strips", action="store_true", help="run the strip driver even at N=1 (exercises the N>1 code path)")
+    ap.add_argument("--leg-timeout", type=float, default=240.0, help="N > 1: seconds one leg (a plan, the pan, the one-GPU frame) may take before the job ends with what is measured")
     ap.add_argument("--no-one-gpu", action="store_true", help="N > 1: skip the whole frame on rank 0's GPU alone (one_gpu_ms / speedup_vs_one_gpu)")
     ap.add_argument("--fuse", action="store_true", help="iterations 0 and 1 as one launch (svgf_atrous_pair): bit-identical, measured slower (DESIGN.md 3.3c)")
     ap.add_argument("--frames-in-flight", type=int, choices=[1, 2], default=1,
@@ -850,26 +851,19 @@ def main():
     from svgf_amd import strips
     wl = args.workload or "8k"
     W, H = WORKLOADS[wl]
-    try:
-        res = strips.bench_strips(W, H, storage, iters, args.variant, args.steps, args.warmup, device, plan=args.halo_plan,
-                                  make_inputs=make_inputs, prime_frames=PRIME_FRAMES,
-                                  plans=() if args.no_extra else ("per-iteration", "grouped"), pan_mv=None if args.no_extra else STRIP_PAN_MV,
-                                  one_gpu_reference=not args.no_one_gpu, busy=(args.prime_ms, args.prime_frames))
-    except Exception as e:  # noqa: BLE001
-        print(f"bench.py: rank {rank}: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
-        os._exit(3)            # a rank that cannot run the measurement asked for ends the job (the launcher reports the exit codes)
-    ms = res["ms_per_step"]    # already the MAX over ranks
-    # roofline of the dominant kernel on rank 0's strip: its a-trous launches (halo rows included) between HIP events
     ab = ALG_BYTES[storage]
-    n_l, ms_l, by_l = res["atrous_timing"](ab["atrous_iter"], ab["atrous_feedback"])
-    roof = None
-    if n_l and ms_l > 0:
-        ach = by_l / (ms_l * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "atrous_lds_kernel", "scope": "rank 0, its strip incl. redundantly computed halo rows",
-                "launches_timed": n_l, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                "algorithmic_bytes_per_launch": int(by_l / n_l), "avg_launch_ms": round(ms_l / n_l, 5), "traffic": None, "traffic_source": None}
-    line = None
-    if rank == 0:
+
+    def strips_line(res, incomplete=None):
+        """The JSON line from what bench_strips has measured so far (the headline plan at least)."""
+        ms = res["ms_per_step"]    # already the MAX over ranks
+        # roofline of the dominant kernel on rank 0's strip: its a-trous launches (halo rows included) between HIP events
+        n_l, ms_l, by_l = res["atrous_timing"](ab["atrous_iter"], ab["atrous_feedback"])
+        roof = None
+        if n_l and ms_l > 0:
+            ach = by_l / (ms_l * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "atrous_lds_kernel", "scope": "rank 0, its strip incl. redundantly computed halo rows",
+                    "launches_timed": n_l, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                    "algorithmic_bytes_per_launch": int(by_l / n_l), "avg_launch_ms": round(ms_l / n_l, 5), "traffic": None, "traffic_source": None}
         mpx = lambda t: round(W * H / (t * 1e-3) / 1e6, 1)      # noqa: E731
         full_gbps = alg_bytes_full(storage, iters) * W * H / (ms * 1e-3) / 1e9
         one = res["one_gpu_ms"]
@@ -908,8 +902,51 @@ def main():
                               "frac_of_aggregate_8TBps": round(full_gbps / (HBM_PEAK_GBPS * world), 4)},
             "host_enqueue_ms_per_frame": res.get("host_ms"),
         }
+        if incomplete:
+            line["incomplete"] = incomplete
+        return line
+
+    # A leg that never returns (an exchange that does not complete on this node) must not take the measured legs with it: every rank runs the
+    # same watchdog; when a leg overruns its allowance, rank 0 prints the line of what IS measured (value = the headline plan, the legs after it
+    # absent and `incomplete` naming the one that hung) and every rank leaves.  Before the headline there is nothing to print: exit code 4.
+    import threading
+    import time as _time
+    watch = {"phase": "start", "deadline": _time.monotonic() + args.leg_timeout, "line": None, "done": False}
+
+    def on_phase(name):
+        watch["phase"], watch["deadline"] = name, _time.monotonic() + args.leg_timeout
+        if name.startswith(os.environ.get("SVGF_BENCH_HANG_AT") or "\0"):       # tests: a leg that never returns
+            _time.sleep(1e6)
+
+    def on_head(res):
+        watch["so_far"] = res
+
+    def watchdog():
+        while not watch["done"]:
+            _time.sleep(0.5)
+            if _time.monotonic() > watch["deadline"] and not watch["done"]:
+                why = f"leg '{watch['phase']}' did not finish within {args.leg_timeout:.0f} s on rank {rank}"
+                print(f"bench.py: {why}: leaving", file=sys.stderr, flush=True)
+                if watch.get("so_far") is None:
+                    os._exit(4)
+                if rank == 0:
+                    emit(strips_line(watch["so_far"], incomplete=why + "; the legs after it are absent"))
+                os._exit(0)
+    threading.Thread(target=watchdog, daemon=True).start()
+
+    try:
+        res = strips.bench_strips(W, H, storage, iters, args.variant, args.steps, args.warmup, device, plan=args.halo_plan,
+                                  make_inputs=make_inputs, prime_frames=PRIME_FRAMES,
+                                  plans=() if args.no_extra else ("per-iteration", "grouped"), pan_mv=None if args.no_extra else STRIP_PAN_MV,
+                                  one_gpu_reference=not args.no_one_gpu, busy=(args.prime_ms, args.prime_frames), on_phase=on_phase, on_head=on_head)
+    except Exception as e:  # noqa: BLE001
+        print(f"bench.py: rank {rank}: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        os._exit(3)            # a rank that cannot run the measurement asked for ends the job (the launcher reports the exit codes)
+    on_phase("closing")
+    line = strips_line(res) if rank == 0 else None
     dist.barrier()
     dist.destroy_process_group()
+    watch["done"] = True
     if line is not None:
         emit(line)
 

@@ -577,13 +577,16 @@ def _strip_pan_frames(W, H, storage, device, mv, y0, y1):
 
 
 def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, make_inputs, prime_frames, motion_reach=None,
-                 plans=("per-iteration", "grouped"), pan_mv=(1.5, -3.5), one_gpu_reference=True, busy=(400.0, 600)):
+                 plans=("per-iteration", "grouped"), pan_mv=(1.5, -3.5), one_gpu_reference=True, busy=(400.0, 600),
+                 on_phase=None, on_head=None):
     """bench.py's N > 1 leg: this rank's strip of a W x H frame; every measurement is `steps` frames between barriers, MAX over ranks.
     Measured: the headline plan (`plan`, static camera), the other halo plans (BASELINE config #4 names "per-iteration"), a camera
     pan whose state exchange really carries moments and history (motion reach >= 3), and — on rank 0 alone, before the strips —
     the whole frame on one GPU, which is what the strip-parallel speed-up is relative to.
     The driver is the C++ strip driver of the library (RCCL groups posted from C++); a rank that cannot bring its communicator up makes
-    every rank raise (bench.py exits non-zero): there is nothing else to fall back to."""
+    every rank raise (bench.py exits non-zero): there is nothing else to fall back to.
+    on_phase(name): called before every leg (bench.py's watchdog: a leg that never returns ends the job with what is measured so far);
+    on_head(result): called with the result so far once the headline plan is measured, and again after every further leg."""
     import math
     import time
     import torch
@@ -604,8 +607,10 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
         return float(t.item())
 
     # ---- the whole frame on ONE GPU (rank 0), through svgf_denoise_frame: the time the N-GPU speed-up is relative to
+    phase = on_phase or (lambda name: None)
     one_gpu_ms = None
     if one_gpu_reference:
+        phase("the whole frame on one GPU (rank 0)")
         if rank == 0:
             gb_w, rads_w = make_inputs(W, H, storage, device, nframes=2)
             gb2 = F.GBuffer(gb_w.motion.clone(), gb_w.normal.clone(), gb_w.uv.clone())
@@ -638,6 +643,7 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
 
     # ---- the strip's static inputs: its rows of the frame; the rows needed depend on the plan, which depends on the motion reach,
     # which is read off the inputs: generate the widest candidate (ghost plan, reach 8), measure, then cut
+    phase("inputs and communicator")
     wide = "ghost" if plan == "auto" else plan
     probe = strips_plan(W, H, rank, world, iters, plan=wide, moments_radius=params.moments_radius, motion_reach=8) \
         if _plan_fits(W, H, rank, world, iters, wide, params.moments_radius, 8) else None
@@ -729,18 +735,31 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
         rads = [r[cut].contiguous() for r in rads_all]
         return lambda n: (rads[n % len(rads)], gbs[n & 1], gbs[(n & 1) ^ 1])
 
+    phase(f"headline: plan {plan}, static camera")
     head = measure(plan, motion_reach, static_frames, keep_timing=True)
-    others = {}
+    others, pan = {}, None
+
+    def so_far():
+        res = dict(head)
+        res.update(driver=Runner.name, other_plans=dict(others), pan=pan, one_gpu_ms=one_gpu_ms, rccl_ranks=rccl_ranks, _comm=comm)
+        return res
+    if on_head:
+        on_head(so_far())
     for pl in plans:
         if pl == head["plan"] or not _plan_fits(W, H, rank, world, iters, pl, params.moments_radius, motion_reach):
             continue
+        phase(f"plan {pl}")
         r = measure(pl, motion_reach, static_frames)
         others[pl] = {k: r[k] for k in ("ms_per_step", "rows_held", "host_ms")}
+        if on_head:
+            on_head(so_far())
         if pl != "ghost":
             # the same plan under round 4's schedule: on real links this pair of numbers is what the edge-rows-first launch is worth
+            phase(f"plan {pl}, three launches per exchanging iteration")
             others[pl]["ms_per_step_three_launches"] = measure(pl, motion_reach, static_frames, edge_first=False)["ms_per_step"]
+            if on_head:
+                on_head(so_far())
 
-    pan = None
     if pan_mv is not None:
         reach = int(math.ceil(abs(pan_mv[1])))
         if _plan_fits(W, H, rank, world, iters, "auto", params.moments_radius, reach):
@@ -754,12 +773,12 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
                     state["prev"] = cur
                     return rads[n & 1], cur, prev
                 return get
+            phase("camera pan")
             r = measure("auto", reach, pan_frames)
             pan = {"mv": list(pan_mv), "motion_reach": reach, "plan": r["plan"], "ms_per_step": r["ms_per_step"], "rows_held": r["rows_held"]}
 
-    res = dict(head)
-    res.update(driver=Runner.name, other_plans=others, pan=pan, one_gpu_ms=one_gpu_ms, rccl_ranks=rccl_ranks, _comm=comm)
-    return res
+    phase("done")
+    return so_far()
 
 
 def rccl_comm_count(comm):

@@ -527,6 +527,27 @@ def test_bench_strips_line_on_one_gpu(G):
     assert set(d["halo_plans"]) == {"ghost", "grouped", "per-iteration"} and d["pan"]["ms_per_step"] > 0 and d["roofline"]["frac"] > 0
 
 
+def test_bench_strips_leg_that_never_returns_leaves_the_measured_legs(G):
+    """A leg of the N > 1 bench that hangs (SVGF_BENCH_HANG_AT: the test's stand-in for an exchange that never completes) does not take the
+    legs before it along: after --leg-timeout the line is printed with the headline plan and the legs measured so far, `incomplete` names
+    the leg, exit code 0.  A hang BEFORE the headline has nothing to print: exit code 4, no line."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--strips", "--steps", "3", "--warmup", "1", "--workload", "1080p", "--prime-ms", "0", "--prime-frames", "0",
+           "--leg-timeout", "15"]
+    p = subprocess.run(cmd, env=dict(env, SVGF_BENCH_HANG_AT="plan grouped"), capture_output=True, text=True, timeout=500)
+    assert p.returncode == 0, (p.returncode, p.stderr[-2000:])
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "plan grouped" in d["incomplete"] and d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert set(d["halo_plans"]) == {"ghost", "per-iteration"} and "ms_per_step_three_launches" in d["halo_plans"]["per-iteration"] and d["pan"] is None
+    p = subprocess.run(cmd, env=dict(env, SVGF_BENCH_HANG_AT="headline"), capture_output=True, text=True, timeout=500)
+    assert p.returncode == 4 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")], (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+    assert "did not finish" in p.stderr
+
+
 @pytest.mark.parametrize("storage", ["f32", "f16"])
 def test_general_tap_path_equals_the_uniform_normal_fast_path(G, storage):
     """SVGF_VARIANT_LDS_GENERAL switches the uniform-normal fast path of the a-trous kernel off (every wave evaluates n.n' per tap):
