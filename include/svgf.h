@@ -56,10 +56,13 @@
  *    Not reproduced: a depth derivative of +inf (or beyond ~1e22 / step) on a sky texel — see "Sky" above.
  *  - Bit-identity next to a NaN.  The streaming a-trous kernel redoes, the reference's way, exactly the pixels whose fast result held a NaN;
  *    every other pixel keeps its bits, so strips and row ranges stay bit-identical to the whole frame with NaN texels present (colour or
- *    G-buffer); the LDS-streaming moments kernel (the first three frames after a reset, crowded frames) does the same.  What still depends on
- *    the path taken (within the stated tolerance): a pixel whose 7x7 WINDOW holds a non-finite texel is rounded differently by the streaming
- *    moments kernel and by the young-pixel launch (svgf_set_adaptive_moments; svgf_moments against the frame driver), and the pair launch
- *    svgf_atrous_pair takes the exact form for every pixel of a band that holds a NaN.
+ *    G-buffer).  Both moments kernels — the LDS-streaming one (the first three frames after a reset, crowded frames, svgf_moments) and the
+ *    young-pixel launch of the drivers — follow the same rule, so which of them serves a frame, svgf_set_adaptive_moments and the stage
+ *    calls against the frame driver change no bit either.  A texel WITHOUT depth that holds a normal (not the all-zero normal of a cleared
+ *    texel) counts for the uniform-normal shortcut like a surface texel; a workgroup whose reference normal holds a NaN takes no shortcut.
+ *    (tests/fuzz_parity.py sweeps sizes, tunables, partitions and poisoned texels for exactly these claims; tests/test_gpu_fuzz.py pins
+ *    what it found.)  What still depends on the path taken, within the stated tolerance: the pair launch svgf_atrous_pair (an opt-in)
+ *    takes the exact form for every pixel of a band that holds a NaN.
  *  - Strips: a context may hold only rows [y0, y0+rows) of a WxH frame (multi-GPU row strips);
  *    "inside the frame" tests always use the global frame, so strip results are bit-identical
  *    to the whole-frame result as long as the halo rows hold valid data.

@@ -62,7 +62,7 @@ __device__ __forceinline__ void lds_store(uint32_t addr, uint32_t v) { *(lds_u32
 // reference does (taps24<.., kTapsNaN>) and a select for the sky centres.  A workgroup whose texels are all finite never gets there.
 // WT: the band's stores are written THROUGH to memory (sc0 sc1) — the ranges that signal (RangePlan): their rows are read by another kernel (RCCL's) while
 // this launch is still running, and making them visible with release fences instead means an L2 write-back per workgroup (measured: the one-launch
-// iteration 0.17 ms SLOWER per frame than three launches, profiles/r05_strip_sim_*.txt)
+// iteration 0.17 ms SLOWER per frame than three launches, profiles/r05_small_experiments.txt)
 template <int ST, int S, int TX, bool EXACT>
 __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, const AtrousLds<S, TX>& L, int x0, int j0, int j1, int ybase, bool wt = false) {
     constexpr int WL = TX + 4 * S;                 // staged columns per ring row
@@ -183,7 +183,10 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
         const TapCentre c = centre_setup<S>(lds_read_a(ca), lds_read_l(cl), lds_read_l(cl + NOFF), dq0, inv_phi_c);
         const bool sky = c.sky;
         const bool wave_has_surface = wave_any(!sky);
-        const bool uniform = !EXACT && !a.no_fastpath && !wave_any(lane < kRing * 8 && lds_load(L.flag(0) + 4 * (lane < kRing * 8 ? lane : 0)) != 0u);
+        // (a reference normal that holds a NaN: no uniform form — its exponent bases are NaN for EVERY centre of the workgroup, the sky texels
+        // that are to be copied included, and the second pass, which looks at the general taps, would not see what the first had stored)
+        const bool uniform = !EXACT && !a.no_fastpath && ref_base.e[0] == ref_base.e[0] &&
+                             !wave_any(lane < kRing * 8 && lds_load(L.flag(0) + 4 * (lane < kRing * 8 ? lane : 0)) != 0u);
         bool redo = true;                          // EXACT: this lane's first-pass result held a NaN — only those texels are stored again
         const float4 o = filter_px<S, kTapDepth, NOFF, EXACT>(rows, c, phi_n, wave_has_surface, uniform, &ref_base, EXACT ? &redo : nullptr);
         if constexpr (!EXACT) nan_out |= lanes_where(__builtin_isunordered(o.x, o.w));

@@ -221,8 +221,13 @@ __device__ __forceinline__ unsigned long long commit_px(const RawPx<ST, DZ>& r, 
         *(lds_f32x2*)(uintptr_t)addr_l = (f32x2){lum, z};
         *(lds_f32x2*)(uintptr_t)(addr_l + noff) = (f32x2){__uint_as_float(r.n.x), nz};
     }
-    // a texel without depth (sky, or outside the frame) has weight 0 through the depth term whatever its normal
-    return lanes_where(z != kSkyZ) & (lanes_where(r.n.x != ref01) | lanes_where((r.n.y & 0xffffu) != refz));
+    // A texel without depth (sky, or outside the frame) whose normal is all-zero — a cleared texel — does not count: its weight is 0 through the
+    // depth term in the uniform form and through n.n' = 0 in the general one (and where the centre's depth is a NaN both forms turn NaN and the
+    // exact form decides).  A texel without depth that DOES hold a normal counts like a surface texel: the general taps read that normal — a NaN
+    // in it makes them NaN and sends the pixel to the exact form — while the uniform taps never look at it, so leaving it out would make the
+    // rounding of the pixels around it depend on what else the workgroup's tile holds, i.e. on how strips and row ranges cut the frame.
+    const uint32_t nzb = r.n.y & 0xffffu;
+    return (lanes_where(z != kSkyZ) | lanes_where((r.n.x | nzb) != 0u)) & (lanes_where(r.n.x != ref01) | lanes_where(nzb != refz));
 }
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
 

@@ -278,9 +278,9 @@ __device__ __forceinline__ void moments_pixel(const Geo& g, const MomentsArgs& a
 // ARITH = 0: the tap weight as moments_pixel evaluates it (variant DIRECT, a radius other than 3, PhiNormal == 0: the stage calls then run
 // moments_pixel).  ARITH = 1: as moments_lds_kernel evaluates it (svgf_moments_lds.h, moments_taps49: the fused exponent on the same
 // bits) — the kernel the default variants run for a frame full of young pixels, so that which of the two serves a frame is a matter of
-// speed alone: the frame driver may switch between them from frame to frame without a bit of the results changing (finite input; a
-// workgroup of the streaming kernel that has staged a NaN evaluates ALL its luminance terms the reference's way, :424, this one only
-// the NaN ones).
+// speed alone: the frame driver may switch between them from frame to frame without a bit of the results changing — next to NaN / inf
+// texels too: both evaluate a pixel whose fused-exponent sums hold a NaN again with the reference's `max(term, 0.0)` (:424) for all its taps,
+// and no other pixel.
 template <int ST, int ARITH>
 __device__ __forceinline__ void moments_group8(const Geo& g, const MomentsArgs& a, bool valid, uint32_t pix) {
     constexpr int RM = 3, NW = 2 * RM + 1;
@@ -326,7 +326,7 @@ __device__ __forceinline__ void moments_group8(const Geo& g, const MomentsArgs& 
     const float ncz1 = unpack_h2(nraw.y).x, il1 = il * kLog2e;
     const float izb1 = hw_rcp(fmaxf(zc == kSkyZ ? 0.0f : mc.w, 1e-8f) * 3.0f) * kLog2e;
     // this lane's seven taps: weight and the values the sums take from them
-    float tw[NW], t0[NW], t1[NW], t2[NW];
+    float tw[NW], twx[NW], t0[NW], t1[NW], t2[NW];
     unsigned okbits = 0u;
 #pragma unroll
     for (int r = 0; r < NW; r++) {
@@ -344,14 +344,16 @@ __device__ __forceinline__ void moments_group8(const Geo& g, const MomentsArgs& 
             const int l2 = xx * xx + yy * yy;                         // moments_taps49's depth scale by tap distance (len_class7)
             const float km = l2 == 1 ? 1.0f : l2 == 2 ? 0.70710678118654752f : l2 == 4 ? 0.5f : l2 == 5 ? 0.44721359549995794f : l2 == 8 ? 0.35355339059327376f
                            : l2 == 9 ? 0.33333333333333333f : l2 == 10 ? 0.31622776601683794f : l2 == 13 ? 0.27735009811261456f : 0.23570226039551584f;
+            // both of moments_taps49's forms: the fused exponent (kTapsGeneral), and the reference's `max(term, 0.0)` = fmax, which drops a NaN
+            // term (:424, kTapsNaN) — the sums take the first; a pixel whose sums come out NaN takes the second for ALL its taps, below
             const float d = clamp01(fmaf(unpack_h2(tn[r].y).x, ncz1, dot2_h2(tn[r].x, nraw.x)));
-            float e = hw_log2(d) * a.phi_normal;
-            const float dl = lum_exact(t0[r], t1[r], t2[r]) - lc;
-            if (dl == dl) e = fmaf(-fabsf(dl), il1, e);               // a NaN luminance: max(|dl| / phi_l, 0.0) is CUDA's fmax, which drops it (:424)
+            const float en = hw_log2(d) * a.phi_normal;
+            const float adl = fabsf(lum_exact(t0[r], t1[r], t2[r]) - lc);
             const float dz = fabsf(zp - zc), izk = l2 == 1 ? izb1 : izb1 * km;
-            const float pz = dz * izk;
-            if (l2 != 0 && pz == pz) e = fmaf(-dz, izk, e);          // a NaN depth term (NaN depth, inf - inf, inf x 0): max(|dz| / phi_z, 0.0) drops it likewise (:424)
+            float e = fmaf(-adl, il1, en), ex = en - fmaxf(adl * il1, 0.0f);
+            if (l2 != 0) { e = fmaf(-dz, izk, e); ex -= fmaxf(dz * izk, 0.0f); }
             tw[r] = hw_exp2(e);
+            twx[r] = hw_exp2(ex);
         }
         okbits |= ok[r] ? 1u << r : 0u;
     }
@@ -359,20 +361,34 @@ __device__ __forceinline__ void moments_group8(const Geo& g, const MomentsArgs& 
     unsigned okc[NW];
 #pragma unroll
     for (int c = 0; c < NW; c++) okc[c] = (unsigned)__shfl((int)okbits, base + c);
-    float sw = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sm1 = 0.f, sm2 = 0.f;
+    float sw, sr, sg, sb, sm1, sm2;
+    auto sums = [&](const float (&wt)[NW]) __attribute__((always_inline)) {
+        sw = 0.f; sr = 0.f; sg = 0.f; sb = 0.f; sm1 = 0.f; sm2 = 0.f;
 #pragma unroll
-    for (int r = 0; r < NW; r++) {
+        for (int r = 0; r < NW; r++) {
 #pragma unroll
-        for (int c = 0; c < NW; c++) {
-            // (all of a row's shuffles issued before its seven taps are accumulated shortens a pass, but costs 40 registers and a third of the
-            // resident waves: slower for this launch, whose passes are spread one per wave - profiles/r04_small_experiments.txt block 9)
-            const float w = __shfl(tw[r], base + c), c0 = __shfl(t0[r], base + c), c1 = __shfl(t1[r], base + c), c2 = __shfl(t2[r], base + c);
-            const float m1 = __shfl(tm[r].x, base + c), m2 = __shfl(tm[r].y, base + c);
-            if ((okc[c] >> r) & 1u) {
-                sw += w;                                              // :497-499
-                sr = fmaf(c0, w, sr); sg = fmaf(c1, w, sg); sb = fmaf(c2, w, sb);
-                sm1 = fmaf(m1, w, sm1); sm2 = fmaf(m2, w, sm2);
+            for (int c = 0; c < NW; c++) {
+                // (all of a row's shuffles issued before its seven taps are accumulated shortens a pass, but costs 40 registers and a third of the
+                // resident waves: slower for this launch, whose passes are spread one per wave - profiles/r04_small_experiments.txt block 9)
+                const float w = __shfl(wt[r], base + c), c0 = __shfl(t0[r], base + c), c1 = __shfl(t1[r], base + c), c2 = __shfl(t2[r], base + c);
+                const float m1 = __shfl(tm[r].x, base + c), m2 = __shfl(tm[r].y, base + c);
+                if ((okc[c] >> r) & 1u) {
+                    sw += w;                                          // :497-499
+                    sr = fmaf(c0, w, sr); sg = fmaf(c1, w, sg); sb = fmaf(c2, w, sb);
+                    sm1 = fmaf(m1, w, sm1); sm2 = fmaf(m2, w, sm2);
+                }
             }
+        }
+    };
+    sums(tw);
+    if constexpr (ARITH == 1) {
+        // moments_lds_kernel's rule (svgf_moments_lds.h): a pixel whose sums hold a NaN — one with a NaN, inf - inf or 0 x inf in its window, and
+        // no other — is evaluated again the reference's way; every other pixel keeps the fused exponent's bits, whichever kernel serves it
+        if (wave_any(__builtin_isunordered(sw, sm2) | __builtin_isunordered(sr, sg) | __builtin_isunordered(sb, sm1))) {
+            const float w1 = sw, r1 = sr, g1 = sg, b1 = sb, a1 = sm1, a2 = sm2;
+            const bool redo = __builtin_isunordered(w1, a2) | __builtin_isunordered(r1, g1) | __builtin_isunordered(b1, a1);
+            sums(twx);
+            if (!redo) { sw = w1; sr = r1; sg = g1; sb = b1; sm1 = a1; sm2 = a2; }
         }
     }
     if (!valid || j != 0) return;                                     // one lane of the group writes

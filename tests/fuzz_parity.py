@@ -1,0 +1,325 @@
+"""Seeded random sweep of the parity and bit-identity claims (test infrastructure: it calls the oracle; nothing in the product imports it).
+
+    python -m tests.fuzz_parity --minutes 10 --seed 1000 [--kinds stage,strips,driver] [--out gpurun_out/fuzz.txt]
+
+Each trial draws a frame size (down to 1 x 1, up past the 128-pixel tile and the 64-lane wave in both directions), a storage format, the
+tunables over the GUI's ranges (GUI.cpp:988-993), a camera motion, optionally NaN / inf radiance texels and poisoned G-buffer texels
+(tests/gbuffer_poison.py), and checks one of
+
+  stage    temporal (bitwise), moments and one a-trous iteration (stage tolerances, tests/gpu_helpers.py:TOL) against the ORACLE from
+           identical inputs, under a random kernel variant;
+  strips   the C++ strip driver with real peer addressing (mailbox transport, random world size, halo plan, motion reach, schedule) against the
+           single-context FRAME DRIVER, bit for bit, over a few frames;
+  driver   the frame driver under a random setting (two frames in flight, general tap path, young-pixel launch only, svgf_set_prev_guide, or the
+           stage calls on caller-owned planes instead) against the plain frame driver, bit for bit, and its history against the oracle's
+           free-running one.
+
+A trial is a pure function of its seed: `run_trial(kind, seed)` re-runs one (tests/test_gpu_fuzz.py pins the seeds that ever failed, and a few
+that never did).  Exit code 1 if any trial failed; the summary lists the seeds."""
+from __future__ import annotations
+
+import argparse
+import sys
+import time
+import traceback
+
+import numpy as np
+
+from svgf_amd import synth
+from tests.gbuffer_poison import poison_gbuffer
+from tests.helpers import CDT, gbuf
+
+KINDS = ("stage", "strips", "driver")
+
+
+def _size(rng):
+    """Frame sizes: mostly ragged mid-sized, sometimes tiny, sometimes just around the tile / wave widths."""
+    c = rng.integers(0, 10)
+    if c == 0:
+        return int(rng.integers(1, 9)), int(rng.integers(1, 9))
+    if c == 1:
+        return int(rng.choice([63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 513])), int(rng.integers(1, 80))
+    if c == 2:
+        return int(rng.integers(1, 40)), int(rng.integers(60, 700))
+    return int(rng.integers(9, 700)), int(rng.integers(9, 260))
+
+
+def _tunables(rng):
+    return dict(phi_colour=float(np.exp(rng.uniform(np.log(0.05), np.log(100.0)))), phi_normal=float(rng.uniform(0.5, 256.0)),
+                depth_threshold=float(rng.uniform(0.0, 3.0)), normal_threshold=float(rng.uniform(0.0, 1.0)),
+                history_base=int(rng.integers(1, 256)), mesh_id_test=int(rng.integers(0, 2)))
+
+
+def _sprinkle(rng, a, n):
+    """n NaN / +inf / -inf texels (single channels) into a float plane."""
+    flat = a.reshape(-1)
+    if flat.size:
+        idx = rng.integers(0, flat.size, n)
+        flat[idx] = rng.choice(np.array([np.nan, np.inf, -np.inf], np.float32), n).astype(a.dtype)
+    return a
+
+
+def _poisoned(rng, f, what):
+    H, W = f["region"].shape
+    if (f["region"] != synth.SKY).sum() < 4:
+        return f
+    return poison_gbuffer(rng, f, what=what, per_value=int(rng.integers(1, 5)))[0]
+
+
+def _close(G, got, want, storage, what, colour_abs=None):
+    from tests.test_gpu_nonfinite import assert_close_with_nan
+    if colour_abs is None:
+        assert_close_with_nan(G, got, want, storage, what)
+    else:
+        assert_close_with_nan(G, got, want, storage, what, colour_abs=colour_abs)
+
+
+# ------------------------------------------------------------------------------------------------------------------ stage vs oracle
+def trial_stage(G, oracle, seed):
+    from svgf_amd import filter as F
+    rng = np.random.default_rng(seed)
+    W, H = _size(rng)
+    storage = ("f32", "f16")[int(rng.integers(0, 2))]
+    dt = CDT[storage]
+    tun = _tunables(rng)
+    variant = str(rng.choice(["auto", "lds", "direct", "lds-general"]))
+    radius = int(rng.choice([3, 3, 1]))
+    step = int(2 ** rng.integers(0, 7))
+    mv = (float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4)))
+    poison = bool(rng.integers(0, 2))
+    f0, f1 = synth.make_frame(W, H, seed % 97, mv=mv), synth.make_frame(W, H, seed % 97 + 1, mv=mv)
+    if poison:
+        f0, f1 = _poisoned(rng, f0, ("motion", "depth", "ddepth", "normal", "id")), _poisoned(rng, f1, ("motion", "depth", "ddepth", "normal", "id"))
+    desc = f"stage seed {seed}: {W}x{H} {storage} {variant} r{radius} step {step} poison {poison}"
+    d = F.Denoiser(W, H, F.Params(storage=storage, moments_radius=radius, variant=variant, **tun))
+    # temporal: bit-exact whatever the inputs
+    prev = rng.uniform(-0.1, 1.2, (H, W, 4)).astype(dt)
+    mom_prev = rng.uniform(0, 1, (H, W, 2)).astype(dt)
+    hist_prev = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    cur = rng.uniform(-0.1, 1.4, (H, W, 4)).astype(dt)
+    if poison:
+        _sprinkle(rng, cur, 5), _sprinkle(rng, prev, 5), _sprinkle(rng, mom_prev, 3)
+    o = np.zeros_like(cur); hist = np.zeros((H, W), np.uint8); mom = np.zeros((H, W, 2), dt)
+    oracle.temporal(W, H, storage, prev, cur, o, gbuf(f1), gbuf(f0), hist_prev, hist, mom, mom_prev, depth_threshold=tun["depth_threshold"],
+                    normal_threshold=tun["normal_threshold"], history_base=tun["history_base"], mesh_id_test=tun["mesh_id_test"])
+    o_col, o_hist, o_mom = d.new_colour(), d.new_history(), d.new_moments()
+    d.TemporalFilter(G.dev(prev), G.dev(cur), o_col, G.gb_dev(f1), G.gb_dev(f0), G.dev(hist_prev), o_hist, o_mom, G.dev(mom_prev))
+    assert np.array_equal(G.host(o_hist), hist), desc + ": history"
+    assert np.array_equal(G.host(o_col).view(np.uint8), o.view(np.uint8)), desc + ": temporal colour"
+    assert np.array_equal(G.host(o_mom).view(np.uint8), mom.view(np.uint8)), desc + ": temporal moments"
+    # the depth-, ddepth- and normal-poisoned G-buffer for the spatial stages (a poisoned motion vector is the temporal stage's business)
+    fs = synth.make_frame(W, H, seed % 97 + 1, mv=mv)
+    if poison:
+        fs = _poisoned(rng, fs, ("depth", "ddepth", "normal"))
+    # moments
+    col = rng.uniform(0, 1, (H, W, 4)).astype(dt)
+    momp = rng.uniform(0, 1, (H, W, 2)).astype(dt)
+    hl = rng.integers(1, 8, (H, W)).astype(np.uint8)
+    want = np.zeros_like(col)
+    oracle.moments(W, H, storage, col, want, momp, gbuf(fs), hl, phi_colour=tun["phi_colour"], phi_normal=tun["phi_normal"], radius=radius)
+    out = d.new_colour()
+    d.FilterMoments(G.dev(col), out, G.dev(momp), G.gb_dev(fs), G.dev(hl))
+    got = G.host(out)
+    keep = hl >= 4
+    assert np.array_equal(got[keep].view(np.uint8), col[keep].view(np.uint8)), desc + ": moments copy"
+    _close(G, got[..., :3], want[..., :3], storage, desc + ": moments colour", colour_abs=2e-5 if storage == "f32" else 1e-3)
+    g, w = got[..., 3].astype(np.float64), want[..., 3].astype(np.float64)
+    lim = 8e-5 if storage == "f32" else 8e-5 + np.abs(w) * 2.0 ** -10
+    assert np.all(np.abs(g - w) <= lim), desc + f": moments variance {np.abs(g - w).max():.3e}"
+    # one a-trous iteration
+    src = np.concatenate([rng.uniform(-0.2, 1.3, (H, W, 3)), rng.uniform(-0.01, 0.2, (H, W, 1))], -1).astype(dt)
+    if poison:
+        _sprinkle(rng, src, 6)
+    want = np.zeros_like(src); fbw = np.full_like(src, 7)
+    oracle.atrous(W, H, storage, src, want, fbw, gbuf(fs), step=step, phi_colour=tun["phi_colour"], phi_normal=tun["phi_normal"], iteration=0)
+    out, fb = d.new_colour(), G.dev(np.full_like(src, 7))
+    d.FilterKernel(G.dev(src), out, fb, G.gb_dev(fs), step, 0)
+    try:
+        _close(G, G.host(out), want, storage, desc + ": a-trous")
+        _close(G, G.host(fb), fbw, storage, desc + ": a-trous feedback")
+    except AssertionError as e:
+        e.ctx = dict(frame=fs, src=src, got=G.host(out), want=want, step=step, denoiser=d, tun=tun)      # (tests/fuzz_debug.py)
+        raise
+    d.close()
+    return desc
+
+
+# ------------------------------------------------------------------------------------------------------------------ strips vs frame driver
+def _sequence(rng, W, H, N, mv, poison, storage):
+    fr = [synth.make_frame(W, H, k, mv=mv) for k in range(N)]
+    if poison:
+        for k in range(N):
+            if rng.integers(0, 2):
+                fr[k] = _poisoned(rng, fr[k], ("motion", "depth", "ddepth", "normal", "id"))
+            if rng.integers(0, 2):
+                fr[k] = dict(fr[k], radiance=_sprinkle(rng, fr[k]["radiance"].copy(), 4))
+    return fr
+
+
+def trial_strips(G, oracle, seed):
+    import torch
+    from svgf_amd import filter as F
+    from svgf_amd import strips
+    rng = np.random.default_rng(seed)
+    storage = ("f32", "f16")[int(rng.integers(0, 2))]
+    tun = _tunables(rng)
+    steps = int(rng.choice([5, 5, 5, 3, 1, 2, 4, 6, 7]))
+    radius = int(rng.choice([3, 3, 1]))
+    world = int(rng.integers(2, 9))
+    plan = str(rng.choice(["ghost", "grouped", "per-iteration", "auto"]))
+    reach = int(rng.integers(0, 7))
+    W = int(rng.choice([int(rng.integers(1, 64)), int(rng.integers(64, 700)), 128, 129, 256]))
+    # a height the plan accepts: walk up from a random start
+    H = int(rng.integers(world, 1200))
+    for _ in range(40):
+        if strips._plan_fits(W, H, 0, world, steps, plan, radius, reach):
+            break
+        H += int(rng.integers(16, 200))
+    else:
+        return f"strips seed {seed}: no height found (skipped)"
+    mvy = float(rng.uniform(-reach, reach)) if reach else 0.0
+    mv = (float(rng.uniform(-4, 4)), mvy)
+    poison = bool(rng.integers(0, 2))
+    N = int(rng.integers(2, 5))
+    edge_first, own_streams = bool(rng.integers(0, 4)), bool(rng.integers(0, 2))
+    desc = (f"strips seed {seed}: {W}x{H} {storage} world {world} plan {plan} reach {reach} mv ({mv[0]:.2f},{mv[1]:.2f}) steps {steps} r{radius} "
+            f"poison {poison} frames {N} edge_first {edge_first} own_streams {own_streams}")
+    fr = _sequence(rng, W, H, N, mv, poison, storage)
+    P = F.Params(storage=storage, steps=steps, moments_radius=radius, **tun)
+    whole = F.Denoiser(W, H, P)
+    streams = [torch.cuda.Stream(priority=-1) for _ in range(world)] if own_streams else None
+    drv = strips.NativeStrips(W, H, world, P, list(range(world)), [0] * world, streams=[s.cuda_stream for s in streams] if streams else None,
+                              plan=plan, motion_reach=reach, transport="mailbox")
+    drv.set_edge_first(edge_first)
+    try:
+        gbs = [G.gb_dev(f) for f in fr]
+        prev_in = None
+        for k in range(N):
+            want = G.host(whole.Render(G.dev(fr[k]["radiance"].astype(G.NPDT[storage])), gbs[k], gbs[k - 1] if k else None))
+            torch.cuda.synchronize()
+            cur_in = []
+            for lay in drv.layouts:
+                sl = slice(lay["y0"], lay["y1"])
+                cur_in.append((G.dev(np.ascontiguousarray(fr[k]["radiance"][sl].astype(G.NPDT[storage]))),
+                               F.GBuffer(*(G.dev(np.ascontiguousarray(fr[k][n][sl])) for n in ("motion", "normal", "uv")))))
+            torch.cuda.synchronize()
+            outs = drv.frame([c[0] for c in cur_in], [c[1] for c in cur_in], [p[1] for p in prev_in] if prev_in else None)
+            drv.sync()
+            got = np.concatenate([G.host(drv.owned(r, o)) for r, o in enumerate(outs)], 0)
+            if not np.array_equal(got.view(np.uint8), want.view(np.uint8)):
+                bad = np.argwhere((got.view(np.uint8) != want.view(np.uint8)).reshape(H, W, -1).any(-1))
+                raise AssertionError(desc + f": frame {k}: {len(bad)} px differ, first {bad[:4].tolist()}")
+            prev_in = cur_in
+        hist = np.concatenate([G.host(drv.owned(r, drv.state_plane(r, F.PLANE_HISTORY, 1 - drv.pingpong(r)))) for r in range(world)], 0)
+        assert np.array_equal(hist, G.host(whole.state_plane(F.PLANE_HISTORY, 1 - whole.pingpong()))), desc + ": history"
+    finally:
+        drv.close()
+        whole.close()
+    return desc
+
+
+# ------------------------------------------------------------------------------------------------------------------ frame driver settings
+def trial_driver(G, oracle, seed):
+    import torch
+    from svgf_amd import filter as F
+    rng = np.random.default_rng(seed)
+    W, H = _size(rng)
+    storage = ("f32", "f16")[int(rng.integers(0, 2))]
+    tun = _tunables(rng)
+    steps = int(rng.choice([5, 5, 3, 0, 1, 2, 7]))
+    radius = int(rng.choice([3, 3, 1]))
+    mv = (float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4)))
+    poison = bool(rng.integers(0, 2))
+    N = int(rng.integers(3, 7))
+    setting = str(rng.choice(["in_flight", "general", "no_adaptive", "prev_guide", "stage_calls"]))
+    desc = f"driver seed {seed}: {W}x{H} {storage} steps {steps} r{radius} poison {poison} frames {N} setting {setting}"
+    fr = _sequence(rng, W, H, N, mv, poison, storage)
+    P = F.Params(storage=storage, steps=steps, moments_radius=radius, **tun)
+    a = F.Denoiser(W, H, P)
+    b = F.Denoiser(W, H, F.Params(storage=storage, steps=steps, moments_radius=radius, variant="lds-general", **tun) if setting == "general" else P)
+    stages = G.HipPipeline(W, H, storage, steps=steps, moments_radius=radius, **tun) if setting == "stage_calls" else None
+    if setting == "in_flight":
+        b.set_frames_in_flight(2)
+    elif setting == "no_adaptive":
+        b.set_adaptive_moments(False)
+    elif setting == "prev_guide":
+        b.set_prev_guide(True)
+    ref = oracle.Pipeline(W, H, storage, steps=steps, nthreads=8, moments_radius=radius, **tun)
+    gbs = [G.gb_dev(f) for f in fr]
+    rads = [G.dev(f["radiance"].astype(G.NPDT[storage])) for f in fr]
+    try:
+        for k in range(N):
+            kp = max(k - 1, 0)
+            x = G.host(a.Render(rads[k], gbs[k], gbs[kp] if k else None))
+            if stages is not None:
+                y = stages.frame(fr[k]["radiance"], gbs[k], gbs[kp])    # svgf_temporal / svgf_moments / svgf_atrous on caller-owned planes
+            else:
+                y = b.Render(rads[k], gbs[k], gbs[kp] if k else None)
+                if setting == "in_flight":
+                    b.flush()                                         # the view is ordered on the context's stream by the next Render / flush / sync
+                y = G.host(y)
+            torch.cuda.synchronize()
+            assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), desc + f": frame {k}"
+            ref.frame(fr[k]["radiance"], gbuf(fr[k]), gbuf(fr[kp]))
+            if not poison:
+                # the accept / reject masks of a free-running device sequence equal the oracle's (NaN-free inputs: a poisoned colour plane may
+                # flip a comparison the two round differently; the stage-wise trials cover those from identical inputs)
+                assert np.array_equal(G.host(a.state_plane(F.PLANE_HISTORY, 1 - a.pingpong())), ref.taps["hist"]), desc + f": frame {k}: history vs oracle"
+    finally:
+        a.close()
+        b.close()
+    return desc
+
+
+TRIALS = {"stage": trial_stage, "strips": trial_strips, "driver": trial_driver}
+
+
+def run_trial(kind, seed, G=None, oracle=None):
+    if G is None:
+        from tests import gpu_helpers as G                    # noqa: N813
+    if oracle is None:
+        from oracle import oracle as oracle                   # noqa: PLW0127
+    return TRIALS[kind](G, oracle, seed)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=5.0)
+    ap.add_argument("--seed", type=int, default=1000)
+    ap.add_argument("--kinds", default=",".join(KINDS))
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    import torch
+    assert torch.cuda.is_available(), "needs an MI355X"
+    from oracle import oracle
+    from tests import gpu_helpers as G                        # noqa: N813
+    oracle.build()
+    kinds = args.kinds.split(",")
+    t_end = time.monotonic() + args.minutes * 60
+    done, failed, lines = {k: 0 for k in kinds}, [], []
+    seed = args.seed
+    while time.monotonic() < t_end:
+        kind = kinds[seed % len(kinds)]
+        try:
+            desc = run_trial(kind, seed, G, oracle)
+            lines.append("ok   " + desc)
+        except Exception as e:  # noqa: BLE001
+            failed.append((kind, seed))
+            msg = str(e).splitlines()[0][:400] if str(e) else type(e).__name__
+            lines.append(f"FAIL {kind} seed {seed}: {type(e).__name__}: {msg}")
+            if not isinstance(e, AssertionError):
+                lines.append(traceback.format_exc())
+            torch.cuda.synchronize()
+        done[kind] += 1
+        seed += 1
+    summary = f"fuzz_parity: seeds {args.seed}..{seed - 1}: " + ", ".join(f"{k} {n}" for k, n in done.items()) + f"; failed {len(failed)}: {failed}"
+    text = "\n".join(lines + [summary])
+    if args.out:
+        with open(args.out, "w") as fh:
+            fh.write(text + "\n")
+    print("\n".join([ln for ln in lines if not ln.startswith("ok")] + [summary]))
+    sys.exit(1 if failed else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -52,7 +52,8 @@ def assert_colour_close(got, want, storage, what=""):
         assert np.array_equal(np.isfinite(got.astype(np.float32)), fin), f"{what}: finite masks differ"
         d = half_ulp_diff(got[fin], want[fin])
         assert d.max() <= t["max_ulp"], f"{what}: {d.max()} half-ulps"
-        assert (d > 0).mean() <= t["frac"], f"{what}: {(d > 0).mean():.2e} of values off by one half-ulp"
+        # (a share of the values — or two of them: on a frame of a few dozen texels one flip is already beyond the share)
+        assert (d > 0).sum() <= max(t["frac"] * d.size, 2), f"{what}: {(d > 0).mean():.2e} of values off by one half-ulp"
 
 
 class HipPipeline:

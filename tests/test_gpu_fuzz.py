@@ -1,0 +1,52 @@
+"""Pinned trials of the seeded sweep (tests/fuzz_parity.py): every seed that ever failed there, with what it found, and a few that never did.
+
+What the sweep found in round 5 (all in frames whose G-buffer holds NaN / out-of-range texels, tests/gbuffer_poison.py):
+  * a SKY texel (depth 0) holding a NaN normal: the general a-trous taps read it, turn NaN and send the pixel to the exact form; the
+    uniform-normal taps never look at it — which of the two roundings the pixels around it got depended on what else the workgroup's tile
+    held, so strips and row ranges differed from the whole frame in the last bit (svgf_device.h:commit_px now counts such a texel);
+  * a reference normal (a workgroup's first texel) holding a NaN while every other counted texel of a tiny frame carried the same bits: the
+    uniform form's exponent bases were NaN for the sky centres too, which are to be copied (svgf_atrous_lds.h: no uniform form then);
+  * the young-pixel launch dropped only the NaN luminance / depth terms of a window, the streaming moments kernel evaluates the whole pixel
+    the reference's way once its sums hold a NaN: the frame driver (which picks one of the two per frame) differed from itself with
+    svgf_set_adaptive_moments(0), and from the stage calls (svgf_kernels.hip:moments_group8 now follows the streaming kernel's rule)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+STRIPS = [1192, 1483, 1531, 1621, 1651, 1969, 2311, 2329, 2755, 3841, 5230, 6463, 40000, 40003, 40006]
+DRIVER = [7313, 1916, 1640, 1787, 2843, 2993, 5447, 7034, 24140, 40001, 40004, 40007, 40010]
+STAGE = [6657, 1266, 3795, 3807, 5883, 2529, 40002, 40005, 40008, 40011]
+
+
+@pytest.fixture(scope="module")
+def G():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from tests import gpu_helpers
+    return gpu_helpers
+
+
+def _check(kind, seed):
+    from tests import fuzz_parity
+    assert fuzz_parity.KINDS[seed % len(fuzz_parity.KINDS)] == kind, "the sweep draws a seed's kind from seed % 3"
+
+
+@pytest.mark.parametrize("seed", STRIPS)
+def test_strips_equal_the_frame_driver(G, oracle, seed):
+    from tests import fuzz_parity
+    _check("strips", seed)
+    fuzz_parity.run_trial("strips", seed, G, oracle)
+
+
+@pytest.mark.parametrize("seed", DRIVER)
+def test_frame_driver_settings_and_stage_calls_give_the_same_bits(G, oracle, seed):
+    from tests import fuzz_parity
+    _check("driver", seed)
+    fuzz_parity.run_trial("driver", seed, G, oracle)
+
+
+@pytest.mark.parametrize("seed", STAGE)
+def test_stages_against_the_oracle(G, oracle, seed):
+    from tests import fuzz_parity
+    _check("stage", seed)
+    fuzz_parity.run_trial("stage", seed, G, oracle)

@@ -173,12 +173,12 @@ def test_free_running_sequence_with_poisoned_gbuffers(G, oracle, storage, mv, va
         assert worst <= env["max_abs"], f"HIP-vs-oracle {worst:.3e} is outside oracle-vs-oracle' {env['max_abs']:.3e}"
 
 
-@pytest.mark.parametrize("variant", ["direct"])
+@pytest.mark.parametrize("variant", ["direct", "auto", "lds-general"])
 def test_frame_driver_with_poisoned_gbuffers_equals_stage_calls(G, variant):
     """The frame driver's fusions (guide plane, sparse temporal colour, young masks / list, exact sky zeros) on poisoned G-buffers == the plain
-    stage sequence, bit for bit, both storages — variant direct, where the stage call and the driver's young-pixel launch run the same tap code
-    (under the default variants svgf_moments runs the streaming kernel, which rounds a pixel whose WINDOW holds a NaN depth differently from the
-    young-pixel launch: include/svgf.h, "Bit-identity next to a NaN"; the free-running test above holds those against the oracle)."""
+    stage sequence, bit for bit, both storages.  Under the default variants svgf_moments runs the streaming kernel for every pixel and the
+    driver serves steady-state young pixels with the young-pixel launch: the two follow the same rule next to a NaN (include/svgf.h,
+    "Bit-identity next to a NaN": a pixel whose fused-exponent sums hold a NaN is evaluated again the reference's way, no other)."""
     from svgf_amd import filter as F
     W, H, N = 203, 77, 7
     fr = _poisoned_sequence(W, H, N, (-2.5, 1.5), 161, which=(1, 3, 4))
@@ -199,9 +199,7 @@ def test_strip_driver_with_poisoned_gbuffers_equals_the_whole_frame(G, plan):
     """Three ranks with real peer addressing (the mailbox transport), a pan with motion reach 3, poisoned G-buffers: every frame equals the
     single-context FRAME DRIVER's BIT FOR BIT.  (A saturated motion vector lands outside the FRAME, so it is a rejection on every rank and
     never a halo violation; a NaN depth makes the streaming kernels redo pixels — only those whose fast result held a NaN, so the finite ones
-    do not depend on how the strips cut tiles and bands.  Against the frame driver, not the stage calls: svgf_moments serves every pixel with
-    the streaming kernel, the drivers serve steady-state young pixels with the young-pixel launch, and the two round a pixel whose WINDOW holds
-    a NaN differently — include/svgf.h, "Bit-identity next to a NaN".)"""
+    do not depend on how the strips cut tiles and bands.)"""
     import torch
     from svgf_amd import filter as F
     from svgf_amd import strips
