@@ -981,7 +981,15 @@ __global__ __launch_bounds__(kBX* kBY) void albedo_kernel(Geo g, const void* in,
     const size_t idx = (size_t)(y - g.y0) * g.W + x;
     const float4 c = Store<ST>::ld4(in, idx), al = Store<ST>::ld4(albedo, idx);
     const float dr = fmaxf(al.x, 1e-3f), dg = fmaxf(al.y, 1e-3f), db = fmaxf(al.z, 1e-3f);
-    const float4 o = MODE == 0 ? make_float4(c.x / dr, c.y / dg, c.z / db, c.w) : make_float4(c.x * dr, c.y * dg, c.z * db, c.w);
+    float4 o;
+    if constexpr (MODE == 0) o = make_float4(c.x / dr, c.y / dg, c.z / db, c.w);
+    else {
+        // (the products are pinned in fp32 registers: a product that is only rounded to half hipcc folds into v_fma_mixlo_f16 with a +0 addend,
+        // which turns -0 x albedo into +0 — found by tests/fuzz_parity.py)
+        float px = c.x * dr, py = c.y * dg, pz = c.z * db;
+        asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));
+        o = make_float4(px, py, pz, c.w);
+    }
     Store<ST>::st4(out, idx, o);
 }
 

@@ -1,6 +1,6 @@
 """Seeded random sweep of the parity and bit-identity claims (test infrastructure: it calls the oracle; nothing in the product imports it).
 
-    python -m tests.fuzz_parity --minutes 10 --seed 1000 [--kinds stage,strips,driver] [--out gpurun_out/fuzz.txt]
+    python -m tests.fuzz_parity --minutes 10 --seed 1000 [--kinds stage,strips,driver,rows,pair,post,stage0] [--out gpurun_out/fuzz.txt]
 
 Each trial draws a frame size (down to 1 x 1, up past the 128-pixel tile and the 64-lane wave in both directions), a storage format, the
 tunables over the GUI's ranges (GUI.cpp:988-993), a camera motion, optionally NaN / inf radiance texels and poisoned G-buffer texels
@@ -12,7 +12,12 @@ tunables over the GUI's ranges (GUI.cpp:988-993), a camera motion, optionally Na
            single-context FRAME DRIVER, bit for bit, over a few frames;
   driver   the frame driver under a random setting (two frames in flight, general tap path, young-pixel launch only, svgf_set_prev_guide, or the
            stage calls on caller-owned planes instead) against the plain frame driver, bit for bit, and its history against the oracle's
-           free-running one.
+           free-running one;
+  rows     a stage call restricted to a row range (svgf_set_rows): the rows inside with the whole-frame call's bits, nothing else written;
+  pair     iterations 0 and 1 in one launch: the frame driver with the fusion against without (finite input, bit for bit), svgf_atrous_pair
+           against the oracle's two iterations (poisoned input, the pair launch's tolerances);
+  stage0   `stage` with -0.0, denormals and the storage type's extremes in the colour and moments planes;
+  post     the stages after the path: TAA + sRGB against the oracle and tiled against per-pixel, albedo (de)modulation bit-exact.
 
 A trial is a pure function of its seed: `run_trial(kind, seed)` re-runs one (tests/test_gpu_fuzz.py pins the seeds that ever failed, and a few
 that never did).  Exit code 1 if any trial failed; the summary lists the seeds."""
@@ -29,7 +34,7 @@ from svgf_amd import synth
 from tests.gbuffer_poison import poison_gbuffer
 from tests.helpers import CDT, gbuf
 
-KINDS = ("stage", "strips", "driver")
+KINDS = ("stage", "strips", "driver", "rows", "pair", "post", "stage0")
 
 
 def _size(rng):
@@ -59,6 +64,17 @@ def _sprinkle(rng, a, n):
     return a
 
 
+def _sprinkle_zeros(rng, a, n):
+    """n texels of -0.0, denormals and the storage type's extremes into a float plane (the kinds added later use it: the first three keep
+    their draws, so that their pinned seeds keep their frames)."""
+    flat = a.reshape(-1)
+    if flat.size:
+        tiny = np.finfo(a.dtype).tiny
+        vals = np.array([-0.0, 0.0, tiny / 4, -tiny / 4, tiny, np.finfo(a.dtype).max, -np.finfo(a.dtype).max], np.float64)
+        flat[rng.integers(0, flat.size, n)] = rng.choice(vals, n).astype(a.dtype)
+    return a
+
+
 def _poisoned(rng, f, what):
     H, W = f["region"].shape
     if (f["region"] != synth.SKY).sum() < 4:
@@ -75,9 +91,12 @@ def _close(G, got, want, storage, what, colour_abs=None):
 
 
 # ------------------------------------------------------------------------------------------------------------------ stage vs oracle
-def trial_stage(G, oracle, seed):
+def trial_stage(G, oracle, seed, zeros=False):
+    """zeros: -0.0, denormals and the storage type's extremes in the colour / moments planes as well (kind "stage0"; drawn from a generator of
+    their own, so that kind "stage" keeps the frames of its pinned seeds)."""
     from svgf_amd import filter as F
     rng = np.random.default_rng(seed)
+    rz = np.random.default_rng(seed ^ 0x5A5A5A)
     W, H = _size(rng)
     storage = ("f32", "f16")[int(rng.integers(0, 2))]
     dt = CDT[storage]
@@ -99,6 +118,8 @@ def trial_stage(G, oracle, seed):
     cur = rng.uniform(-0.1, 1.4, (H, W, 4)).astype(dt)
     if poison:
         _sprinkle(rng, cur, 5), _sprinkle(rng, prev, 5), _sprinkle(rng, mom_prev, 3)
+    if zeros:
+        _sprinkle_zeros(rz, cur, 8), _sprinkle_zeros(rz, prev, 8), _sprinkle_zeros(rz, mom_prev, 4)
     o = np.zeros_like(cur); hist = np.zeros((H, W), np.uint8); mom = np.zeros((H, W, 2), dt)
     oracle.temporal(W, H, storage, prev, cur, o, gbuf(f1), gbuf(f0), hist_prev, hist, mom, mom_prev, depth_threshold=tun["depth_threshold"],
                     normal_threshold=tun["normal_threshold"], history_base=tun["history_base"], mesh_id_test=tun["mesh_id_test"])
@@ -115,6 +136,9 @@ def trial_stage(G, oracle, seed):
     col = rng.uniform(0, 1, (H, W, 4)).astype(dt)
     momp = rng.uniform(0, 1, (H, W, 2)).astype(dt)
     hl = rng.integers(1, 8, (H, W)).astype(np.uint8)
+    if zeros:
+        flat = col.reshape(-1)
+        flat[rz.integers(0, flat.size, 6)] = rz.choice(np.array([-0.0, 0.0, np.finfo(dt).tiny / 4, np.finfo(dt).tiny], np.float64), 6).astype(dt)
     want = np.zeros_like(col)
     oracle.moments(W, H, storage, col, want, momp, gbuf(fs), hl, phi_colour=tun["phi_colour"], phi_normal=tun["phi_normal"], radius=radius)
     out = d.new_colour()
@@ -130,6 +154,9 @@ def trial_stage(G, oracle, seed):
     src = np.concatenate([rng.uniform(-0.2, 1.3, (H, W, 3)), rng.uniform(-0.01, 0.2, (H, W, 1))], -1).astype(dt)
     if poison:
         _sprinkle(rng, src, 6)
+    if zeros:
+        flat = src.reshape(-1)
+        flat[rz.integers(0, flat.size, 8)] = rz.choice(np.array([-0.0, 0.0, np.finfo(dt).tiny / 4, -np.finfo(dt).tiny / 4, np.finfo(dt).tiny], np.float64), 8).astype(dt)
     want = np.zeros_like(src); fbw = np.full_like(src, 7)
     oracle.atrous(W, H, storage, src, want, fbw, gbuf(fs), step=step, phi_colour=tun["phi_colour"], phi_normal=tun["phi_normal"], iteration=0)
     out, fb = d.new_colour(), G.dev(np.full_like(src, 7))
@@ -141,7 +168,7 @@ def trial_stage(G, oracle, seed):
         e.ctx = dict(frame=fs, src=src, got=G.host(out), want=want, step=step, denoiser=d, tun=tun)      # (tests/fuzz_debug.py)
         raise
     d.close()
-    return desc
+    return desc + (" zeros" if zeros else "")
 
 
 # ------------------------------------------------------------------------------------------------------------------ strips vs frame driver
@@ -271,7 +298,165 @@ def trial_driver(G, oracle, seed):
     return desc
 
 
-TRIALS = {"stage": trial_stage, "strips": trial_strips, "driver": trial_driver}
+
+# ------------------------------------------------------------------------------------------------------------------ row ranges
+def trial_rows(G, oracle, seed):
+    """A stage call restricted to a row range (svgf_set_rows) writes those rows with the whole-frame call's bits and touches nothing else."""
+    import torch
+    from svgf_amd import filter as F
+    rng = np.random.default_rng(seed)
+    W, H = _size(rng)
+    storage = ("f32", "f16")[int(rng.integers(0, 2))]
+    dt = CDT[storage]
+    tun = _tunables(rng)
+    variant = str(rng.choice(["auto", "lds", "direct", "lds-general"]))
+    radius = int(rng.choice([3, 3, 1]))
+    step = int(2 ** rng.integers(0, 7))
+    poison = bool(rng.integers(0, 2))
+    r0 = int(rng.integers(0, H))
+    r1 = int(rng.integers(r0 + 1, H + 1))
+    mv = (float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4)))
+    desc = f"rows seed {seed}: {W}x{H} {storage} {variant} r{radius} step {step} poison {poison} rows [{r0},{r1})"
+    f0, f1 = synth.make_frame(W, H, seed % 89, mv=mv), synth.make_frame(W, H, seed % 89 + 1, mv=mv)
+    if poison:
+        f0, f1 = _poisoned(rng, f0, ("motion", "depth", "ddepth", "normal", "id")), _poisoned(rng, f1, ("motion", "depth", "ddepth", "normal", "id"))
+    d = F.Denoiser(W, H, F.Params(storage=storage, moments_radius=radius, variant=variant, **tun))
+    g0, g1 = G.gb_dev(f0), G.gb_dev(f1)
+    src = np.concatenate([rng.uniform(-0.2, 1.3, (H, W, 3)), rng.uniform(-0.01, 0.2, (H, W, 1))], -1).astype(dt)
+    momp = rng.uniform(0, 1, (H, W, 2)).astype(dt)
+    hl = rng.integers(0, 9, (H, W)).astype(np.uint8)
+    if poison:
+        _sprinkle(rng, src, 6), _sprinkle(rng, momp, 3)
+    _sprinkle_zeros(rng, src, 6), _sprinkle_zeros(rng, momp, 3)
+    s_d, m_d, h_d = G.dev(src), G.dev(momp), G.dev(hl)
+
+    def both(call, nout):
+        """call(outs) once on the whole frame and once on [r0, r1) into planes pre-filled with a sentinel"""
+        whole = [torch.full_like(t, 7) for t in nout]
+        call(whole)
+        part = [torch.full_like(t, 7) for t in nout]
+        d.set_rows(r0, r1)
+        call(part)
+        d.set_rows()
+        torch.cuda.synchronize()
+        for i, (w_, p_) in enumerate(zip(whole, part)):
+            w_, p_ = G.host(w_), G.host(p_)
+            assert np.array_equal(p_[r0:r1].view(np.uint8), w_[r0:r1].view(np.uint8)), desc + f": output {i}: rows inside the range"
+            rest = np.concatenate([p_[:r0], p_[r1:]], 0)
+            assert (rest == 7).all(), desc + f": output {i}: rows outside the range were written"
+    col, mo, hi = d.new_colour(), d.new_moments(), d.new_history()
+    both(lambda o: d.FilterKernel(s_d, o[0], o[1], g1, step, 0), [col, col])
+    both(lambda o: d.FilterMoments(s_d, o[0], m_d, g1, h_d), [col])
+    both(lambda o: d.TemporalFilter(s_d, G.dev(src[::-1].copy()), o[0], g1, g0, h_d, o[1], o[2], m_d), [col, hi, mo])
+    d.close()
+    return desc
+
+
+# ------------------------------------------------------------------------------------------------------------------ the pair launch
+def trial_pair(G, oracle, seed):
+    """Iterations 0 and 1 in one launch: finite input — the frame driver with the fusion == without, bit for bit, state planes included;
+    poisoned input — svgf_atrous_pair against the oracle's two iterations within the pair launch's tolerances."""
+    import torch
+    from svgf_amd import filter as F
+    rng = np.random.default_rng(seed)
+    W, H = _size(rng)
+    storage = ("f32", "f16")[int(rng.integers(0, 2))]
+    dt = CDT[storage]
+    tun = _tunables(rng)
+    poison = bool(rng.integers(0, 3) == 0)
+    variant = str(rng.choice(["auto", "lds-general"]))
+    desc = f"pair seed {seed}: {W}x{H} {storage} {variant} poison {poison}"
+    if poison:
+        fs = _poisoned(rng, synth.make_frame(W, H, seed % 83), ("depth", "ddepth", "normal"))
+        src = np.concatenate([rng.uniform(-0.2, 1.3, (H, W, 3)), rng.uniform(-0.01, 0.2, (H, W, 1))], -1).astype(dt)
+        _sprinkle(rng, src, 4)
+        mid = np.zeros_like(src); want = np.zeros_like(src); want_fb = np.full_like(src, 7)
+        oracle.atrous(W, H, storage, src, mid, want_fb, gbuf(fs), step=1, phi_colour=tun["phi_colour"], phi_normal=tun["phi_normal"], iteration=0)
+        oracle.atrous(W, H, storage, mid, want, None, gbuf(fs), step=2, phi_colour=tun["phi_colour"], phi_normal=tun["phi_normal"], iteration=1)
+        d = F.Denoiser(W, H, F.Params(storage=storage, variant=variant, **tun))
+        out, fb = d.new_colour(), G.dev(np.full_like(src, 7))
+        d.FilterKernelPair(G.dev(src), out, fb, G.gb_dev(fs))
+        _close(G, G.host(fb), want_fb, storage, desc + ": pair feedback")
+        # iteration 1's result: against the device's own two launches (the pair launch takes the exact form for every pixel of a band that
+        # holds a NaN, the two launches only for the pixels whose fast result does: the same values up to the rounding of iteration 0, which
+        # iteration 1's weights amplify — by up to ~50x at the small PhiColour the sweep draws; fp16 storage: a half-ulp flip of iteration 0)
+        mid_d, out2 = d.new_colour(), d.new_colour()
+        d.FilterKernel(G.dev(src), mid_d, None, G.gb_dev(fs), 1, 1)
+        d.FilterKernel(mid_d, out2, None, G.gb_dev(fs), 2, 1)
+        got, two = G.host(out).astype(np.float32), G.host(out2).astype(np.float32)
+        assert np.array_equal(np.isnan(got), np.isnan(two)) and np.array_equal(np.isnan(got), np.isnan(want.astype(np.float32))), desc + ": pair result: NaN masks"
+        with np.errstate(all="ignore"):
+            err = np.abs(np.nan_to_num(got, posinf=0, neginf=0) - np.nan_to_num(two, posinf=0, neginf=0)).max()
+        amp = max(1.0, 50.0 / tun["phi_colour"])         # (iteration 1's weights: exp(-|dl| / (PhiColour * sqrt(variance))) of iteration 0's last bit)
+        assert err <= (2e-4 * amp if storage == "f32" else 2e-2), desc + f": pair against two launches: {err:.3e} (PhiColour {tun['phi_colour']:.3g})"
+        d.close()
+        return desc
+    steps = int(rng.choice([2, 3, 5, 7]))
+    N = int(rng.integers(2, 6))
+    mv = (float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4)))
+    desc += f" steps {steps} frames {N}"
+    fr = [synth.make_frame(W, H, k, mv=mv) for k in range(N)]
+    P = F.Params(storage=storage, steps=steps, variant=variant, **tun)
+    a, b = F.Denoiser(W, H, P), F.Denoiser(W, H, P)
+    a.set_iteration_fusion(True)
+    gbs = [G.gb_dev(f) for f in fr]
+    for k in range(N):
+        rad = G.dev(fr[k]["radiance"].astype(G.NPDT[storage]))
+        ra, rb = a.Render(rad, gbs[k], gbs[k - 1] if k else None), b.Render(rad, gbs[k], gbs[k - 1] if k else None)
+        torch.cuda.synchronize()
+        assert torch.equal(ra.view(torch.uint8), rb.view(torch.uint8)), desc + f": frame {k}"
+        for plane in (F.PLANE_COLOUR, F.PLANE_MOMENTS, F.PLANE_HISTORY):
+            assert torch.equal(a.state_plane(plane, 1 - a.pingpong()).view(torch.uint8), b.state_plane(plane, 1 - b.pingpong()).view(torch.uint8)), desc + f": frame {k}: plane {plane}"
+    a.close(); b.close()
+    return desc
+
+
+# ------------------------------------------------------------------------------------------------------------------ the stages after the path
+def trial_post(G, oracle, seed):
+    """TAA + sRGB against the oracle (and the LDS-tiled kernel against the per-pixel one, bit for bit); albedo (de)modulation bit-exact."""
+    from svgf_amd import filter as F
+    from tests.helpers import half_ulp_diff
+    rng = np.random.default_rng(seed)
+    W, H = _size(rng)
+    storage = ("f32", "f16")[int(rng.integers(0, 2))]
+    dt = CDT[storage]
+    poison = bool(rng.integers(0, 2))
+    desc = f"post seed {seed}: {W}x{H} {storage} poison {poison}"
+    filt = rng.uniform(-0.1, 1.2, (H, W, 4)).astype(dt)
+    hist = rng.uniform(0, 1, (H, W, 4)).astype(dt)
+    if poison:
+        _sprinkle(rng, filt, 8), _sprinkle(rng, hist, 6)
+    _sprinkle_zeros(rng, filt, 6), _sprinkle_zeros(rng, hist, 4)
+    want = np.zeros_like(filt)
+    oracle.taa(W, H, storage, filt, hist, want)
+    outs = []
+    for variant in ("auto", "direct"):
+        d = F.Denoiser(W, H, F.Params(storage=storage, variant=variant))
+        out = d.new_colour()
+        d.TAA(G.dev(filt), G.dev(hist), out)
+        outs.append(G.host(out))
+        if variant == "direct":
+            al = _sprinkle_zeros(rng, rng.uniform(-0.1, 1.0, (H, W, 4)).astype(dt), 4)
+            for mode, fn in ((0, d.Demodulate), (1, d.Modulate)):
+                w2 = np.zeros_like(filt)
+                oracle.albedo(mode, W, H, storage, filt, al, w2)
+                o2 = d.new_colour()
+                fn(G.dev(filt), G.dev(al), o2)
+                assert np.array_equal(G.host(o2).view(np.uint8), w2.view(np.uint8)), desc + f": albedo mode {mode}"
+        d.close()
+    got = outs[0]
+    assert np.array_equal(got.view(np.uint8), outs[1].view(np.uint8)), desc + ": TAA tiled vs per-pixel"
+    assert not np.isnan(got.astype(np.float32)).any(), desc
+    black_w, black_g = (want[..., :3].astype(np.float32) == 0).all(-1), (got[..., :3].astype(np.float32) == 0).all(-1)
+    assert np.array_equal(black_w, black_g), desc + ": black (NaN-guarded) pixels differ"
+    if storage == "f32":
+        assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= 2e-6, desc + ": TAA"
+    else:
+        assert half_ulp_diff(got, want).max() <= 1, desc + ": TAA"
+    return desc
+
+
+TRIALS = {"stage0": lambda G, oracle, seed: trial_stage(G, oracle, seed, zeros=True), "stage": trial_stage, "strips": trial_strips, "driver": trial_driver, "rows": trial_rows, "pair": trial_pair, "post": trial_post}
 
 
 def run_trial(kind, seed, G=None, oracle=None):
