@@ -1,6 +1,6 @@
 """Seeded random sweep of the parity and bit-identity claims (test infrastructure: it calls the oracle; nothing in the product imports it).
 
-    python -m tests.fuzz_parity --minutes 10 --seed 1000 [--kinds stage,strips,driver,rows,pair,post,stage0] [--out gpurun_out/fuzz.txt]
+    python -m tests.fuzz_parity --minutes 10 --seed 1000 [--kinds stage,strips,driver,rows,pair,post,stage0,strips2,driver2] [--out gpurun_out/fuzz.txt]
 
 Each trial draws a frame size (down to 1 x 1, up past the 128-pixel tile and the 64-lane wave in both directions), a storage format, the
 tunables over the GUI's ranges (GUI.cpp:988-993), a camera motion, optionally NaN / inf radiance texels and poisoned G-buffer texels
@@ -16,6 +16,10 @@ tunables over the GUI's ranges (GUI.cpp:988-993), a camera motion, optionally Na
   rows     a stage call restricted to a row range (svgf_set_rows): the rows inside with the whole-frame call's bits, nothing else written;
   pair     iterations 0 and 1 in one launch: the frame driver with the fusion against without (finite input, bit for bit), svgf_atrous_pair
            against the oracle's two iterations (poisoned input, the pair launch's tolerances);
+  strips2  the strip driver over RCCL's own kernels (loop-back communicator) or the mailbox, one or two frames in flight, svgf_set_prev_guide, the
+           fusion of iterations 0 + 1 (finite input) against the plain frame driver, bit for bit;
+  driver2  the frame driver across svgf_reset_history / svgf_resize / svgf_set_params between frames: plain, under a random setting, and a fresh
+           context from the last restart on — bit for bit;
   stage0   `stage` with -0.0, denormals and the storage type's extremes in the colour and moments planes;
   post     the stages after the path: TAA + sRGB against the oracle and tiled against per-pixel, albedo (de)modulation bit-exact.
 
@@ -34,7 +38,7 @@ from svgf_amd import synth
 from tests.gbuffer_poison import poison_gbuffer
 from tests.helpers import CDT, gbuf
 
-KINDS = ("stage", "strips", "driver", "rows", "pair", "post", "stage0")
+KINDS = ("stage", "strips", "driver", "rows", "pair", "post", "stage0", "strips2", "driver2")
 
 
 def _size(rng):
@@ -237,6 +241,101 @@ def trial_strips(G, oracle, seed):
                 bad = np.argwhere((got.view(np.uint8) != want.view(np.uint8)).reshape(H, W, -1).any(-1))
                 raise AssertionError(desc + f": frame {k}: {len(bad)} px differ, first {bad[:4].tolist()}")
             prev_in = cur_in
+        hist = np.concatenate([G.host(drv.owned(r, drv.state_plane(r, F.PLANE_HISTORY, 1 - drv.pingpong(r)))) for r in range(world)], 0)
+        assert np.array_equal(hist, G.host(whole.state_plane(F.PLANE_HISTORY, 1 - whole.pingpong()))), desc + ": history"
+    finally:
+        drv.close()
+        whole.close()
+    return desc
+
+
+
+_LOOP_COMM = []
+
+
+def _loop_comm():
+    """ONE RCCL communicator of world size 1 for the process (every send / recv of the virtual ranks has communicator rank 0 as its peer)."""
+    if not _LOOP_COMM:
+        from svgf_amd import strips
+        _LOOP_COMM.append(strips.rccl_comm(1, 0, 0))
+    return _LOOP_COMM[0]
+
+
+def trial_strips2(G, oracle, seed):
+    """The strip driver under the settings `strips` leaves alone: RCCL's own kernels over the loop-back communicator or the mailbox, one or two
+    frames in flight (results read one call later, no synchronisation in between), svgf_set_prev_guide, iterations 0 + 1 in one launch (finite
+    input) — against the plain frame driver, bit for bit."""
+    import torch
+    from svgf_amd import filter as F
+    from svgf_amd import strips
+    rng = np.random.default_rng(seed)
+    storage = ("f32", "f16")[int(rng.integers(0, 2))]
+    tun = _tunables(rng)
+    steps = int(rng.choice([5, 5, 3, 2, 4, 6, 7]))
+    world = int(rng.integers(2, 9))
+    plan = str(rng.choice(["ghost", "grouped", "per-iteration", "auto"]))
+    reach = int(rng.integers(0, 7))
+    W = int(rng.choice([int(rng.integers(1, 64)), int(rng.integers(64, 700)), 128, 129, 256]))
+    H = int(rng.integers(world, 1200))
+    for _ in range(40):
+        if strips._plan_fits(W, H, 0, world, steps, plan, 3, reach):
+            break
+        H += int(rng.integers(16, 200))
+    else:
+        return f"strips2 seed {seed}: no height found (skipped)"
+    mv = (float(rng.uniform(-4, 4)), float(rng.uniform(-reach, reach)) if reach else 0.0)
+    poison = bool(rng.integers(0, 2))
+    N = int(rng.integers(3, 6))
+    transport = str(rng.choice(["mailbox", "rccl"]))
+    in_flight = int(rng.integers(1, 3))
+    prev_guide = bool(rng.integers(0, 2))
+    fusion = bool(rng.integers(0, 2)) and not poison and steps >= 2
+    desc = (f"strips2 seed {seed}: {W}x{H} {storage} world {world} plan {plan} reach {reach} steps {steps} poison {poison} frames {N} {transport} "
+            f"in flight {in_flight} prev_guide {prev_guide} fusion {fusion}")
+    fr = _sequence(rng, W, H, N, mv, poison, storage)
+    P = F.Params(storage=storage, steps=steps, **tun)
+    whole = F.Denoiser(W, H, P)
+    side = torch.cuda.Stream(priority=-1)
+    kw = dict(comms=[_loop_comm()], loopback=True) if transport == "rccl" else dict(transport="mailbox")
+    drv = strips.NativeStrips(W, H, world, P, list(range(world)), [0] * world, streams=[side.cuda_stream] * world, plan=plan, motion_reach=reach, **kw)
+    try:
+        drv.set_frames_in_flight(in_flight)
+        if prev_guide:
+            drv.set_prev_guide(True)
+        if fusion:
+            drv.set_iteration_fusion(True)
+        gbs = [G.gb_dev(f) for f in fr]
+        want = [G.host(whole.Render(G.dev(fr[k]["radiance"].astype(G.NPDT[storage])), gbs[k], gbs[k - 1] if k else None)) for k in range(N)]
+        torch.cuda.synchronize()
+        inputs = []
+        for k in range(N):                                # every frame's planes stay alive and untouched
+            cur = []
+            for lay in drv.layouts:
+                sl = slice(lay["y0"], lay["y1"])
+                cur.append((G.dev(np.ascontiguousarray(fr[k]["radiance"][sl].astype(G.NPDT[storage]))),
+                            F.GBuffer(*(G.dev(np.ascontiguousarray(fr[k][n][sl])) for n in ("motion", "normal", "uv")))))
+            inputs.append(cur)
+        torch.cuda.synchronize()
+        outs, got = {}, {}
+
+        def collect(k):                                   # on the ranks' compute stream: ordered behind frame k by call k + 1
+            with torch.cuda.stream(side):
+                got[k] = [drv.owned(r, o).clone() for r, o in enumerate(outs[k])]
+        for k in range(N):
+            outs[k] = drv.frame([c[0] for c in inputs[k]], [c[1] for c in inputs[k]], [p[1] for p in inputs[k - 1]] if k else None)
+            if in_flight == 1:
+                collect(k)
+            elif k >= 1:
+                collect(k - 1)
+        drv.sync()
+        if in_flight == 2:
+            collect(N - 1)
+        torch.cuda.synchronize()
+        for k in range(N):
+            g = np.concatenate([G.host(t) for t in got[k]], 0)
+            if not np.array_equal(g.view(np.uint8), want[k].view(np.uint8)):
+                bad = np.argwhere((g.view(np.uint8) != want[k].view(np.uint8)).reshape(H, W, -1).any(-1))
+                raise AssertionError(desc + f": frame {k}: {len(bad)} px differ, first {bad[:4].tolist()}")
         hist = np.concatenate([G.host(drv.owned(r, drv.state_plane(r, F.PLANE_HISTORY, 1 - drv.pingpong(r)))) for r in range(world)], 0)
         assert np.array_equal(hist, G.host(whole.state_plane(F.PLANE_HISTORY, 1 - whole.pingpong()))), desc + ": history"
     finally:
@@ -456,7 +555,90 @@ def trial_post(G, oracle, seed):
     return desc
 
 
-TRIALS = {"stage0": lambda G, oracle, seed: trial_stage(G, oracle, seed, zeros=True), "stage": trial_stage, "strips": trial_strips, "driver": trial_driver, "rows": trial_rows, "pair": trial_pair, "post": trial_post}
+
+def trial_driver2(G, oracle, seed):
+    """The frame driver across svgf_reset_history, svgf_resize (to the same or another size) and svgf_set_params between frames: a plain driver, a
+    driver under a random setting (two frames in flight, svgf_set_prev_guide, young-pixel launch only, the fusion on finite input) given the
+    same calls, and — from the last restart on — a FRESH context: all bit for bit, history and moments planes included."""
+    import torch
+    from svgf_amd import filter as F
+    rng = np.random.default_rng(seed)
+    sizes = [_size(rng), _size(rng)]
+    storage = ("f32", "f16")[int(rng.integers(0, 2))]
+    tuns = [_tunables(rng), _tunables(rng)]
+    steps = [int(rng.choice([5, 3, 0, 1, 2, 7])), int(rng.choice([5, 4, 2]))]
+    radius = int(rng.choice([3, 3, 1]))
+    mv = (float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4)))
+    poison = bool(rng.integers(0, 2))
+    N = int(rng.integers(4, 9))
+    setting = str(rng.choice(["in_flight", "prev_guide", "no_adaptive", "fusion", "plain"]))
+    if setting == "fusion" and poison:
+        setting = "plain"
+    events = {int(k): str(rng.choice(["reset", "resize_same", "resize_other", "params"])) for k in rng.choice(np.arange(1, N), size=int(rng.integers(1, 4)), replace=False)}
+    desc = f"driver2 seed {seed}: {sizes} {storage} steps {steps} r{radius} poison {poison} frames {N} setting {setting} events {dict(sorted(events.items()))}"
+    P = [F.Params(storage=storage, steps=steps[i], moments_radius=radius, **tuns[i]) for i in range(2)]
+    si, pi = 0, 0
+    W, H = sizes[0]
+    x, y = F.Denoiser(W, H, P[0]), F.Denoiser(W, H, P[0])
+    z = None                                              # the fresh context of the last restart
+
+    def configure(d):
+        if setting == "in_flight":
+            d.set_frames_in_flight(2)
+        elif setting == "prev_guide":
+            d.set_prev_guide(True)
+        elif setting == "no_adaptive":
+            d.set_adaptive_moments(False)
+        elif setting == "fusion":
+            d.set_iteration_fusion(True)
+    configure(y)
+    frames_of = {}
+    try:
+        prev_gb = None
+        for k in range(N):
+            ev = events.get(k)
+            if ev == "reset":
+                x.reset_history(); y.reset_history()
+            elif ev in ("resize_same", "resize_other"):
+                if ev == "resize_other":
+                    si ^= 1
+                W, H = sizes[si]
+                x.Resize(W, H); y.Resize(W, H)
+                prev_gb = None if ev == "resize_other" else prev_gb
+            elif ev == "params":
+                pi ^= 1
+                x.set_params(P[pi]); y.set_params(P[pi])
+                if z is not None:
+                    z.set_params(P[pi])
+            if ev in ("reset", "resize_same", "resize_other"):
+                if z is not None:
+                    z.close()
+                z = F.Denoiser(W, H, P[pi])
+            if (W, H) not in frames_of:
+                frames_of[(W, H)] = _sequence(np.random.default_rng(seed + 7 * W + H), W, H, N, mv, poison, storage)
+            f = frames_of[(W, H)][k]
+            gb, rad = G.gb_dev(f), G.dev(f["radiance"].astype(G.NPDT[storage]))
+            a = G.host(x.Render(rad, gb, prev_gb))
+            b = y.Render(rad, gb, prev_gb)
+            if setting == "in_flight":
+                y.flush()
+            b = G.host(b)
+            torch.cuda.synchronize()
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), desc + f": frame {k}: setting"
+            if z is not None:
+                c = G.host(z.Render(rad, gb, prev_gb))
+                assert np.array_equal(a.view(np.uint8), c.view(np.uint8)), desc + f": frame {k}: against the fresh context"
+                for plane in (F.PLANE_HISTORY, F.PLANE_MOMENTS):
+                    assert torch.equal(x.state_plane(plane, 1 - x.pingpong()).view(torch.uint8), z.state_plane(plane, 1 - z.pingpong()).view(torch.uint8)), desc + f": frame {k}: plane {plane}"
+            prev_gb = gb
+    finally:
+        x.close(); y.close()
+        if z is not None:
+            z.close()
+    return desc
+
+
+TRIALS = {"driver2": trial_driver2, "strips2": trial_strips2, "stage0": lambda G, oracle, seed: trial_stage(G, oracle, seed, zeros=True), "stage": trial_stage, "strips": trial_strips, "driver": trial_driver, "rows": trial_rows, "pair": trial_pair, "post": trial_post}
 
 
 def run_trial(kind, seed, G=None, oracle=None):

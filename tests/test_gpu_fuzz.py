@@ -19,7 +19,9 @@ STRIPS = [1192, 1483, 1531, 1621, 1651, 1969, 2311, 2329, 2755, 3841, 5230, 6463
 DRIVER = [7313, 1916, 1640, 1787, 2843, 2993, 5447, 7034, 24140, 40001, 40004, 40007, 40010]
 STAGE = [6657, 1266, 3795, 3807, 5883, 2529, 40002, 40005, 40008, 40011]
 OTHER = [("post", 213350), ("post", 215738), ("post", 320621), ("post", 400001), ("rows", 400000), ("rows", 400003), ("rows", 400006), ("rows", 400009),
-         ("pair", 400004), ("pair", 400007), ("pair", 400010), ("pair", 400013), ("stage0", 500000), ("stage0", 500001), ("stage0", 500002), ("stage0", 500003)]
+         ("pair", 400004), ("pair", 400007), ("pair", 400010), ("pair", 400013), ("stage0", 500000), ("stage0", 500001), ("stage0", 500002), ("stage0", 500003),
+         ("strips2", 600000), ("strips2", 600001), ("strips2", 600002), ("strips2", 600003), ("strips2", 600004), ("strips2", 600005),
+         ("driver2", 700000), ("driver2", 700001), ("driver2", 700002), ("driver2", 700003), ("driver2", 700004), ("driver2", 700005)]
 
 
 @pytest.fixture(scope="module")
@@ -49,6 +51,6 @@ def test_stages_against_the_oracle(G, oracle, seed):
 
 
 @pytest.mark.parametrize("kind,seed", OTHER)
-def test_row_ranges_pair_launch_and_the_stages_after_the_path(G, oracle, kind, seed):
+def test_the_kinds_added_later(G, oracle, kind, seed):
     from tests import fuzz_parity
     fuzz_parity.run_trial(kind, seed, G, oracle)
