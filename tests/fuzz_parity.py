@@ -1,6 +1,6 @@
 """Seeded random sweep of the parity and bit-identity claims (test infrastructure: it calls the oracle; nothing in the product imports it).
 
-    python -m tests.fuzz_parity --minutes 10 --seed 1000 [--kinds stage,strips,driver,rows,pair,post,stage0,strips2,driver2] [--out gpurun_out/fuzz.txt]
+    python -m tests.fuzz_parity --minutes 10 --seed 1000 [--kinds stage,strips,driver,rows,pair,post,stage0,strips2,driver2,wide,widestrips] [--out gpurun_out/fuzz.txt]
 
 Each trial draws a frame size (down to 1 x 1, up past the 128-pixel tile and the 64-lane wave in both directions), a storage format, the
 tunables over the GUI's ranges (GUI.cpp:988-993), a camera motion, optionally NaN / inf radiance texels and poisoned G-buffer texels
@@ -20,6 +20,7 @@ tunables over the GUI's ranges (GUI.cpp:988-993), a camera motion, optionally Na
            fusion of iterations 0 + 1 (finite input) against the plain frame driver, bit for bit;
   driver2  the frame driver across svgf_reset_history / svgf_resize / svgf_set_params between frames: plain, under a random setting, and a fresh
            context from the last restart on — bit for bit;
+  wide, widestrips   `stage` and `strips` on frames 1 024 - 8 200 columns wide (many column tiles: the XCD-aware tile order; few rows);
   stage0   `stage` with -0.0, denormals and the storage type's extremes in the colour and moments planes;
   post     the stages after the path: TAA + sRGB against the oracle and tiled against per-pixel, albedo (de)modulation bit-exact.
 
@@ -38,7 +39,7 @@ from svgf_amd import synth
 from tests.gbuffer_poison import poison_gbuffer
 from tests.helpers import CDT, gbuf
 
-KINDS = ("stage", "strips", "driver", "rows", "pair", "post", "stage0", "strips2", "driver2")
+KINDS = ("stage", "strips", "driver", "rows", "pair", "post", "stage0", "strips2", "driver2", "wide", "widestrips")
 
 
 def _size(rng):
@@ -95,13 +96,15 @@ def _close(G, got, want, storage, what, colour_abs=None):
 
 
 # ------------------------------------------------------------------------------------------------------------------ stage vs oracle
-def trial_stage(G, oracle, seed, zeros=False):
+def trial_stage(G, oracle, seed, zeros=False, wide=False):
     """zeros: -0.0, denormals and the storage type's extremes in the colour / moments planes as well (kind "stage0"; drawn from a generator of
     their own, so that kind "stage" keeps the frames of its pinned seeds)."""
     from svgf_amd import filter as F
     rng = np.random.default_rng(seed)
     rz = np.random.default_rng(seed ^ 0x5A5A5A)
     W, H = _size(rng)
+    if wide:                                              # (kind "wide": many column tiles — the XCD-aware tile order, rows shorter than a band)
+        W, H = int(rz.choice([int(rz.integers(1024, 8200)), 1920, 3840, 4096, 7680, 8191])), int(rz.integers(1, 48))
     storage = ("f32", "f16")[int(rng.integers(0, 2))]
     dt = CDT[storage]
     tun = _tunables(rng)
@@ -187,7 +190,7 @@ def _sequence(rng, W, H, N, mv, poison, storage):
     return fr
 
 
-def trial_strips(G, oracle, seed):
+def trial_strips(G, oracle, seed, wide=False):
     import torch
     from svgf_amd import filter as F
     from svgf_amd import strips
@@ -202,6 +205,9 @@ def trial_strips(G, oracle, seed):
     W = int(rng.choice([int(rng.integers(1, 64)), int(rng.integers(64, 700)), 128, 129, 256]))
     # a height the plan accepts: walk up from a random start
     H = int(rng.integers(world, 1200))
+    if wide:
+        rz = np.random.default_rng(seed ^ 0x5A5A5A)
+        W, H = int(rz.choice([int(rz.integers(1024, 8200)), 1920, 3840, 7680])), int(rz.integers(world, 400))
     for _ in range(40):
         if strips._plan_fits(W, H, 0, world, steps, plan, radius, reach):
             break
@@ -638,7 +644,8 @@ def trial_driver2(G, oracle, seed):
     return desc
 
 
-TRIALS = {"driver2": trial_driver2, "strips2": trial_strips2, "stage0": lambda G, oracle, seed: trial_stage(G, oracle, seed, zeros=True), "stage": trial_stage, "strips": trial_strips, "driver": trial_driver, "rows": trial_rows, "pair": trial_pair, "post": trial_post}
+TRIALS = {"wide": lambda G, oracle, seed: trial_stage(G, oracle, seed, wide=True), "widestrips": lambda G, oracle, seed: trial_strips(G, oracle, seed, wide=True),
+          "driver2": trial_driver2, "strips2": trial_strips2, "stage0": lambda G, oracle, seed: trial_stage(G, oracle, seed, zeros=True), "stage": trial_stage, "strips": trial_strips, "driver": trial_driver, "rows": trial_rows, "pair": trial_pair, "post": trial_post}
 
 
 def run_trial(kind, seed, G=None, oracle=None):

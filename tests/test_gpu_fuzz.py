@@ -21,6 +21,7 @@ STAGE = [6657, 1266, 3795, 3807, 5883, 2529, 40002, 40005, 40008, 40011]
 OTHER = [("post", 213350), ("post", 215738), ("post", 320621), ("post", 400001), ("rows", 400000), ("rows", 400003), ("rows", 400006), ("rows", 400009),
          ("pair", 400004), ("pair", 400007), ("pair", 400010), ("pair", 400013), ("stage0", 500000), ("stage0", 500001), ("stage0", 500002), ("stage0", 500003),
          ("strips2", 600000), ("strips2", 600001), ("strips2", 600002), ("strips2", 600003), ("strips2", 600004), ("strips2", 600005),
+         ("wide", 800000), ("wide", 800002), ("widestrips", 800001), ("widestrips", 800003),
          ("driver2", 700000), ("driver2", 700001), ("driver2", 700002), ("driver2", 700003), ("driver2", 700004), ("driver2", 700005)]
 
 
