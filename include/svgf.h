@@ -249,6 +249,7 @@ int svgf_pack_gbuffer(svgf_ctx* ctx, const void* position, const void* normal, c
  * so there is no reference call site; the definition is the SVGF paper's:
  *   svgf_demodulate: out.rgb = radiance.rgb / max(albedo.rgb, 1e-3), out.w = radiance.w       (before svgf_temporal)
  *   svgf_modulate:   out.rgb = filtered.rgb * max(albedo.rgb, 1e-3), out.w = filtered.w       (after the last svgf_atrous)
+ * (`max` is fmaxf, as CUDA's max(float, float) is: a NaN albedo reads as the floor 1e-3; a NaN / inf colour goes through the division / product.)
  * `albedo` is a {r,g,b,-} plane in the context's storage type; `out` may alias the first argument.  Note that the
  * reference's imageLoad clamps colour to [0,1] (Filter.cuh:78-83): illumination above 1 is clipped by the temporal stage,
  * so a caller with bright lights over dark albedo should pre-scale its radiance. */

@@ -199,7 +199,10 @@ def _tex(k, n):
 
 
 def _enc(rgb):
-    c = np.power(rgb, f32(2.0)).astype(np.float32)
+    # pow(rgb, 2.0) (:268): the square.  (np.power on a strided float32 view takes a SIMD path that is off by an ulp in a fifth of the values, on a
+    # contiguous one it squares; the C++ oracle's powf(x, 2) is x * x in all but ~0.07 % of the values — tests/fuzz_oracle.py.  The difference matters
+    # where the decoded channel cancels to ~1e-7 and the square root and the sRGB slope of 12.92 amplify its last bit to 1e-4.)
+    c = np.square(rgb).astype(np.float32)
     r, g, b = c[..., 0], c[..., 1], c[..., 2]
     return np.stack([(r * f32(0.299) + g * f32(0.587)) + b * f32(0.114),
                      (r * f32(-0.14713) + g * f32(-0.28886)) + b * f32(0.436),
@@ -297,7 +300,7 @@ def albedo(mode, inp, alb):
     """Albedo demodulation (mode 0) / re-modulation (mode 1), SURVEY.md 8f-4 (the build's own definition; the reference has
     none, README.md:14).  inp, alb: (..., 4) arrays in the storage dtype; fp32 arithmetic, one rounding per operation."""
     c, a = inp.astype(np.float32), alb.astype(np.float32)
-    d = np.maximum(a[..., :3], np.float32(1e-3))
+    d = np.fmax(a[..., :3], np.float32(1e-3))               # fmaxf: a NaN albedo reads as the floor (include/svgf.h)
     o = c.copy()
     o[..., :3] = (c[..., :3] / d) if mode == 0 else (c[..., :3] * d)
     return o.astype(inp.dtype)

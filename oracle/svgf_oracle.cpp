@@ -399,7 +399,7 @@ void taa(const Geo& g, const void* input, const void* history, void* out, int nt
 // ---------------------------------------------------------------- C entry -----
 // Albedo demodulation / re-modulation around the filter.  NOT in the reference — its README says so
 // (README.md:14,172-174) — so this restates the build's own definition (include/svgf.h), not reference code:
-//   demodulate: illumination.rgb = radiance.rgb / max(albedo.rgb, 1e-3), .w = radiance.w      (IEEE division)
+//   demodulate: illumination.rgb = radiance.rgb / max(albedo.rgb, 1e-3), .w = radiance.w      (IEEE division; max = fmaxf)
 //   modulate:   colour.rgb = illumination.rgb * max(albedo.rgb, 1e-3),   .w = illumination.w
 template <class T> void albedo_op(int mode, size_t n, const void* in, const void* albedo, void* out) {
     for (size_t i = 0; i < n; i++) {
@@ -407,7 +407,7 @@ template <class T> void albedo_op(int mode, size_t n, const void* in, const void
         T::ld4(in, i, c);
         T::ld4(albedo, i, al);
         for (int k = 0; k < 3; k++) {
-            const float d = std::max(al[k], 1e-3f);
+            const float d = std::fmax(al[k], 1e-3f);                                 // max(float, float) as CUDA has it: fmaxf — a NaN albedo reads as the floor
             o[k] = mode == 0 ? c[k] / d : c[k] * d;
         }
         o[3] = c[3];

@@ -1,0 +1,182 @@
+"""Seeded random sweep of the C++ oracle against the independently written NumPy restatement (oracle/svgf_numpy.py) — CPU only, test
+infrastructure.  The reference holds no vectors for this path, so the two restatements of SURVEY.md Appendix A checking each other over
+random sizes, tunables, motions and poisoned texels is the widest pin the oracle can have here.
+
+    python -m tests.fuzz_oracle --minutes 5 --seed 1 [--out file]
+
+A trial (a pure function of its seed; tests/test_oracle_fuzz.py pins some): frame size 1 x 1 .. 220 x 120, storage, the tunables over the GUI's
+ranges, NaN / inf / -0 / denormal colour texels and poisoned G-buffer texels (tests/gbuffer_poison.py) with probability 1/2; temporal bit for
+bit (history = the accept / reject mask, colour, moments); moments, one a-trous iteration and TAA within the two libms' distance (NaN masks
+and infinities identical); albedo bit for bit."""
+from __future__ import annotations
+
+import argparse
+import sys
+import time
+import traceback
+
+import numpy as np
+
+from oracle import svgf_numpy as snp
+from svgf_amd import synth
+from tests.fuzz_parity import _poisoned, _sprinkle, _sprinkle_zeros, _tunables
+from tests.helpers import CDT, gbuf, half_ulp_diff
+
+
+def _size(rng):
+    c = rng.integers(0, 8)
+    if c == 0:
+        return int(rng.integers(1, 9)), int(rng.integers(1, 9))
+    if c == 1:
+        return int(rng.choice([63, 64, 65, 127, 128, 129])), int(rng.integers(1, 40))
+    return int(rng.integers(9, 220)), int(rng.integers(9, 120))
+
+
+def _same_nonfinite(a, b, what):
+    a32, b32 = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    assert np.array_equal(np.isnan(a32), np.isnan(b32)), f"{what}: NaN masks differ ({int(np.isnan(a32).sum())} vs {int(np.isnan(b32).sum())}; first at {np.argwhere(np.isnan(a32) != np.isnan(b32))[:3].tolist()})"
+    inf = np.isinf(b32)
+    assert np.array_equal(a32[inf], b32[inf]), f"{what}: infinities differ"
+    return np.isfinite(b32) & np.isfinite(a32)
+
+
+def _near(got, want, storage, what, f32_abs, f32_rel=0.0):
+    fin = _same_nonfinite(got, want, what)
+    g, w = got.astype(np.float64), want.astype(np.float64)
+    if storage == "f32":
+        err = np.abs(g[fin] - w[fin])
+        lim = f32_abs + f32_rel * np.abs(w[fin])
+        assert np.all(err <= lim), f"{what}: max err {err.max():.3e}"
+    else:
+        d = half_ulp_diff(got[fin], want[fin])
+        assert d.size == 0 or d.max() <= 1, f"{what}: {d.max()} half-ulps"
+        assert (d > 0).sum() <= max(2e-3 * d.size, 2), f"{what}: {(d > 0).mean():.2e} of values differ by one half-ulp"
+
+
+def run_trial(seed, oracle=None):
+    if oracle is None:
+        from oracle import oracle as oracle                   # noqa: PLW0127
+    rng = np.random.default_rng(seed)
+    W, H = _size(rng)
+    storage = ("f32", "f16")[int(rng.integers(0, 2))]
+    dt = CDT[storage]
+    tun = _tunables(rng)
+    radius = int(rng.choice([3, 3, 1, 2]))
+    step = int(2 ** rng.integers(0, 7))
+    mv = (float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4)))
+    poison = bool(rng.integers(0, 2))
+    desc = f"oracle seed {seed}: {W}x{H} {storage} r{radius} step {step} poison {poison}"
+    f0, f1 = synth.make_frame(W, H, seed % 97, mv=mv), synth.make_frame(W, H, seed % 97 + 1, mv=mv)
+    if poison:
+        f0, f1 = _poisoned(rng, f0, ("motion", "depth", "ddepth", "normal", "id")), _poisoned(rng, f1, ("motion", "depth", "ddepth", "normal", "id"))
+    # ---- temporal: bit for bit
+    prev = rng.uniform(-0.1, 1.2, (H, W, 4)).astype(dt)
+    mom_prev = rng.uniform(0, 1, (H, W, 2)).astype(dt)
+    hist_prev = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    cur = rng.uniform(-0.1, 1.4, (H, W, 4)).astype(dt)
+    if poison:
+        _sprinkle(rng, cur, 5), _sprinkle(rng, prev, 5), _sprinkle(rng, mom_prev, 3)
+        _sprinkle_zeros(rng, cur, 5), _sprinkle_zeros(rng, prev, 5), _sprinkle_zeros(rng, mom_prev, 3)
+    out = np.zeros_like(cur); hist = np.zeros((H, W), np.uint8); mom = np.zeros((H, W, 2), dt)
+    tk = dict(depth_threshold=tun["depth_threshold"], normal_threshold=tun["normal_threshold"], history_base=tun["history_base"], mesh_id_test=tun["mesh_id_test"])
+    oracle.temporal(W, H, storage, prev, cur, out, gbuf(f1), gbuf(f0), hist_prev, hist, mom, mom_prev, **tk)
+    with np.errstate(all="ignore"):
+        w_out, w_hist, w_mom = snp.temporal(prev, cur, gbuf(f1), gbuf(f0), hist_prev, mom_prev, **tk)
+    assert np.array_equal(hist, w_hist), desc + f": temporal history ({int((hist != w_hist).sum())} px)"
+    u = np.uint32 if storage == "f32" else np.uint16
+    for got, want, name in ((out, w_out, "colour"), (mom, w_mom, "moments")):
+        fin = _same_nonfinite(got, want, desc + f": temporal {name}")
+        assert np.array_equal(got.view(u)[fin], want.view(u)[fin]), desc + f": temporal {name}: finite bits ({int((got.view(u)[fin] != want.view(u)[fin]).sum())} values)"
+    # ---- moments
+    fs = synth.make_frame(W, H, seed % 97 + 1, mv=mv)
+    if poison:
+        fs = _poisoned(rng, fs, ("depth", "ddepth", "normal"))
+    col = rng.uniform(0, 1, (H, W, 4)).astype(dt)
+    momp = rng.uniform(0, 1, (H, W, 2)).astype(dt)
+    hl = rng.integers(0, 8, (H, W)).astype(np.uint8)
+    if poison:
+        _sprinkle(rng, col, 4), _sprinkle(rng, momp, 3)
+    got = np.zeros_like(col)
+    oracle.moments(W, H, storage, col, got, momp, gbuf(fs), hl, phi_colour=tun["phi_colour"], phi_normal=tun["phi_normal"], radius=radius)
+    with np.errstate(all="ignore"):
+        want = snp.moments(col, momp, gbuf(fs), hl, phi_colour=tun["phi_colour"], phi_normal=tun["phi_normal"], radius=radius)
+    keep = hl >= 4
+    assert np.array_equal(got[keep].view(u), col[keep].view(u)), desc + ": moments copy"
+    young = (hl < 4) & (hl > 0)                                                   # (history 0: 4 / 0 — compared through the NaN / inf masks only)
+    _same_nonfinite(got, want, desc + ": moments")
+    _near(got[young][..., :3], want[young][..., :3], storage, desc + ": moments colour", 2e-6, 1e-5)
+    gv, wv = got[young][..., 3].astype(np.float64), want[young][..., 3].astype(np.float64)
+    fin = np.isfinite(gv) & np.isfinite(wv)
+    assert np.all(np.abs(gv[fin] - wv[fin]) <= (4e-5 if storage == "f32" else 8e-5 + np.abs(wv[fin]) * 2.0 ** -9)), desc + f": moments variance {np.abs(gv[fin] - wv[fin]).max():.3e}"
+    # ---- one a-trous iteration
+    src = np.concatenate([rng.uniform(-0.2, 1.3, (H, W, 3)), rng.uniform(-0.01, 0.2, (H, W, 1))], -1).astype(dt)
+    if poison:
+        _sprinkle(rng, src, 6), _sprinkle_zeros(rng, src, 4)
+    o = np.zeros_like(src); fb = np.full_like(src, 7)
+    oracle.atrous(W, H, storage, src, o, fb, gbuf(fs), step=step, phi_colour=tun["phi_colour"], phi_normal=tun["phi_normal"], iteration=0)
+    with np.errstate(all="ignore"):
+        w, wfb = snp.atrous(src, gbuf(fs), step=step, phi_colour=tun["phi_colour"], phi_normal=tun["phi_normal"])
+    _near(o, w, storage, desc + ": a-trous", 2e-6, 2e-5)
+    assert np.array_equal(fb[wfb].view(u), o[wfb].view(u)) and (fb[~wfb] == 7).all(), desc + ": a-trous feedback"
+    # ---- TAA + sRGB, albedo
+    filt = rng.uniform(-0.1, 1.2, (H, W, 4)).astype(dt)
+    histc = rng.uniform(0, 1, (H, W, 4)).astype(dt)
+    if poison:
+        _sprinkle(rng, filt, 5), _sprinkle(rng, histc, 4), _sprinkle_zeros(rng, filt, 4)
+    t = np.zeros_like(filt)
+    oracle.taa(W, H, storage, filt, histc, t)
+    with np.errstate(all="ignore"):
+        tw = snp.taa(filt, histc)
+    if storage == "f32":
+        # TAA's decode ends in sqrt(r) of a channel r that may cancel to ~1e-7, followed by the sRGB slope of 12.92: a last-bit difference of the
+        # two libms' pow(x, 2) / pow(x, 0.5) (each within an ulp) shows as up to 3e-4 in such a texel.  Compared where it is conditioned: the
+        # output itself within 1e-6, or — back through sRGB and the square root — the channel r within 3e-7.
+        fin = _same_nonfinite(t, tw, desc + ": TAA")
+        g64, w64 = t.astype(np.float64), tw.astype(np.float64)
+        lin = lambda c: np.where(c <= 0.0031308 * 12.92, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)          # noqa: E731
+        ok = (np.abs(g64 - w64) <= 1e-6) | (np.abs(lin(g64) ** 2 - lin(w64) ** 2) <= 3e-7)
+        assert ok[fin].all(), desc + f": TAA: {int((~ok[fin]).sum())} values, max err {np.abs(g64 - w64)[fin & ~ok].max():.3e}"
+    else:
+        _near(t, tw.astype(dt), storage, desc + ": TAA", 1e-6)
+    al = _sprinkle_zeros(rng, rng.uniform(-0.1, 1.0, (H, W, 4)).astype(dt), 4)
+    if poison:
+        _sprinkle(rng, al, 4)                                                     # (a NaN albedo reads as the floor: fmaxf)
+    for mode in (0, 1):
+        a = np.zeros_like(filt)
+        oracle.albedo(mode, W, H, storage, filt, al, a)
+        with np.errstate(all="ignore"):
+            aw = snp.albedo(mode, filt, al)
+        fin = _same_nonfinite(a, aw, desc + f": albedo mode {mode}")
+        assert np.array_equal(a.view(u)[fin], aw.view(u)[fin]), desc + f": albedo mode {mode}"
+    return desc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=3.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    from oracle import oracle
+    oracle.build()
+    t_end = time.monotonic() + args.minutes * 60
+    seed, failed, lines = args.seed, [], []
+    while time.monotonic() < t_end:
+        try:
+            lines.append("ok   " + run_trial(seed, oracle))
+        except Exception as e:  # noqa: BLE001
+            failed.append(seed)
+            lines.append(f"FAIL seed {seed}: {type(e).__name__}: {(str(e).splitlines() or [''])[0][:400]}")
+            if not isinstance(e, AssertionError):
+                lines.append(traceback.format_exc())
+        seed += 1
+    summary = f"fuzz_oracle: seeds {args.seed}..{seed - 1}: {seed - args.seed} trials; failed {len(failed)}: {failed}"
+    if args.out:
+        with open(args.out, "w") as fh:
+            fh.write("\n".join(lines + [summary]) + "\n")
+    print("\n".join([ln for ln in lines if not ln.startswith("ok")][:60] + [summary]))
+    sys.exit(1 if failed else 0)
+
+
+if __name__ == "__main__":
+    main()

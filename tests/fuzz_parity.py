@@ -542,12 +542,16 @@ def trial_post(G, oracle, seed):
         outs.append(G.host(out))
         if variant == "direct":
             al = _sprinkle_zeros(rng, rng.uniform(-0.1, 1.0, (H, W, 4)).astype(dt), 4)
+            if poison:
+                _sprinkle(rng, al, 4)                                             # (a NaN albedo reads as the floor: fmaxf)
             for mode, fn in ((0, d.Demodulate), (1, d.Modulate)):
                 w2 = np.zeros_like(filt)
                 oracle.albedo(mode, W, H, storage, filt, al, w2)
                 o2 = d.new_colour()
                 fn(G.dev(filt), G.dev(al), o2)
-                assert np.array_equal(G.host(o2).view(np.uint8), w2.view(np.uint8)), desc + f": albedo mode {mode}"
+                g2 = G.host(o2)
+                nn = ~np.isnan(w2.astype(np.float32))                             # (a NaN the operation itself makes — 0 x inf — has the sign the machine gives it)
+                assert np.array_equal(np.isnan(g2.astype(np.float32)), ~nn) and np.array_equal(g2[nn].view(np.uint8), w2[nn].view(np.uint8)), desc + f": albedo mode {mode}"
         d.close()
     got = outs[0]
     assert np.array_equal(got.view(np.uint8), outs[1].view(np.uint8)), desc + ": TAA tiled vs per-pixel"

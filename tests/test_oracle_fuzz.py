@@ -1,0 +1,13 @@
+"""Pinned trials of tests/fuzz_oracle.py (the C++ oracle against the NumPy restatement over random sizes, tunables and poisoned texels): a
+few dozen seeds, among them those whose TAA texels sit where the decode is ill-conditioned (a channel cancelling to ~1e-7 in front of the
+square root: the sweep's first 1 460 trials had 187 of them beyond a plain 1e-6 — the NumPy side's strided np.power(x, 2) being off by an ulp
+in a fifth of the values; it squares now, and the comparison goes back through the square root where the output itself is not conditioned)."""
+import pytest
+
+SEEDS = list(range(1, 25)) + [267, 274, 289, 327, 421, 435, 5000, 5001, 5002, 5003]
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_oracle_equals_the_numpy_restatement(oracle, seed):
+    from tests import fuzz_oracle
+    fuzz_oracle.run_trial(seed, oracle)
