@@ -223,7 +223,9 @@ __global__ __launch_bounds__(kMTX* kRS, 4) void moments_lds_kernel(Geo g, Moment
         // every wave's word of every ring row (lanes 0 .. kBadWord-1) and the workgroup's sticky word (lane kBadWord): one read, one compare
         const unsigned long long flagged = __builtin_amdgcn_ballot_w64(lane <= kBadWord && mflag[lane <= kBadWord ? lane : 0] != 0u);
         const bool uniform = !a.no_fastpath && (flagged & ((1ull << kBadWord) - 1ull)) == 0ull;
-        const bool exact = (flagged >> kBadWord) != 0ull;
+        // ... or PhiColour is 0 (the GUI's range starts there, GUI.cpp:992): |dl| / 0 is inf — or NaN for the taps of the centre's own luminance, the
+        // centre itself among them — which `max(., 0.0)` = fmax turns into "no term" (:424): every pixel's fused-exponent sums are NaN then
+        const bool exact = (flagged >> kBadWord) != 0ull || !(il < __builtin_inff());
         MomSums s{0.0f, 0.0f, {0.f, 0.f}, {0.f, 0.f}};
         // a cleared sky texel (zero normal): every weight is exactly 0, the result (0,0,0,0) while the window is finite (see moments_pixel)
         const bool zero_normal = !exact && ((c.nc01 & 0x7fff7fffu) == 0u) && (c.ncz == 0.0f);

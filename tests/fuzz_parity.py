@@ -1,6 +1,6 @@
 """Seeded random sweep of the parity and bit-identity claims (test infrastructure: it calls the oracle; nothing in the product imports it).
 
-    python -m tests.fuzz_parity --minutes 10 --seed 1000 [--kinds stage,strips,driver,rows,pair,post,stage0,strips2,driver2,wide,widestrips] [--out gpurun_out/fuzz.txt]
+    python -m tests.fuzz_parity --minutes 10 --seed 1000 [--kinds stage,strips,driver,rows,pair,post,stage0,strips2,driver2,wide,widestrips,edge,edgedriver] [--out gpurun_out/fuzz.txt]
 
 Each trial draws a frame size (down to 1 x 1, up past the 128-pixel tile and the 64-lane wave in both directions), a storage format, the
 tunables over the GUI's ranges (GUI.cpp:988-993), a camera motion, optionally NaN / inf radiance texels and poisoned G-buffer texels
@@ -14,13 +14,16 @@ tunables over the GUI's ranges (GUI.cpp:988-993), a camera motion, optionally Na
            stage calls on caller-owned planes instead) against the plain frame driver, bit for bit, and its history against the oracle's
            free-running one;
   rows     a stage call restricted to a row range (svgf_set_rows): the rows inside with the whole-frame call's bits, nothing else written;
-  pair     iterations 0 and 1 in one launch: the frame driver with the fusion against without (finite input, bit for bit), svgf_atrous_pair
-           against the oracle's two iterations (poisoned input, the pair launch's tolerances);
+  pair     iterations 0 and 1 in one launch: the frame driver with the fusion against without (finite input, bit for bit); poisoned input:
+           svgf_atrous_pair's feedback plane against the oracle, its result against the device's own two launches (NaN masks, a bound);
   strips2  the strip driver over RCCL's own kernels (loop-back communicator) or the mailbox, one or two frames in flight, svgf_set_prev_guide, the
            fusion of iterations 0 + 1 (finite input) against the plain frame driver, bit for bit;
   driver2  the frame driver across svgf_reset_history / svgf_resize / svgf_set_params between frames: plain, under a random setting, and a fresh
            context from the last restart on — bit for bit;
   wide, widestrips   `stage` and `strips` on frames 1 024 - 8 200 columns wide (many column tiles: the XCD-aware tile order; few rows);
+  edge     `stage` with the tunables at and beyond the ends of their ranges (PhiColour / PhiNormal 0, NaN / inf / negative thresholds, a history base of
+           0, 256, 1 000, -5) and steps the LDS kernel does not serve (3, 5, 7, 100, 128, 256, 512);
+  edgedriver   `driver` with those tunables;
   stage0   `stage` with -0.0, denormals and the storage type's extremes in the colour and moments planes;
   post     the stages after the path: TAA + sRGB against the oracle and tiled against per-pixel, albedo (de)modulation bit-exact.
 
@@ -39,7 +42,7 @@ from svgf_amd import synth
 from tests.gbuffer_poison import poison_gbuffer
 from tests.helpers import CDT, gbuf
 
-KINDS = ("stage", "strips", "driver", "rows", "pair", "post", "stage0", "strips2", "driver2", "wide", "widestrips")
+KINDS = ("stage", "strips", "driver", "rows", "pair", "post", "stage0", "strips2", "driver2", "wide", "widestrips", "edge", "edgedriver")
 
 
 def _size(rng):
@@ -87,6 +90,14 @@ def _poisoned(rng, f, what):
     return poison_gbuffer(rng, f, what=what, per_value=int(rng.integers(1, 5)))[0]
 
 
+def _same_bits(a, b):
+    """Bit for bit — except that a NaN is a NaN: one that the arithmetic MAKES (inf x 0, inf - inf) carries the sign the machine gives it
+    (x86: set, gfx950: clear), one that is passed through keeps its bits on both."""
+    na, nb = np.isnan(a.astype(np.float32)), np.isnan(b.astype(np.float32))
+    u = {2: np.uint16, 4: np.uint32}[a.dtype.itemsize]
+    return np.array_equal(na, nb) and np.array_equal(a.view(u)[~na], b.view(u)[~nb])
+
+
 def _close(G, got, want, storage, what, colour_abs=None):
     from tests.test_gpu_nonfinite import assert_close_with_nan
     if colour_abs is None:
@@ -96,7 +107,7 @@ def _close(G, got, want, storage, what, colour_abs=None):
 
 
 # ------------------------------------------------------------------------------------------------------------------ stage vs oracle
-def trial_stage(G, oracle, seed, zeros=False, wide=False):
+def trial_stage(G, oracle, seed, zeros=False, wide=False, edge=False):
     """zeros: -0.0, denormals and the storage type's extremes in the colour / moments planes as well (kind "stage0"; drawn from a generator of
     their own, so that kind "stage" keeps the frames of its pinned seeds)."""
     from svgf_amd import filter as F
@@ -113,10 +124,17 @@ def trial_stage(G, oracle, seed, zeros=False, wide=False):
     step = int(2 ** rng.integers(0, 7))
     mv = (float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4)))
     poison = bool(rng.integers(0, 2))
+    if edge:                                              # (kind "edge": the ends of the tunables' ranges and beyond, steps the LDS kernel does not serve)
+        pick = lambda vals: vals[int(rz.integers(0, len(vals)))]       # noqa: E731
+        tun = dict(phi_colour=pick([0.0, 1e-6, 1e6, tun["phi_colour"]]), phi_normal=pick([0.0, 1e-3, 512.0, tun["phi_normal"]]),
+                   depth_threshold=pick([0.0, -1.0, float("inf"), float("nan"), tun["depth_threshold"]]),
+                   normal_threshold=pick([-1.0, 0.0, 1.0, 2.0, float("nan"), tun["normal_threshold"]]),
+                   history_base=pick([0, 1, 2, 255, 256, 1000, -5]), mesh_id_test=tun["mesh_id_test"])
+        step = pick([step, 3, 5, 7, 100, 128, 256, 512])
     f0, f1 = synth.make_frame(W, H, seed % 97, mv=mv), synth.make_frame(W, H, seed % 97 + 1, mv=mv)
     if poison:
         f0, f1 = _poisoned(rng, f0, ("motion", "depth", "ddepth", "normal", "id")), _poisoned(rng, f1, ("motion", "depth", "ddepth", "normal", "id"))
-    desc = f"stage seed {seed}: {W}x{H} {storage} {variant} r{radius} step {step} poison {poison}"
+    desc = f"stage seed {seed}: {W}x{H} {storage} {variant} r{radius} step {step} poison {poison}" + (f" edge {tun}" if edge else "")
     d = F.Denoiser(W, H, F.Params(storage=storage, moments_radius=radius, variant=variant, **tun))
     # temporal: bit-exact whatever the inputs
     prev = rng.uniform(-0.1, 1.2, (H, W, 4)).astype(dt)
@@ -132,9 +150,13 @@ def trial_stage(G, oracle, seed, zeros=False, wide=False):
                     normal_threshold=tun["normal_threshold"], history_base=tun["history_base"], mesh_id_test=tun["mesh_id_test"])
     o_col, o_hist, o_mom = d.new_colour(), d.new_history(), d.new_moments()
     d.TemporalFilter(G.dev(prev), G.dev(cur), o_col, G.gb_dev(f1), G.gb_dev(f0), G.dev(hist_prev), o_hist, o_mom, G.dev(mom_prev))
-    assert np.array_equal(G.host(o_hist), hist), desc + ": history"
-    assert np.array_equal(G.host(o_col).view(np.uint8), o.view(np.uint8)), desc + ": temporal colour"
-    assert np.array_equal(G.host(o_mom).view(np.uint8), mom.view(np.uint8)), desc + ": temporal moments"
+    try:
+        assert np.array_equal(G.host(o_hist), hist), desc + ": history"
+        assert _same_bits(G.host(o_col), o), desc + ": temporal colour"
+        assert _same_bits(G.host(o_mom), mom), desc + ": temporal moments"
+    except AssertionError as e:
+        e.ctx = dict(stage="temporal", got=(G.host(o_hist), G.host(o_col), G.host(o_mom)), want=(hist, o, mom), prev=prev, cur=cur, mom_prev=mom_prev, hist_prev=hist_prev, f0=f0, f1=f1)
+        raise
     # the depth-, ddepth- and normal-poisoned G-buffer for the spatial stages (a poisoned motion vector is the temporal stage's business)
     fs = synth.make_frame(W, H, seed % 97 + 1, mv=mv)
     if poison:
@@ -351,20 +373,30 @@ def trial_strips2(G, oracle, seed):
 
 
 # ------------------------------------------------------------------------------------------------------------------ frame driver settings
-def trial_driver(G, oracle, seed):
+def _edge_tunables(rz, tun):
+    pick = lambda vals: vals[int(rz.integers(0, len(vals)))]       # noqa: E731
+    return dict(phi_colour=pick([0.0, 1e-6, 1e6, tun["phi_colour"]]), phi_normal=pick([0.0, 1e-3, 512.0, tun["phi_normal"]]),
+                depth_threshold=pick([0.0, -1.0, float("inf"), float("nan"), tun["depth_threshold"]]),
+                normal_threshold=pick([-1.0, 0.0, 1.0, 2.0, float("nan"), tun["normal_threshold"]]),
+                history_base=pick([0, 1, 2, 255, 256, 1000, -5]), mesh_id_test=tun["mesh_id_test"])
+
+
+def trial_driver(G, oracle, seed, edge=False):
     import torch
     from svgf_amd import filter as F
     rng = np.random.default_rng(seed)
     W, H = _size(rng)
     storage = ("f32", "f16")[int(rng.integers(0, 2))]
     tun = _tunables(rng)
+    if edge:
+        tun = _edge_tunables(np.random.default_rng(seed ^ 0x5A5A5A), tun)
     steps = int(rng.choice([5, 5, 3, 0, 1, 2, 7]))
     radius = int(rng.choice([3, 3, 1]))
     mv = (float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4)))
     poison = bool(rng.integers(0, 2))
     N = int(rng.integers(3, 7))
     setting = str(rng.choice(["in_flight", "general", "no_adaptive", "prev_guide", "stage_calls"]))
-    desc = f"driver seed {seed}: {W}x{H} {storage} steps {steps} r{radius} poison {poison} frames {N} setting {setting}"
+    desc = f"driver seed {seed}: {W}x{H} {storage} steps {steps} r{radius} poison {poison} frames {N} setting {setting}" + (f" edge {tun}" if edge else "")
     fr = _sequence(rng, W, H, N, mv, poison, storage)
     P = F.Params(storage=storage, steps=steps, moments_radius=radius, **tun)
     a = F.Denoiser(W, H, P)
@@ -648,7 +680,7 @@ def trial_driver2(G, oracle, seed):
     return desc
 
 
-TRIALS = {"wide": lambda G, oracle, seed: trial_stage(G, oracle, seed, wide=True), "widestrips": lambda G, oracle, seed: trial_strips(G, oracle, seed, wide=True),
+TRIALS = {"edgedriver": lambda G, oracle, seed: trial_driver(G, oracle, seed, edge=True), "edge": lambda G, oracle, seed: trial_stage(G, oracle, seed, edge=True), "wide": lambda G, oracle, seed: trial_stage(G, oracle, seed, wide=True), "widestrips": lambda G, oracle, seed: trial_strips(G, oracle, seed, wide=True),
           "driver2": trial_driver2, "strips2": trial_strips2, "stage0": lambda G, oracle, seed: trial_stage(G, oracle, seed, zeros=True), "stage": trial_stage, "strips": trial_strips, "driver": trial_driver, "rows": trial_rows, "pair": trial_pair, "post": trial_post}
 
 

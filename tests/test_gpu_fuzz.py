@@ -10,7 +10,10 @@ What the sweep found in round 5 (all in frames whose G-buffer holds NaN / out-of
     the reference's way once its sums hold a NaN: the frame driver (which picks one of the two per frame) differed from itself with
     svgf_set_adaptive_moments(0), and from the stage calls (svgf_kernels.hip:moments_group8 now follows the streaming kernel's rule);
   * svgf_modulate in fp16 storage turned -0 x albedo into +0 in one channel: hipcc folds a product that is only rounded to half into
-    v_fma_mixlo_f16 with a +0 addend (svgf_kernels.hip:albedo_kernel pins the products in fp32 registers)."""
+    v_fma_mixlo_f16 with a +0 addend (svgf_kernels.hip:albedo_kernel pins the products in fp32 registers);
+  * PhiColour = 0 (the GUI's drag starts there, GUI.cpp:992): |dl| / 0 is inf, or NaN for the taps of the centre's own luminance — the centre
+    among them — and `max(., 0.0)` = fmax reads that as "no term" (Filter.cuh:424); the streaming moments kernel wrote NaN for every young pixel
+    (its second, exact evaluation was tied to a non-finite TEXEL having been staged; svgf_moments_lds.h now also takes it when 1 / PhiColour is inf)."""
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -21,6 +24,8 @@ STAGE = [6657, 1266, 3795, 3807, 5883, 2529, 40002, 40005, 40008, 40011]
 OTHER = [("post", 213350), ("post", 215738), ("post", 320621), ("post", 400001), ("rows", 400000), ("rows", 400003), ("rows", 400006), ("rows", 400009),
          ("pair", 400004), ("pair", 400007), ("pair", 400010), ("pair", 400013), ("stage0", 500000), ("stage0", 500001), ("stage0", 500002), ("stage0", 500003),
          ("strips2", 600000), ("strips2", 600001), ("strips2", 600002), ("strips2", 600003), ("strips2", 600004), ("strips2", 600005),
+         ("edge", 955563), ("edge", 955568), ("edge", 955878), ("edge", 950042), ("edge", 955806), ("edge", 950208), ("edge", 960000), ("edge", 960001),
+         ("edgedriver", 970000), ("edgedriver", 970001), ("edgedriver", 970002), ("edgedriver", 970003),
          ("wide", 800000), ("wide", 800002), ("widestrips", 800001), ("widestrips", 800003),
          ("driver2", 700000), ("driver2", 700001), ("driver2", 700002), ("driver2", 700003), ("driver2", 700004), ("driver2", 700005)]
 

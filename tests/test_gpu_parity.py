@@ -608,6 +608,48 @@ def test_atrous_large_steps_and_degenerate_phis(G, oracle, storage):
         G.assert_colour_close(G.host(out), want, storage, f"step {step} phi_colour {phi_c} phi_normal {phi_n}")
 
 
+@pytest.mark.parametrize("variant", ["auto", "direct", "lds-general"])
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_moments_degenerate_phis(G, oracle, storage, variant):
+    """The spatial estimate at the ends of the GUI's drags (src/GUI.cpp:991-992, both start at 0): PhiColour = 0 makes |dl| / PhiColour inf — or
+    NaN where the tap's luminance IS the centre's, the centre tap included — and `max(., 0.0)` = fmax reads a NaN as no term (Filter.cuh:422-424):
+    finite results.  (Found by tests/fuzz_parity.py: the streaming kernel's exact second evaluation was tied to a non-finite texel having been
+    staged and wrote NaN for every young pixel.)  PhiNormal = 0: pow(x, 0) = 1 also at x = 0.  Stage call and frame driver (cold frames: the
+    streaming kernel; steady state: the young-pixel launch)."""
+    from svgf_amd import filter as F
+    W, H = 203, 131
+    rng = np.random.default_rng(9)
+    f = synth.make_frame(W, H, 0)
+    dt = CDT[storage]
+    col = rng.uniform(0, 1, (H, W, 4)).astype(dt)
+    col[40:60, 50:90, :3] = col[40, 50, :3]                   # a patch of equal luminance: its taps pass PhiColour = 0
+    mom = rng.uniform(0, 1, (H, W, 2)).astype(dt)
+    hist = rng.integers(1, 6, (H, W)).astype(np.uint8)
+    for phi_c, phi_n in [(0.0, 128.0), (10.0, 0.0), (0.0, 0.0), (1e-6, 1e-3)]:
+        want = np.zeros_like(col)
+        oracle.moments(W, H, storage, col, want, mom, gbuf(f), hist, phi_colour=phi_c, phi_normal=phi_n, radius=3)
+        assert np.isfinite(want.astype(np.float32)).all()
+        d = F.Denoiser(W, H, F.Params(storage=storage, phi_colour=phi_c, phi_normal=phi_n, variant=variant))
+        out = d.new_colour()
+        d.FilterMoments(G.dev(col), out, G.dev(mom), G.gb_dev(f), G.dev(hist))
+        got = G.host(out)
+        assert np.isfinite(got.astype(np.float32)).all(), (phi_c, phi_n)
+        if storage == "f32":
+            assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= 8e-5, (phi_c, phi_n)
+        else:
+            G.assert_colour_close(got[..., :3], want[..., :3], storage, f"moments phi {phi_c} {phi_n}")
+        # the frame driver over the cold -> steady transition of a pan: finite, history equal to the oracle's
+        fr = frames(W, H, 6, mv=(1.0, -1.5))
+        ref = oracle.Pipeline(W, H, storage, steps=2, nthreads=8, phi_colour=phi_c, phi_normal=phi_n)
+        dd = F.Denoiser(W, H, F.Params(storage=storage, steps=2, phi_colour=phi_c, phi_normal=phi_n, variant=variant))
+        gbs = [G.gb_dev(x) for x in fr]
+        for k in range(6):
+            w = ref.frame(fr[k]["radiance"], gbuf(fr[k]), gbuf(fr[max(k - 1, 0)]))
+            g = G.host(dd.Render(G.dev(fr[k]["radiance"].astype(G.NPDT[storage])), gbs[k], gbs[k - 1] if k else None))
+            assert np.isfinite(g.astype(np.float32)).all() and np.isfinite(w.astype(np.float32)).all(), (phi_c, phi_n, k)
+            assert np.array_equal(G.host(dd.state_plane(F.PLANE_HISTORY, 1 - dd.pingpong())), ref.taps["hist"]), (phi_c, phi_n, k)
+
+
 def test_frame_sizes_and_ten_iterations(G, oracle):
     """Odd sizes around the 256-column / 64-lane tiles, narrower than one tile, and the GUI's maximum of 10 iterations."""
     for (W, H, steps) in [(1, 1, 2), (7, 3, 5), (17, 130, 5), (130, 2, 5), (64, 40, 3), (255, 33, 5), (257, 65, 5), (513, 130, 10)]:
