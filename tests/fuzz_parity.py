@@ -1,6 +1,6 @@
 """Seeded random sweep of the parity and bit-identity claims (test infrastructure: it calls the oracle; nothing in the product imports it).
 
-    python -m tests.fuzz_parity --minutes 10 --seed 1000 [--kinds stage,strips,driver,rows,pair,post,stage0,strips2,driver2,wide,widestrips,edge,edgedriver] [--out gpurun_out/fuzz.txt]
+    python -m tests.fuzz_parity --minutes 10 --seed 1000 [--kinds stage,strips,driver,rows,pair,post,stage0,strips2,driver2,wide,widestrips,edge,edgedriver,edgestrips] [--out gpurun_out/fuzz.txt]
 
 Each trial draws a frame size (down to 1 x 1, up past the 128-pixel tile and the 64-lane wave in both directions), a storage format, the
 tunables over the GUI's ranges (GUI.cpp:988-993), a camera motion, optionally NaN / inf radiance texels and poisoned G-buffer texels
@@ -23,7 +23,7 @@ tunables over the GUI's ranges (GUI.cpp:988-993), a camera motion, optionally Na
   wide, widestrips   `stage` and `strips` on frames 1 024 - 8 200 columns wide (many column tiles: the XCD-aware tile order; few rows);
   edge     `stage` with the tunables at and beyond the ends of their ranges (PhiColour / PhiNormal 0, NaN / inf / negative thresholds, a history base of
            0, 256, 1 000, -5) and steps the LDS kernel does not serve (3, 5, 7, 100, 128, 256, 512);
-  edgedriver   `driver` with those tunables;
+  edgedriver, edgestrips   `driver` and `strips` with those tunables, a moments radius of 0-3 and 0-10 (0-7) iterations;
   stage0   `stage` with -0.0, denormals and the storage type's extremes in the colour and moments planes;
   post     the stages after the path: TAA + sRGB against the oracle and tiled against per-pixel, albedo (de)modulation bit-exact.
 
@@ -42,7 +42,7 @@ from svgf_amd import synth
 from tests.gbuffer_poison import poison_gbuffer
 from tests.helpers import CDT, gbuf
 
-KINDS = ("stage", "strips", "driver", "rows", "pair", "post", "stage0", "strips2", "driver2", "wide", "widestrips", "edge", "edgedriver")
+KINDS = ("stage", "strips", "driver", "rows", "pair", "post", "stage0", "strips2", "driver2", "wide", "widestrips", "edge", "edgedriver", "edgestrips")
 
 
 def _size(rng):
@@ -131,6 +131,7 @@ def trial_stage(G, oracle, seed, zeros=False, wide=False, edge=False):
                    normal_threshold=pick([-1.0, 0.0, 1.0, 2.0, float("nan"), tun["normal_threshold"]]),
                    history_base=pick([0, 1, 2, 255, 256, 1000, -5]), mesh_id_test=tun["mesh_id_test"])
         step = pick([step, 3, 5, 7, 100, 128, 256, 512])
+        radius = pick([radius, 0, 2, 3])
     f0, f1 = synth.make_frame(W, H, seed % 97, mv=mv), synth.make_frame(W, H, seed % 97 + 1, mv=mv)
     if poison:
         f0, f1 = _poisoned(rng, f0, ("motion", "depth", "ddepth", "normal", "id")), _poisoned(rng, f1, ("motion", "depth", "ddepth", "normal", "id"))
@@ -212,7 +213,7 @@ def _sequence(rng, W, H, N, mv, poison, storage):
     return fr
 
 
-def trial_strips(G, oracle, seed, wide=False):
+def trial_strips(G, oracle, seed, wide=False, edge=False):
     import torch
     from svgf_amd import filter as F
     from svgf_amd import strips
@@ -221,6 +222,10 @@ def trial_strips(G, oracle, seed, wide=False):
     tun = _tunables(rng)
     steps = int(rng.choice([5, 5, 5, 3, 1, 2, 4, 6, 7]))
     radius = int(rng.choice([3, 3, 1]))
+    if edge:
+        re_ = np.random.default_rng(seed ^ 0xA5A5A5)
+        tun = _edge_tunables(re_, tun)
+        radius, steps = int(re_.integers(0, 4)), int(re_.integers(0, 8))
     world = int(rng.integers(2, 9))
     plan = str(rng.choice(["ghost", "grouped", "per-iteration", "auto"]))
     reach = int(rng.integers(0, 7))
@@ -242,7 +247,7 @@ def trial_strips(G, oracle, seed, wide=False):
     N = int(rng.integers(2, 5))
     edge_first, own_streams = bool(rng.integers(0, 4)), bool(rng.integers(0, 2))
     desc = (f"strips seed {seed}: {W}x{H} {storage} world {world} plan {plan} reach {reach} mv ({mv[0]:.2f},{mv[1]:.2f}) steps {steps} r{radius} "
-            f"poison {poison} frames {N} edge_first {edge_first} own_streams {own_streams}")
+            f"poison {poison} frames {N} edge_first {edge_first} own_streams {own_streams}" + (f" edge {tun}" if edge else ""))
     fr = _sequence(rng, W, H, N, mv, poison, storage)
     P = F.Params(storage=storage, steps=steps, moments_radius=radius, **tun)
     whole = F.Denoiser(W, H, P)
@@ -388,14 +393,17 @@ def trial_driver(G, oracle, seed, edge=False):
     W, H = _size(rng)
     storage = ("f32", "f16")[int(rng.integers(0, 2))]
     tun = _tunables(rng)
+    rz = np.random.default_rng(seed ^ 0x5A5A5A)
     if edge:
-        tun = _edge_tunables(np.random.default_rng(seed ^ 0x5A5A5A), tun)
+        tun = _edge_tunables(rz, tun)
     steps = int(rng.choice([5, 5, 3, 0, 1, 2, 7]))
     radius = int(rng.choice([3, 3, 1]))
     mv = (float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4)))
     poison = bool(rng.integers(0, 2))
     N = int(rng.integers(3, 7))
     setting = str(rng.choice(["in_flight", "general", "no_adaptive", "prev_guide", "stage_calls"]))
+    if edge:
+        radius, steps = int(rz.integers(0, 4)), int(rz.integers(0, 11))          # (the GUI: 0-10 iterations, GUI.cpp:988)
     desc = f"driver seed {seed}: {W}x{H} {storage} steps {steps} r{radius} poison {poison} frames {N} setting {setting}" + (f" edge {tun}" if edge else "")
     fr = _sequence(rng, W, H, N, mv, poison, storage)
     P = F.Params(storage=storage, steps=steps, moments_radius=radius, **tun)
@@ -680,7 +688,7 @@ def trial_driver2(G, oracle, seed):
     return desc
 
 
-TRIALS = {"edgedriver": lambda G, oracle, seed: trial_driver(G, oracle, seed, edge=True), "edge": lambda G, oracle, seed: trial_stage(G, oracle, seed, edge=True), "wide": lambda G, oracle, seed: trial_stage(G, oracle, seed, wide=True), "widestrips": lambda G, oracle, seed: trial_strips(G, oracle, seed, wide=True),
+TRIALS = {"edgestrips": lambda G, oracle, seed: trial_strips(G, oracle, seed, edge=True), "edgedriver": lambda G, oracle, seed: trial_driver(G, oracle, seed, edge=True), "edge": lambda G, oracle, seed: trial_stage(G, oracle, seed, edge=True), "wide": lambda G, oracle, seed: trial_stage(G, oracle, seed, wide=True), "widestrips": lambda G, oracle, seed: trial_strips(G, oracle, seed, wide=True),
           "driver2": trial_driver2, "strips2": trial_strips2, "stage0": lambda G, oracle, seed: trial_stage(G, oracle, seed, zeros=True), "stage": trial_stage, "strips": trial_strips, "driver": trial_driver, "rows": trial_rows, "pair": trial_pair, "post": trial_post}
 
 
