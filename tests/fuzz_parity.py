@@ -1,6 +1,6 @@
 """Seeded random sweep of the parity and bit-identity claims (test infrastructure: it calls the oracle; nothing in the product imports it).
 
-    python -m tests.fuzz_parity --minutes 10 --seed 1000 [--kinds stage,strips,driver,rows,pair,post,stage0,strips2,driver2,wide,widestrips,edge,edgedriver,edgestrips] [--out gpurun_out/fuzz.txt]
+    python -m tests.fuzz_parity --minutes 10 --seed 1000 [--kinds stage,strips,driver,rows,pair,post,stage0,strips2,driver2,wide,widestrips,edge,edgedriver,edgestrips,graph,fullsize] [--out gpurun_out/fuzz.txt]
 
 Each trial draws a frame size (down to 1 x 1, up past the 128-pixel tile and the 64-lane wave in both directions), a storage format, the
 tunables over the GUI's ranges (GUI.cpp:988-993), a camera motion, optionally NaN / inf radiance texels and poisoned G-buffer texels
@@ -24,6 +24,8 @@ tunables over the GUI's ranges (GUI.cpp:988-993), a camera motion, optionally Na
   edge     `stage` with the tunables at and beyond the ends of their ranges (PhiColour / PhiNormal 0, NaN / inf / negative thresholds, a history base of
            0, 256, 1 000, -5) and steps the LDS kernel does not serve (3, 5, 7, 100, 128, 256, 512);
   edgedriver, edgestrips   `driver` and `strips` with those tunables, a moments radius of 0-3 and 0-10 (0-7) iterations;
+  graph    the frame driver recorded into a HIP graph and replayed against the directly enqueued frames, bit for bit;
+  fullsize   1920x1080 and 3840x2160: strip driver and frame driver under a setting against the plain frame driver, bit for bit, poisoned frames;
   stage0   `stage` with -0.0, denormals and the storage type's extremes in the colour and moments planes;
   post     the stages after the path: TAA + sRGB against the oracle and tiled against per-pixel, albedo (de)modulation bit-exact.
 
@@ -42,7 +44,7 @@ from svgf_amd import synth
 from tests.gbuffer_poison import poison_gbuffer
 from tests.helpers import CDT, gbuf
 
-KINDS = ("stage", "strips", "driver", "rows", "pair", "post", "stage0", "strips2", "driver2", "wide", "widestrips", "edge", "edgedriver", "edgestrips")
+KINDS = ("stage", "strips", "driver", "rows", "pair", "post", "stage0", "strips2", "driver2", "wide", "widestrips", "edge", "edgedriver", "edgestrips", "graph", "fullsize")
 
 
 def _size(rng):
@@ -688,7 +690,101 @@ def trial_driver2(G, oracle, seed):
     return desc
 
 
-TRIALS = {"edgestrips": lambda G, oracle, seed: trial_strips(G, oracle, seed, edge=True), "edgedriver": lambda G, oracle, seed: trial_driver(G, oracle, seed, edge=True), "edge": lambda G, oracle, seed: trial_stage(G, oracle, seed, edge=True), "wide": lambda G, oracle, seed: trial_stage(G, oracle, seed, wide=True), "widestrips": lambda G, oracle, seed: trial_strips(G, oracle, seed, wide=True),
+
+def trial_graph(G, oracle, seed):
+    """svgf_denoise_frame recorded into a HIP graph (two frames per graph, inputs at fixed addresses refilled before each replay) against the
+    directly enqueued frames, bit for bit, state planes included (tests/test_gpu_graph.py's harness on random sizes and settings)."""
+    from tests.test_gpu_graph import _assert_same, _direct, _replayed
+    rng = np.random.default_rng(seed)
+    W, H = _size(rng)
+    storage = ("f32", "f16")[int(rng.integers(0, 2))]
+    steps = int(rng.choice([5, 5, 3, 0, 1, 2, 7]))
+    mv = (float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4)))
+    poison = bool(rng.integers(0, 2))
+    warm = int(rng.choice([4, 6]))
+    N = warm + 2 * int(rng.integers(1, 4))
+    kw = dict(steps=steps, variant=str(rng.choice(["auto", "direct", "lds-general"])), prev_guide=bool(rng.integers(0, 2)))
+    kw["fusion"] = bool(rng.integers(0, 2)) and not poison and steps >= 2 and kw["variant"] != "direct"
+    in_flight = int(rng.integers(1, 3))
+    desc = f"graph seed {seed}: {W}x{H} {storage} poison {poison} frames {N} warm {warm} in flight {in_flight} {kw}"
+    seq = _sequence(rng, W, H, N, mv, poison, storage)
+    try:
+        _assert_same(_direct(G, seq, storage, **kw), _replayed(G, seq, storage, warm=warm, in_flight=in_flight, **kw))
+    except AssertionError as e:
+        raise AssertionError(desc + ": " + str(e)) from e
+    return desc
+
+
+
+_FULL = {}
+
+
+def trial_fullsize(G, oracle, seed):
+    """BASELINE.json's frame sizes themselves (1920x1080, 3840x2160): the strip driver (mailbox, world 2-8, any plan) and the frame driver under a
+    random setting against the plain frame driver, bit for bit, on poisoned frames; the history against the oracle's would need minutes of CPU
+    per trial and is left to tests/test_gpu_round2.py's full-size cases.  (The frames of a size are made once per process: synth needs seconds.)"""
+    import torch
+    from svgf_amd import filter as F
+    from svgf_amd import strips
+    rng = np.random.default_rng(seed)
+    W, H = [(1920, 1080), (3840, 2160)][int(rng.integers(0, 2))]
+    storage = ("f32", "f16")[int(rng.integers(0, 2))]
+    tun = _tunables(rng)
+    steps = int(rng.choice([5, 5, 3, 7]))
+    world = int(rng.integers(2, 9))
+    plan = str(rng.choice(["ghost", "grouped", "per-iteration", "auto"]))
+    mv = [(0.0, 0.0), (1.5, -2.5)][int(rng.integers(0, 2))]
+    reach = 3 if mv[1] else int(rng.integers(0, 3))
+    setting = str(rng.choice(["in_flight", "general", "no_adaptive", "prev_guide"]))
+    N = 3
+    desc = f"fullsize seed {seed}: {W}x{H} {storage} steps {steps} world {world} plan {plan} reach {reach} mv {mv} setting {setting}"
+    if not strips._plan_fits(W, H, 0, world, steps, plan, 3, reach):
+        return desc + " (plan does not fit: skipped)"
+    key = (W, H, mv)
+    if key not in _FULL:
+        _FULL.clear()                                     # one size at a time in memory
+        _FULL[key] = [synth.make_frame(W, H, k, mv=mv) for k in range(N)]
+    fr = []
+    for k in range(N):
+        f = _FULL[key][k]
+        f = _poisoned(rng, f, ("motion", "depth", "ddepth", "normal", "id")) if rng.integers(0, 2) else f
+        fr.append(dict(f, radiance=_sprinkle(rng, f["radiance"].copy(), 6)))
+    P = F.Params(storage=storage, steps=steps, **tun)
+    whole, other = F.Denoiser(W, H, P), F.Denoiser(W, H, F.Params(storage=storage, steps=steps, variant="lds-general", **tun) if setting == "general" else P)
+    if setting == "in_flight":
+        other.set_frames_in_flight(2)
+    elif setting == "no_adaptive":
+        other.set_adaptive_moments(False)
+    elif setting == "prev_guide":
+        other.set_prev_guide(True)
+    drv = strips.NativeStrips(W, H, world, P, list(range(world)), [0] * world, plan=plan, motion_reach=reach, transport="mailbox")
+    try:
+        gbs = [G.gb_dev(f) for f in fr]
+        prev_in = None
+        for k in range(N):
+            rad = G.dev(fr[k]["radiance"].astype(G.NPDT[storage]))
+            want = whole.Render(rad, gbs[k], gbs[k - 1] if k else None).clone()
+            y = other.Render(rad, gbs[k], gbs[k - 1] if k else None)
+            if setting == "in_flight":
+                other.flush()
+            torch.cuda.synchronize()
+            assert torch.equal(y.view(torch.uint8), want.view(torch.uint8)), desc + f": frame {k}: setting"
+            cur_in = []
+            for lay in drv.layouts:
+                sl = slice(lay["y0"], lay["y1"])
+                cur_in.append((rad[sl].contiguous(), F.GBuffer(gbs[k].motion[sl].contiguous(), gbs[k].normal[sl].contiguous(), gbs[k].uv[sl].contiguous())))
+            torch.cuda.synchronize()
+            outs = drv.frame([c[0] for c in cur_in], [c[1] for c in cur_in], [p[1] for p in prev_in] if prev_in else None)
+            drv.sync()
+            got = torch.cat([drv.owned(r, o) for r, o in enumerate(outs)], 0)
+            assert torch.equal(got.view(torch.uint8), want.view(torch.uint8)), desc + f": frame {k}: strips"
+            prev_in = cur_in
+    finally:
+        drv.close(); whole.close(); other.close()
+    return desc
+
+
+TRIALS = {"fullsize": trial_fullsize, "graph": trial_graph, "edgestrips": lambda G, oracle, seed: trial_strips(G, oracle, seed, edge=True), "edgedriver": lambda G, oracle, seed: trial_driver(G, oracle, seed, edge=True), "edge": lambda G, oracle, seed: trial_stage(G, oracle, seed, edge=True), "wide": lambda G, oracle, seed: trial_stage(G, oracle, seed, wide=True), "widestrips": lambda G, oracle, seed: trial_strips(G, oracle, seed, wide=True),
           "driver2": trial_driver2, "strips2": trial_strips2, "stage0": lambda G, oracle, seed: trial_stage(G, oracle, seed, zeros=True), "stage": trial_stage, "strips": trial_strips, "driver": trial_driver, "rows": trial_rows, "pair": trial_pair, "post": trial_post}
 
 

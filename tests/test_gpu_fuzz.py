@@ -25,6 +25,7 @@ OTHER = [("post", 213350), ("post", 215738), ("post", 320621), ("post", 400001),
          ("pair", 400004), ("pair", 400007), ("pair", 400010), ("pair", 400013), ("stage0", 500000), ("stage0", 500001), ("stage0", 500002), ("stage0", 500003),
          ("strips2", 600000), ("strips2", 600001), ("strips2", 600002), ("strips2", 600003), ("strips2", 600004), ("strips2", 600005),
          ("edge", 955563), ("edge", 955568), ("edge", 955878), ("edge", 950042), ("edge", 955806), ("edge", 950208), ("edge", 960000), ("edge", 960001),
+         ("graph", 1100000), ("graph", 1100001), ("graph", 1100002), ("graph", 1100003), ("graph", 1100004), ("fullsize", 1200001),
          ("edgestrips", 990000), ("edgestrips", 990001), ("edgestrips", 990011), ("edgestrips", 990002),
          ("edgedriver", 970000), ("edgedriver", 970001), ("edgedriver", 970002), ("edgedriver", 970003),
          ("wide", 800000), ("wide", 800002), ("widestrips", 800001), ("widestrips", 800003),
