@@ -511,7 +511,8 @@ int svgf_rccl_comm_count(void* comm, int* count) {
 }
 
 int svgf_strips_plan(int width, int height, int rank, int world, int steps, int plan, int moments_radius, int motion_reach, svgf_strip_layout* out) {
-    if (!out || width <= 0 || height <= 0 || world < 1 || rank < 0 || rank >= world || steps < 0 || steps > SVGF_MAX_STEPS || motion_reach < 0) return SVGF_ERR_INVALID;
+    if (!out || width <= 0 || height <= 0 || world < 1 || rank < 0 || rank >= world || steps < 0 || steps > SVGF_MAX_STEPS || motion_reach < 0 ||
+        moments_radius < 0 || moments_radius > 3) return SVGF_ERR_INVALID;            // (the radius svgf_create accepts)
     svgf_strip_plan_geo g;
     int chosen = plan;
     if (plan == SVGF_PLAN_AUTO) {
