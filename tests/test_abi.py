@@ -68,26 +68,14 @@ def test_product_never_touches_the_oracle():
 def test_strip_plan_matches_python_geometry():
     """svgf_strips_plan (C++, what the strip driver runs on) == svgf_amd.strips.Geometry.make (what the CPU gloo tests run on),
     over frame sizes, world sizes, iteration counts, plans, radii and motion reaches; and the same refusals."""
-    from svgf_amd import strips
+    from tests.strip_geometry_checks import check_plan_against_python
     n = 0
     for (W, H) in ((7680, 4320), (3840, 2160), (320, 420), (96, 312), (64, 200)):
         for world in (1, 2, 3, 8):
             for steps in (0, 1, 3, 5):
                 for plan in ("ghost", "grouped", "per-iteration", "auto"):
                     for mr, reach in ((3, 4), (1, 0), (3, 9)):
-                        for rank in sorted({0, world // 2, world - 1}):
-                            try:
-                                g = strips.Geometry.make(W, H, rank, world, steps, plan=plan, moments_radius=mr, motion_reach=reach)
-                            except ValueError:
-                                with pytest.raises(ValueError):
-                                    strips.strips_plan(W, H, rank, world, steps, plan, mr, reach)
-                                continue
-                            lay = strips.strips_plan(W, H, rank, world, steps, plan, mr, reach)
-                            assert (lay["y0"], lay["y1"], lay["own"]) == (g.y0, g.y1, g.own), (W, H, world, steps, plan, rank)
-                            assert lay["ext_atrous"] == g.ext_atrous and lay["halo_group"] == g.halo_group
-                            assert (lay["ext_moments"], lay["ext_temporal"], lay["halo_state"], lay["halo_max"]) == (g.ext_moments, g.ext_temporal, g.halo_state, g.halo_max)
-                            assert lay["plan"] == (g.plan if isinstance(g.plan, str) else plan)
-                            n += 1
+                        n += check_plan_against_python(W, H, world, steps, plan, mr, reach, ranks=sorted({0, world // 2, world - 1}))
     assert n > 500
 
 
@@ -96,8 +84,9 @@ def test_every_posted_send_has_its_mirror_receive_on_the_neighbour():
     both storages, frame sizes with uneven strips and several motion reaches: within every exchange, the sends of rank a to rank b and the
     receives rank b posts with peer a are the SAME sequence of (plane, global rows, bytes) — RCCL matches the sends and receives of a pair
     of ranks in posting order, so an unmatched or mis-ordered message is a deadlock (or rows in the wrong place) on a real node.  Also: peers
-    are direct neighbours, a rank receives only rows outside its own strip and inside what it holds, sends only rows it owns."""
-    from svgf_amd import strips
+    are direct neighbours, a rank receives only rows outside its own strip and inside what it holds, sends only rows it owns.
+    (tests/strip_geometry_checks.py; `python -m tests.strip_geometry_checks --minutes 2` sweeps random partitions with the same checks.)"""
+    from tests.strip_geometry_checks import check_messages
     cases = 0
     for (W, H) in ((7680, 4320), (3840, 2160), (640, 1003), (96, 700)):
         for world in range(2, 9):
@@ -105,38 +94,15 @@ def test_every_posted_send_has_its_mirror_receive_on_the_neighbour():
                 for plan in ("ghost", "grouped", "per-iteration", "auto"):
                     for mr, reach in ((3, 4), (1, 0), (3, 9)):
                         for storage in ("f32", "f16"):
-                            try:
-                                lays = [strips.strips_plan(W, H, r, world, steps, plan, mr, reach) for r in range(world)]
-                            except ValueError:
-                                with pytest.raises(ValueError):
-                                    strips.strip_messages(W, H, 0, world, steps, plan, mr, reach, storage)
-                                continue
-                            msgs = [strips.strip_messages(W, H, r, world, steps, plan, mr, reach, storage) for r in range(world)]
-                            nex = 1 + max(0, len(lays[0]["halo_group"]) - 1)
-                            # (no iteration and no motion reach: every state row a rank needs it has computed itself — nothing travels)
-                            state = steps > 0 or reach > 0
-                            assert {m["exchange"] for r in range(world) for m in msgs[r]} == set(range(0 if state else 1, nex)), (W, H, world, steps, plan)
-                            for ex in range(nex):
-                                for a in range(world):
-                                    for b in (a - 1, a + 1):
-                                        if not 0 <= b < world:
-                                            assert not [m for m in msgs[a] if m["peer"] == b]
-                                            continue
-                                        sent = [(m["plane"], m["rows"], m["bytes"]) for m in msgs[a] if m["exchange"] == ex and m["send"] and m["peer"] == b]
-                                        recv = [(m["plane"], m["rows"], m["bytes"]) for m in msgs[b] if m["exchange"] == ex and not m["send"] and m["peer"] == a]
-                                        assert sent == recv and (sent or (ex == 0 and not state)), (W, H, world, steps, plan, ex, a, b, sent, recv)
-                            for r in range(world):
-                                own, y0, y1 = lays[r]["own"], lays[r]["y0"], lays[r]["y1"]
-                                for m in msgs[r]:
-                                    assert abs(m["peer"] - r) == 1
-                                    lo, hi = m["rows"]
-                                    assert lo < hi and m["bytes"] == (hi - lo) * W * {0: 16, 1: 8, 2: 16, 3: 1}[m["plane"]] // ((2 if m["plane"] != 3 else 1) if storage == "f16" else 1)
-                                    if m["send"]:
-                                        assert own[0] <= lo and hi <= own[1], (r, m, own)
-                                    else:
-                                        assert y0 <= lo and hi <= y1 and (hi <= own[0] or lo >= own[1]), (r, m, own, y0, y1)
-                            cases += 1
+                            cases += check_messages(W, H, world, steps, plan, mr, reach, storage)
     assert cases > 1000
+
+
+def test_random_partitions_seeded():
+    """The same two checks on 400 random partitions (world up to 16, 0-10 iterations, moments radius 0-3, motion reach 0-24, ragged sizes)."""
+    from tests.strip_geometry_checks import random_case
+    done = sum(random_case(seed) for seed in range(400))
+    assert done > 150          # (the others: partitions the plan refuses — checked to be refused by both sides)
 
 
 def test_strip_driver_refuses_without_gpu_or_bad_arguments():
