@@ -25,6 +25,9 @@ int fail(svgf_ctx* c, int code, const std::string& msg) {
     return code;
 }
 int hip_fail(svgf_ctx* c, hipError_t e, const char* what) {
+    // the failure is reported through this library's own status and text: the runtime's "last error" is cleared, so that the host's next HIP call —
+    // or the next hipGetLastError() of a framework that checks after every launch — does not trip over an error it did not cause
+    (void)hipGetLastError();
     return fail(c, SVGF_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 
@@ -467,7 +470,8 @@ int svgf_create_strip(svgf_ctx** out, int width, int height, const svgf_strip* s
     int rc = check_geometry(width, height, strip);
     if (rc != SVGF_OK) return rc;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return SVGF_ERR_NO_DEVICE;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return SVGF_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) return SVGF_ERR_NO_DEVICE;
     svgf_ctx* c = new (std::nothrow) svgf_ctx();
     if (!c) return SVGF_ERR_ALLOC;
     c->W = width; c->H = height; c->strip = *strip; c->rb = strip->own_begin; c->re = strip->own_end;

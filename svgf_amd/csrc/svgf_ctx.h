@@ -89,7 +89,10 @@ struct DeviceGuard {
     int prev = -1;
     bool switched = false;
     explicit DeviceGuard(int device) {
-        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) {
+            switched = hipSetDevice(device) == hipSuccess;
+            if (!switched) (void)hipGetLastError();        // (a device that does not exist: the caller's entry point fails on its own; nothing is left pending for the host)
+        }
     }
     ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
     DeviceGuard(const DeviceGuard&) = delete;

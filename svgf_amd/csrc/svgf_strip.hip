@@ -590,6 +590,11 @@ int svgf_strips_create(svgf_strips** out, int width, int height, int world, cons
         std::vector<char> seen(world, 0);
         for (int k = 0; k < nlocal; k++) { if (ranks[k] < 0 || ranks[k] >= world || seen[ranks[k]]) return SVGF_ERR_INVALID; seen[ranks[k]] = 1; }
     }
+    {   // every device named must exist BEFORE anything is created on any of them
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return SVGF_ERR_NO_DEVICE; }
+        for (int k = 0; k < nlocal; k++) if (devices[k] < 0 || devices[k] >= ndev) return SVGF_ERR_NO_DEVICE;
+    }
     std::unique_ptr<svgf_strips> s(new (std::nothrow) svgf_strips());
     if (!s) return SVGF_ERR_ALLOC;
     s->W = width; s->H = height; s->world = world; s->steps = params->steps; s->motion_reach = motion_reach;

@@ -40,6 +40,15 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _runtime_is_clean():
+    """Nothing is left pending in the HIP runtime for the host: a refused call must not make the NEXT runtime call of the host — here torch's, which
+    checks hipGetLastError after its launches — report an error it did not cause (a refused device number used to: "invalid device ordinal")."""
+    import torch
+    t = torch.from_numpy(np.arange(8, dtype=np.float32)).to("cuda:0")
+    assert float((t + 1).sum().item()) == 36.0
+    torch.cuda.synchronize()
+
+
 def test_null_context_everywhere(G):
     """Every entry point that takes a context or a strip driver refuses NULL (no crash): a negative status, NULL, 0 — or, for the two
     destructors, nothing."""
@@ -75,6 +84,7 @@ def test_null_context_everywhere(G):
     lib.svgf_destroy(N)
     lib.svgf_strips_destroy(N)
     lib.svgf_default_params(N)
+    _runtime_is_clean()
 
 
 def test_create_refuses_bad_arguments(G):
@@ -109,6 +119,7 @@ def test_create_refuses_bad_arguments(G):
         rc = lib.svgf_create_strip(C.byref(hdl), W, H, C.byref(st), C.byref(pc), 0, None)
         assert rc < 0, (strip, rc)
     assert lib.svgf_create_strip(C.byref(C.c_void_p()), W, H, None, C.byref(pc), 0, None) < 0
+    _runtime_is_clean()
 
 
 def test_stage_calls_refuse_what_they_cannot_run_and_the_context_goes_on(G, env):
@@ -190,6 +201,7 @@ def test_stage_calls_refuse_what_they_cannot_run_and_the_context_goes_on(G, env)
     no(lib.svgf_import_gbuffer_pitched(h, 0, _p(p["col"]), 3, _p(p["col2"])), "svgf_import_gbuffer_pitched pitch 3")
     assert lib.svgf_state_plane(h, 99, 0) is None and lib.svgf_state_plane(h, 0, 2) is None and lib.svgf_plane_bytes(h, 99) == 0
     assert len(refused) >= 44
+    _runtime_is_clean()
     # ... and the context is what it was: three frames equal a fresh context's
     fresh = F.Denoiser(W, H, F.Params(storage="f32", steps=3))
     for k in range(3):
@@ -224,3 +236,4 @@ def test_strip_plans_and_drivers_refuse_bad_geometry(G):
         assert rc < 0, (kw, rc)
     # two ranks, RCCL transport, no communicators: refused (the mailbox is the only transport that needs none)
     assert lib.svgf_strips_create(C.byref(hdl), 320, 400, 2, C.byref(pc), 0, 0, 2, ranks, devs, None, None, F.TRANSPORT["rccl"]) < 0
+    _runtime_is_clean()
