@@ -18,7 +18,9 @@
  *    History planes are uint8 (Filter.cuh:359,400).
  *  - Calls enqueue work on the context's HIP stream and return without synchronising, like the
  *    reference's launches on the default stream (App.cu:471-505).  Errors are returned (0 = ok,
- *    negative = SVGF_ERR_*), never asserted (the reference asserts: App.cu:41-48).
+ *    negative = SVGF_ERR_*), never asserted (the reference asserts: App.cu:41-48).  A refused call launches nothing, leaves the
+ *    context as it was and nothing pending in the HIP runtime (hipGetLastError is clean afterwards: a host or framework that checks it
+ *    after its own launches does not trip over this library's refusals — tests/test_gpu_errors.py).
  *  - A context is not thread-safe (like the reference's single render thread, App.cu:692-734): one host thread at a
  *    time per context; different contexts are independent, may share a device or live on different devices of one
  *    process (every entry point makes the context's device current and restores the caller's).  svgf_resize is
