@@ -151,11 +151,50 @@ def run_trial(seed, oracle=None):
     return desc
 
 
+def run_pipeline_trial(seed, oracle=None):
+    """A free-running sequence through BOTH restatements' frame sequencing (oracle.Pipeline, tests/helpers.NumpyPipeline): the history plane — the
+    accept / reject mask of every frame — bit for bit; the output within the two libms' distance as the feedback compounds it (finite frames), its
+    NaN mask identical (poisoned frames)."""
+    from tests.fuzz_parity import _sequence
+    from tests.helpers import NumpyPipeline
+    if oracle is None:
+        from oracle import oracle as oracle                   # noqa: PLW0127
+    rng = np.random.default_rng(seed)
+    W, H = int(rng.integers(1, 90)), int(rng.integers(1, 60))
+    storage = ("f32", "f16")[int(rng.integers(0, 2))]
+    tun = _tunables(rng)
+    tun["phi_colour"] = max(tun["phi_colour"], 1.0)           # (below, a free-running sequence amplifies the libms' last bit beyond any useful bound)
+    steps = int(rng.choice([5, 3, 0, 1, 2]))
+    radius = int(rng.choice([3, 3, 1]))
+    mv = (float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4)))
+    poison = bool(rng.integers(0, 2))
+    N = int(rng.integers(3, 7))
+    desc = f"pipeline seed {seed}: {W}x{H} {storage} steps {steps} r{radius} poison {poison} frames {N}"
+    fr = _sequence(rng, W, H, N, mv, poison, storage)
+    a = oracle.Pipeline(W, H, storage, steps=steps, moments_radius=radius, **tun)
+    b = NumpyPipeline(W, H, storage, steps=steps, moments_radius=radius, **tun)
+    for k in range(N):
+        ga, gp = gbuf(fr[k]), gbuf(fr[max(k - 1, 0)])
+        oa = a.frame(fr[k]["radiance"], ga, gp)
+        with np.errstate(all="ignore"):
+            ob = b.frame(fr[k]["radiance"], ga, gp)
+        if not poison:
+            assert np.array_equal(a.hist[a.P ^ 1], b.taps["hist"]), desc + f": frame {k}: history"
+            d = np.abs(oa.astype(np.float64) - ob.astype(np.float64))
+            assert d.max() <= (2e-4 if storage == "f32" else 4e-3), desc + f": frame {k}: {d.max():.3e}"
+        else:
+            # (a NaN in the colour history reaches the next frames' reprojected colour, never the accept / reject tests: the masks stay equal)
+            assert np.array_equal(a.hist[a.P ^ 1], b.taps["hist"]), desc + f": frame {k}: history"
+            assert np.array_equal(np.isnan(oa.astype(np.float32)), np.isnan(ob.astype(np.float32))), desc + f": frame {k}: NaN masks"
+    return desc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=3.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--pipeline", action="store_true", help="free-running sequences through both restatements' frame sequencing instead of the stages")
     args = ap.parse_args()
     from oracle import oracle
     oracle.build()
@@ -163,7 +202,7 @@ def main():
     seed, failed, lines = args.seed, [], []
     while time.monotonic() < t_end:
         try:
-            lines.append("ok   " + run_trial(seed, oracle))
+            lines.append("ok   " + (run_pipeline_trial if args.pipeline else run_trial)(seed, oracle))
         except Exception as e:  # noqa: BLE001
             failed.append(seed)
             lines.append(f"FAIL seed {seed}: {type(e).__name__}: {(str(e).splitlines() or [''])[0][:400]}")

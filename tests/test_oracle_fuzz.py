@@ -11,3 +11,10 @@ SEEDS = list(range(1, 25)) + [267, 274, 289, 327, 421, 435, 5000, 5001, 5002, 50
 def test_oracle_equals_the_numpy_restatement(oracle, seed):
     from tests import fuzz_oracle
     fuzz_oracle.run_trial(seed, oracle)
+
+
+@pytest.mark.parametrize("seed", list(range(1, 21)))
+def test_oracle_pipeline_equals_the_numpy_pipeline(oracle, seed):
+    """Free-running sequences through both restatements' frame sequencing: accept / reject masks of every frame bit for bit, NaN masks identical."""
+    from tests import fuzz_oracle
+    fuzz_oracle.run_pipeline_trial(seed, oracle)
