@@ -197,7 +197,7 @@ def trial_stage(G, oracle, seed, zeros=False, wide=False, edge=False):
         _close(G, G.host(out), want, storage, desc + ": a-trous")
         _close(G, G.host(fb), fbw, storage, desc + ": a-trous feedback")
     except AssertionError as e:
-        e.ctx = dict(frame=fs, src=src, got=G.host(out), want=want, step=step, denoiser=d, tun=tun)      # (tests/fuzz_debug.py)
+        e.ctx = dict(frame=fs, src=src, got=G.host(out), want=want, step=step, denoiser=d, tun=tun)      # (for whoever re-runs the seed by hand: run_trial raises with the planes attached)
         raise
     d.close()
     return desc + (" zeros" if zeros else "")
