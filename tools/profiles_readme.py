@@ -74,6 +74,7 @@ def main(tag):
         (f"{tag}_pytest_gpu.txt", "summary line of `pytest tests -q -m gpu` in the same call as the bench lines"),
         (f"{tag}_pytest_gpu_soak.txt", "five more full `pytest tests -q -m gpu` runs in one call at the final sources (the round-2 suite abort: not seen)"),
         (f"{tag}_parity_report.json", "`tests/test_gpu_round2.py::test_parity_report`: max / mean error per stage against the oracle, mask mismatch counts"),
+        (f"{tag}_fuzz_parity.txt", "the seeded sweeps: `tests/fuzz_parity.py` on MI355X (every run's summary line, what each finding was), `tests/fuzz_oracle.py` and `tests/strip_geometry_checks.py` on the CPU"),
     ]
     for name, what in files:
         first = name.split(",")[0].strip()
