@@ -20,7 +20,11 @@ def _ld(a):                      # storage -> float32
 
 
 def _clamp01(a):
-    return np.minimum(np.maximum(a, f32(0)), f32(1))
+    # glm::clamp = min(max(x, 0), 1) from `(x < y) ? y : x` (Filter.cuh:63-69,78-83): a NaN stays — and so does -0.0, which np.maximum(-0.0, 0.0)
+    # turns into +0.0 (tests/fuzz_oracle.py seed 800425: one texel in 107 000 trials where the sign of a zero survived to the output)
+    with np.errstate(invalid="ignore"):
+        lo = np.where(a < f32(0), f32(0), a)
+        return np.where(f32(1) < lo, f32(1), lo).astype(np.float32)
 
 
 def _lum(c):                     # A.2 / Filter.cuh:262

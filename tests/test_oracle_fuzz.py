@@ -4,7 +4,7 @@ square root: the sweep's first 1 460 trials had 187 of them beyond a plain 1e-6 
 in a fifth of the values; it squares now, and the comparison goes back through the square root where the output itself is not conditioned)."""
 import pytest
 
-SEEDS = list(range(1, 25)) + [267, 274, 289, 327, 421, 435, 5000, 5001, 5002, 5003]
+SEEDS = list(range(1, 25)) + [267, 274, 289, 327, 421, 435, 5000, 5001, 5002, 5003, 800425]      # (800425: -0.0 through glm's clamp)
 
 
 @pytest.mark.parametrize("seed", SEEDS)
@@ -13,7 +13,7 @@ def test_oracle_equals_the_numpy_restatement(oracle, seed):
     fuzz_oracle.run_trial(seed, oracle)
 
 
-@pytest.mark.parametrize("seed", list(range(1, 21)))
+@pytest.mark.parametrize("seed", list(range(1, 21)) + [905113])
 def test_oracle_pipeline_equals_the_numpy_pipeline(oracle, seed):
     """Free-running sequences through both restatements' frame sequencing: accept / reject masks of every frame bit for bit, NaN masks identical."""
     from tests import fuzz_oracle
