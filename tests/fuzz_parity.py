@@ -94,10 +94,13 @@ def _poisoned(rng, f, what):
 
 def _same_bits(a, b):
     """Bit for bit — except that a NaN is a NaN: one that the arithmetic MAKES (inf x 0, inf - inf) carries the sign the machine gives it
-    (x86: set, gfx950: clear), one that is passed through keeps its bits on both."""
+    (x86: set, gfx950: clear), one that is passed through keeps its bits on both — and that a zero is a zero: the reference's value clamp is
+    built from comparisons and keeps -0.0 (Filter.cuh:63-69), the hardware's result clamp returns +0.0 (include/svgf.h, "Sign of zero": seed
+    4007112 of kind stage0, one texel in 20 000 trials that plant -0.0 texels)."""
     na, nb = np.isnan(a.astype(np.float32)), np.isnan(b.astype(np.float32))
     u = {2: np.uint16, 4: np.uint32}[a.dtype.itemsize]
-    return np.array_equal(na, nb) and np.array_equal(a.view(u)[~na], b.view(u)[~nb])
+    a0, b0 = (a + a.dtype.type(0)), (b + b.dtype.type(0))            # -0.0 + 0.0 = +0.0; every other value, NaN payloads included, as it was
+    return np.array_equal(na, nb) and np.array_equal(a0.view(u)[~na], b0.view(u)[~nb])
 
 
 def _close(G, got, want, storage, what, colour_abs=None):
