@@ -45,11 +45,10 @@
  *    masks identical to the oracle's, finite values within the stage tolerances): a host that wants its NaNs healed must clean the
  *    radiance before the temporal stage — the reference does not, and neither does this library.  svgf_taa likewise: a NaN texel goes
  *    through glm's min / max position by position (Filter.cuh:330-338) and the NaN test of :351 writes the pixel black.
- *  - Sign of zero.  The reference's value clamp, built from `(x < y) ? y : x`, passes -0.0 through (Filter.cuh:63-69,78-83); the kernels clamp
- *    with the hardware's result modifier, which returns +0.0.  A colour or moments texel of -0.0 that the reference would store as -0.0 (both
- *    terms of the temporal mix -0.0: one texel in ~20 000 random frames that plant such texels, tests/fuzz_parity.py kind stage0) is stored as
- *    +0.0.  The two compare equal in everything downstream — no weight, sum or test of the three stages divides by or takes the sign of a colour
- *    value — so no other bit of any result depends on it; "bit for bit" in this header and in the tests means up to the sign of such a zero.
+ *  - Sign of zero.  The reference's value clamp, built from `(x < y) ? y : x`, passes -0.0 through (Filter.cuh:57-82); so do the kernels: the
+ *    temporal stage, the copied sky texels of the wavelet filter and svgf_taa store the reference's bits, a filtered texel that comes out
+ *    zero carries the reference's sign (tests: test_temporal_bit_exact, test_atrous, tests/fuzz_parity.py compare raw bits).  One exception:
+ *    svgf_atrous_pair (opt-in) rounds the texels of a band that holds a -0.0 texel as it does next to a NaN — within the stage tolerance.
  *  - Non-finite / out-of-range G-buffer texels: what the reference's binary does, reproduced (tests/test_gpu_gbuffer_nonfinite.py):
  *        motion   `Coord + ivec2(MotionVector)` (Filter.cuh:232) is a float -> int conversion toward zero that SATURATES and turns a NaN
  *                 into 0, added to the pixel coordinate with wrap-around: a NaN motion reprojects the pixel onto itself; +-inf and anything

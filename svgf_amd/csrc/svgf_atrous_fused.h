@@ -84,7 +84,7 @@ __device__ __forceinline__ bool fused_band(const Geo& g, const AtrousArgs& a, ch
         ref01 = __builtin_amdgcn_readfirstlane(n.x); refz = __builtin_amdgcn_readfirstlane(n.y & 0xffffu);
     }
     if (t < 2 * (kFRA + kFRB)) flagA[t] = 0u;
-    unsigned long long nan_out = 0ull;             // lanes whose output held a NaN (EXACT = false)
+    unsigned long long nan_out = 0ull;             // lanes whose output held a NaN, or that staged a sky texel with a -0.0 channel (EXACT = false)
     const float phi_n = a.phi_normal;              // != 0 (launcher)
     const float inv_phi_c = hw_rcp(a.phi_colour) * kLog2e;     // log2(e) / PhiColour
 
@@ -116,12 +116,16 @@ __device__ __forceinline__ bool fused_band(const Geo& g, const AtrousArgs& a, ch
             raw_load<ST, true>(st.o, rs, vo_c, vo_m, vo_n, srow, n_shift, m_off);
             if (halo_wave) raw_load<ST, false>(st.h, rs, vh_c, vh_m, vh_n, srow, n_shift, m_off);
         };
-        auto commit = [&](int sl, const Staged& st) __attribute__((always_inline)) {
+        auto commit = [&](int sl, const Staged& st, int jn) __attribute__((always_inline)) {      // jn: as fetched (EXACT only: which texels lie outside the frame)
             int so = sl + rg; so = so >= kFRA ? so - kFRA : so;
             constexpr int noff = kFRA * kFWA * 8;
             const int at_o = so * kFWA + oli, at_h = so * kFWA + hli;
-            unsigned long long differs = commit_px<ST, true>(st.o, lds_addr(aA) + at_o * 16, lds_addr(aL) + at_o * 8, noff, ref01, refz);
-            if (halo_wave) differs |= commit_px<ST, false>(st.h, lds_addr(aA) + at_h * 16, lds_addr(aL) + at_h * 8, noff, ref01, refz, has_halo);
+            bool row_out = false;
+            if constexpr (EXACT) { const int y = g.yb + jn + rg; row_out = y < 0 || y >= g.H; }
+            unsigned long long negzero = 0ull;              // (a texel with a -0.0 channel: the band is run again — commit_px, svgf_device.h)
+            unsigned long long differs = commit_px<ST, true, EXACT>(st.o, lds_addr(aA) + at_o * 16, lds_addr(aL) + at_o * 8, noff, ref01, refz, true, &negzero, row_out || !own_ok);
+            if constexpr (!EXACT) nan_out |= negzero;
+            if (halo_wave) differs |= commit_px<ST, false, EXACT>(st.h, lds_addr(aA) + at_h * 16, lds_addr(aL) + at_h * 8, noff, ref01, refz, has_halo, nullptr, row_out || !halo_ok);
             if (lane == 0) flagA[so * 2 + wig] = differs != 0ull ? kFlagNormal : 0u;
         };
         float dq0 = 0.f, dq1 = 0.f;
@@ -130,7 +134,7 @@ __device__ __forceinline__ bool fused_band(const Geo& g, const AtrousArgs& a, ch
         {
             Staged s0, s1, s2;                                    // one round of memory latency (the tap loop's registers are free here)
             fetch(j0 - 6, s0); fetch(j0 - 4, s1); fetch(j0 - 2, s2);
-            commit(0, s0); commit(2, s1); commit(4, s2);
+            commit(0, s0, j0 - 6); commit(2, s1, j0 - 4); commit(4, s2, j0 - 2);
             dq0 = __uint_as_float(s1.o.zd.y); dq1 = __uint_as_float(s2.o.zd.y);
         }
         constexpr int PD = kFPrefetch;
@@ -158,7 +162,7 @@ __device__ __forceinline__ bool fused_band(const Geo& g, const AtrousArgs& a, ch
                 const bool uniform = !EXACT && !a.no_fastpath && !wave_any(lane < 2 * kFRA && flagA[lane < 2 * kFRA ? lane : 0] != 0u);
                 // (EXACT: the exact form for every pixel of the second pass — the one-launch-per-iteration kernel keeps the first pass's value of the finite
                 // ones (filter_px), which costs a second set of taps this kernel has no registers for.  Around a NaN texel the pair launch therefore rounds
-                // as the exact form does: within the stage tolerance, not bit-identical to two launches there)
+                // as the exact form does: within the stage tolerance, not bit-identical to two launches there; the same around a texel with a -0.0 channel)
                 o = filter_px<1, TD, kFRA * kFWA * 8, EXACT, false>(rows_from_index(aA, aL, rowbase), c, phi_n, wave_has_surface, uniform);
                 if constexpr (!EXACT) nan_out |= lanes_where(__builtin_isunordered(o.x, o.w));
                 // ring B record: the texel iteration 1 would load from the plane iteration 0 stores (:618 unclamped, in the storage type;
@@ -166,7 +170,12 @@ __device__ __forceinline__ bool fused_band(const Geo& g, const AtrousArgs& a, ch
                 float4 q = o;
                 if constexpr (ST == 1) { const float2 lo = unpack_h2(pack_h2(o.x, o.y)), hi = unpack_h2(pack_h2(o.z, o.w)); q = make_float4(lo.x, lo.y, hi.x, hi.y); }
                 const f32x2 q01 = clamp01_pk((f32x2){q.x, q.y}), q23 = clamp01_pk((f32x2){q.z, q.w});
-                q = make_float4(q01.x, q01.y, q23.x, q23.y);
+                if constexpr (!EXACT) q = make_float4(q01.x, q01.y, q23.x, q23.y);
+                else {                                                              // (-0.0 kept: clamp01_ref; a pixel outside the frame: the sums' identity, commit_px)
+                    q = make_float4(q.x == 0.0f ? q.x : q01.x, q.y == 0.0f ? q.y : q01.y, q.z == 0.0f ? q.z : q23.x, q.w == 0.0f ? q.w : q23.y);
+                    const int yi = g.yb + j0 - kFReach1 + 2 * k + rg;
+                    if (yi < 0 || yi >= g.H || !own_ok) q = make_float4(-0.0f, -0.0f, -0.0f, -0.0f);
+                }
                 const int bi = slotB * kFT0 + col;
                 bA[bi] = (f32x4){q.x, q.y, q.z, q.w};
                 bL[bi] = (f32x2){lum_exact(q.x, q.y, q.z), sky ? kSkyZ : c.lz.y};
@@ -178,7 +187,7 @@ __device__ __forceinline__ bool fused_band(const Geo& g, const AtrousArgs& a, ch
             }
             lds_barrier();                                        // every wave is done reading ring A's two oldest rows
             if (more && !(SVGF_FUSED_DIAG & 4)) {
-                commit(slotA, cs);
+                commit(slotA, cs, j0 + 2 * k);
                 dq0 = dq1; dq1 = __uint_as_float(cs.o.zd.y);
                 slotA += 2; if (slotA >= kFRA) slotA -= kFRA;
             }

@@ -50,7 +50,7 @@ __device__ __forceinline__ uint32_t lds_load(uint32_t addr) { return *(const lds
 __device__ __forceinline__ void lds_store(uint32_t addr, uint32_t v) { *(lds_u32*)(uintptr_t)addr = v; }
 
 // One workgroup streaming down its band: decimated rows [j0, j1) of the residue whose row j is global row ybase + S*j, columns
-// [x0, x0 + kTX).  EXACT = false is the product path.  -> (per wave) "one of my outputs came out NaN".
+// [x0, x0 + kTX).  EXACT = false is the product path.  -> (per wave) "one of my outputs came out NaN, or one of my texels holds a -0.0".
 //
 // NaN.  The reference's clamp keeps a NaN texel (svgf_device.h), and so do the records here.  The reference's weight then stays FINITE —
 // `max(weightLillum, 0.0)` in Filter.cuh:424 is CUDA's fmax, which drops the NaN — and the NaN reaches the sums through the channels
@@ -125,13 +125,23 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
         }
     };
     uint32_t ref01 = 0, refz = 0;
-    auto commit = [&](int sl, const Staged& st) __attribute__((always_inline)) {
+    // EXACT = false: the lanes whose output held a NaN, or whose own texel holds a -0.0 channel (commit_px): the band is run again
+    unsigned long long rerun = 0ull;
+    // jn: the decimated row the step fetched (fetch(jn, st)); EXACT only: which texels lie outside the frame
+    auto commit = [&](int sl, const Staged& st, int jn) __attribute__((always_inline)) {
         int so = sl + rg; so = so >= kRing ? so - kRing : so;                           // scalar
+        bool row_out = false;
+        if constexpr (EXACT) { const int y = ybase + S * (jn + rg); row_out = y < 0 || y >= g.H; }
         // (own pixel: column + 2S of the ring row — a scalar added to the column's address, no register of its own)
-        unsigned long long differs = commit_px<ST, true>(st.o, colA + (uint32_t)(so * (WL * 16) + 2 * S * 16), colL + (uint32_t)(so * (WL * 8) + 2 * S * 8), NOFF, ref01, refz);
+        unsigned long long negzero = 0ull;
+        unsigned long long differs = commit_px<ST, true, EXACT>(st.o, colA + (uint32_t)(so * (WL * 16) + 2 * S * 16), colL + (uint32_t)(so * (WL * 8) + 2 * S * 8), NOFF, ref01, refz,
+                                                                true, &negzero, row_out || !own_ok);
+        if constexpr (!EXACT) rerun |= negzero;
         if (halo_wave) {
 #pragma unroll
-            for (int p = 0; p < HP; p++) differs |= commit_px<ST, false>(st.h[p], haloA[p] + (uint32_t)(so * (WL * 16)), haloL[p] + (uint32_t)(so * (WL * 8)), NOFF, ref01, refz, has_halo[p]);
+            for (int p = 0; p < HP; p++)
+                differs |= commit_px<ST, false, EXACT>(st.h[p], haloA[p] + (uint32_t)(so * (WL * 16)), haloL[p] + (uint32_t)(so * (WL * 8)), NOFF, ref01, refz, has_halo[p], nullptr,
+                                                       row_out || vh_c[p] == kOob);
         }
         if (lane == 0) lds_store(L.flag(so * 8 + wig), differs != 0ull ? kFlagNormal : 0u);   // a ring slot is always staged by the same waves
     };
@@ -153,7 +163,7 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
             __syncthreads();
             ref01 = lds_load(L.nref(0)); refz = lds_load(L.nref(1));
         }
-        commit(r, st);
+        commit(r, st, j0 - 2 + r);
         if (r == 2) dq0 = __uint_as_float(st.o.zd.y);
         if (r == 4) dq1 = __uint_as_float(st.o.zd.y);
     }
@@ -166,7 +176,6 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
 #pragma unroll
     for (int k = 0; k < 5; k++) ref_base.e[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ref_base.e[k])));
     int slot0 = 0;
-    unsigned long long nan_out = 0ull;             // lanes whose output held a NaN (EXACT = false)
     Staged cs;                                     // the rows the NEXT step needs: requested at the start of a step, committed at its end
     for (int j = j0; j < j1; j += kRS) {
         const bool more = (j + kRS) < j1;
@@ -189,13 +198,14 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
                              !wave_any(lane < kRing * 8 && lds_load(L.flag(0) + 4 * (lane < kRing * 8 ? lane : 0)) != 0u);
         bool redo = true;                          // EXACT: this lane's first-pass result held a NaN — only those texels are stored again
         const float4 o = filter_px<S, kTapDepth, NOFF, EXACT>(rows, c, phi_n, wave_has_surface, uniform, &ref_base, EXACT ? &redo : nullptr);
-        if constexpr (!EXACT) nan_out |= lanes_where(__builtin_isunordered(o.x, o.w));
+        if constexpr (!EXACT) rerun |= lanes_where(__builtin_isunordered(o.x, o.w));
+        else redo = redo | has_negzero(make_float4(c.A.x, c.A.y, c.A.z, c.A.w));            // the sign of a zero (commit_px): only such a centre can come out -0.0
 
         // Output values now, their stores AFTER the ring refill: hipcc's vmcnt bookkeeping cannot tell that the rows committed
         // below were fetched long before this step's stores, so stores issued first would be waited for.
         if (more) {
             lds_barrier();                         // every wave is done reading the two oldest ring rows
-            commit(slot0, cs);
+            commit(slot0, cs, j + kRS + 2);
             dq0 = dq1; dq1 = __uint_as_float(cs.o.zd.y);                                 // row j+4+rg: the centre two steps on
             slot0 += kRS; if (slot0 >= kRing) slot0 -= kRing;
             lds_barrier();
@@ -228,7 +238,7 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
             }
         }
     }
-    return nan_out != 0ull;
+    return rerun != 0ull;
 }
 
 // What the kernel knows of its row ranges.  One range (every launch but the strip driver's): rows [g.yb, g.ye).  Several (AtrousRanges): the

@@ -108,7 +108,7 @@ __device__ __forceinline__ void taps24(const TapRows& rows, const TapCentre& c, 
         } else {
             const f32x2 N = qN[t];
             float d = fmaf(N.y, c.nz, dot2_h2(__float_as_uint(N.x), c.n01));
-            if constexpr (MODE == kTapsNaN) d = clamp01_ref(d != d ? 0.0f : d);          // (the wave runs with keep_nan_in_clamps())
+            if constexpr (MODE == kTapsNaN) d = clamp01_hw(d != d ? 0.0f : d);           // (the wave runs with keep_nan_in_clamps())
             else d = clamp01(d);
             e = fmaf(hw_log2(d), phi_n, klog2(axx, ayy));
         }

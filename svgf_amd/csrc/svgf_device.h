@@ -57,7 +57,12 @@ __device__ __forceinline__ float4 clamp01(float4 v) { return make_float4(clamp01
 // (MODE is per-wave state; nothing the compiler generates for these kernels depends on the bit except `saturate(n.n')` of the taps,
 // where a NaN can only come from a non-finite normal.)
 __device__ __forceinline__ void keep_nan_in_clamps() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 8, 1), 0" ::: "memory"); }
-__device__ __forceinline__ float clamp01_ref(float v) { float r; asm("v_max_f32 %0, %1, %1 clamp" : "=v"(r) : "v"(v)); return r; }   // needs keep_nan_in_clamps()
+__device__ __forceinline__ float clamp01_hw(float v) { float r; asm("v_max_f32 %0, %1, %1 clamp" : "=v"(r) : "v"(v)); return r; }   // needs keep_nan_in_clamps()
+// ... except for the sign of a zero: `(x < 0) ? 0 : x` and `(1 < x) ? 1 : x` hand -0.0 through, the result clamp returns +0.0.  The
+// per-pixel kernels (temporal, direct a-trous, TAA: none of them bound by vector issue) put the input back where it compares equal to
+// zero (one v_cmp + one v_cndmask per channel; a NaN compares unequal and keeps the clamp's result, itself).  The streaming kernels
+// keep clamp01_pk for the texels they stage and repair a -0.0 where it can reach memory (commit_px below, atrous_band).
+__device__ __forceinline__ float clamp01_ref(float v) { const float r = clamp01_hw(v); return v == 0.0f ? v : r; }
 __device__ __forceinline__ float4 clamp01_ref(float4 v) { return make_float4(clamp01_ref(v.x), clamp01_ref(v.y), clamp01_ref(v.z), clamp01_ref(v.w)); }
 
 // (z, dz) of a motion texel; depth 0 = sky sentinel (Filter.cuh:199-207)
@@ -202,16 +207,36 @@ constexpr uint32_t kFlagNormal = 1u;
 // materialised as 0 / 1 in a vector register and compared again — so every compare is balloted by itself and the masks are combined on
 // the scalar unit.  `store` masks the LDS writes only: everything else runs on every lane (the halo pass's idle lanes hold all-zero
 // texels: no depth, so they never differ).
+//
+// Sign of zero.  The reference's clamp keeps a -0.0 channel (clamp01_ref above); clamp01_pk — two channels per instruction — returns +0.0.
+// Where can the difference reach memory?  A SKY centre is copied (:554-558), bit for bit.  A filtered pixel's sums start from the centre's
+// channel and add weight x tap (:567-568,604-608): the result is -0.0 iff the centre AND every tap inside the frame hold -0.0 in that channel,
+// and +0.0 or positive otherwise.  Either way only a pixel whose OWN texel holds a -0.0 channel can come out -0.0.  So the product pass
+// (EXACT = false) only LOOKS: *negzero receives the lanes whose own texel holds one (v_min3_i32 + v_min_i32 + one compare: INT_MIN is
+// the bit pattern of -0.0 and the smallest integer), the band is run again like one that produced a NaN, and the second pass (EXACT = true)
+// stages with the sign-keeping clamp, gives the texels OUTSIDE the frame the colour -0.0 — the identity of the sums: their weight is exactly
+// +0 (no depth), and fma(+0, -0.0, s) = s whatever s is, which is what skipping the tap does (:579,584) — and stores those pixels again
+// (atrous_band).  No frame without a -0.0 texel gets there.
 __device__ __forceinline__ unsigned long long lanes_where(bool single_compare) { return __builtin_amdgcn_ballot_w64(single_compare); }
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+__device__ __forceinline__ bool has_negzero(float4 c) {
+    const int m = min(min(__float_as_int(c.x), __float_as_int(c.y)), min(__float_as_int(c.z), __float_as_int(c.w)));
+    return m == (int)0x80000000;
+}
 // addr_a / addr_l: LDS byte addresses of the pixel's colour and {luminance, depth} records; its normal record sits noff bytes behind the latter.
-template <int ST, bool DZ>
-__device__ __forceinline__ unsigned long long commit_px(const RawPx<ST, DZ>& r, uint32_t addr_a, uint32_t addr_l, int noff, uint32_t ref01, uint32_t refz, bool store = true) {
+template <int ST, bool DZ, bool EXACT = false>
+__device__ __forceinline__ unsigned long long commit_px(const RawPx<ST, DZ>& r, uint32_t addr_a, uint32_t addr_l, int noff, uint32_t ref01, uint32_t refz, bool store = true,
+                                                        unsigned long long* negzero = nullptr, bool outside = false) {
     float4 c;
     if constexpr (ST == 0) c = make_float4(__uint_as_float(r.c.x), __uint_as_float(r.c.y), __uint_as_float(r.c.z), __uint_as_float(r.c.w));
     else { float2 lo = unpack_h2(r.c.x), hi = unpack_h2(r.c.y); c = make_float4(lo.x, lo.y, hi.x, hi.y); }
+    const float4 raw = c;
     const f32x2 c01 = clamp01_pk((f32x2){c.x, c.y}), c23 = clamp01_pk((f32x2){c.z, c.w});    // imageLoad, :78-83,586
     c = make_float4(c01.x, c01.y, c23.x, c23.y);
+    if constexpr (EXACT) {
+        c = make_float4(raw.x == 0.0f ? raw.x : c.x, raw.y == 0.0f ? raw.y : c.y, raw.z == 0.0f ? raw.z : c.z, raw.w == 0.0f ? raw.w : c.w);
+        if (outside) c = make_float4(-0.0f, -0.0f, -0.0f, -0.0f);
+    }
     float z;
     if constexpr (DZ) z = __uint_as_float(r.zd.x); else z = __uint_as_float(r.zd);
     if (z == 0.0f) z = kSkyZ;                                           // GetDepth, :199-207
@@ -227,7 +252,9 @@ __device__ __forceinline__ unsigned long long commit_px(const RawPx<ST, DZ>& r, 
     // in it makes them NaN and sends the pixel to the exact form — while the uniform taps never look at it, so leaving it out would make the
     // rounding of the pixels around it depend on what else the workgroup's tile holds, i.e. on how strips and row ranges cut the frame.
     const uint32_t nzb = r.n.y & 0xffffu;
-    return (lanes_where(z != kSkyZ) | lanes_where((r.n.x | nzb) != 0u)) & (lanes_where(r.n.x != ref01) | lanes_where(nzb != refz));
+    const unsigned long long surface = lanes_where(z != kSkyZ);
+    if constexpr (!EXACT) { if (negzero) *negzero = lanes_where(has_negzero(raw)); }
+    return (surface | lanes_where((r.n.x | nzb) != 0u)) & (lanes_where(r.n.x != ref01) | lanes_where(nzb != refz));
 }
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
 

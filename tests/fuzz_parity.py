@@ -93,14 +93,18 @@ def _poisoned(rng, f, what):
 
 
 def _same_bits(a, b):
-    """Bit for bit — except that a NaN is a NaN: one that the arithmetic MAKES (inf x 0, inf - inf) carries the sign the machine gives it
-    (x86: set, gfx950: clear), one that is passed through keeps its bits on both — and that a zero is a zero: the reference's value clamp is
-    built from comparisons and keeps -0.0 (Filter.cuh:63-69), the hardware's result clamp returns +0.0 (include/svgf.h, "Sign of zero": seed
-    4007112 of kind stage0, one texel in 20 000 trials that plant -0.0 texels)."""
+    """Bit for bit, the sign of a zero included (the reference's value clamp is built from comparisons and keeps -0.0, Filter.cuh:57-82: so do
+    clamp01_ref and the streaming kernels' second pass, svgf_device.h) — except that a NaN is a NaN: one that the arithmetic MAKES (inf x 0,
+    inf - inf) carries the sign the machine gives it (x86: set, gfx950: clear), one that is passed through keeps its bits on both."""
     na, nb = np.isnan(a.astype(np.float32)), np.isnan(b.astype(np.float32))
     u = {2: np.uint16, 4: np.uint32}[a.dtype.itemsize]
-    a0, b0 = (a + a.dtype.type(0)), (b + b.dtype.type(0))            # -0.0 + 0.0 = +0.0; every other value, NaN payloads included, as it was
-    return np.array_equal(na, nb) and np.array_equal(a0.view(u)[~na], b0.view(u)[~nb])
+    return np.array_equal(na, nb) and np.array_equal(a.view(u)[~na], b.view(u)[~nb])
+
+
+def _sky_mask(frame):
+    """GetDepth() == the sentinel (Filter.cuh:199-207,552): depth 0, or literally 1e30 — the texels FilterKernel copies."""
+    z = frame["motion"][..., 2]
+    return (z == 0) | (z == np.float32(1e30))
 
 
 def _close(G, got, want, storage, what, colour_abs=None):
@@ -199,6 +203,11 @@ def trial_stage(G, oracle, seed, zeros=False, wide=False, edge=False):
     try:
         _close(G, G.host(out), want, storage, desc + ": a-trous")
         _close(G, G.host(fb), fbw, storage, desc + ": a-trous feedback")
+        skym = _sky_mask(fs)                                  # the copied texels (:554-558): raw bits, -0.0 included; no feedback for them
+        assert _same_bits(G.host(out)[skym], want[skym]), desc + ": a-trous sky copy"
+        assert _same_bits(G.host(fb)[skym], fbw[skym]), desc + ": a-trous feedback on sky"
+        zero = (want == 0) & (G.host(out) == 0)               # a filtered zero carries the reference's sign (svgf_device.h: commit_px)
+        assert np.array_equal(np.signbit(G.host(out)[zero]), np.signbit(want[zero])), desc + ": a-trous sign of zero"
     except AssertionError as e:
         e.ctx = dict(frame=fs, src=src, got=G.host(out), want=want, step=step, denoiser=d, tun=tun)      # (for whoever re-runs the seed by hand: run_trial raises with the planes attached)
         raise

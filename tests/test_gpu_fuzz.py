@@ -13,7 +13,9 @@ What the sweep found in round 5 (all in frames whose G-buffer holds NaN / out-of
     v_fma_mixlo_f16 with a +0 addend (svgf_kernels.hip:albedo_kernel pins the products in fp32 registers);
   * PhiColour = 0 (the GUI's drag starts there, GUI.cpp:992): |dl| / 0 is inf, or NaN for the taps of the centre's own luminance — the centre
     among them — and `max(., 0.0)` = fmax reads that as "no term" (Filter.cuh:424); the streaming moments kernel wrote NaN for every young pixel
-    (its second, exact evaluation was tied to a non-finite TEXEL having been staged; svgf_moments_lds.h now also takes it when 1 / PhiColour is inf)."""
+    (its second, exact evaluation was tied to a non-finite TEXEL having been staged; svgf_moments_lds.h now also takes it when 1 / PhiColour is inf);
+  * the sign of a zero through the value clamp (seed 4007112 of kind stage0): `(x < 0) ? 0 : x` keeps -0.0, the hardware's result clamp returned
+    +0.0 — fixed in round 6 (svgf_device.h: clamp01_ref; commit_px + atrous_band for the copied sky texels); the sweep compares raw bits again."""
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -22,7 +24,7 @@ STRIPS = [1192, 1483, 1531, 1621, 1651, 1969, 2311, 2329, 2755, 3841, 5230, 6463
 DRIVER = [7313, 1916, 1640, 1787, 2843, 2993, 5447, 7034, 24140, 40001, 40004, 40007, 40010]
 STAGE = [6657, 1266, 3795, 3807, 5883, 2529, 40002, 40005, 40008, 40011]
 OTHER = [("post", 213350), ("post", 215738), ("post", 320621), ("post", 400001), ("rows", 400000), ("rows", 400003), ("rows", 400006), ("rows", 400009),
-         ("pair", 400004), ("pair", 400007), ("pair", 400010), ("pair", 400013), ("stage0", 500000), ("stage0", 500001), ("stage0", 500002), ("stage0", 500003),
+         ("pair", 400004), ("pair", 400007), ("pair", 400010), ("pair", 400013), ("stage0", 500000), ("stage0", 500001), ("stage0", 500002), ("stage0", 500003), ("stage0", 4007112),
          ("strips2", 600000), ("strips2", 600001), ("strips2", 600002), ("strips2", 600003), ("strips2", 600004), ("strips2", 600005),
          ("edge", 955563), ("edge", 955568), ("edge", 955878), ("edge", 950042), ("edge", 955806), ("edge", 950208), ("edge", 960000), ("edge", 960001),
          ("graph", 1100000), ("graph", 1100001), ("graph", 1100002), ("graph", 1100003), ("graph", 1100004), ("fullsize", 1200001),

@@ -32,9 +32,15 @@ def test_temporal_bit_exact(G, oracle, storage, mv, mesh):
     mom_prev = rng.uniform(0, 1, (H, W, 2)).astype(dt)
     hist_prev = rng.integers(0, 40, (H, W)).astype(np.uint8)
     cur = (f1["radiance"] * 1.3 - 0.1).astype(dt)
+    # the sign of a zero: the reference's clamp, built from comparisons, keeps -0.0 (Filter.cuh:57-82), so -0.0 x (1 - a) + -0.0 x a stays -0.0
+    # (:398) and is stored as such (:401); whole rows of it in both frames (any reprojection lands on one), single channels elsewhere
+    cur[40:52] = -0.0; prev[34:58] = -0.0
+    cur[60:70, :, 1] = -0.0; prev[56:74, :, 1] = -0.0; cur[80:84, ::3, 2] = -0.0; prev[76:88, :, 2] = -0.0
+    mom_prev[34:58] = -0.0
     out = np.zeros_like(cur); hist = np.zeros((H, W), np.uint8); mom = np.zeros((H, W, 2), dt)
     oracle.temporal(W, H, storage, prev, cur, out, gbuf(f1), gbuf(f0), hist_prev, hist, mom, mom_prev,
                     depth_threshold=0.8, normal_threshold=0.9, history_base=24, mesh_id_test=mesh)
+    assert (out.view(np.uint32 if storage == "f32" else np.uint16) == (0x80000000 if storage == "f32" else 0x8000)).sum() > 1000, "the case holds no -0.0 result"
     d = F.Denoiser(W, H, F.Params(storage=storage, mesh_id_test=mesh))
     o_col, o_hist, o_mom = d.new_colour(), d.new_history(), d.new_moments()
     d.TemporalFilter(G.dev(prev), G.dev(cur), o_col, G.gb_dev(f1), G.gb_dev(f0), G.dev(hist_prev), o_hist, o_mom, G.dev(mom_prev))
@@ -116,15 +122,30 @@ def test_atrous(G, oracle, storage, step, variant):
     f = synth.make_frame(W, H, 0)
     dt = CDT[storage]
     src = np.concatenate([f["radiance"][..., :3] * 1.2 - 0.05, rng.uniform(-0.01, 0.05, (H, W, 1)).astype(np.float32)], -1).astype(dt)
+    # -0.0 channels: a sky texel is copied with the sign of its zeros (the reference's clamp keeps it, Filter.cuh:57-82,554-558); a surface
+    # texel's sums lose it unless every tap holds it too (a whole block does)
+    sky = f["region"] == synth.SKY
+    ys, xs = np.nonzero(sky)
+    assert len(ys) > 200
+    src[ys[::5], xs[::5]] = -0.0
+    src[ys[1::5], xs[1::5], rng.integers(0, 4, len(ys[1::5]))] = -0.0
+    sy, sx = np.nonzero(~sky)
+    src[sy[::41], sx[::41], rng.integers(0, 4, len(sy[::41]))] = -0.0
+    src[100:140, 150:200, 1] = -0.0
     want = np.zeros_like(src); want_fb = np.full_like(src, 7)
     oracle.atrous(W, H, storage, src, want, want_fb, gbuf(f), step=step, phi_colour=10.0, phi_normal=128.0, iteration=0)
+    u = np.uint32 if storage == "f32" else np.uint16
+    assert (want[sky].view(u) == (0x80000000 if storage == "f32" else 0x8000)).sum() > 100, "the case holds no -0.0 sky texel"
     d = F.Denoiser(W, H, F.Params(storage=storage, variant=variant))
     out = d.new_colour(); fb = G.dev(np.full_like(src, 7))
     d.FilterKernel(G.dev(src), out, fb, G.gb_dev(f), step, 0)
     got, got_fb = G.host(out), G.host(fb)
     G.assert_colour_close(got, want, storage, f"atrous step {step} {variant}")
-    sky = f["region"] == synth.SKY
-    assert np.array_equal(got[sky].view(np.uint8), want[sky].view(np.uint8))            # clamped copy, exact
+    assert np.array_equal(got[sky].view(np.uint8), want[sky].view(np.uint8))            # clamped copy, exact: raw bits, the sign of a zero included
+    zero = want == 0                                                                     # ... and a filtered zero carries the reference's sign too
+    if step == 1:
+        assert (np.signbit(want[zero]) & ~sky[..., None].repeat(4, -1)[zero]).sum() > 1000, "the case holds no filtered -0.0"
+    assert np.array_equal(got[zero] == 0, want[zero] == 0) and np.array_equal(np.signbit(got[zero]), np.signbit(want[zero]))
     assert np.all(got_fb[sky] == 7)                                                      # no feedback on sky
     assert np.array_equal(got_fb[~sky].view(np.uint8), got[~sky].view(np.uint8))
     out2 = d.new_colour(); fb2 = G.dev(np.full_like(src, 7))
