@@ -17,6 +17,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "svgf.h"
+#include "svgf_ext.h"      // svgf_set_prev_guide / svgf_set_adaptive_moments: the shim exposes the two opt-ins
 
 namespace gpupt {
 

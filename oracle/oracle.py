@@ -25,12 +25,34 @@ DEFAULTS = dict(steps=3, depth_threshold=0.8, normal_threshold=0.9, history_base
                 phi_colour=10.0, phi_normal=128.0, moments_radius=3, mesh_id_test=1)  # src/App.h:109-114
 
 
-def build(force: bool = False) -> str:
+_FLAVOURS = {"oracle": "libsvgf_oracle.so", "fp32fma": "libsvgf_oracle_fp32fma.so", "fp32": "libsvgf_oracle_fp32.so", "fma": "libsvgf_oracle_fma.so",
+             "fused": "libsvgf_oracle_fused.so"}
+
+
+def _stale(path):
     src = os.path.join(_HERE, "svgf_oracle.cpp")
-    stale = lambda p: not os.path.exists(p) or os.path.getmtime(p) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "Makefile")))   # noqa: E731
-    if force or stale(_LIB_PATH) or stale(_ENV_PATH):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
-    return _LIB_PATH
+    return not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "Makefile")))
+
+
+def build(force: bool = False, flavour: str = "oracle") -> str:
+    """Builds ONE library: the checker by default.  The envelope flavours (fp32fma, fma, fused: -mfma, x86 with FMA only) are built when something asks
+    for them (lib(flavour)) — a host whose compiler cannot build them still gets the checker, and only the envelope tests skip.
+    force=True builds the checker and, as far as this host can, every flavour (__graft_entry__.build())."""
+    path = os.path.join(_HERE, _FLAVOURS[flavour])
+    if force or _stale(path):
+        subprocess.check_call(["make", "-C", _HERE, "-B", _FLAVOURS[flavour]], stdout=subprocess.DEVNULL)
+    if force and flavour == "oracle":
+        for other in _FLAVOURS:
+            if other != "oracle":
+                try:
+                    subprocess.check_call(["make", "-C", _HERE, "-B", _FLAVOURS[other]], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                except subprocess.CalledProcessError:
+                    pass                       # (no FMA on this host: lib(other) will raise EnvelopeUnavailable, the envelope tests skip)
+    return path
+
+
+class EnvelopeUnavailable(RuntimeError):
+    """An envelope flavour of the oracle cannot be built on this host (its compiler or CPU lacks x86 FMA)."""
 
 
 _flavour = "oracle"
@@ -40,9 +62,13 @@ def lib(flavour=None):
     """flavour None: the library the module-level stage functions currently run on (the oracle, unless inside `using("fp32fma")`)."""
     flavour = flavour or _flavour
     if flavour not in _libs:
-        build()
-        L = C.CDLL({"oracle": _LIB_PATH, "fp32fma": _ENV_PATH, "fp32": os.path.join(_HERE, "libsvgf_oracle_fp32.so"),
-                    "fma": os.path.join(_HERE, "libsvgf_oracle_fma.so"), "fused": os.path.join(_HERE, "libsvgf_oracle_fused.so")}[flavour])
+        try:
+            path = build(flavour=flavour)
+        except subprocess.CalledProcessError as e:
+            if flavour == "oracle":
+                raise
+            raise EnvelopeUnavailable(f"oracle flavour {flavour!r} cannot be built here: {e}") from e
+        L = C.CDLL(path)
         L.svgf_oracle_f2h.restype = C.c_uint16
         L.svgf_oracle_f2h.argtypes = [C.c_float]
         L.svgf_oracle_h2f.restype = C.c_float
@@ -121,6 +147,21 @@ def albedo(mode, W, rows, storage, inp, alb, out):
     """Albedo demodulation (mode 0) / re-modulation (mode 1): the build's own definition (the reference has none)."""
     rc = lib().svgf_oracle_albedo(int(mode), W, rows, STORAGE[storage], _p(inp), _p(alb), _p(out))
     assert rc == 0
+
+
+def pack_gbuffer(position, normal, bary, view_proj, prev_view_proj, cam):
+    """GBuffer.frag:62-88 + GBuffer.vert:21-34 from linear attribute planes (float32 (H, W, 4) each; matrices: 16 floats, column-major)
+    -> (motion float32 (H, W, 4), normal uint16 (H, W, 4), uv uint16 (H, W, 4)).  The C++ twin of oracle/svgf_numpy.py:pack_gbuffer."""
+    H, W = position.shape[:2]
+    f = lambda a, n=None: np.ascontiguousarray(np.asarray(a, np.float32).reshape(-1) if n else a, dtype=np.float32)      # noqa: E731
+    pos, nrm, bar = f(position), f(normal), f(bary)
+    vp, pvp, cm = f(view_proj, 16), f(prev_view_proj, 16), f(cam, 3)
+    assert vp.size == 16 and pvp.size == 16 and cm.size == 3
+    motion, nout, uvout = np.zeros((H, W, 4), np.float32), np.zeros((H, W, 4), np.uint16), np.zeros((H, W, 4), np.uint16)
+    with np.errstate(all="ignore"):
+        rc = lib().svgf_oracle_pack_gbuffer(W, H, _p(pos), _p(nrm), _p(bar), _p(vp), _p(pvp), _p(cm), _p(motion), _p(nout), _p(uvout))
+    assert rc == 0
+    return motion, nout, uvout
 
 
 class Pipeline:

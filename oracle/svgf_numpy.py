@@ -288,7 +288,7 @@ def pack_gbuffer(position, normal, bary, view_proj, prev_view_proj, cam):
     xpc, ypc = np.minimum(xp, W - 1), np.minimum(yp, H - 1)
     ddx = np.where(okx & covered[Y, xpc], np.abs(depth[Y, xpc] - depth), f32(0))
     ddy = np.where(oky & covered[ypc, X], np.abs(depth[ypc, X] - depth), f32(0))
-    motion = np.stack([mvx, mvy, depth, np.maximum(ddx, ddy)], -1).astype(np.float32)
+    motion = np.stack([mvx, mvy, depth, np.fmax(ddx, ddy)], -1).astype(np.float32)      # GLSL max() leaves a NaN operand undefined; the GPUs' max instruction (and fmaxf in the kernel) drops it
     motion[~covered] = 0
     with np.errstate(all="ignore"):
         ln = np.sqrt((n[..., 0] * n[..., 0] + n[..., 1] * n[..., 1]) + n[..., 2] * n[..., 2]).astype(np.float32)

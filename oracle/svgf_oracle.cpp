@@ -471,6 +471,62 @@ int svgf_oracle_albedo(int mode, int W, int rows, int storage, const void* in, c
     return 0;
 }
 
+// The stage in front of the path: what resources/shaders/GBuffer.frag:62-88 writes per fragment, given GBuffer.vert:21-34's
+// interpolated attributes as linear planes (position {world xyz, primitive id}, normal {world normal, material id}, bary {b0,b1,b2, instance id};
+// float4 each), MVP = view_proj, PreviousMVP = prev_view_proj (column-major, static geometry: ModelMatrix = identity), CameraPosition = cam.
+//   GBuffer.vert:23,31      CurrentScreenPos = MVP * vec4(p, 1);  PrevScreenPos = PreviousMVP * vec4(p, 1)
+//   GBuffer.frag:65-67      both / .w;  MotionVector = (prev.xy - cur.xy) * (0.5 * vec2(Width, Height))
+//   GBuffer.frag:68         Depth = distance(CameraPosition, OutPosition.xyz)
+//   GBuffer.frag:69         DepthDerivative = max(abs(dFdx(Depth)), abs(dFdy(Depth))): differences inside the fragment's 2x2 quad (x ^ 1, y ^ 1);
+//                           a neighbour without geometry contributes 0 (OpenGL extrapolates the triangle there: no image-space adapter can)
+//   GBuffer.frag:62,77,84   OutNormal = packHalf(normalize(FragNormal), MaterialIndex);  :61,76,85  OutUV = packHalf(BarycentricCoord, InstanceIndex)
+// A texel whose normal is (0,0,0) has no geometry: the cleared texel, all zero (App.cu:383-384).  Unfused fp32, one rounding per operation
+// (this file is built with -ffp-contract=off), written from the shader, not from the NumPy restatement (oracle/svgf_numpy.py:pack_gbuffer) it is
+// checked against in tests/test_oracle_fuzz.py.
+int svgf_oracle_pack_gbuffer(int W, int H, const float* position, const float* normal, const float* bary, const float* view_proj,
+                             const float* prev_view_proj, const float* cam, float* motion_out, uint16_t* normal_out, uint16_t* uv_out) {
+    if (W <= 0 || H <= 0 || !position || !normal || !bary || !view_proj || !prev_view_proj || !cam || !motion_out || !normal_out || !uv_out) return -1;
+    auto covered = [&](int x, int y) { const float* n = normal + ((size_t)y * W + x) * 4; return !(n[0] == 0.0f && n[1] == 0.0f && n[2] == 0.0f); };
+    auto depth_at = [&](int x, int y) {
+        const float* p = position + ((size_t)y * W + x) * 4;
+        const float dx = cam[0] - p[0], dy = cam[1] - p[1], dz = cam[2] - p[2];
+        return std::sqrt((dx * dx + dy * dy) + dz * dz);                              // distance()
+    };
+    auto mul = [](const float* m, const float* p, float* o) {                         // column-major m * vec4(p, 1)
+        for (int r = 0; r < 4; r++) o[r] = ((m[r] * p[0] + m[4 + r] * p[1]) + m[8 + r] * p[2]) + m[12 + r];
+    };
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t i = (size_t)y * W + x;
+            float* mo = motion_out + i * 4;
+            uint16_t* no = normal_out + i * 4;
+            uint16_t* uo = uv_out + i * 4;
+            if (!covered(x, y)) {
+                for (int k = 0; k < 4; k++) { mo[k] = 0.0f; no[k] = 0; uo[k] = 0; }
+                continue;
+            }
+            const float* p = position + i * 4;
+            float cur[4], prev[4];
+            mul(view_proj, p, cur);
+            mul(prev_view_proj, p, prev);
+            mo[0] = (prev[0] / prev[3] - cur[0] / cur[3]) * (0.5f * (float)W);
+            mo[1] = (prev[1] / prev[3] - cur[1] / cur[3]) * (0.5f * (float)H);
+            const float d = depth_at(x, y);
+            float ddx = 0.0f, ddy = 0.0f;
+            const int xp = x ^ 1, yp = y ^ 1;
+            if (xp < W && covered(xp, y)) ddx = std::fabs(depth_at(xp, y) - d);
+            if (yp < H && covered(x, yp)) ddy = std::fabs(depth_at(x, yp) - d);
+            mo[2] = d;
+            mo[3] = std::fmax(ddx, ddy);
+            const float* n = normal + i * 4;
+            const float len = std::sqrt((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);    // normalize()
+            no[0] = f2h(n[0] / len); no[1] = f2h(n[1] / len); no[2] = f2h(n[2] / len); no[3] = f2h(n[3]);
+            const float* b = bary + i * 4;
+            for (int k = 0; k < 4; k++) uo[k] = f2h(b[k]);
+        }
+    return 0;
+}
+
 // converters exported so the tests can pin them against numpy's float16
 uint16_t svgf_oracle_f2h(float f) { return f2h(f); }
 float svgf_oracle_h2f(uint16_t h) { return h2f(h); }

@@ -9,7 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsvgf_mi355x.so")
 SOURCES = ["svgf_kernels.hip", "svgf_api.hip", "svgf_strip.hip"]
-HEADERS = ["svgf_kernels.h", "svgf_ctx.h", "svgf_device.h", "svgf_atrous_taps.h", "svgf_atrous_lds.h", "svgf_atrous_fused.h", "svgf_moments_lds.h", os.path.join("..", "..", "include", "svgf.h")]
+HEADERS = ["svgf_kernels.h", "svgf_ctx.h", "svgf_device.h", "svgf_atrous_taps.h", "svgf_atrous_lds.h", "svgf_atrous_fused.h", "svgf_moments_lds.h", os.path.join("..", "..", "include", "svgf.h"),
+           os.path.join("..", "..", "include", "svgf_ext.h"), os.path.join("..", "..", "include", "svgf_test.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 

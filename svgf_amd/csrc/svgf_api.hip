@@ -326,6 +326,14 @@ void commit_guide(svgf_ctx* c, const svgf_gbuffer* cur, bool written) {
     c->guide_prev_valid = true;
 }
 
+// svgf_path_stats_enable: the counter pair of step 1 << i (the LDS-streaming kernel's steps), or null
+static unsigned long long* path_stats_of(const svgf_ctx* c, int step) {
+    if (!c->path_stats || step < 1 || (step & (step - 1)) != 0) return nullptr;
+    int i = 0;
+    while ((1 << i) < step) i++;
+    return i < SVGF_PATH_STAT_STEPS ? c->path_stats + 2 * i : nullptr;
+}
+
 int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const svgf_gbuffer* g, int step, int iteration, const void* guide) {
     if (!in || !out) return fail(c, SVGF_ERR_INVALID, "svgf_atrous: null plane");
     if (in == out || in == feedback) return fail(c, SVGF_ERR_INVALID, "svgf_atrous: in-place filtering is a race");
@@ -334,7 +342,7 @@ int atrous_impl(svgf_ctx* c, const void* in, void* out, void* feedback, const sv
     if (rc == SVGF_OK) rc = check_halo(c, 2 * step, "svgf_atrous");
     if (rc != SVGF_OK) return rc;
     svgf::AtrousArgs a{in, out, iteration == 0 ? feedback : nullptr, (const float4*)g->motion, (const uint2*)g->normal,
-                       step, c->p.phi_colour, c->p.phi_normal, (const uint4*)guide, c->p.variant == SVGF_VARIANT_LDS_GENERAL};
+                       step, c->p.phi_colour, c->p.phi_normal, (const uint4*)guide, c->p.variant == SVGF_VARIANT_LDS_GENERAL, path_stats_of(c, step)};
     SVGF_HIP(c, svgf::launch_atrous(geo_of(c), c->p.storage, c->p.variant, a, c->stream));
     return SVGF_OK;
 }
@@ -356,7 +364,7 @@ int atrous_ranges_impl(svgf_ctx* c, const void* in, void* out, void* feedback, c
     c->rb = rb; c->re = re;
     if (rc != SVGF_OK) return rc;
     svgf::AtrousArgs a{in, out, iteration == 0 ? feedback : nullptr, (const float4*)g->motion, (const uint2*)g->normal,
-                       step, c->p.phi_colour, c->p.phi_normal, (const uint4*)guide, c->p.variant == SVGF_VARIANT_LDS_GENERAL};
+                       step, c->p.phi_colour, c->p.phi_normal, (const uint4*)guide, c->p.variant == SVGF_VARIANT_LDS_GENERAL, path_stats_of(c, step)};
     SVGF_HIP(c, svgf::launch_atrous_ranges(geo_of(c), c->p.storage, a, r, c->stream));
     return SVGF_OK;
 }
@@ -506,6 +514,7 @@ void svgf_destroy(svgf_ctx* c) {
     drop_side(c);
     free_state(c);
     if (c->halo_violations) (void)hipFree(c->halo_violations);
+    if (c->path_stats) (void)hipFree(c->path_stats);
     for (auto& f : c->pending) for (auto e : f.ev) (void)hipEventDestroy(e);
     for (auto e : c->pool) (void)hipEventDestroy(e);
     delete c;
@@ -980,6 +989,35 @@ int svgf_sync(svgf_ctx* c) {
     if (!c->halo_violations) SVGF_HIP(c, hipStreamSynchronize(c->stream));
     if (n) return fail(c, SVGF_ERR_HALO, "temporal stage: " + std::to_string(n) + " reprojection(s) landed inside the frame but outside the rows this strip holds "
                                                                                 "(motion larger than the state halo): the strip differs from the whole frame there");
+    return SVGF_OK;
+}
+
+// Diagnostics: which tap path the waves of the LDS-streaming a-trous launches of this context take (svgf_kernels.h: AtrousArgs::path_stats).
+int svgf_path_stats_enable(svgf_ctx* c, int on) {
+    if (!c) return SVGF_ERR_INVALID;
+    DeviceGuard dg(c->device);
+    SVGF_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->side) SVGF_HIP(c, hipStreamSynchronize(c->side));
+    if (on && !c->path_stats) {
+        SVGF_HIP(c, hipMalloc((void**)&c->path_stats, 2 * SVGF_PATH_STAT_STEPS * sizeof(unsigned long long)));
+        SVGF_HIP(c, hipMemset(c->path_stats, 0, 2 * SVGF_PATH_STAT_STEPS * sizeof(unsigned long long)));
+    } else if (!on && c->path_stats) {
+        (void)hipFree(c->path_stats);
+        c->path_stats = nullptr;
+    }
+    return SVGF_OK;
+}
+
+int svgf_path_stats_read(svgf_ctx* c, unsigned long long* counts, int slots) {
+    if (!c || !counts || slots <= 0) return SVGF_ERR_INVALID;
+    if (!c->path_stats) return fail(c, SVGF_ERR_INVALID, "svgf_path_stats_read: not enabled (svgf_path_stats_enable)");
+    DeviceGuard dg(c->device);
+    SVGF_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->side) SVGF_HIP(c, hipStreamSynchronize(c->side));
+    unsigned long long h[2 * SVGF_PATH_STAT_STEPS];
+    SVGF_HIP(c, hipMemcpy(h, c->path_stats, sizeof(h), hipMemcpyDeviceToHost));
+    SVGF_HIP(c, hipMemset(c->path_stats, 0, sizeof(h)));
+    for (int i = 0; i < slots; i++) counts[i] = i < 2 * SVGF_PATH_STAT_STEPS ? h[i] : 0ull;
     return SVGF_OK;
 }
 

@@ -42,15 +42,16 @@ template <int S, int TX> struct AtrousLds {
     static constexpr int NOFF = kRing * WL * 8;                         // bytes from a pixel's {luminance, depth} record to its normal record
     __device__ __forceinline__ uint32_t flag(int i) const { return l() + 2 * NOFF + 4 * i; }
     __device__ __forceinline__ uint32_t nref(int i) const { return flag(kRing * 8 + i); }
-    // nref(3): the waves that have finished; nref(4..11): what the end of a signalling workgroup needs (stashed by thread 0 at the start)
-    static constexpr size_t bytes = (size_t)kRing * WL * kRecBytes + (kRing * 8 + 12) * sizeof(uint32_t);
+    // nref(3): the waves that have finished; nref(4..11): what the end of a signalling workgroup needs (stashed by thread 0 at the start);
+    // nref(12..13): AtrousArgs::path_stats
+    static constexpr size_t bytes = (size_t)kRing * WL * kRecBytes + (kRing * 8 + 14) * sizeof(uint32_t);
 };
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ uint32_t lds_load(uint32_t addr) { return *(const lds_u32*)(uintptr_t)addr; }
 __device__ __forceinline__ void lds_store(uint32_t addr, uint32_t v) { *(lds_u32*)(uintptr_t)addr = v; }
 
 // One workgroup streaming down its band: decimated rows [j0, j1) of the residue whose row j is global row ybase + S*j, columns
-// [x0, x0 + kTX).  EXACT = false is the product path.  -> (per wave) "one of my outputs came out NaN, or one of my texels holds a -0.0".
+// [x0, x0 + kTX).  EXACT = false is the product path.  -> the wave's report (`state` below).
 //
 // NaN.  The reference's clamp keeps a NaN texel (svgf_device.h), and so do the records here.  The reference's weight then stays FINITE —
 // `max(weightLillum, 0.0)` in Filter.cuh:424 is CUDA's fmax, which drops the NaN — and the NaN reaches the sums through the channels
@@ -64,7 +65,7 @@ __device__ __forceinline__ void lds_store(uint32_t addr, uint32_t v) { *(lds_u32
 // this launch is still running, and making them visible with release fences instead means an L2 write-back per workgroup (measured: the one-launch
 // iteration 0.17 ms SLOWER per frame than three launches, profiles/r05_small_experiments.txt)
 template <int ST, int S, int TX, bool EXACT>
-__device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, const AtrousLds<S, TX>& L, int x0, int j0, int j1, int ybase, bool wt = false) {
+__device__ __forceinline__ uint32_t atrous_band(const Geo& g, const AtrousArgs& a, const AtrousLds<S, TX>& L, int x0, int j0, int j1, int ybase, bool wt = false) {
     constexpr int WL = TX + 4 * S;                 // staged columns per ring row
     constexpr int CB = ST == 0 ? 16 : 8;           // bytes per colour texel
     constexpr int NH = 4 * S;                      // halo pixels per ring row.  Steps 1-16: all staged by wave 0 of the row group (lanes
@@ -125,8 +126,11 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
         }
     };
     uint32_t ref01 = 0, refz = 0;
-    // EXACT = false: the lanes whose output held a NaN, or whose own texel holds a -0.0 channel (commit_px): the band is run again
-    unsigned long long rerun = 0ull;
+    // What the wave reports of its band (EXACT = false), ONE scalar register (the kernel has none to spare: one more and the S = 2 .. 8 kernels spill):
+    //   bit 31      an output held a NaN, or an own texel holds a -0.0 channel (commit_px): the band is run again;
+    //   bits 0-15   steps in which the wave filtered a surface pixel, bits 16-30 those of them on the uniform-normal path (svgf_path_stats_enable).
+    uint32_t state = 0u;
+    auto rerun_if = [&](unsigned long long lanes) { state |= (((uint32_t)lanes | (uint32_t)(lanes >> 32)) != 0u) ? 0x80000000u : 0u; };
     // jn: the decimated row the step fetched (fetch(jn, st)); EXACT only: which texels lie outside the frame
     auto commit = [&](int sl, const Staged& st, int jn) __attribute__((always_inline)) {
         int so = sl + rg; so = so >= kRing ? so - kRing : so;                           // scalar
@@ -136,7 +140,7 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
         unsigned long long negzero = 0ull;
         unsigned long long differs = commit_px<ST, true, EXACT>(st.o, colA + (uint32_t)(so * (WL * 16) + 2 * S * 16), colL + (uint32_t)(so * (WL * 8) + 2 * S * 8), NOFF, ref01, refz,
                                                                 true, &negzero, row_out || !own_ok);
-        if constexpr (!EXACT) rerun |= negzero;
+        if constexpr (!EXACT) rerun_if(negzero);
         if (halo_wave) {
 #pragma unroll
             for (int p = 0; p < HP; p++)
@@ -197,8 +201,9 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
         const bool uniform = !EXACT && !a.no_fastpath && ref_base.e[0] == ref_base.e[0] &&
                              !wave_any(lane < kRing * 8 && lds_load(L.flag(0) + 4 * (lane < kRing * 8 ? lane : 0)) != 0u);
         bool redo = true;                          // EXACT: this lane's first-pass result held a NaN — only those texels are stored again
-        const float4 o = filter_px<S, kTapDepth, NOFF, EXACT>(rows, c, phi_n, wave_has_surface, uniform, &ref_base, EXACT ? &redo : nullptr);
-        if constexpr (!EXACT) rerun |= lanes_where(__builtin_isunordered(o.x, o.w));
+        // (&state: svgf_path_stats_enable's two counts, added where filter_px branches anyway — one scalar add per step, no register of their own)
+        const float4 o = filter_px<S, kTapDepth, NOFF, EXACT>(rows, c, phi_n, wave_has_surface, uniform, &ref_base, EXACT ? &redo : nullptr, EXACT ? nullptr : &state);
+        if constexpr (!EXACT) rerun_if(lanes_where(__builtin_isunordered(o.x, o.w)));
         else redo = redo | has_negzero(make_float4(c.A.x, c.A.y, c.A.z, c.A.w));            // the sign of a zero (commit_px): only such a centre can come out -0.0
 
         // Output values now, their stores AFTER the ring refill: hipcc's vmcnt bookkeeping cannot tell that the rows committed
@@ -238,7 +243,7 @@ __device__ __forceinline__ bool atrous_band(const Geo& g, const AtrousArgs& a, c
             }
         }
     }
-    return rerun != 0ull;
+    return state;
 }
 
 // What the kernel knows of its row ranges.  One range (every launch but the strip driver's): rows [g.yb, g.ye).  Several (AtrousRanges): the
@@ -288,6 +293,7 @@ __global__ __launch_bounds__(TX * kRS, atrous_waves(S)) void atrous_lds_kernel(G
         // what the end of the workgroup needs to signal, kept in LDS: in scalar registers through the band it spilled the product loop's
         // (the kernel sits at its SGPR and VGPR limits; tests/test_kernel_budgets.py)
         lds_store(L.nref(4), first ? 1u : 0u);
+        lds_store(L.nref(12), (uint32_t)(uintptr_t)a.path_stats); lds_store(L.nref(13), (uint32_t)((uintptr_t)a.path_stats >> 32));
         if (first) {
             lds_store(L.nref(5), (uint32_t)(uintptr_t)rp.arrivals); lds_store(L.nref(6), (uint32_t)((uintptr_t)rp.arrivals >> 32));
             lds_store(L.nref(7), (uint32_t)(uintptr_t)rp.signal); lds_store(L.nref(8), (uint32_t)((uintptr_t)rp.signal >> 32));
@@ -299,10 +305,17 @@ __global__ __launch_bounds__(TX * kRS, atrous_waves(S)) void atrous_lds_kernel(G
     else {
         const int j1 = min(nj, j0 + band_rows);
         const int ybase = yb + rv;                 // global row of decimated index j: ybase + S*j
-        const bool nan_wave = atrous_band<ST, S, TX, false>(g, a, L, x0, j0, j1, ybase, first);
-        if (nan_wave && (threadIdx.x & 63) == 0) lds_store(L.nref(2), 1u);
+        const uint32_t report = atrous_band<ST, S, TX, false>(g, a, L, x0, j0, j1, ybase, first);
+        if ((report >> 31) != 0u && (threadIdx.x & 63) == 0) lds_store(L.nref(2), 1u);
         __syncthreads();
-        if (lds_load(L.nref(2)) != 0u) {           // (no frame without a NaN gets here)
+        if ((lds_load(L.nref(12)) | lds_load(L.nref(13))) != 0u) {      // diagnostics (svgf_path_stats_enable); off: two LDS words read per wave
+            unsigned long long* stats = (unsigned long long*)((uintptr_t)lds_load(L.nref(12)) | ((uintptr_t)lds_load(L.nref(13)) << 32));
+            if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u && (report & 0xffffu) != 0u) {
+                (void)__hip_atomic_fetch_add(stats, (unsigned long long)(report & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                (void)__hip_atomic_fetch_add(stats + 1, (unsigned long long)((report >> 16) & 0x7fffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (lds_load(L.nref(2)) != 0u) {           // (no frame without a NaN or a -0.0 texel gets here)
             __syncthreads();                       // (the band's prologue writes the flag words again)
             (void)atrous_band<ST, S, TX, true>(g, a, L, x0, j0, j1, ybase, lds_load(L.nref(4)) != 0u);
         }
@@ -312,7 +325,14 @@ __global__ __launch_bounds__(TX * kRS, atrous_waves(S)) void atrous_lds_kernel(G
     // for (hipStreamWaitValue64).  No thread index, no argument is used here: they would have to live through the band.
     if (lds_load(L.nref(4)) != 0u) {
         // this wave's stores were written through (atrous_band, WT): once they have been acknowledged they are in memory — no release fence, which
-        // on this part is a write-back of the XCD's whole L2, per workgroup, under the interior tiles' feet
+        // on this part is a write-back of the XCD's whole L2, per workgroup, under the interior tiles' feet.
+        // This is OUTSIDE the compiler's memory model and rests on three hardware facts: (1) a store with sc0 sc1 is written through to
+        // memory, never left dirty in this XCD's L2; (2) s_waitcnt vmcnt(0) returns only when the memory side has acknowledged the wave's stores;
+        // (3) whoever reads these rows is a kernel launched LATER on THIS device — RCCL's send kernel behind hipStreamWaitValue64, whose launch
+        // invalidates the caches it reads through; no other device reads them in place.  Checked bit for bit on one device over RCCL's own kernels
+        // and over the mailbox (tests/test_gpu_strips_mailbox.py, tests/fuzz_parity.py); on real peers `bench.py --gpus N` checks the strips
+        // against the one-GPU frame itself and keeps the three-launch schedule unless that check passes.  Hence an opt-in
+        // (svgf_strips_set_edge_first, default 0): the default schedule orders the exchange behind an event, inside the memory model.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         if (lane == 0 && __hip_atomic_fetch_add((lds_u32*)(uintptr_t)L.nref(3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u == (unsigned)(TX * kRS / 64)) {

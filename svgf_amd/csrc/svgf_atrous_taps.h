@@ -140,7 +140,7 @@ __device__ __forceinline__ void taps24(const TapRows& rows, const TapCentre& c, 
 // as in round 4 — around a NaN texel its finite pixels then round as the exact form does (within the stage tolerance).
 template <int CS, int D, int NOFF, bool EXACT = false, bool KEEP_FAST = true>
 __device__ __forceinline__ float4 filter_px(const TapRows& rows, const TapCentre& c, float phi_n, bool wave_has_surface, bool uniform, const UniBase* shared_base = nullptr,
-                                            bool* fast_bad = nullptr) {
+                                            bool* fast_bad = nullptr, uint32_t* path_count = nullptr) {
     float sw = 1.0f;                                                                     // :567
     f32x2 srg = {c.A.x, c.A.y}, sbv = {c.A.z, c.A.w};                                    // :568
     if constexpr (EXACT && !KEEP_FAST) {
@@ -151,9 +151,10 @@ __device__ __forceinline__ float4 filter_px(const TapRows& rows, const TapCentre
         const float inv = hw_rcp(sw);
         return make_float4(srg.x * inv, srg.y * inv, sbv.x * inv, sbv.y * (inv * inv));
     }
+    // path_count (svgf_path_stats_enable, the caller's scalar report word): + 1 for a step that filters a surface pixel, + 0x10000 more on the uniform path
     if (wave_has_surface) {
-        if (!EXACT && uniform) taps24<CS, D, kTapsUniform, NOFF>(rows, c, phi_n, sw, srg, sbv, shared_base);
-        else taps24<CS, D, kTapsGeneral, NOFF>(rows, c, phi_n, sw, srg, sbv, nullptr);
+        if (!EXACT && uniform) { taps24<CS, D, kTapsUniform, NOFF>(rows, c, phi_n, sw, srg, sbv, shared_base); if (path_count) *path_count += 0x10001u; }
+        else { taps24<CS, D, kTapsGeneral, NOFF>(rows, c, phi_n, sw, srg, sbv, nullptr); if (path_count) *path_count += 1u; }
     }
     const float inv = hw_rcp(sw);                                                        // sw >= 1 (a sky centre: exactly 1, and the sums are its colour)
     const float4 o = make_float4(srg.x * inv, srg.y * inv, sbv.x * inv, sbv.y * (inv * inv));  // :615

@@ -2,6 +2,8 @@
 // svgf_strip.hip (the multi-GPU strip driver).
 #pragma once
 #include "../../include/svgf.h"
+#include "../../include/svgf_ext.h"
+#include "../../include/svgf_test.h"
 #include "svgf_kernels.h"
 
 #include <string>
@@ -70,6 +72,7 @@ struct svgf_ctx {
     int debug_mode = SVGF_DEBUG_FINAL;     // SVGFDebugOutput, App.cu:545-649
     bool have_state = false;
     svgf_strip_driver* strip_drv = nullptr;
+    unsigned long long* path_stats = nullptr;   // svgf_path_stats_enable: device counters, a pair per step 1 << i (svgf_kernels.h: AtrousArgs::path_stats), or null
     // per-stage timing
     int timing = 0;               // 0 = off, n = stage events on every n-th frame
     int timing_phase = 0;

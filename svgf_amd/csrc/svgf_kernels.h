@@ -85,6 +85,8 @@ struct AtrousArgs {
     int step; float phi_colour, phi_normal;
     const uint4* guide;          // TemporalArgs::guide_out of the same frame (LDS kernel only; motion / normal are then not read), or null
     int no_fastpath;             // SVGF_VARIANT_LDS_GENERAL: every wave takes the general tap path (bit-identical, slower)
+    unsigned long long* path_stats;   // svgf_path_stats_enable (diagnostics; LDS-streaming kernel): {wave-steps that filtered a surface pixel, those of them on the
+                                 // uniform-normal tap path} of this launch are ADDED here, one pair of atomics per wave and band; null: nothing is counted out
 };
 // Strip driver: ONE launch over up to three row ranges of an iteration, the first `nfirst` of them — the rows a neighbour rank waits for —
 // produced by the launch's first workgroups; the last of those to finish publishes `value` in `signal` (device memory), which the

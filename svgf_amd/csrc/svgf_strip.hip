@@ -127,12 +127,16 @@ struct svgf_strips {
         hipEvent_t ready = nullptr, halo_done = nullptr, state_done = nullptr;
         hipEvent_t mb_ready = nullptr, mb_done = nullptr;      // mailbox: this rank's communication stream has reached the group / has received what the group sends it
         // edge rows first (svgf_strips_set_edge_first): the iteration in front of an exchange is ONE launch whose first workgroups produce the rows the
-        // neighbours wait for; the last of them writes edge_value into edge_signal[0] (device memory; the arrival counter sits 128 B behind it) and
-        // the communication stream waits for that word (hipStreamWaitValue64) instead of for an event behind two extra launches
-        // Two slots, 256 B apart: launches on the filter stream use slot 0, launches on the side stream (two frames in flight: a frame's tail) slot 1 —
+        // neighbours wait for; the last of them writes edge_value into its slot's signal word and the communication stream waits for that word
+        // (hipStreamWaitValue64) instead of for an event behind two extra launches
+        // Two slots: launches on the filter stream use slot 0, launches on the side stream (two frames in flight: a frame's tail) slot 1 —
         // the two streams run CONCURRENTLY, and a word (or an arrival counter) shared between them is written out of order: the wait for the
         // smaller sequence number passes early and the one for the larger never (round 5's first version hung exactly there).
-        unsigned long long* edge_signal = nullptr;
+        // The two signal words are HSA signal memory (hipExtMallocWithFlags(hipMallocSignalMemory): what hipStreamWaitValue64 is documented for; plain
+        // device memory works on this ROCm build too — tools/ubench/wait_value.hip — but is not promised), the arrival counters plain device memory.
+        // No signal memory: edge_signal stays null and every exchanging iteration keeps the three-launch schedule.
+        unsigned long long* edge_signal[2] = {nullptr, nullptr};
+        unsigned* edge_arrivals = nullptr;                     // two counters, 256 B apart
         unsigned long long edge_value[2] = {0, 0};
         int edge_slot = 0;                                     // the slot of the launch just enqueued
         bool edge_pending = false;                             // the launch just enqueued signals: the next exchange waits for edge_value[edge_slot]
@@ -149,7 +153,7 @@ struct svgf_strips {
     std::vector<Local> local;
     int timing_every = 0, timing_base = 0, frame_no = 0;       // timed: frames timing_base, timing_base + every, ...
     int frames_in_flight = 1;
-    bool edge_first = true;                // svgf_strips_set_edge_first
+    bool edge_first = false;               // svgf_strips_set_edge_first (opt-in, svgf_ext.h)
     double t_ms = 0, t_px_iter = 0, t_px_fb = 0;
     int t_launches = 0;
     std::string err;
@@ -374,7 +378,7 @@ int post_exchange(svgf_strips* s, const std::vector<PlaneSpec>& planes, int h, b
     // (edge rows first: the rows a rank sends are final when the first workgroups of the launch it has just enqueued have signalled — the
     // communication stream waits for that word, not for the launch; everything enqueued BEFORE that launch is complete by then, stream order)
     auto wait_for = [&](svgf_strips::Local& on, svgf_strips::Local& of) -> int {
-        if (of.edge_pending) SVGF_SHIP(s, hipStreamWaitValue64(on.comm_stream, of.edge_signal + 32 * of.edge_slot, of.edge_value[of.edge_slot], hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
+        if (of.edge_pending) SVGF_SHIP(s, hipStreamWaitValue64(on.comm_stream, of.edge_signal[of.edge_slot], of.edge_value[of.edge_slot], hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
         else SVGF_SHIP(s, hipStreamWaitEvent(on.comm_stream, of.ready, 0));
         return SVGF_OK;
     };
@@ -454,7 +458,7 @@ int launch_atrous_rows(svgf_strips* s, svgf_strips::Local& l, Rows rows, int src
         r.nfirst = r.n;
         add(inner->a, inner->b);
         const int slot = l.cur == l.compute ? 0 : 1;
-        r.signal = l.edge_signal + 32 * slot; r.arrivals = (unsigned*)(l.edge_signal + 32 * slot + 16); r.value = ++l.edge_value[slot];
+        r.signal = l.edge_signal[slot]; r.arrivals = l.edge_arrivals + 64 * slot; r.value = ++l.edge_value[slot];
         rc = atrous_ranges_impl(c, c->filter[src], c->filter[dst], i == 0 ? c->colour[P] : nullptr, cur, 1 << i, i, guide, r);
         if (rc == SVGF_OK) { l.edge_pending = r.nfirst > 0; l.edge_slot = slot; }
     } else rc = pair ? atrous_pair_impl(c, c->filter[src], c->filter[dst], c->colour[P], cur, guide)
@@ -516,8 +520,11 @@ int svgf_strips_plan(int width, int height, int rank, int world, int steps, int 
     svgf_strip_plan_geo g;
     int chosen = plan;
     if (plan == SVGF_PLAN_AUTO) {
-        // the plan with the fewest exchanges whose halo still fits the strips
-        const int order[3] = {SVGF_PLAN_GHOST, SVGF_PLAN_GROUPED, SVGF_PLAN_PER_ITERATION};
+        // the plan with the fewest exchanges BETWEEN iterations — but at least one: what BASELINE.json configs[3] names is a halo exchange between
+        // a-trous iterations — whose halo fits the strips: grouped (one), else per-iteration (one in front of every iteration).  Grouped is also the
+        // fastest of the three on an 8K/8 strip (profiles/r05_strip_sim_8k_over_8.txt: 6.19x against ghost 5.87x, per-iteration 5.71x).  Ghost (no
+        // exchange between iterations, 62 ghost rows) needs the tallest halo of the three: it never fits where grouped does not; last, for completeness.
+        const int order[3] = {SVGF_PLAN_GROUPED, SVGF_PLAN_PER_ITERATION, SVGF_PLAN_GHOST};
         bool ok = false;
         for (int cand : order) if (make_geo(width, height, rank, world, steps, cand, moments_radius, motion_reach, g)) { chosen = cand; ok = true; break; }
         if (!ok) return SVGF_ERR_HALO;
@@ -640,8 +647,17 @@ int svgf_strips_create(svgf_strips** out, int width, int height, int world, cons
             int can = 0;
             // (a part or runtime without stream memory operations keeps round 4's three launches per exchanging iteration)
             if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, l.device) == hipSuccess && can) {
-                e = hipMalloc((void**)&l.edge_signal, 512);
-                if (e == hipSuccess) e = hipMemset(l.edge_signal, 0, 512);
+                bool sig = true;
+                for (int k = 0; k < 2 && sig; k++) {
+                    sig = hipExtMallocWithFlags((void**)&l.edge_signal[k], 8, hipMallocSignalMemory) == hipSuccess && hipMemset(l.edge_signal[k], 0, 8) == hipSuccess;
+                    if (!sig) (void)hipGetLastError();
+                }
+                if (!sig) {                                    // no signal memory here: the three-launch schedule (edge_signal[0] == null says so)
+                    for (auto& p : l.edge_signal) { if (p) (void)hipFree(p); p = nullptr; }
+                } else {
+                    e = hipMalloc((void**)&l.edge_arrivals, 512);
+                    if (e == hipSuccess) e = hipMemset(l.edge_arrivals, 0, 512);
+                }
             }
         }
         if (e == hipSuccess && s->mailbox) e = hipEventCreateWithFlags(&l.mb_ready, hipEventDisableTiming);
@@ -668,7 +684,8 @@ void svgf_strips_destroy(svgf_strips* s) {
         if (l.ready) (void)hipEventDestroy(l.ready);
         if (l.halo_done) (void)hipEventDestroy(l.halo_done);
         if (l.state_done) (void)hipEventDestroy(l.state_done);
-        if (l.edge_signal) (void)hipFree(l.edge_signal);
+        for (void* p : l.edge_signal) if (p) (void)hipFree(p);
+        if (l.edge_arrivals) (void)hipFree(l.edge_arrivals);
         if (l.mb_ready) (void)hipEventDestroy(l.mb_ready);
         if (l.mb_done) (void)hipEventDestroy(l.mb_done);
         if (l.own_comm_stream && l.comm_stream) (void)hipStreamDestroy(l.comm_stream);
@@ -842,7 +859,7 @@ int svgf_strips_frame(svgf_strips* s, const void* const* radiance, const svgf_gb
             // in the same launch — instead of two edge launches, the exchange's event, and an interior launch (three launches' ramp and tail)
             std::vector<Rows> rest(n, Rows{0, 0});
             bool one_launch = split && s->edge_first;
-            for (int k = 0; k < n && one_launch; k++) one_launch = atrous_ranges_ok(s->local[k].ctx, 1 << i) && s->local[k].edge_signal != nullptr;
+            for (int k = 0; k < n && one_launch; k++) one_launch = atrous_ranges_ok(s->local[k].ctx, 1 << i) && s->local[k].edge_signal[0] != nullptr;
             for (int k = 0; k < n; k++) {
                 auto& l = s->local[k];
                 const Rows rows = grown(l.g, s->H, l.g.ext_atrous[i]);

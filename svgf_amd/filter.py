@@ -1,5 +1,5 @@
 """Python host-side mirror of the reference's filter entry points, bound to the C ABI of
-include/svgf.h (libsvgf_mi355x.so) with ctypes.
+include/svgf.h, svgf_ext.h and svgf_test.h (libsvgf_mi355x.so) with ctypes.
 
 `Denoiser.TemporalFilter / FilterMoments / WaveletFilter / Render` keep the names, argument meaning
 and sequencing of `application::TemporalFilter/FilterMoments/WaveletFilter` (src/App.cu:469-514)
@@ -26,14 +26,15 @@ EXPORTS = [
     "svgf_default_params", "svgf_status_string", "svgf_last_error", "svgf_abi_version", "svgf_create",
     "svgf_create_strip", "svgf_destroy", "svgf_set_params", "svgf_set_stream", "svgf_set_rows", "svgf_temporal", "svgf_temporal_moments", "svgf_demodulate", "svgf_modulate",
     "svgf_moments", "svgf_atrous", "svgf_atrous_pair", "svgf_set_iteration_fusion", "svgf_taa", "svgf_pack_gbuffer", "svgf_denoise_frame", "svgf_reset_history", "svgf_set_frames_in_flight", "svgf_flush", "svgf_state_plane",
-    "svgf_state_pingpong", "svgf_plane_bytes", "svgf_timing_enable", "svgf_timing_read",
+    "svgf_state_pingpong", "svgf_plane_bytes", "svgf_timing_enable", "svgf_timing_read", "svgf_path_stats_enable", "svgf_path_stats_read",
     "svgf_resize", "svgf_resize_strip", "svgf_get_size", "svgf_sync", "svgf_halo_violations", "svgf_set_valid_rows", "svgf_set_debug_mode", "svgf_set_prev_guide", "svgf_set_adaptive_moments", "svgf_adaptive_moments_state", "svgf_adaptive_moments_sample",
     "svgf_import_gbuffer_pitched", "svgf_import_gbuffer_array", "svgf_export_to_array",
     "svgf_strips_plan", "svgf_rccl_unique_id", "svgf_rccl_comm_init", "svgf_rccl_comm_destroy", "svgf_rccl_comm_count", "svgf_strips_create", "svgf_strips_destroy",
     "svgf_strips_last_error", "svgf_strips_context", "svgf_strips_layout", "svgf_strips_frame", "svgf_strips_sync",
     "svgf_strips_timing_enable", "svgf_strips_timing_read", "svgf_strips_set_frames_in_flight", "svgf_strips_messages", "svgf_strips_transport_stats", "svgf_strips_mailbox_fault", "svgf_strips_set_edge_first",
 ]
-ABI_VERSION = 7
+ABI_VERSION = 8
+PATH_STAT_STEPS = 7
 TRANSPORT = {"rccl": 0, "rccl-loopback": 1, "mailbox": 2}
 DEBUG_MODE = {"final": 0, "temporal": 1, "atrous": 2}
 HALO_PLAN = {"auto": 0, "ghost": 1, "grouped": 2, "per-iteration": 3}
@@ -162,6 +163,8 @@ def load_library():
     lib.svgf_plane_bytes.restype = C.c_size_t
     lib.svgf_timing_enable.argtypes = [vp, ip]
     lib.svgf_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(ip), ip]
+    lib.svgf_path_stats_enable.argtypes = [vp, ip]
+    lib.svgf_path_stats_read.argtypes = [vp, C.POINTER(C.c_ulonglong), ip]
     lib.svgf_resize.argtypes = [vp, ip, ip]
     lib.svgf_resize_strip.argtypes = [vp, ip, ip, C.POINTER(StripC)]
     lib.svgf_get_size.argtypes = [vp, C.POINTER(ip), C.POINTER(ip), C.POINTER(StripC)]
@@ -472,3 +475,13 @@ class Denoiser:
         fr = C.c_int()
         self._check(self.lib.svgf_timing_read(self._h, arr, C.byref(fr), n), "svgf_timing_read")
         return list(arr)[: 2 + self.params.steps], fr.value
+
+    def path_stats_enable(self, on=True):
+        """Diagnostics (include/svgf_ext.h): count, per a-trous step, the wave-steps that filtered a surface pixel and those on the uniform-normal path."""
+        self._check(self.lib.svgf_path_stats_enable(self._h, int(bool(on))), "svgf_path_stats_enable")
+
+    def path_stats_read(self):
+        """-> {step: (wave-steps with a surface pixel, those of them on the uniform-normal tap path)} since the last read; synchronises."""
+        arr = (C.c_ulonglong * (2 * PATH_STAT_STEPS))()
+        self._check(self.lib.svgf_path_stats_read(self._h, arr, 2 * PATH_STAT_STEPS), "svgf_path_stats_read")
+        return {1 << i: (int(arr[2 * i]), int(arr[2 * i + 1])) for i in range(PATH_STAT_STEPS)}

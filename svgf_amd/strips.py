@@ -30,7 +30,7 @@ PLANS = {
     "ghost": lambda n: [list(range(n))] if n else [],
 }
 DEFAULT_PLAN = "grouped"
-AUTO_ORDER = ("ghost", "grouped", "per-iteration")
+AUTO_ORDER = ("grouped", "per-iteration", "ghost")      # svgf_strips_plan's order (svgf_strip.hip): the fewest exchanges between iterations, but at least one
 
 
 def partition(H: int, world: int):
@@ -63,8 +63,7 @@ class Geometry:
     @staticmethod
     def make(W, H, rank, world, steps, plan=DEFAULT_PLAN, moments_radius=3, motion_reach=4):
         if plan == "auto":
-            # the plan with the fewest exchanges whose halo still fits the strips: "ghost" needs one exchange per frame
-            # (the state, overlapped with iterations 1..), no transfer sits between two iterations
+            # the plan with the fewest exchanges between iterations — but at least one (BASELINE.json configs[3]) — whose halo fits the strips
             for cand in AUTO_ORDER:
                 try:
                     g = Geometry.make(W, H, rank, world, steps, cand, moments_radius, motion_reach)
@@ -480,7 +479,7 @@ class NativeStrips:
         self._check(self.lib.svgf_strips_set_frames_in_flight(self._h, int(frames)), "svgf_strips_set_frames_in_flight")
 
     def set_edge_first(self, enable=True):
-        """svgf_strips_set_edge_first: the iteration in front of an exchange as ONE launch whose first workgroups produce the edge rows and signal (default on)."""
+        """svgf_strips_set_edge_first: the iteration in front of an exchange as ONE launch whose first workgroups produce the edge rows and signal (an opt-in: default off, include/svgf_ext.h)."""
         self._check(self.lib.svgf_strips_set_edge_first(self._h, 1 if enable else 0))
 
     def set_iteration_fusion(self, enable=True):
@@ -533,7 +532,7 @@ class _NativeRunner:
         self.lay = self.drv.layouts[0]
 
     def frame(self, rad, cur, prev):
-        return self.drv.frame([rad], [cur], [prev])[0]
+        return self.drv.frame([rad], [cur], [prev] if prev is not None else None)[0]
 
     def owned(self, t):
         return self.drv.owned(0, t)
@@ -553,6 +552,18 @@ class _NativeRunner:
 
     def close(self):
         self.drv.close()
+
+
+VERIFY_FRAMES = 6        # bench_strips' check of the strips against the one-GPU frame: frames from a fresh start (history passes 4: cold and steady moments paths)
+
+
+def _checksum(t):
+    """Two 64-bit sums over the raw 32-bit words of a device tensor (wrap-around arithmetic): a plain sum and a position-weighted one.  Equal
+    checksums of 66 MB of pixels are, for every practical purpose, equal pixels; the position weights catch rows that arrive in the wrong place."""
+    import torch
+    v = t.contiguous().view(torch.int32).flatten().to(torch.int64) & 0xFFFFFFFF
+    w = (torch.arange(v.numel(), device=v.device, dtype=torch.int64) % 65521) + 1
+    return torch.stack([v.sum(), (v * w).sum()])
 
 
 def _strip_pan_frames(W, H, storage, device, mv, y0, y1):
@@ -608,7 +619,7 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
 
     # ---- the whole frame on ONE GPU (rank 0), through svgf_denoise_frame: the time the N-GPU speed-up is relative to
     phase = on_phase or (lambda name: None)
-    one_gpu_ms = None
+    one_gpu_ms, ref_sums = None, None
     if one_gpu_reference:
         phase("the whole frame on one GPU (rank 0)")
         if rank == 0:
@@ -636,8 +647,15 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
                 torch.cuda.synchronize(device)
                 wins.append((time.perf_counter() - t0) * 1e3 / steps)
             one_gpu_ms = sorted(wins)[len(wins) // 2]
+            # ... and, from a fresh start, the VERIFY_FRAMES frames every strip schedule below is checked against, bit for bit (verify())
+            d.reset_history()
+            for k in range(VERIFY_FRAMES):
+                out_w = d.Render(rads_w[k & 1], gbp[k & 1], gbp[(k & 1) ^ 1] if k else None)
+            torch.cuda.synchronize(device)
+            parts = partition(H, world)
+            ref_sums = torch.stack([_checksum(out_w[a:b]) for a, b in parts])       # [world, 2]: what rank r's owned rows must sum to
             d.close()
-            del d, gb_w, gb2, rads_w, gbp
+            del d, gb_w, gb2, rads_w, gbp, out_w
             torch.cuda.empty_cache()
         one_gpu_ms = max_over_ranks(one_gpu_ms or 0.0)          # every rank learns rank 0's figure (and waits for it)
 
@@ -671,13 +689,12 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
                               "nothing is measured (RCCL wants one device per rank)")
     Runner = _NativeRunner
 
-    def measure(plan_name, reach, frame_of, keep_timing=False, edge_first=True):
+    def measure(plan_name, reach, frame_of, keep_timing=False, edge_first=False):
         """One driver under one plan: prime, then `steps` frames between barriers.  frame_of(n) -> (radiance, cur, prev) of THIS layout.
-        edge_first=False: round 4's schedule (three launches per exchanging iteration, svgf_strips_set_edge_first(0)), for comparison."""
+        edge_first=False: the library's default schedule (three launches per exchanging iteration); True: svgf_strips_set_edge_first(1)."""
         lay = strips_plan(W, H, rank, world, iters, plan=plan_name, moments_radius=params.moments_radius, motion_reach=reach)
         run = Runner(W, H, world, rank, params, device, side.cuda_stream, comm, lay["plan"], reach)
-        if not edge_first:
-            run.drv.set_edge_first(False)
+        run.drv.set_edge_first(bool(edge_first))
         get = frame_of(lay)
         n = 0
         dist.barrier()                           # the ranks enter the untimed frames together ...
@@ -727,21 +744,57 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
         run.close()
         return res
 
-    def static_frames(lay):
+    def static_frames(lay, nrad=None):
         assert lay["y0"] >= y0p and lay["y1"] <= y1p, "the probe rows do not cover this layout"
         cut = slice(lay["y0"] - y0p, lay["y1"] - y0p)
         # current and previous G-buffer in DISTINCT planes, ping-ponged (src/App.cu:471-474), also with a static camera
         gbs = [F.GBuffer(gb_all.motion[cut].clone(), gb_all.normal[cut].clone(), gb_all.uv[cut].clone()) for _ in range(2)]
-        rads = [r[cut].contiguous() for r in rads_all]
+        rads = [r[cut].contiguous() for r in rads_all[:nrad]]
         return lambda n: (rads[n % len(rads)], gbs[n & 1], gbs[(n & 1) ^ 1])
 
+    def verify(plan_name, edge_first):
+        """VERIFY_FRAMES frames from a fresh start through the strips under one schedule; every rank's OWNED rows of the last result against the
+        same rows of the one-GPU frame (rank 0's reference above), as 2 x 64-bit checksums over the raw bits: -> True / False on every rank."""
+        lay = strips_plan(W, H, rank, world, iters, plan=plan_name, moments_radius=params.moments_radius, motion_reach=motion_reach)
+        run = Runner(W, H, world, rank, params, device, side.cuda_stream, comm, lay["plan"], motion_reach)
+        run.drv.set_edge_first(edge_first)
+        get = static_frames(lay, nrad=2)
+        dist.barrier()
+        for k in range(VERIFY_FRAMES):
+            rad, cur, prev = get(k)
+            out = run.frame(rad, cur, prev if k else None)
+        run.sync()
+        mine = _checksum(run.owned(out)).to(device)
+        sums = [torch.zeros_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(sums, mine)
+        else:
+            sums = [mine]
+        ok = torch.tensor([1 if (rank != 0 or bool((torch.stack(sums).cpu() == ref_sums.cpu()).all())) else 0], device=device, dtype=torch.int32)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        run.close()
+        return bool(int(ok.item()))
+
+    # ---- which schedule is timed: the library's default orders every exchange behind an event (three launches per exchanging iteration); the opt-in
+    # "edge rows first" (svgf_strips_set_edge_first) signals from inside ONE launch and is faster in the one-GPU simulation — it is used for the timed
+    # legs if and only if THIS run, on THESE ranks, reproduces the one-GPU frame bit for bit with it (include/svgf_ext.h; ADVICE r05)
+    verified = None
+    if ref_sums is not None or (one_gpu_reference and rank != 0):
+        phase("verification against the one-GPU frame")
+        head_plan = strips_plan(W, H, rank, world, iters, plan=plan, moments_radius=params.moments_radius, motion_reach=motion_reach)["plan"]
+        verified = {"frames": VERIFY_FRAMES, "plan": head_plan, "what": "owned rows of every rank after that many frames from a fresh start == the same rows of the one-GPU frame (raw bits, 2 x 64-bit checksums)",
+                    "three_launches": verify(head_plan, False), "edge_first": verify(head_plan, True)}
+    use_edge_first = bool(verified and verified["edge_first"])
+
     phase(f"headline: plan {plan}, static camera")
-    head = measure(plan, motion_reach, static_frames, keep_timing=True)
+    head = measure(plan, motion_reach, static_frames, keep_timing=True, edge_first=use_edge_first)
+    head["edge_first"] = use_edge_first
     others, pan = {}, None
 
     def so_far():
         res = dict(head)
-        res.update(driver=Runner.name, other_plans=dict(others), pan=pan, one_gpu_ms=one_gpu_ms, rccl_ranks=rccl_ranks, _comm=comm)
+        res.update(driver=Runner.name, other_plans=dict(others), pan=pan, one_gpu_ms=one_gpu_ms, rccl_ranks=rccl_ranks, _comm=comm, verified=verified)
         return res
     if on_head:
         on_head(so_far())
@@ -749,16 +802,22 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
         if pl == head["plan"] or not _plan_fits(W, H, rank, world, iters, pl, params.moments_radius, motion_reach):
             continue
         phase(f"plan {pl}")
-        r = measure(pl, motion_reach, static_frames)
+        r = measure(pl, motion_reach, static_frames, edge_first=use_edge_first)
         others[pl] = {k: r[k] for k in ("ms_per_step", "rows_held", "host_ms")}
+        others[pl]["edge_first"] = use_edge_first
         if on_head:
             on_head(so_far())
-        if pl != "ghost":
-            # the same plan under round 4's schedule: on real links this pair of numbers is what the edge-rows-first launch is worth
+        if pl != "ghost" and use_edge_first:
+            # the same plan under the default schedule: on real links this pair of numbers is what the edge-rows-first launch is worth
             phase(f"plan {pl}, three launches per exchanging iteration")
             others[pl]["ms_per_step_three_launches"] = measure(pl, motion_reach, static_frames, edge_first=False)["ms_per_step"]
             if on_head:
                 on_head(so_far())
+    if use_edge_first and head["plan"] != "ghost":
+        phase(f"plan {head['plan']}, three launches per exchanging iteration")
+        head["ms_per_step_three_launches"] = measure(head["plan"], motion_reach, static_frames, edge_first=False)["ms_per_step"]
+        if on_head:
+            on_head(so_far())
 
     if pan_mv is not None:
         reach = int(math.ceil(abs(pan_mv[1])))
@@ -774,7 +833,7 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
                     return rads[n & 1], cur, prev
                 return get
             phase("camera pan")
-            r = measure("auto", reach, pan_frames)
+            r = measure("auto", reach, pan_frames, edge_first=use_edge_first)
             pan = {"mv": list(pan_mv), "motion_reach": reach, "plan": r["plan"], "ms_per_step": r["ms_per_step"], "rows_held": r["rows_held"]}
 
     phase("done")

@@ -52,9 +52,49 @@ _N_QUAD_A = np.array([0.0, 0.0, -1.0])
 _N_QUAD_B = np.array([0.6, 0.0, -0.8])
 
 
-def _scene_rows(width, height, frame, mv, row_begin, row_end, seed, col_begin=0):
+def _curved_geometry(u, v, H):
+    """The "curved" scene: every surface is smooth-shaded — what GBuffer.frag:65 writes for a mesh with interpolated vertex normals,
+    `normalize(FragNormal)`, a different normal in (nearly) every texel.  Rolling terrain instead of the ground plane, a large sphere and an
+    upright cylinder instead of the quads; depth and its screen-space derivative analytic.  -> region, z, dz, n."""
+    a, ku, kv = 0.35, 9.0, 7.0
+    region = np.full(u.shape, GROUND, dtype=np.int32)
+    z = 12.0 + 3.0 * u - 6.0 * (v - 0.5) + a * np.sin(ku * u) * np.cos(kv * v)
+    zu = 3.0 + a * ku * np.cos(ku * u) * np.cos(kv * v)
+    zv = -6.0 - a * kv * np.sin(ku * u) * np.sin(kv * v)
+    dz = np.maximum(np.abs(zu), np.abs(zv)) / H
+    n = np.stack([-0.1 * zu, 0.9486833 - 0.05 * (zv + 6.0), np.full_like(u, -0.31622777) - 0.02 * zu], -1)
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    # sphere
+    cx, cy, r = 0.55, 0.62, 0.30
+    dx, dy = (u - cx) / r, (v - cy) / r
+    rho2 = dx * dx + dy * dy
+    m = rho2 < 1.0
+    if m.any():
+        s = np.sqrt(np.clip(1.0 - rho2, 0.0, 1.0))
+        region[m] = SPHERE
+        z[m] = (6.0 - 2.0 * r * s)[m]
+        dz[m] = (2.0 * np.maximum(np.abs(dx), np.abs(dy)) / np.maximum(s, 0.2) / H)[m]
+        n[m] = np.stack([dx[m], dy[m], -s[m]], -1)
+    # upright cylinder (axis along v)
+    cc, rc = 1.25, 0.2
+    t = (u - cc) / rc
+    m = (np.abs(t) < 1.0) & (v >= 0.15) & (v < 0.9)
+    if m.any():
+        c = np.sqrt(np.clip(1.0 - t * t, 0.0, 1.0))
+        region[m] = QUAD_B
+        z[m] = (7.0 - 2.0 * rc * c)[m]
+        dz[m] = (2.0 * np.abs(t) / np.maximum(c, 0.2) / H)[m]
+        n[m] = np.stack([t[m], np.zeros(int(m.sum())), -c[m]], -1)
+    return region, z, dz, n
+
+
+SCENES = ("planar", "curved")
+
+
+def _scene_rows(width, height, frame, mv, row_begin, row_end, seed, col_begin=0, scene="planar"):
     """Geometry of rows [row_begin,row_end) x columns [col_begin, col_begin+width): motion/normal/uv planes, region ids and
-    the noise-free radiance.  `height` is the scale of the world coordinates (the frame height), whatever the ranges."""
+    the noise-free radiance.  `height` is the scale of the world coordinates (the frame height), whatever the ranges.
+    scene: "planar" (a tilted ground plane, quads, one sphere — piecewise constant normals) or "curved" (_curved_geometry)."""
     rows = row_end - row_begin
     ys = np.arange(row_begin, row_end, dtype=np.int64)
     xs = np.arange(col_begin, col_begin + width, dtype=np.int64)
@@ -64,6 +104,11 @@ def _scene_rows(width, height, frame, mv, row_begin, row_end, seed, col_begin=0)
     u[...] = ((xs.astype(np.float64) + frame * float(mv[0])) / H)[None, :]
     v[...] = ((ys.astype(np.float64) + frame * float(mv[1])) / H)[:, None]
 
+    if scene == "curved":
+        region, z, dz, n = _curved_geometry(u, v, H)
+        return _finish_rows(width, rows, ys, xs, u, v, mv, seed, region, z, dz, n)
+    if scene != "planar":
+        raise ValueError(scene)
     region = np.full((rows, width), GROUND, dtype=np.int32)
     z = 12.0 + 3.0 * u - 6.0 * (v - 0.5)
     dz = np.full_like(z, 6.0 / H)
@@ -105,6 +150,11 @@ def _scene_rows(width, height, frame, mv, row_begin, row_end, seed, col_begin=0)
         dz[m] = 0.0
         n[m] = _N_QUAD_A
 
+    return _finish_rows(width, rows, ys, xs, u, v, mv, seed, region, z, dz, n)
+
+
+def _finish_rows(width, rows, ys, xs, u, v, mv, seed, region, z, dz, n):
+    """The sky band, the plane formats and the noise-free radiance of a scene's geometry."""
     # sky band (>= 5 % of the frame): depth 0, normal/uv all-zero bits (SURVEY.md App. A.3)
     sky = v < (0.08 + 0.02 * np.sin(7.0 * u))
     if sky.any():
@@ -164,7 +214,7 @@ _CHUNK = 128
 
 
 def make_scene(width: int, height: int, frame: int = 0, *, mv=(0.0, 0.0), row_begin: int = 0, row_end: int | None = None,
-               seed: int = SEED, col_begin: int = 0, col_end: int | None = None):
+               seed: int = SEED, col_begin: int = 0, col_end: int | None = None, scene: str = "planar"):
     """G-buffer planes + region ids + noise-free radiance ('base') of rows [row_begin,row_end) of frame `frame`.
 
     `mv` is the constant per-frame pan (prev - cur, pixels): the surface point seen at pixel p in frame f was at
@@ -180,7 +230,7 @@ def make_scene(width: int, height: int, frame: int = 0, *, mv=(0.0, 0.0), row_be
            "base": np.empty((rows, width_out, 3), np.float32)}
     for a in range(row_begin, row_end, _CHUNK):
         b = min(a + _CHUNK, row_end)
-        mo, no, uv, rg, ba = _scene_rows(width_out, height, frame, mv, a, b, seed, col_begin)
+        mo, no, uv, rg, ba = _scene_rows(width_out, height, frame, mv, a, b, seed, col_begin, scene)
         sl = slice(a - row_begin, b - row_begin)
         out["motion"][sl], out["normal"][sl], out["uv"][sl], out["region"][sl], out["base"][sl] = mo, no, uv, rg, ba
     return out
@@ -197,9 +247,9 @@ def make_radiance(base: np.ndarray, width: int, frame: int, *, row_begin: int = 
 
 
 def make_frame(width: int, height: int, frame: int, *, mv=(0.0, 0.0), row_begin: int = 0, row_end: int | None = None,
-               seed: int = SEED, noise: str = "1spp"):
+               seed: int = SEED, noise: str = "1spp", scene: str = "planar"):
     """Rows [row_begin, row_end) of synthetic frame `frame`: dict(motion, normal, uv, radiance, region, base)."""
-    sc = make_scene(width, height, frame, mv=mv, row_begin=row_begin, row_end=row_end, seed=seed)
+    sc = make_scene(width, height, frame, mv=mv, row_begin=row_begin, row_end=row_end, seed=seed, scene=scene)
     sc["radiance"] = make_radiance(sc["base"], width, frame, row_begin=row_begin, seed=seed, noise=noise)
     return sc
 

@@ -7,7 +7,7 @@ random sizes, tunables, motions and poisoned texels is the widest pin the oracle
 A trial (a pure function of its seed; tests/test_oracle_fuzz.py pins some): frame size 1 x 1 .. 220 x 120, storage, the tunables over the GUI's
 ranges, NaN / inf / -0 / denormal colour texels and poisoned G-buffer texels (tests/gbuffer_poison.py) with probability 1/2; temporal bit for
 bit (history = the accept / reject mask, colour, moments); moments, one a-trous iteration and TAA within the two libms' distance (NaN masks
-and infinities identical); albedo bit for bit."""
+and infinities identical); albedo and the G-buffer adapter (GBuffer.frag:62-88, from random attribute planes and cameras) bit for bit."""
 from __future__ import annotations
 
 import argparse
@@ -148,7 +148,43 @@ def run_trial(seed, oracle=None):
             aw = snp.albedo(mode, filt, al)
         fin = _same_nonfinite(a, aw, desc + f": albedo mode {mode}")
         assert np.array_equal(a.view(u)[fin], aw.view(u)[fin]), desc + f": albedo mode {mode}"
+    # the G-buffer adapter (GBuffer.frag:62-88): the C++ twin against the NumPy one, bit for bit (drawn from a generator of its own: the trials above keep their frames)
+    _pack_gbuffer_trial(np.random.default_rng(seed ^ 0x6B0FFE), W, H, poison, oracle, desc)
     return desc
+
+
+def _pack_gbuffer_trial(rg, W, H, poison, oracle, desc):
+    def look_at(eye):
+        f = -np.asarray(eye, float); f /= np.linalg.norm(f)
+        s_ = np.cross(f, (0.0, 1.0, 0.0)); s_ /= np.linalg.norm(s_)
+        m = np.eye(4); m[0, :3], m[1, :3], m[2, :3] = s_, np.cross(s_, f), -f
+        m[:3, 3] = -m[:3, :3] @ np.asarray(eye, float)
+        return m
+    fy = 1.0 / np.tan(rg.uniform(0.3, 1.2) / 2)
+    proj = np.zeros((4, 4)); proj[0, 0], proj[1, 1], proj[2, 2], proj[2, 3], proj[3, 2] = fy * H / W, fy, -1.002, -0.2002, -1.0
+    eye1 = rg.uniform(-1, 1, 3) + np.array([0.0, 0.0, 5.0])
+    eye0 = eye1 + rg.uniform(-0.05, 0.05, 3) * rg.integers(0, 2)                      # (half the trials: a static camera)
+    cm = lambda m: m.T.astype(np.float32).ravel()                                       # noqa: E731
+    vp, pvp = cm(proj @ look_at(eye1)), cm(proj @ look_at(eye0))
+    pos = np.concatenate([rg.uniform(-2, 2, (H, W, 3)), rg.integers(0, 900, (H, W, 1))], -1).astype(np.float32)
+    nrm = np.concatenate([rg.normal(size=(H, W, 3)), rg.integers(0, 20, (H, W, 1))], -1).astype(np.float32)
+    nrm[rg.uniform(size=(H, W)) < 0.15, :3] = 0                                       # texels without geometry
+    bary = np.concatenate([rg.uniform(0, 1, (H, W, 3)), rg.integers(0, 70000, (H, W, 1))], -1).astype(np.float32)    # (ids beyond half's range: inf)
+    if poison:                                                                          # non-finite / degenerate attributes; a point in the camera plane (w = 0)
+        for plane in (pos, nrm, bary):
+            flat = plane.reshape(-1)
+            flat[rg.integers(0, flat.size, 4)] = rg.choice(np.array([np.nan, np.inf, -np.inf, -0.0, 1e-42, 3e38], np.float32), 4)
+        pos[rg.integers(0, H), rg.integers(0, W), :3] = eye1.astype(np.float32)
+    got = oracle.pack_gbuffer(pos, nrm, bary, vp, pvp, eye1.astype(np.float32))
+    with np.errstate(all="ignore"):
+        want = snp.pack_gbuffer(pos, nrm, bary, vp, pvp, eye1.astype(np.float32))
+    for name, g_, w_ in zip(("motion", "normal", "uv"), got, want):
+        if g_.dtype == np.float32:
+            fin = _same_nonfinite(g_, w_, desc + f": pack_gbuffer {name}")
+            assert np.array_equal(g_.view(np.uint32)[fin], w_.view(np.uint32)[fin]), desc + f": pack_gbuffer {name}"
+        else:                                                                           # half bits: a NaN is a NaN, everything else bit for bit
+            gn, wn = np.isnan(g_.view(np.float16)), np.isnan(w_.view(np.float16))
+            assert np.array_equal(gn, wn) and np.array_equal(g_[~gn], w_[~wn]), desc + f": pack_gbuffer {name}"
 
 
 def run_pipeline_trial(seed, oracle=None):

@@ -1,6 +1,6 @@
 """Seeded random sweep of the parity and bit-identity claims (test infrastructure: it calls the oracle; nothing in the product imports it).
 
-    python -m tests.fuzz_parity --minutes 10 --seed 1000 [--kinds stage,strips,driver,rows,pair,post,stage0,strips2,driver2,wide,widestrips,edge,edgedriver,edgestrips,graph,fullsize] [--out gpurun_out/fuzz.txt]
+    python -m tests.fuzz_parity --minutes 10 --seed 1000 [--kinds stage,strips,driver,rows,pair,post,stage0,negzero,strips2,driver2,wide,widestrips,edge,edgedriver,edgestrips,graph,fullsize] [--out gpurun_out/fuzz.txt]
 
 Each trial draws a frame size (down to 1 x 1, up past the 128-pixel tile and the 64-lane wave in both directions), a storage format, the
 tunables over the GUI's ranges (GUI.cpp:988-993), a camera motion, optionally NaN / inf radiance texels and poisoned G-buffer texels
@@ -27,6 +27,7 @@ tunables over the GUI's ranges (GUI.cpp:988-993), a camera motion, optionally Na
   graph    the frame driver recorded into a HIP graph and replayed against the directly enqueued frames, bit for bit;
   fullsize   1920x1080 and 3840x2160: strip driver and frame driver under a setting against the plain frame driver, bit for bit, poisoned frames;
   stage0   `stage` with -0.0, denormals and the storage type's extremes in the colour and moments planes;
+  negzero  `stage0` with rectangles of -0.0 (inside, across the border, over the whole frame) and a tenth of all texels -0.0 in one channel;
   post     the stages after the path: TAA + sRGB against the oracle and tiled against per-pixel, albedo (de)modulation bit-exact.
 
 A trial is a pure function of its seed: `run_trial(kind, seed)` re-runs one (tests/test_gpu_fuzz.py pins the seeds that ever failed, and a few
@@ -44,7 +45,7 @@ from svgf_amd import synth
 from tests.gbuffer_poison import poison_gbuffer
 from tests.helpers import CDT, gbuf
 
-KINDS = ("stage", "strips", "driver", "rows", "pair", "post", "stage0", "strips2", "driver2", "wide", "widestrips", "edge", "edgedriver", "edgestrips", "graph", "fullsize")
+KINDS = ("stage", "strips", "driver", "rows", "pair", "post", "stage0", "negzero", "strips2", "driver2", "wide", "widestrips", "edge", "edgedriver", "edgestrips", "graph", "fullsize")
 
 
 def _size(rng):
@@ -82,6 +83,20 @@ def _sprinkle_zeros(rng, a, n):
         tiny = np.finfo(a.dtype).tiny
         vals = np.array([-0.0, 0.0, tiny / 4, -tiny / 4, tiny, np.finfo(a.dtype).max, -np.finfo(a.dtype).max], np.float64)
         flat[rng.integers(0, flat.size, n)] = rng.choice(vals, n).astype(a.dtype)
+    return a
+
+
+def _blocks_of_negzero(rng, a, n):
+    """n rectangles of -0.0 (a random subset of the channels each; some touch the frame's border, some cover it) plus a tenth of the texels:
+    kind "negzero" — the sign a zero keeps through the reference's comparison-built clamp (Filter.cuh:57-82) and the sums that start from it."""
+    H, W, C = a.shape
+    for _ in range(n):
+        h, w = int(rng.integers(1, max(2, H))), int(rng.integers(1, max(2, W)))
+        y, x = int(rng.integers(-h // 2, H)), int(rng.integers(-w // 2, W))
+        ch = np.nonzero(rng.integers(0, 2, C))[0]
+        a[max(y, 0):y + h, max(x, 0):x + w, ch if len(ch) else slice(None)] = -0.0
+    m = rng.random((H, W)) < 0.1
+    a[m, rng.integers(0, C, int(m.sum()))] = -0.0
     return a
 
 
@@ -155,6 +170,8 @@ def trial_stage(G, oracle, seed, zeros=False, wide=False, edge=False):
         _sprinkle(rng, cur, 5), _sprinkle(rng, prev, 5), _sprinkle(rng, mom_prev, 3)
     if zeros:
         _sprinkle_zeros(rz, cur, 8), _sprinkle_zeros(rz, prev, 8), _sprinkle_zeros(rz, mom_prev, 4)
+    if zeros == 2:
+        _blocks_of_negzero(rz, cur, 4), _blocks_of_negzero(rz, prev, 4), _blocks_of_negzero(rz, mom_prev, 2)
     o = np.zeros_like(cur); hist = np.zeros((H, W), np.uint8); mom = np.zeros((H, W, 2), dt)
     oracle.temporal(W, H, storage, prev, cur, o, gbuf(f1), gbuf(f0), hist_prev, hist, mom, mom_prev, depth_threshold=tun["depth_threshold"],
                     normal_threshold=tun["normal_threshold"], history_base=tun["history_base"], mesh_id_test=tun["mesh_id_test"])
@@ -196,6 +213,8 @@ def trial_stage(G, oracle, seed, zeros=False, wide=False, edge=False):
     if zeros:
         flat = src.reshape(-1)
         flat[rz.integers(0, flat.size, 8)] = rz.choice(np.array([-0.0, 0.0, np.finfo(dt).tiny / 4, -np.finfo(dt).tiny / 4, np.finfo(dt).tiny], np.float64), 8).astype(dt)
+    if zeros == 2:
+        _blocks_of_negzero(rz, src, 5)
     want = np.zeros_like(src); fbw = np.full_like(src, 7)
     oracle.atrous(W, H, storage, src, want, fbw, gbuf(fs), step=step, phi_colour=tun["phi_colour"], phi_normal=tun["phi_normal"], iteration=0)
     out, fb = d.new_colour(), G.dev(np.full_like(src, 7))
@@ -797,7 +816,7 @@ def trial_fullsize(G, oracle, seed):
 
 
 TRIALS = {"fullsize": trial_fullsize, "graph": trial_graph, "edgestrips": lambda G, oracle, seed: trial_strips(G, oracle, seed, edge=True), "edgedriver": lambda G, oracle, seed: trial_driver(G, oracle, seed, edge=True), "edge": lambda G, oracle, seed: trial_stage(G, oracle, seed, edge=True), "wide": lambda G, oracle, seed: trial_stage(G, oracle, seed, wide=True), "widestrips": lambda G, oracle, seed: trial_strips(G, oracle, seed, wide=True),
-          "driver2": trial_driver2, "strips2": trial_strips2, "stage0": lambda G, oracle, seed: trial_stage(G, oracle, seed, zeros=True), "stage": trial_stage, "strips": trial_strips, "driver": trial_driver, "rows": trial_rows, "pair": trial_pair, "post": trial_post}
+          "driver2": trial_driver2, "strips2": trial_strips2, "stage0": lambda G, oracle, seed: trial_stage(G, oracle, seed, zeros=True), "negzero": lambda G, oracle, seed: trial_stage(G, oracle, seed, zeros=2), "stage": trial_stage, "strips": trial_strips, "driver": trial_driver, "rows": trial_rows, "pair": trial_pair, "post": trial_post}
 
 
 def run_trial(kind, seed, G=None, oracle=None):

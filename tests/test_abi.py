@@ -1,5 +1,5 @@
-"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol include/svgf.h
-declares, and refuses to work (loudly) without a GPU.  No compute calls here."""
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol include/svgf.h, svgf_ext.h and svgf_test.h
+declare, and refuses to work (loudly) without a GPU.  No compute calls here."""
 import ctypes as C
 import os
 import re
@@ -9,8 +9,11 @@ import pytest
 from tests.conftest import ROOT
 
 
-def _declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "svgf.h")).read()
+HEADERS = ("svgf.h", "svgf_ext.h", "svgf_test.h")     # what a host binds; opt-ins and diagnostics; test hooks — one library
+
+
+def _declared_symbols(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(svgf_[a-z_]+)\s*\(", txt)))
 
@@ -18,12 +21,17 @@ def _declared_symbols():
 def test_header_symbols_all_exported():
     from svgf_amd import filter as F
     lib = F.load_library()
-    syms = _declared_symbols()
-    assert len(syms) >= 18
-    for s in syms:
-        assert hasattr(lib, s), f"{s} declared in include/svgf.h but not exported"
-    assert sorted(F.EXPORTS) == syms
-    assert lib.svgf_abi_version() == F.ABI_VERSION == 7
+    per = {h: _declared_symbols(h) for h in HEADERS}
+    assert len(per["svgf.h"]) >= 18
+    for h, syms in per.items():
+        for s in syms:
+            assert hasattr(lib, s), f"{s} declared in include/{h} but not exported"
+    assert not (set(per["svgf.h"]) & set(per["svgf_ext.h"])) and not (set(per["svgf.h"]) & set(per["svgf_test.h"])) and not (set(per["svgf_ext.h"]) & set(per["svgf_test.h"]))
+    assert sorted(F.EXPORTS) == sorted(s for syms in per.values() for s in syms)
+    assert lib.svgf_abi_version() == F.ABI_VERSION == 8
+    # the header a host of the reference reads stays short, and the test hooks stay out of it
+    assert len(open(os.path.join(ROOT, "include", "svgf.h")).read().splitlines()) <= 260
+    assert "mailbox_fault" not in open(os.path.join(ROOT, "include", "svgf.h")).read()
 
 
 def test_default_params_match_reference_defaults():

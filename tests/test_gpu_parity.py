@@ -710,10 +710,10 @@ def _perspective(fovy, aspect, zn, zf):
     return m
 
 
-def test_pack_gbuffer_adapter(G):
+def test_pack_gbuffer_adapter(G, oracle):
     """The stage in front of the path: GBuffer.frag texels from linear attribute planes, bit for
-    bit against the NumPy restatement, then fed to the temporal stage: a camera that does not move must reproject
-    every covered pixel onto itself."""
+    bit against the C++ oracle (svgf_oracle_pack_gbuffer) and its NumPy twin, then fed to the temporal stage: a camera
+    that does not move must reproject every covered pixel onto itself."""
     from oracle import svgf_numpy as snp
     from svgf_amd import filter as F
     W, H = 301, 187
@@ -726,7 +726,9 @@ def test_pack_gbuffer_adapter(G):
     nrm[rng.uniform(size=(H, W)) < 0.1, :3] = 0                      # texels without geometry
     bary = np.concatenate([rng.uniform(0, 1, (H, W, 3)), rng.integers(0, 50, (H, W, 1))], -1).astype(np.float32)
     colmajor = lambda m: m.T.astype(np.float32).ravel()               # noqa: E731
-    want_m, want_n, want_uv = snp.pack_gbuffer(pos, nrm, bary, colmajor(vp), colmajor(pvp), eye1.astype(np.float32))
+    want_m, want_n, want_uv = oracle.pack_gbuffer(pos, nrm, bary, colmajor(vp), colmajor(pvp), eye1.astype(np.float32))
+    for a_, b_ in zip((want_m, want_n, want_uv), snp.pack_gbuffer(pos, nrm, bary, colmajor(vp), colmajor(pvp), eye1.astype(np.float32))):
+        assert np.array_equal(a_.view(np.uint8), b_.view(np.uint8)), "the two restatements of GBuffer.frag disagree"
     d = F.Denoiser(W, H, F.Params(storage="f32"))
     gb = d.PackGBuffer(G.dev(pos), G.dev(nrm), G.dev(bary), colmajor(vp), colmajor(pvp), eye1)
     got_m, got_n, got_uv = G.host(gb.motion), G.host(gb.normal).view(np.uint16), G.host(gb.uv).view(np.uint16)

@@ -530,7 +530,7 @@ def test_bench_strips_line_on_one_gpu(G):
 def test_bench_strips_leg_that_never_returns_leaves_the_measured_legs(G):
     """A leg of the N > 1 bench that hangs (SVGF_BENCH_HANG_AT: the test's stand-in for an exchange that never completes) does not take the
     legs before it along: after --leg-timeout the line is printed with the headline plan and the legs measured so far, `incomplete` names
-    the leg, exit code 0.  A hang BEFORE the headline has nothing to print: exit code 4, no line."""
+    the leg, exit code 5 (a hang is never reported as success: ADVICE r05).  A hang BEFORE the headline has nothing to print: exit code 4, no line."""
     import subprocess
     import sys
     env = dict(os.environ)
@@ -538,11 +538,11 @@ def test_bench_strips_leg_that_never_returns_leaves_the_measured_legs(G):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--strips", "--steps", "3", "--warmup", "1", "--workload", "1080p", "--prime-ms", "0", "--prime-frames", "0",
            "--leg-timeout", "15"]
-    p = subprocess.run(cmd, env=dict(env, SVGF_BENCH_HANG_AT="plan grouped"), capture_output=True, text=True, timeout=500)
-    assert p.returncode == 0, (p.returncode, p.stderr[-2000:])
+    p = subprocess.run(cmd, env=dict(env, SVGF_BENCH_HANG_AT="plan ghost"), capture_output=True, text=True, timeout=500)
+    assert p.returncode == 5, (p.returncode, p.stderr[-2000:])
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
-    assert "plan grouped" in d["incomplete"] and d["value"] > 0 and d["roofline"]["frac"] > 0
-    assert set(d["halo_plans"]) == {"ghost", "per-iteration"} and "ms_per_step_three_launches" in d["halo_plans"]["per-iteration"] and d["pan"] is None
+    assert "plan ghost" in d["incomplete"] and d["value"] > 0 and d["roofline"]["frac"] > 0 and d["config"]["halo_plan"] == "grouped"
+    assert set(d["halo_plans"]) == {"grouped", "per-iteration"} and "ms_per_step_three_launches" in d["halo_plans"]["per-iteration"] and d["pan"] is None
     p = subprocess.run(cmd, env=dict(env, SVGF_BENCH_HANG_AT="headline"), capture_output=True, text=True, timeout=500)
     assert p.returncode == 4 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")], (p.returncode, p.stdout[-500:], p.stderr[-1500:])
     assert "did not finish" in p.stderr

@@ -244,16 +244,18 @@ def test_taa_strip_geometry(oracle):
     assert np.array_equal(lo[yb - y0:], whole[yb:ye])
 
 
-def test_pack_gbuffer_numpy_kat():
-    """GBuffer.frag:62-88 restated: a point on the optical axis has zero motion under a pure dolly, depth is the
-    Euclidean camera distance, normals come out normalised as half bits."""
+@pytest.mark.parametrize("twin", ["numpy", "c++"])
+def test_pack_gbuffer_kat(oracle, twin):
+    """GBuffer.frag:62-88 restated (both twins: oracle/svgf_numpy.py and svgf_oracle_pack_gbuffer): a point on the optical axis has zero
+    motion under a pure dolly, depth is the Euclidean camera distance, normals come out normalised as half bits."""
+    pack = snp.pack_gbuffer if twin == "numpy" else oracle.pack_gbuffer
     W, H = 8, 6
     pos = np.zeros((H, W, 4), np.float32); pos[..., 2] = -3.0
     nrm = np.zeros((H, W, 4), np.float32); nrm[..., 2] = 2.0; nrm[..., 3] = 7
     nrm[0, 0, :3] = 0
     bary = np.zeros((H, W, 4), np.float32); bary[..., 0] = 1; bary[..., 3] = 3
     eye = np.eye(4, dtype=np.float32).T.ravel()
-    m, n, uv = snp.pack_gbuffer(pos, nrm, bary, eye, eye, np.array([0, 0, 1], np.float32))
+    m, n, uv = pack(pos, nrm, bary, eye, eye, np.array([0, 0, 1], np.float32))
     assert np.all(m[1:, :, 2] == 4.0) and np.all(m[..., :2] == 0) and np.all(m[0, 0] == 0)
     assert np.all(n[1:, :, 2] == np.float16(1.0).view(np.uint16)) and np.all(n[1:, :, 3] == np.float16(7).view(np.uint16))
     assert np.all(uv[1:, :, 3] == np.float16(3).view(np.uint16)) and np.all(n[0, 0] == 0) and np.all(uv[0, 0] == 0)

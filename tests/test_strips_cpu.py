@@ -121,3 +121,56 @@ def test_gloo_world2_bit_identical(oracle, plan):
     for k in range(N):
         got = np.concatenate([res[r][k] for r in range(world)], 0)
         assert np.array_equal(got.view(np.uint8), want[k].view(np.uint8)), f"frame {k}"
+
+
+def test_auto_plan_exchanges_between_iterations():
+    """SVGF_PLAN_AUTO (both restatements): grouped where its halo fits the strips — BASELINE.json configs[3] names a halo exchange between
+    a-trous iterations, and ghost has none — else per-iteration; ghost only where neither applies (steps <= 1: all three coincide)."""
+    from svgf_amd import filter as F
+    assert strips.Geometry.make(7680, 4320, 3, 8, 5, plan="auto").plan == "grouped"
+    assert strips.strips_plan(7680, 4320, 3, 8, 5, plan="auto")["plan"] == F.HALO_PLAN_NAME[F.HALO_PLAN["grouped"]]
+    # strips of 40 rows: grouped's 48-row halo does not fit, per-iteration's 32 does
+    assert strips.Geometry.make(640, 320, 3, 8, 5, plan="auto", motion_reach=0).plan == "per-iteration"
+    assert strips.strips_plan(640, 320, 3, 8, 5, plan="auto", motion_reach=0)["plan"] == "per-iteration"
+    with pytest.raises(ValueError):
+        strips.Geometry.make(640, 160, 3, 8, 5, plan="auto")
+
+
+def test_bench_line_of_an_eight_rank_run_from_canned_timings():
+    """bench.py's rank-0 assembly of the N > 1 line (strips_line) on canned per-rank results for world 8 — no GPU, no communicator: the first
+    real 8-GPU run must not die in Python glue after the measurement.  Every plan carries its speed-up over one GPU, its share of the
+    aggregate roofline and the north_star's >= 6x target; the headline is the plan `auto` resolves to (grouped), never ghost."""
+    import argparse
+    import json
+    import bench
+    W, H, world = 7680, 4320, 8
+    args = argparse.Namespace(steps=20, warmup=5)
+    res = dict(ms_per_step=0.444, plan="grouped", rows_per_rank=540, rows_held=636, host_ms=0.31, motion_reach=0, edge_first=True, ms_per_step_three_launches=0.466,
+               verified={"frames": 6, "plan": "grouped", "three_launches": True, "edge_first": True},
+               atrous_timing=lambda b_it, b_fb: (25, 25 * 0.052, (5 * 560 * W) * 5 * b_it + (5 * 560 * W) * b_fb),
+               driver="C++ (svgf_strips_frame)", one_gpu_ms=2.75, rccl_ranks=8, _comm=object(), pan={"mv": [1.5, -3.5], "motion_reach": 4, "plan": "grouped", "ms_per_step": 0.47, "rows_held": 644},
+               other_plans={"per-iteration": dict(ms_per_step=0.4816, rows_held=604, host_ms=0.33, ms_per_step_three_launches=0.53),
+                            "ghost": dict(ms_per_step=0.4685, rows_held=678, host_ms=0.29, edge_first=True)})
+    line = bench.strips_line(res, args, W, H, "f32", 5, world)
+    d = json.loads(json.dumps(line))                       # serialisable as it stands
+    assert d["metric"] == bench.METRIC and d["n_gpus"] == 8 and d["unit"] == "Mpixels/s" and d["scaling"] == "strong"
+    assert d["config"]["halo_plan"] == "grouped" and d["config"]["world_size"] == 8 and "7680x4320" in d["config"]["workload"]
+    assert abs(d["value"] - W * H / 0.444e-3 / 1e6) < 1 and d["ms_per_step"] == 0.444
+    assert set(d["halo_plans"]) == {"grouped", "per-iteration", "ghost"}
+    for name, p in d["halo_plans"].items():
+        assert p["target_speedup"] == 6.0 and p["target_met"] == (2.75 / p["ms_per_step"] >= 6.0), name
+        assert abs(p["speedup_vs_one_gpu"] - 2.75 / p["ms_per_step"]) < 1e-3
+        assert abs(p["frac_of_aggregate_8TBps"] - 459 * W * H / (p["ms_per_step"] * 1e-3) / 1e9 / 64000) < 1e-3
+    assert d["halo_plans"]["grouped"]["target_met"] and not d["halo_plans"]["per-iteration"]["target_met"] and not d["halo_plans"]["ghost"]["target_met"]
+    assert d["target_met"] is True and d["speedup_vs_one_gpu"] == d["halo_plans"]["grouped"]["speedup_vs_one_gpu"]
+    assert d["fastest_plan"] == "grouped" and d["fastest_plan_that_exchanges_between_iterations"] == "grouped"
+    assert d["config"]["edge_first"] is True and d["verified"]["edge_first"] is True and d["halo_plans"]["grouped"]["ms_per_step_three_launches"] == 0.466
+    assert d["halo_plans"]["per-iteration"]["edge_first"] is False and d["halo_plans"]["ghost"]["edge_first"] is True
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["unit"] == "GB/s" and d["pan"]["Mpixels/s"] > 0 and d["rccl_ranks"] == 8
+    # a leg that hung after the headline: the same line with what was measured, and `incomplete`
+    part = dict(res, other_plans={}, pan=None)
+    d2 = json.loads(json.dumps(bench.strips_line(part, args, W, H, "f32", 5, world, incomplete="leg 'plan ghost' did not finish")))
+    assert set(d2["halo_plans"]) == {"grouped"} and d2["pan"] is None and "plan ghost" in d2["incomplete"]
+    # other world sizes carry no target; no one-GPU reference: no speed-up
+    d4 = bench.strips_line(dict(res, one_gpu_ms=None), args, W, H, "f32", 5, 4)
+    assert d4["target_speedup"] is None and d4["speedup_vs_one_gpu"] is None and all(p["target_met"] is None for p in d4["halo_plans"].values())
