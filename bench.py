@@ -244,7 +244,7 @@ def run_single(pool: FramePool, W, H, storage, iters, variant, steps, warmup, de
 
     def rewarm(ms=60.0, frames=0):
         """untimed frames right before a timed window whenever the host has just kept the device idle (timing_read, a garbage collection):
-        after >= 2 ms of idleness the part needs tens of milliseconds to be back at its clocks (tools/idle_gap.py: the next 10-40 frames run
+        after >= 2 ms of idleness the part needs tens of milliseconds to be back at its clocks (tools/archive/idle_gap.py: the next 10-40 frames run
         5-20 % slower).  The first call also runs `frames` frames: a process sees ONE stall of 20-65 ms when it has enqueued its first
         ~4 000 stream operations (tools/strip_sim.py --per-frame) - it belongs in front of the timed windows, not in one of them."""
         nonlocal n
@@ -915,7 +915,7 @@ def main():
         if not args.no_extra and wl == "4k" and args.frames_in_flight == 1 and storage == "f32":
             # Heavy disocclusion: every 8th column of ONE of the two G-buffers the frames alternate between has its normals flipped, so those columns fail
             # the reprojection test in every frame (12 % of the surface pixels young, some in EVERY wave of the temporal launch): what thin geometry under
-            # motion or a fast camera does to the young-pixel machinery (tools/young_worst_case.py)
+            # motion or a fast camera does to the young-pixel machinery (tools/archive/young_worst_case.py)
             import torch
             cp = FramePool(scene, storage, "static")
             cp.gb[1].normal.view(torch.int16)[:, ::8, 0:3] ^= -32768

@@ -90,7 +90,7 @@ int svgf_flush(svgf_ctx* ctx);
  *     with unjoined work, and on ROCm 7.2 leaves its streams unusable afterwards);
  *   - per-stage timing skips captured frames; svgf_sync / svgf_halo_violations / svgf_timing_read wait for the device and are not
  *     capturable, as any synchronising call; the strip driver (svgf_strips_frame) is not capturable.
- * Replayed frames equal directly enqueued ones bit for bit (tests/test_gpu_graph.py).  Measured (tools/graph_replay.py): with one
+ * Replayed frames equal directly enqueued ones bit for bit (tests/test_gpu_graph.py).  Measured (tools/archive/graph_replay.py): with one
  * frame in flight a replay costs the device what the calls cost (the launches are not host-bound: 7 us against 30 us of host time
  * per frame, no device time saved); with two frames in flight the cross-stream edges of a graph are cheaper than the event waits of
  * the calls: -5 % at 1080p and -9 % at 720p against one frame in flight enqueued call by call. */

@@ -706,7 +706,7 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
         torch.cuda.synchronize(device)
         # ... and keep the device busy for >= busy[0] = 400 ms and >= busy[1] = 600 frames before anything is timed: after the idle gaps of the set-up
         # (allocations, rank 0's whole-frame reference) the part needs tens of milliseconds at load to be back at its clocks
-        # (tools/idle_gap.py), and a process sees one stall of 20-65 ms when it has enqueued its first ~4 000 stream operations (~300
+        # (tools/archive/idle_gap.py), and a process sees one stall of 20-65 ms when it has enqueued its first ~4 000 stream operations (~300
         # frames; tools/strip_sim.py --per-frame) that would otherwise land in the timed frames.  The number of extra frames comes from
         # the all-reduced per-frame time, so every rank runs the same count (frames exchange halos).
         done = prime_frames + warmup

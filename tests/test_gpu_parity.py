@@ -245,7 +245,7 @@ def test_pipeline_free_running(G, oracle, storage, mv, variant):
     ref = oracle.Pipeline(W, H, storage, steps=5, nthreads=8)
     hip = G.HipPipeline(W, H, storage, steps=5, variant=variant)
     gbs = [G.gb_dev(f) for f in fr]
-    # measured on MI355X (profiles/r0N_parity_report.json, tools/diag_free.py): f32 max 2.5e-4 with < 1e-3 of the values beyond 2e-5;
+    # measured on MI355X (profiles/r0N_parity_report.json, tools/archive/diag_free.py): f32 max 2.5e-4 with < 1e-3 of the values beyond 2e-5;
     # f16 max 1.0e-2 (static camera, frame 3: ten half-ulps at 0.5-1.0 on a handful of pixels) with < 1e-4 of the values beyond 1e-3 —
     # all in frames 3-4, where the first pixels leave the spatial variance estimate.  The bounds are 2x the measured maxima
     # (tests/helpers.py:FREE_RUNNING) — and, round 5, the measured ENVELOPE of the same frames: the distance between two correct CPU

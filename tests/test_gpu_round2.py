@@ -158,8 +158,8 @@ def test_native_strip_driver_with_two_frames_in_flight(G, loop_comm, plan):
 
 
 def test_config4_8k_as_eight_strips_of_540_rows(G, loop_comm):
-    """BASELINE.json configs[3]: 7680x4320 fp32 cut into 8 strips x 540 rows (plan auto = ghost, 69-row halo), two frames through
-    the C++ strip driver with its RCCL exchanges, bitwise against the whole frame on the same device."""
+    """BASELINE.json configs[3]: 7680x4320 fp32 cut into 8 strips x 540 rows (plan auto = grouped: one exchange of filter rows between iterations 2 and 3,
+    48-row halo), two frames through the C++ strip driver with its RCCL exchanges, bitwise against the whole frame on the same device."""
     import torch
     from svgf_amd import filter as F
     from svgf_amd import strips
@@ -168,8 +168,8 @@ def test_config4_8k_as_eight_strips_of_540_rows(G, loop_comm):
     rads = [synth.make_radiance(sc["base"], W, k) for k in range(2)]
     params = F.Params(storage=storage, steps=5)
     drv = strips.NativeStrips(W, H, world, params, list(range(world)), [0] * world, comms=[loop_comm], plan="auto", motion_reach=4, loopback=True)
-    assert drv.plan == "ghost" and [lay["own"][1] - lay["own"][0] for lay in drv.layouts] == [540] * 8
-    assert drv.layouts[3]["y0"] == 1620 - 69 and drv.layouts[3]["y1"] == 2160 + 69
+    assert drv.plan == "grouped" and [lay["own"][1] - lay["own"][0] for lay in drv.layouts] == [540] * 8
+    assert drv.layouts[3]["y0"] == 1620 - 48 and drv.layouts[3]["y1"] == 2160 + 48
     whole = G.HipPipeline(W, H, storage, steps=5)
     gb = G.gb_dev(sc)
     strip_gb = [F.GBuffer(*(gb_t[lay["y0"]:lay["y1"]].contiguous() for gb_t in (gb.motion, gb.normal, gb.uv))) for lay in drv.layouts]

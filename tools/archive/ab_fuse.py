@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Iterations 0 + 1 as one launch (svgf_atrous_pair) against one launch per iteration, interleaved in ONE process on ONE device:
-    python tools/ab_fuse.py [rounds] [workload ...]        (workloads: 4k 1080p 8k; default 4k 1080p)
+    python tools/archive/ab_fuse.py [rounds] [workload ...]        (workloads: 4k 1080p 8k; default 4k 1080p)
 Prints per round the frame time and the stage times (temporal, moments, iterations; the pair sits in the first iteration slot)."""
 import os
 import sys

@@ -1,7 +1,7 @@
 """Diagnostic: svgf_denoise_frame enqueued call by call against the same frames replayed from a hipGraph (two frames per graph: the context
 ping-pongs, include/svgf.h "Stream capture"), per frame size.  Three figures per size: back to back (the device never idle: what bench.py
 times), one frame at a time (host waits for every frame, as an interactive host does between its own passes), and the host's enqueue time.
-    python3 tools/graph_replay.py [f32|f16] [in_flight]"""
+    python3 tools/archive/graph_replay.py [f32|f16] [in_flight]"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)

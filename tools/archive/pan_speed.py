@@ -1,5 +1,5 @@
 """Diagnostic: the young-pixel machinery under faster pans than the bench's (-2.5, +1.5) px per frame: stage times, the frame driver's sample and its choice.
-    python3 tools/pan_speed.py [scale ...]      (multiples of the bench pan; default 1 2 4 8)"""
+    python3 tools/archive/pan_speed.py [scale ...]      (multiples of the bench pan; default 1 2 4 8)"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)

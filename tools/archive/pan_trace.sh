@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel durations of the temporal and moments launches for prebuilt twins (build/libsvgf_<name>.so), bench pan by default:
-#   tools/pan_trace.sh "A B" [static|pan]
+#   tools/archive/pan_trace.sh "A B" [static|pan]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 for v in $1; do

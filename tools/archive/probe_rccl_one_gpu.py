@@ -1,5 +1,5 @@
 """Can two RCCL ranks share ONE device?  (If they can, the strip driver's multi-process path runs on a one-GPU box with the product transport.)
-Run: python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/probe_rccl_one_gpu.py"""
+Run: python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/archive/probe_rccl_one_gpu.py"""
 import os
 import sys
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Counters of the young-pixel moments launch under the bench's pan (separate PMC passes, no tracing): tools/prof_pan_moments.sh <tag>
+# Counters of the young-pixel moments launch under the bench's pan (separate PMC passes, no tracing): tools/archive/prof_pan_moments.sh <tag>
 TAG=${1:-pan}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG

@@ -2,7 +2,7 @@
 running as long as the a-trous interior beside it: is that the transfer, or the kernel waiting for the chip?)
 A loop-back group {2 x ncclSend, 2 x ncclRecv} of `bytes` each (the two boundaries of a middle strip), through librccl directly, timed with events
 on its stream: (a) on an idle device, (b) while 8K denoiser frames run on a high-priority stream.  Communication stream at normal and at high priority.
-    python tools/rccl_selfcopy.py"""
+    python tools/archive/rccl_selfcopy.py"""
 import ctypes as C
 import os
 import sys

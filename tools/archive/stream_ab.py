@@ -1,7 +1,7 @@
 """Diagnostic: does the stream a context enqueues on matter?  The same frames through two contexts of one process — one on the legacy default
 stream (what torch.cuda.current_stream() is unless the host says otherwise, and what the reference uses: App.cu never creates a stream), one on
 a stream created by the host — in alternating timed windows (sync, K frames, sync), per frame size.
-    python3 tools/stream_ab.py [f32|f16]"""
+    python3 tools/archive/stream_ab.py [f32|f16]"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# strip_sim for several prebuilt libraries (build/libsvgf_<name>.so), interleaved: tools/strip_ab.sh "A B" [rounds] [strip_sim args]
+# strip_sim for several prebuilt libraries (build/libsvgf_<name>.so), interleaved: tools/archive/strip_ab.sh "A B" [rounds] [strip_sim args]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 NAMES="$1"; ROUNDS=${2:-2}; shift; shift

@@ -2,7 +2,7 @@
 frames alternate between differ in the normals of every `period`-th column, so those columns fail the reprojection test in every frame, stay at
 history 1, and every wave of the temporal launch appends to the young list (one atomic per wave on one counter) while the moments launch walks a list
 of W x H / period pixels.  Prints the stage times next to the static scene's.
-    python3 tools/young_worst_case.py [period ...]"""
+    python3 tools/archive/young_worst_case.py [period ...]"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)

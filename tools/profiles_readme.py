@@ -63,14 +63,14 @@ def main(tag):
         ("hbm_traffic.json", "HBM bytes per launch from this round's PMC passes (`tools/make_traffic.py`), stamped with the hash of the kernel sources; `bench.py` attaches it (`roofline.traffic`, `traffic_source`) only when the sources it runs hash to the same value"),
         (f"{tag}_strip_sim_8k_over_8.txt", "`tools/strip_sim.py`, plans ghost / grouped / per-iteration (round 5: each with edge rows first and with round 4's three launches, and the whole 8K frame on the same GPU in the same call): the middle strip of an 8K/8 partition with loop-back RCCL groups"),
         (f"{tag}_strip_trace_per-iteration_three_launches.txt, _one_launch.txt, _two_launches.txt, {tag}_strip_trace_ghost.txt", "`tools/strip_trace.py`: a strip frame as the device ran it (rocprofv3 kernel trace of `strip_sim.py`): timeline of one frame, mean kernel durations, mean gap between consecutive filter kernels — round 4's schedule, edge rows first in one launch, and with the interior in two launches"),
-        (f"{tag}_rccl_selfcopy.txt", "`tools/rccl_selfcopy.py`: one loop-back halo exchange (2 sends + 2 receives, 4 KB - 3.9 MB) on an idle device and beside filter launches, communication stream at normal / highest priority"),
-        (f"{tag}_probe_wait_value.txt, {tag}_probe_cu_mask.txt, {tag}_probe_rccl_two_ranks_one_gpu.txt", "`tools/ubench/wait_value.hip`, `tools/ubench/cu_mask.hip`, `tools/probe_rccl_one_gpu.py`: stream memory operations against a running kernel; CU masks; two RCCL ranks on one device (refused)"),
+        (f"{tag}_rccl_selfcopy.txt", "`tools/archive/rccl_selfcopy.py`: one loop-back halo exchange (2 sends + 2 receives, 4 KB - 3.9 MB) on an idle device and beside filter launches, communication stream at normal / highest priority"),
+        (f"{tag}_probe_wait_value.txt, {tag}_probe_cu_mask.txt, {tag}_probe_rccl_two_ranks_one_gpu.txt", "`tools/ubench/wait_value.hip`, `tools/ubench/cu_mask.hip`, `tools/archive/probe_rccl_one_gpu.py`: stream memory operations against a running kernel; CU masks; two RCCL ranks on one device (refused)"),
         (f"{tag}_strip_sim_reserved_cus.txt", "`strip_sim.py` with the filter stream kept off one CU pair per XCD (`hipExtStreamCreateWithCUMask`): slower for every plan (the helper left the ABI)"),
         (f"{tag}_parity_envelope.json", "`tools/parity_envelope.py` (CPU): the oracle against its fp32 / fma / fp32fma / fused builds, free-running on the parity frames"),
         (f"{tag}_fused_pair_ablations.txt", "iterations 0 + 1 as one launch: A/B against two launches, its knobs, what it is made of; the fp16 half-record experiment"),
-        (f"{tag}_small_experiments.txt", "the `tools/abn.sh` / `tools/strip_ab.sh` blocks of the round (interleaved A/B of prebuilt twins on one device)"),
+        (f"{tag}_small_experiments.txt", "the `tools/abn.sh` / `tools/archive/strip_ab.sh` blocks of the round (interleaved A/B of prebuilt twins on one device)"),
         (f"{tag}_cold_frames.txt", "`tools/cold_frames.py`: per-frame stage times over the cold -> steady transition (fp32, fp16)"),
-        (f"{tag}_repeat_suite_prefix.txt", "`tools/repeat_suite_prefix.py 200`: the tests around the spot where two round-2 suite runs hung, 200 times in one process"),
+        (f"{tag}_repeat_suite_prefix.txt", "`tools/archive/repeat_suite_prefix.py 200`: the tests around the spot where two round-2 suite runs hung, 200 times in one process"),
         (f"{tag}_pytest_gpu.txt", "summary line of `pytest tests -q -m gpu` in the same call as the bench lines"),
         (f"{tag}_pytest_gpu_soak.txt", "five more full `pytest tests -q -m gpu` runs in one call at the final sources (the round-2 suite abort: not seen)"),
         (f"{tag}_parity_report.json", "`tests/test_gpu_round2.py::test_parity_report`: max / mean error per stage against the oracle, mask mismatch counts"),

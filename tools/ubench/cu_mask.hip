@@ -1,5 +1,5 @@
 // cu_mask.hip — can a stream be kept OFF a few compute units, so that the halo exchange's kernels always find room beside a filter launch that
-// oversubscribes the chip?  (tools/rccl_selfcopy.py: a loop-back RCCL group takes 15-23 us on an idle device and 75-150 us beside the filter
+// oversubscribes the chip?  (tools/archive/rccl_selfcopy.py: a loop-back RCCL group takes 15-23 us on an idle device and 75-150 us beside the filter
 // launches, at any stream priority: its workgroups wait for whole CUs' worth of resources that the dispatcher keeps handing to the next filter workgroup.)
 //   1. hipExtStreamCreateWithCUMask with n of the low mask bits set: how long does a fixed grid take?  (which bits are which CUs: per-XCD interleaved or blocked)
 //   2. a saturating "filter" kernel on a stream masked to all but k CUs per XCD, and an 8-workgroup x 512-thread "exchange" kernel (64 KB of LDS each) on an unmasked
