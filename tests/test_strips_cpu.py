@@ -174,3 +174,21 @@ def test_bench_line_of_an_eight_rank_run_from_canned_timings():
     # other world sizes carry no target; no one-GPU reference: no speed-up
     d4 = bench.strips_line(dict(res, one_gpu_ms=None), args, W, H, "f32", 5, 4)
     assert d4["target_speedup"] is None and d4["speedup_vs_one_gpu"] is None and all(p["target_met"] is None for p in d4["halo_plans"].values())
+
+
+def test_strip_verification_checksum_sees_a_flipped_bit_and_a_misplaced_row():
+    """bench_strips checks every rank's owned rows against the one-GPU frame through strips._checksum (two 64-bit sums over the raw words, one of
+    them position-weighted): equal planes give equal sums; one flipped bit, a -0.0 for a +0.0, or two rows swapped do not."""
+    rng = np.random.default_rng(9)
+    a = torch.from_numpy(rng.uniform(0, 1, (37, 129, 4)).astype(np.float32))
+    s = strips._checksum(a)
+    assert torch.equal(s, strips._checksum(a.clone()))
+    b = a.clone(); b.view(torch.int32)[5, 7, 2] ^= 1
+    assert not torch.equal(s, strips._checksum(b))
+    c = a.clone(); c[3, 3, 1] = 0.0
+    d = c.clone(); d[3, 3, 1] = -0.0
+    assert not torch.equal(strips._checksum(c), strips._checksum(d))
+    e = a.clone(); e[[4, 9]] = e[[9, 4]]
+    assert torch.equal(strips._checksum(e)[0], s[0]) and not torch.equal(strips._checksum(e)[1], s[1])      # same words, other places
+    h = torch.from_numpy(rng.uniform(0, 1, (8, 64, 4)).astype(np.float16))                                       # fp16 storage: 8 B per pixel = two words
+    assert torch.equal(strips._checksum(h), strips._checksum(h.clone())) and strips._checksum(h).shape == (2,)
