@@ -1,7 +1,7 @@
 #!/bin/bash
 # After `gpurun -- tools/final_round.sh <tag>`: copy what was measured into profiles/ (run here, in the container), then
 # `python3 tools/profiles_readme.py <tag>` regenerates that round's section of profiles/README.md FROM the copied files.
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/$TAG
 RN=$(echo $TAG | sed 's/^r0*//')
@@ -14,5 +14,6 @@ for f in bench_4k_f32 bench_4k_f16 bench_1080p_f32 bench_8k_f32 bench_4k_f32_pai
 cp $O/strip_sim.txt profiles/${TAG}_strip_sim_8k_over_8.txt
 [ -f $O/cold_frames.txt ] && cp $O/cold_frames.txt profiles/${TAG}_cold_frames.txt
 cp $O/pytest_gpu.log profiles/${TAG}_pytest_gpu.txt
+[ -f $O/fuzz_parity.txt ] && { echo "# tests/fuzz_parity.py on MI355X in the round's final call (tools/final_round.sh): summary lines"; grep -E "^FAIL|^fuzz_parity:" $O/fuzz_parity.txt; } >> profiles/${TAG}_fuzz_parity.txt
 cp gpurun_out/parity_report.json profiles/${TAG}_parity_report.json
 python3 tools/profiles_readme.py $TAG

@@ -2,7 +2,7 @@
 # Everything the round's profiles/ files come from, in one gpurun call on one box: tools/final_round.sh <tag>
 # Order: tests, the rocprofv3 passes (trace; PMC in separate runs), profiles/hbm_traffic.json from those PMC passes (stamped with the hash
 # of the kernel sources), THEN the bench lines — so that the lines carry roofline.traffic measured on this box, in this call, on these sources.
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; O=gpurun_out/$TAG; mkdir -p $O
 RN=$(echo $TAG | sed 's/^r0*//')
@@ -24,6 +24,8 @@ python3 bench.py --frames-in-flight 2 --no-cpu --no-extra 2>/dev/null | grep "^{
 python3 bench.py --strips --workload 8k --steps 20 --warmup 3 2>/dev/null | grep "^{" > $O/bench_8k_f32_stripdriver_1gpu.json
 python3 tools/strip_sim.py --rounds 3 2>&1 | grep -E "ms/frame|whole|wire|MB per" > $O/strip_sim.txt
 python3 tools/cold_frames.py 2>&1 | grep "frame" > $O/cold_frames.txt
+# the seeded sweep of the parity / bit-identity claims, LAST (whatever it finds, the measurements above stand): ${FUZZ_MINUTES:-10} minutes
+python3 -m tests.fuzz_parity --minutes ${FUZZ_MINUTES:-10} --seed ${FUZZ_SEED:-6100000} --out $O/fuzz_parity_full.txt > $O/fuzz_parity.txt 2>&1
 # the raw per-dispatch tables stay on the box (gpurun merges at most 64 MiB back): the summaries, hbm_traffic.json and kernel_stats.csv were made from them above
 find gpurun_out/prof_${TAG}_* -name "*kernel_trace.csv" -delete; find gpurun_out/prof_${TAG}_* -name "*counter_collection.csv" -delete
-cat $O/pytest_gpu.log; cut -c1-160 $O/bench_4k_f32.json; cat $O/strip_sim.txt
+cat $O/pytest_gpu.log; cut -c1-160 $O/bench_4k_f32.json; cat $O/strip_sim.txt; tail -2 $O/fuzz_parity.txt

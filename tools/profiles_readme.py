@@ -103,6 +103,15 @@ def main(tag):
         notes.append(f"* `{tag}_bench_4k_f32.json` (no tracer, same call, same box): {b['ms_per_step']} ms per frame (windows {b.get('ms_per_step_min')}-{b.get('ms_per_step_max')}), "
                      f"{r['avg_launch_ms'] * 1e3:.1f} us per `{r['kernel']}` launch, `roofline.frac` {r['frac']}, stage sum {b.get('stage_sum_ms')} ms, "
                      f"{b.get('event_overhead_ms_per_step')} ms of event overhead per frame; traffic {r.get('traffic')} B from `{r.get('traffic_source')}`.")
+        if r.get("atrous_x5_ms") is not None:
+            notes.append(f"* BASELINE.md's line for the iterations alone: a-trous x5 = **{r['atrous_x5_ms']} ms** against the 60 % target of {r['atrous_x5_target_ms']} ms: "
+                         f"{'met' if r['atrous_x5_target_met'] else 'MISSED'} (`roofline.atrous_x5_*`).")
+        if b.get("uniform_normal_path_share"):
+            notes.append(f"* share of the a-trous wave-steps on the uniform-normal tap path, counted on the device (`svgf_path_stats_enable`), headline scene: {b['uniform_normal_path_share']}.")
+        cs = (b.get("also") or {}).get("curved_scene")
+        if cs:
+            notes.append(f"* also `curved_scene` (per-texel normals: terrain, sphere, cylinder): **{cs['ms_per_step']} ms** per frame = {cs['Mpixels/s']} Mpixel/s = **{cs['frac_of_8TBps']}** of the pass "
+                         f"roofline (60 % target {'met' if cs['target_met'] else 'MISSED'}), a-trous x5 {cs.get('atrous_x5_ms')} ms, uniform-path share {cs['uniform_normal_path_share'].get('all')}.")
         if "pan" in b:
             notes.append(f"* pan ({b['pan']['mv']}): {b['pan']['ms_per_step']} ms per frame, moments launch {b['pan']['moments_ms'] * 1e3:.1f} us.")
         for k, v in (b.get("also") or {}).items():
@@ -153,7 +162,7 @@ def main(tag):
     if d:
         hp = "; ".join(f"{k} {v['ms_per_step']} ms" for k, v in d["halo_plans"].items())
         notes.append(f"* `{tag}_bench_8k_f32_stripdriver_1gpu.json`: world size 1 through the C++ strip driver: {hp}; one GPU through `svgf_denoise_frame` {d['one_gpu_ms']} ms; "
-                     f"pan (reach {d['pan']['motion_reach']}) {d['pan']['ms_per_step']} ms.")
+                     f"pan (reach {d['pan']['motion_reach']}) {d['pan']['ms_per_step']} ms; headline plan {d['config'].get('halo_plan')}, verified against the one-GPU frame: {d.get('verified')}.")
     sim = os.path.join(P, f"{tag}_strip_sim_8k_over_8.txt")
     if os.path.exists(sim):
         for ln in open(sim):
@@ -179,4 +188,4 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r05")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r06")
