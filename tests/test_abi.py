@@ -128,3 +128,18 @@ def test_strip_driver_refuses_without_gpu_or_bad_arguments():
     ranks, devs = (C.c_int * 1)(0), (C.c_int * 1)(0)
     rc = lib.svgf_strips_create(C.byref(h), 640, 480, 1, C.byref(p), 0, 0, 1, ranks, devs, None, None, 0)
     assert rc == -3 and not h.value                                                                        # no device: no driver
+
+
+def test_headers_are_plain_c():
+    """The boundary is a C ABI: each of the three headers compiles on its own as C99 (gcc -pedantic), the C++ shim as C++17 against them."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    inc = os.path.join(ROOT, "include")
+    with tempfile.TemporaryDirectory() as tmp:
+        for h in HEADERS:
+            src = os.path.join(tmp, "t.c")
+            open(src, "w").write(f'#include "{h}"\nint main(void) {{ return SVGF_ABI_VERSION == 8 ? 0 : 1; }}\n')
+            subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, src])
