@@ -70,6 +70,7 @@ def test_null_context_everywhere(G):
         "svgf_set_debug_mode": (N, 0), "svgf_set_prev_guide": (N, 1), "svgf_set_adaptive_moments": (N, 1), "svgf_adaptive_moments_sample": (N, C.byref(up), C.byref(up)),
         "svgf_import_gbuffer_pitched": (N, 0, N, 64, N), "svgf_import_gbuffer_array": (N, 0, N, N), "svgf_export_to_array": (N, N, N),
         "svgf_timing_enable": (N, 1), "svgf_timing_read": (N, C.byref(dp), C.byref(ip), 1),
+        "svgf_path_stats_enable": (N, 1), "svgf_path_stats_read": (N, C.byref(ull), 1),
         "svgf_strips_layout": (N, 0, C.byref(lay)), "svgf_strips_frame": (N, N, N, N, N), "svgf_strips_sync": (N,), "svgf_strips_set_frames_in_flight": (N, 2),
         "svgf_strips_set_edge_first": (N, 1), "svgf_strips_timing_enable": (N, 1), "svgf_strips_timing_read": (N, C.byref(ip), C.byref(dp), C.byref(dp), C.byref(dp)),
         "svgf_strips_mailbox_fault": (N, 0, 0), "svgf_strips_transport_stats": (N, C.byref(ull), C.byref(ull), C.byref(ull)),
