@@ -566,6 +566,24 @@ def _checksum(t):
     return torch.stack([v.sum(), (v * w).sum()])
 
 
+def _all_ranks_match(mine, ref_sums, rank, world):
+    """bench_strips' verification, the part that talks to the other ranks: every rank contributes the checksum of its owned rows (`mine`, a tensor on
+    the process group's device), rank 0 compares the gathered list with the checksums of the same rows of its one-GPU frame (`ref_sums`, [world, 2];
+    None on the other ranks) and every rank learns the verdict.  -> bool, the same on every rank."""
+    import torch
+    import torch.distributed as dist
+    sums = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(sums, mine)
+    else:
+        sums = [mine]
+    good = rank != 0 or bool((torch.stack(sums).cpu() == ref_sums.cpu()).all())
+    ok = torch.tensor([1 if good else 0], device=mine.device, dtype=torch.int32)
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    return bool(int(ok.item()))
+
+
 def _strip_pan_frames(W, H, storage, device, mv, y0, y1):
     """Two consecutive frames of a camera pan (rows [y0, y1)), walked forth and back: frame n shows canvas n & 1; walking back, a
     frame's predecessor is the other one with the motion vector negated (bench.py's FramePool, pool of 2).
@@ -764,17 +782,9 @@ def bench_strips(W, H, storage, iters, variant, steps, warmup, device, plan, mak
             rad, cur, prev = get(k)
             out = run.frame(rad, cur, prev if k else None)
         run.sync()
-        mine = _checksum(run.owned(out)).to(device)
-        sums = [torch.zeros_like(mine) for _ in range(world)]
-        if world > 1:
-            dist.all_gather(sums, mine)
-        else:
-            sums = [mine]
-        ok = torch.tensor([1 if (rank != 0 or bool((torch.stack(sums).cpu() == ref_sums.cpu()).all())) else 0], device=device, dtype=torch.int32)
-        if world > 1:
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        ok = _all_ranks_match(_checksum(run.owned(out)).to(device), ref_sums, rank, world)
         run.close()
-        return bool(int(ok.item()))
+        return ok
 
     # ---- The headline FIRST, under the library's default schedule (every exchange ordered behind an event: three launches per exchanging iteration) —
     # whatever happens afterwards, this line exists (bench.py's watchdog prints what is measured when a later leg hangs).

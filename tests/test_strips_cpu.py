@@ -192,3 +192,43 @@ def test_strip_verification_checksum_sees_a_flipped_bit_and_a_misplaced_row():
     assert torch.equal(strips._checksum(e)[0], s[0]) and not torch.equal(strips._checksum(e)[1], s[1])      # same words, other places
     h = torch.from_numpy(rng.uniform(0, 1, (8, 64, 4)).astype(np.float16))                                       # fp16 storage: 8 B per pixel = two words
     assert torch.equal(strips._checksum(h), strips._checksum(h.clone())) and strips._checksum(h).shape == (2,)
+
+
+def _verify_worker(rank, world, port, q):
+    """One rank of the bench's verification over gloo: a frame cut into `world` strips, every rank checksums ITS rows; rank 0 holds the reference."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H, W = 60, 40
+        frame = torch.from_numpy(np.random.default_rng(3).uniform(0, 1, (H, W, 4)).astype(np.float32))
+        parts = strips.partition(H, world)
+        ref = torch.stack([strips._checksum(frame[a:b]) for a, b in parts]) if rank == 0 else None
+        a, b = parts[rank]
+        verdicts = [strips._all_ranks_match(strips._checksum(frame[a:b]), ref, rank, world)]            # every rank holds the right rows
+        bad = frame[a:b].clone()
+        if rank == world - 1:
+            bad.view(torch.int32)[1, 2, 3] ^= 1                                                          # ... the last rank one flipped bit
+        verdicts.append(strips._all_ranks_match(strips._checksum(bad), ref, rank, world))
+        q.put((rank, verdicts))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_strip_verification_over_a_real_process_group():
+    """strips._all_ranks_match (the collective half of bench_strips' check against the one-GPU frame) over torch.distributed with three gloo ranks and
+    uneven strips: every rank learns "equal" when all strips are right, and every rank learns "not equal" when ONE rank's rows differ by one bit."""
+    import torch.multiprocessing as mp
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_verify_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res[r] == [True, False] for r in range(world)), res
