@@ -102,3 +102,44 @@ def test_stages_on_the_smooth_shaded_scene_match_the_oracle(G, oracle, storage):
         G.assert_colour_close(G.host(fb), fbw, storage, f"curved scene, feedback step {step}")
         sky = f1["region"] == synth.SKY
         assert np.array_equal(G.host(o)[sky].view(np.uint8), want[sky].view(np.uint8))
+
+
+@pytest.mark.parametrize("edge_first", [False, True])
+def test_the_bench_check_of_the_strips_against_the_one_gpu_frame(G, edge_first):
+    """What bench_strips does before it trusts a schedule (svgf_amd/strips.py: verify, _checksum), here with every rank of the partition in this
+    process (mailbox transport: real peer addressing, real exchanges): VERIFY_FRAMES frames from a fresh start through four strips and through the
+    whole-frame driver, every rank's owned rows against the same rows of the whole frame as 2 x 64-bit checksums — equal under both schedules;
+    and a strip whose radiance differs in ONE texel of ONE frame is seen."""
+    import torch
+    from svgf_amd import filter as F
+    from svgf_amd import strips
+    W, H, world, storage = 640, 600, 4, "f32"
+    P = F.Params(storage=storage, steps=5)
+    fr = [synth.make_frame(W, H, k) for k in range(2)]
+    gbw = [G.gb_dev(fr[0]), G.gb_dev(fr[0])]
+    whole = F.Denoiser(W, H, P)
+    for k in range(strips.VERIFY_FRAMES):
+        out_w = whole.Render(G.dev(fr[k & 1]["radiance"]), gbw[k & 1], gbw[(k & 1) ^ 1] if k else None)
+    torch.cuda.synchronize()
+    parts = strips.partition(H, world)
+    ref = torch.stack([strips._checksum(out_w[a:b]) for a, b in parts]).cpu()
+
+    def run(spoil):
+        drv = strips.NativeStrips(W, H, world, P, list(range(world)), [0] * world, plan="auto", motion_reach=0, transport="mailbox")
+        drv.set_edge_first(edge_first)
+        assert drv.plan == "grouped"
+        try:
+            gbs = [[F.GBuffer(*(G.dev(np.ascontiguousarray(fr[0][n][lay["y0"]:lay["y1"]])) for n in ("motion", "normal", "uv"))) for lay in drv.layouts] for _ in range(2)]
+            for k in range(strips.VERIFY_FRAMES):
+                rads = [np.ascontiguousarray(fr[k & 1]["radiance"][lay["y0"]:lay["y1"]]).copy() for lay in drv.layouts]
+                if spoil and k == 2:
+                    lay = drv.layouts[2]
+                    rads[2][lay["own"][0] - lay["y0"] + 7, 100, 1] += np.float32(2.0 ** -20)       # one texel of rank 2's own rows, one frame
+                outs = drv.frame([G.dev(r) for r in rads], gbs[k & 1], gbs[(k & 1) ^ 1] if k else None)
+            drv.sync()
+            return torch.stack([strips._checksum(drv.owned(r, o)) for r, o in enumerate(outs)]).cpu()
+        finally:
+            drv.close()
+    assert torch.equal(run(False), ref), f"strips (edge_first={edge_first}) differ from the whole frame"
+    bad = run(True)
+    assert not torch.equal(bad[2], ref[2]), "a spoiled texel must show in its rank's checksum"
