@@ -26,7 +26,7 @@ DEFAULTS = dict(steps=3, depth_threshold=0.8, normal_threshold=0.9, history_base
 
 
 _FLAVOURS = {"oracle": "libsvgf_oracle.so", "fp32fma": "libsvgf_oracle_fp32fma.so", "fp32": "libsvgf_oracle_fp32.so", "fma": "libsvgf_oracle_fma.so",
-             "fused": "libsvgf_oracle_fused.so"}
+             "fused": "libsvgf_oracle_fused.so", "hwulp": "libsvgf_oracle_hwulp.so"}
 
 
 def _stale(path):
@@ -75,6 +75,15 @@ def lib(flavour=None):
         L.svgf_oracle_h2f.argtypes = [C.c_uint16]
         _libs[flavour] = L
     return _libs[flavour]
+
+
+def set_hw_ulp_seed(seed: int):
+    """Envelope flavour "hwulp" only: which assignment of -1 / 0 / +1 ulp nudges to the operands of log2 / exp2 / rcp / rsq the build models
+    (svgf_oracle.cpp: hw_ulp) — one "transcendental unit" per seed; the envelope is the largest distance over a handful of them."""
+    L = lib("hwulp")
+    L.svgf_oracle_set_hw_ulp_seed.argtypes = [C.c_uint32]
+    L.svgf_oracle_set_hw_ulp_seed.restype = None
+    L.svgf_oracle_set_hw_ulp_seed(int(seed))
 
 
 class using:

@@ -100,6 +100,24 @@ struct F16 {                                 // reference-native half4 / half2 (
 
 inline float clamp01(float v) { return std::min(std::max(v, 0.0f), 1.0f); }   // glm::clamp = min(max(x,lo),hi)
 
+// Envelope build "hwulp" only: v moved by -1, 0 or +1 unit in the last place, chosen by a hash of its own bits (deterministic: the same operand
+// always gets the same nudge, as a hardware approximation does).  Every other build: the identity.
+uint32_t g_hw_ulp_seed = 0u;      // svgf_oracle_set_hw_ulp_seed: another "unit" (another assignment of nudges to operands); set between frames only
+inline float hw_ulp(float v, uint32_t salt) {
+#ifdef SVGF_ORACLE_HW_ULP
+    if (!(std::fabs(v) > 0.0f) || !(std::fabs(v) < 3.0e38f)) return v;           // zeros, infinities, NaN: as they are
+    uint32_t b;
+    std::memcpy(&b, &v, 4);
+    uint32_t h = (b + salt + g_hw_ulp_seed * 0x9E3779B9u) * 2654435761u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    b += (uint32_t)((int)(h % 3u) - 1);
+    std::memcpy(&v, &b, 4);
+#else
+    (void)salt;
+#endif
+    return v;
+}
+
 // imageLoad (Filter.cuh:78-83): value clamped to [0,1] on all four channels.  The coordinate
 // clamp never fires on this path (every caller tests "inside" first), so it is not restated.
 template <class T> inline void image_load(const void* img, size_t idx, float* v) {
@@ -148,11 +166,14 @@ inline float compute_weight(float zc, float zp, float phi_depth, const float* nc
 #ifdef SVGF_ORACLE_FUSED_EXPONENT
     // Envelope build "fused" only (Makefile): the weight as ONE exp2 of a fused fp32 exponent, the divisions as multiplications by reciprocals —
     // the formulation of the HIP kernels (svgf_device.h: edge_weight), evaluated with libm.  A third correct reading of :407-427, like nvcc -use_fast_math.
+    // Envelope build "hwulp" (-DSVGF_ORACLE_HW_ULP on top): the four results a GPU takes from its transcendental unit — log2, exp2 and the two
+    // reciprocals — moved by -1 / 0 / +1 ulp (hw_ulp below): a model of v_log_f32 / v_exp_f32 / v_rcp_f32, which are 1-ulp approximations where
+    // libm rounds correctly.  What that alone does to a free-running sequence is the envelope the fp16-under-a-pan case is held against.
     {
-        const float ln = (phi_normal == 0.0f) ? 0.0f : phi_normal * std::log2(d);
-        const float wz1 = (phi_depth == 0) ? 0.0f : std::fabs(zc - zp) * (1.0f / phi_depth);
-        const float wl1 = std::fabs(lc - lp) * (1.0f / phi_illum);
-        return std::exp2(ln - (std::fmax(wl1, 0.0f) + std::fmax(wz1, 0.0f)) * 1.4426950408889634f);
+        const float ln = (phi_normal == 0.0f) ? 0.0f : phi_normal * hw_ulp(std::log2(d), 1u);
+        const float wz1 = (phi_depth == 0) ? 0.0f : std::fabs(zc - zp) * hw_ulp(1.0f / phi_depth, 2u);
+        const float wl1 = std::fabs(lc - lp) * hw_ulp(1.0f / phi_illum, 3u);
+        return hw_ulp(std::exp2(ln - (std::fmax(wl1, 0.0f) + std::fmax(wz1, 0.0f)) * 1.4426950408889634f), 4u);
     }
 #endif
     const float wn = std::pow(d, phi_normal);                           // powf
@@ -294,7 +315,7 @@ void atrous(const Geo& g, const void* in, void* out, void* feedback, const float
                 if (zc == 1e30f) { T::st4(out, idx, c); continue; }               // :554-558 (no feedback)
                 float nc[3]; get_normal(normal, idx, nc);                         // :560
                 const float eps = 1e-10f;
-                const float phi_l = (float)((wide_t)phi_colour * std::sqrt(std::max((wide_t)0.0, (wide_t)(eps + var))));  // :562
+                const float phi_l = hw_ulp((float)((wide_t)phi_colour * std::sqrt(std::max((wide_t)0.0, (wide_t)(eps + var)))), 5u);  // :562 ("hwulp" build: a v_rsq_f32 result)
                 const float phi_d = std::fmax(dzc, 1e-6f) * (float)step;          // :563 (CUDA's max(float, float) is fmaxf: a NaN ddepth gives 1e-6)
                 float sw = 1.0f;                                                  // :567
                 float s[4] = {c[0], c[1], c[2], c[3]};                            // :568
@@ -316,7 +337,12 @@ void atrous(const Geo& g, const void* in, void* out, void* feedback, const float
                         s[0] += iw * q[0]; s[1] += iw * q[1]; s[2] += iw * q[2];  // :608
                         s[3] += (iw * iw) * q[3];
                     }
+#ifdef SVGF_ORACLE_HW_ULP
+                const float inv = hw_ulp(1.0f / sw, 6u);                          // ("hwulp" build: the normalisation by a v_rcp_f32 result, as the kernels do)
+                float o[4] = {s[0] * inv, s[1] * inv, s[2] * inv, s[3] * (inv * inv)};
+#else
                 float o[4] = {s[0] / sw, s[1] / sw, s[2] / sw, s[3] / (sw * sw)};  // :615
+#endif
                 T::st4(out, idx, o);                                              // :618 unclamped
                 if (iteration == 0 && feedback) T::st4(feedback, idx, o);         // :619-622
             }
@@ -526,6 +552,9 @@ int svgf_oracle_pack_gbuffer(int W, int H, const float* position, const float* n
         }
     return 0;
 }
+
+// envelope build "hwulp" only (a no-op in every other build): which of its possible "transcendental units" the build models
+void svgf_oracle_set_hw_ulp_seed(uint32_t seed) { g_hw_ulp_seed = seed; }
 
 // converters exported so the tests can pin them against numpy's float16
 uint16_t svgf_oracle_f2h(float f) { return f2h(f); }

@@ -62,10 +62,15 @@ def half_ulp_diff(a, b):
     return np.abs(ai - bi)
 
 
+HW_ULP_SEEDS = 12
+
+
 def free_running_envelope(oracle, fr, storage, steps=5, flavour="fp32fma", tight=None, **params):
     """How far apart two CORRECT implementations of Filter.cuh end up on the frames `fr`, each feeding itself: the oracle (fp64 islands, no FMA
-    contraction) against its envelope build (oracle/Makefile; default: all fp32 + FMA contraction, nvcc's defaults on the reference's source).
-    -> dict(max_abs, frac_beyond_tight, mask_mismatches): the bound a free-running device sequence is held against (VERDICT r04 #4)."""
+    contraction) against an envelope build of itself (oracle/Makefile).  flavour "fp32fma" (default): all fp32 + FMA contraction, nvcc's defaults on
+    the reference's source.  flavour "hwulp": on top of that the fused exponent with log2 / exp2 / rcp / rsq results moved by -1 / 0 / +1 ulp — a
+    model of a GPU's transcendental unit — over HW_ULP_SEEDS assignments of the nudges; the envelope is the largest distance over them.
+    -> dict(max_abs, frac_beyond_tight, mask_mismatches): the bound a free-running device sequence is held against (VERDICT r04 #4, r05 weak #5)."""
     try:
         oracle.lib(flavour)                         # (built on first use; -mfma: x86 with FMA only)
     except oracle.EnvelopeUnavailable as e:
@@ -74,33 +79,45 @@ def free_running_envelope(oracle, fr, storage, steps=5, flavour="fp32fma", tight
     H, W = fr[0]["radiance"].shape[:2]
     tight = tight if tight is not None else (2e-5 if storage == "f32" else 1e-3)
     a = oracle.Pipeline(W, H, storage, steps=steps, nthreads=8, **params)
-    b = oracle.Pipeline(W, H, storage, steps=steps, nthreads=8, **params)
-    worst, worst_frac, mism = 0.0, 0.0, 0
+    ref, hists = [], []
     for k in range(len(fr)):
-        kp = max(k - 1, 0)
-        wa = a.frame(fr[k]["radiance"], gbuf(fr[k]), gbuf(fr[kp])).astype(np.float64)
-        ha = a.taps["hist"].copy()
-        with oracle.using(flavour):
-            wb = b.frame(fr[k]["radiance"], gbuf(fr[k]), gbuf(fr[kp])).astype(np.float64)
-        mism += int((ha != b.taps["hist"]).sum())
-        with np.errstate(all="ignore"):
-            err = np.abs(np.nan_to_num(wa) - np.nan_to_num(wb))[..., :3]
-        worst = max(worst, float(err.max()))
-        worst_frac = max(worst_frac, float((err > tight + 1e-5 * np.abs(np.nan_to_num(wa)[..., :3])).mean()))
-    return dict(max_abs=worst, frac_beyond_tight=worst_frac, mask_mismatches=mism)
+        ref.append(a.frame(fr[k]["radiance"], gbuf(fr[k]), gbuf(fr[max(k - 1, 0)])).astype(np.float64))
+        hists.append(a.taps["hist"].copy())
+    worst, worst_frac, mism, per_seed = 0.0, 0.0, 0, []
+    for seed in (range(HW_ULP_SEEDS) if flavour == "hwulp" else (None,)):
+        if seed is not None:
+            oracle.set_hw_ulp_seed(seed)
+        b = oracle.Pipeline(W, H, storage, steps=steps, nthreads=8, **params)
+        mine = 0.0
+        for k in range(len(fr)):
+            with oracle.using(flavour):
+                wb = b.frame(fr[k]["radiance"], gbuf(fr[k]), gbuf(fr[max(k - 1, 0)])).astype(np.float64)
+            mism += int((hists[k] != b.taps["hist"]).sum())
+            with np.errstate(all="ignore"):
+                err = np.abs(np.nan_to_num(ref[k]) - np.nan_to_num(wb))[..., :3]
+            mine = max(mine, float(err.max()))
+            worst_frac = max(worst_frac, float((err > tight + 1e-5 * np.abs(np.nan_to_num(ref[k])[..., :3])).mean()))
+        per_seed.append(mine)
+        worst = max(worst, mine)
+    if flavour == "hwulp":
+        oracle.set_hw_ulp_seed(0)
+    return dict(max_abs=worst, frac_beyond_tight=worst_frac, mask_mismatches=mism, per_seed=per_seed)
 
 
 # Free-running bounds of the device sequences (tests/test_gpu_parity.py): per (storage, camera).  `loose` is 2x the maximum measured on MI355X
 # (profiles/r05_parity_report.json), `frac` the share of values allowed beyond the tight (stage-wise) tolerance.  Next to them every test also
-# holds the device against the ENVELOPE of its own frames (free_running_envelope): fp32 storage sits inside it in both motions; fp16 storage
-# sits inside it with a static camera and OUTSIDE it under the pan (2.1e-3 against 7.3e-4: the two oracle builds share libm's correctly rounded
-# exp / pow, so their halfs rarely flip, while v_exp_f32 / v_log_f32 / v_rcp_f32 / v_rsq_f32 are 1-ulp approximations whose half-ulp flips —
-# <= 1 half-ulp per stage on < 0.2 % of the values, the stage-wise claim — compound over five requantised iterations and eight frames).
+# holds the device against the ENVELOPE of its own frames (free_running_envelope): fp32 storage sits inside the fp32fma envelope in both motions;
+# fp16 storage sits inside it with a static camera and OUTSIDE it under the pan (2.1e-3 against 7.3e-4: the two oracle builds share libm's
+# correctly rounded exp / pow, so their halfs rarely flip, while v_exp_f32 / v_log_f32 / v_rcp_f32 / v_rsq_f32 are 1-ulp approximations whose
+# half-ulp flips — <= 1 half-ulp per stage on < 0.2 % of the values, the stage-wise claim — compound over five requantised iterations and eight
+# frames).  Round 6 measures THAT too: the envelope build "hwulp" moves exactly those four results by -1 / 0 / +1 ulp, and over twelve
+# assignments of the nudges the oracle ends up 3.7e-4 ... 2.4e-3 away from it on those frames (profiles/r06_parity_envelope.json) — the device's
+# 2.1e-3 is one draw of that distribution.  inside_envelope names the flavour the case is held against.
 FREE_RUNNING = {
-    ("f32", False): dict(tight=2e-5, loose=5e-4, frac=1e-3, inside_envelope=True),
-    ("f32", True): dict(tight=2e-5, loose=5e-4, frac=1e-3, inside_envelope=True),
-    ("f16", False): dict(tight=1e-3, loose=2e-2, frac=2e-3, inside_envelope=True),
-    ("f16", True): dict(tight=1e-3, loose=5e-3, frac=2e-3, inside_envelope=False),
+    ("f32", False): dict(tight=2e-5, loose=5e-4, frac=1e-3, inside_envelope="fp32fma"),
+    ("f32", True): dict(tight=2e-5, loose=5e-4, frac=1e-3, inside_envelope="fp32fma"),
+    ("f16", False): dict(tight=1e-3, loose=2e-2, frac=2e-3, inside_envelope="fp32fma"),
+    ("f16", True): dict(tight=1e-3, loose=5e-3, frac=2e-3, inside_envelope="hwulp"),
 }
 
 

@@ -262,10 +262,9 @@ def test_pipeline_free_running(G, oracle, storage, mv, variant):
         worst = max(worst, float(err.max()))
         assert err.max() <= loose, f"frame {k}: max colour error {err.max():.3e}"
         assert (err > tight + 1e-5 * np.abs(want[..., :3])).mean() <= frac, f"frame {k}: {(err > tight).mean():.2e} of values beyond the tight tolerance"
-    env = free_running_envelope(oracle, fr, storage)
+    env = free_running_envelope(oracle, fr, storage, flavour=b["inside_envelope"])      # (fp16 under a pan: the 1-ulp transcendental model, tests/helpers.py)
     assert env["mask_mismatches"] == 0
-    if b["inside_envelope"]:
-        assert worst <= env["max_abs"], f"HIP-vs-oracle {worst:.3e} is outside oracle-vs-oracle' {env['max_abs']:.3e}"
+    assert worst <= env["max_abs"], f"HIP-vs-oracle {worst:.3e} is outside oracle-vs-oracle' ({b['inside_envelope']}) {env['max_abs']:.3e}"
 
 
 @pytest.mark.parametrize("storage", ["f32", "f16"])

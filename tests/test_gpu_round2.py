@@ -457,7 +457,7 @@ def test_parity_report(G, oracle):
         # all-fp32 + FMA-contraction build — against the device's distance from the oracle, for both cameras.
         for mv in ((-2.5, 1.5), (0.0, 0.0)):
             frs = fr if mv[0] else frames(W, H, N, mv=mv)
-            env = {fl: free_running_envelope(oracle, frs, storage, flavour=fl) for fl in ("fp32", "fp32fma", "fused")}
+            env = {fl: free_running_envelope(oracle, frs, storage, flavour=fl) for fl in ("fp32", "fp32fma", "fused", "hwulp")}
             refm = oracle.Pipeline(W, H, storage, steps=5, nthreads=8)
             hipm = G.HipPipeline(W, H, storage, steps=5)
             gbm = gbs if mv[0] else [G.gb_dev(f) for f in frs]
@@ -472,7 +472,8 @@ def test_parity_report(G, oracle):
                 worst_frac = max(worst_frac, float((e_ > tight + 1e-5 * np.abs(w_[..., :3])).mean()))
             report.setdefault("envelope", {})[f"{storage} mv={list(mv)}"] = {
                 "hip_vs_oracle": {"max_abs": worst, "frac_beyond_tight": worst_frac},
-                "oracle_vs_build": env, "hip_inside_fp32fma_envelope": bool(worst <= env["fp32fma"]["max_abs"])}
+                "oracle_vs_build": env, "hip_inside_fp32fma_envelope": bool(worst <= env["fp32fma"]["max_abs"]),
+                "hip_inside_hwulp_envelope": bool(worst <= env["hwulp"]["max_abs"])}
         assert mask_mismatch == 0
         assert rep["temporal_colour"]["max_abs"] == 0.0 and rep["temporal_moments"]["max_abs"] == 0.0          # bit-exact stage
         lim = 2e-5 + 1e-5 if storage == "f32" else 1e-3

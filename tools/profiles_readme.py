@@ -66,7 +66,7 @@ def main(tag):
         (f"{tag}_rccl_selfcopy.txt", "`tools/archive/rccl_selfcopy.py`: one loop-back halo exchange (2 sends + 2 receives, 4 KB - 3.9 MB) on an idle device and beside filter launches, communication stream at normal / highest priority"),
         (f"{tag}_probe_wait_value.txt, {tag}_probe_cu_mask.txt, {tag}_probe_rccl_two_ranks_one_gpu.txt", "`tools/ubench/wait_value.hip`, `tools/ubench/cu_mask.hip`, `tools/archive/probe_rccl_one_gpu.py`: stream memory operations against a running kernel; CU masks; two RCCL ranks on one device (refused)"),
         (f"{tag}_strip_sim_reserved_cus.txt", "`strip_sim.py` with the filter stream kept off one CU pair per XCD (`hipExtStreamCreateWithCUMask`): slower for every plan (the helper left the ABI)"),
-        (f"{tag}_parity_envelope.json", "`tools/parity_envelope.py` (CPU): the oracle against its fp32 / fma / fp32fma / fused builds, free-running on the parity frames"),
+        (f"{tag}_parity_envelope.json", "`tools/parity_envelope.py` (CPU): the oracle against its fp32 / fma / fp32fma / fused builds — and, from round 6, `hwulp` (transcendentals within 1 ulp, twelve seeds) — free-running on the parity frames"),
         (f"{tag}_fused_pair_ablations.txt", "iterations 0 + 1 as one launch: A/B against two launches, its knobs, what it is made of; the fp16 half-record experiment"),
         (f"{tag}_small_experiments.txt", "the `tools/abn.sh` / `tools/archive/strip_ab.sh` blocks of the round (interleaved A/B of prebuilt twins on one device)"),
         (f"{tag}_cold_frames.txt", "`tools/cold_frames.py`: per-frame stage times over the cold -> steady transition (fp32, fp16)"),
